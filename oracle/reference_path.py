@@ -1,0 +1,303 @@
+"""numpy restatement of the reference's association path -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+
+Follows /root/reference/src/normalisr/ (v1.0.0), function by function, in fp64 numpy; the p-value
+arithmetic (scipy.stats.beta.cdf at association.py:249) is the C restatement in normalisr_oracle.c.
+Pinned against golden vectors generated from the reference itself (tests/golden/*.npz, made by
+tests/golden/make_golden.py); see tests/test_oracle.py.
+
+Not imported by the product path.  Allowed users: tests/, __graft_entry__.smoke(), bench.py cpu_baseline.
+"""
+import ctypes
+import itertools
+import logging
+import os
+import subprocess
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'libnrm_oracle.so')
+_lib = None
+
+
+def ensure_built():
+	"""Compile oracle/normalisr_oracle.c with gcc (oracle/Makefile) if needed and load it."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	src = os.path.join(_HERE, 'normalisr_oracle.c')
+	if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+		subprocess.run(['make', '-s', '-C', _HERE], check=True)
+	lib = ctypes.CDLL(_SO)
+	dp = ctypes.POINTER(ctypes.c_double)
+	lib.nrm_oracle_pvalues.argtypes = [dp, ctypes.c_size_t, ctypes.c_double, dp]
+	lib.nrm_oracle_pvalues.restype = None
+	lib.nrm_oracle_beta_cdf_half.argtypes = [ctypes.c_double, ctypes.c_double]
+	lib.nrm_oracle_beta_cdf_half.restype = ctypes.c_double
+	lib.nrm_oracle_lngamma_ratio_half.argtypes = [ctypes.c_double]
+	lib.nrm_oracle_lngamma_ratio_half.restype = ctypes.c_double
+	lib.nrm_oracle_block.argtypes = [dp, dp, dp, dp] + [ctypes.c_long] * 6 + [dp] * 5
+	lib.nrm_oracle_block.restype = None
+	_lib = lib
+	return lib
+
+
+def _dp(a):
+	return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def pvalues(r2, dof):
+	"""beta.cdf(1-r2, dof/2, 0.5) elementwise (association.py:249)."""
+	lib = ensure_built()
+	r2 = np.ascontiguousarray(r2, dtype=np.float64)
+	out = np.empty_like(r2)
+	lib.nrm_oracle_pvalues(_dp(r2), r2.size, float(dof), _dp(out))
+	return out
+
+
+def beta_cdf_half(x, a):
+	return ensure_built().nrm_oracle_beta_cdf_half(float(x), float(a))
+
+
+def inv_rank(m, tol=1E-8):
+	"""Truncated-SVD pseudo-inverse and integer rank of a symmetric PSD matrix.
+
+	association.py:67-80 (2-D, method='scipy'): singular values below tol*largest are dropped;
+	rank = number kept; inverse = (Vh[:r].T / s[:r]) @ Vh[:r], transposed.
+	"""
+	m = np.asarray(m, dtype=np.float64)
+	if m.ndim != 2 or m.shape[0] != m.shape[1]:
+		raise ValueError('Wrong shape for m.')
+	if tol <= 0:
+		raise ValueError('tol must be positive.')
+	u, s, vh = np.linalg.svd(m)
+	n = m.shape[0]
+	r = int(n - np.searchsorted(s[::-1], tol * s[0]))
+	mi = np.matmul(vh[:r].T / s[:r], vh[:r]).T
+	return mi, r
+
+
+def association_test_1(vx, vy, dx, dy, dc, dci, dcr, dimreduce=0, lowmem=False):
+	"""One (x-block, y-block) tile: association.py:137-260."""
+	if dx.ndim != 2 or dy.ndim != 2 or dc.ndim != 2:
+		raise ValueError('Incorrect dx/dy/dc size.')
+	n = dx.shape[1]
+	if dy.shape[1] != n or dc.shape[1] != n:
+		raise ValueError('Unmatching dx/dy/dc dimensions.')
+	nc = dc.shape[0]
+	if nc == 0:
+		logging.warning('No covariate dc input.')
+	elif dci.shape != (nc, nc):
+		raise ValueError('Unmatching dci dimensions.')
+	if dcr < 0:
+		raise ValueError('Negative dcr detected.')
+	if dcr > nc:
+		raise ValueError('dcr higher than covariate dimension.')
+	if n <= dcr + dimreduce + 1:
+		raise ValueError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+	nx, ny = dx.shape[0], dy.shape[0]
+	rx, ry = dx, dy
+	if dcr > 0:
+		bx = np.matmul(dci, np.matmul(dc, dx.T)).T  # :226
+		by = np.matmul(dci, np.matmul(dc, dy.T)).T  # :227
+		rx = dx - np.matmul(bx, dc)  # :228
+		ry = dy - np.matmul(by, dc)  # :229
+	varx = (rx**2).mean(axis=1)  # :230
+	varx[varx == 0] = 1
+	vary = (ry**2).mean(axis=1)
+	vary[vary == 0] = 1
+	gam = (np.matmul(ry, rx.T) / (n * varx)).T  # :234
+	r2 = ((gam**2).T * varx).T / vary  # :235
+	if lowmem:
+		alpha = None
+	elif dcr > 0:
+		alpha = by[None, :, :] - gam[:, :, None] * bx[:, None, :]  # :238-243
+	else:
+		alpha = np.zeros((nx, ny, nc), dtype=dx.dtype)
+	assert (r2 >= 0).all() and (r2 <= 1 + 1E-8).all()  # :248
+	p = pvalues(r2, n - 1 - dcr - dimreduce).astype(r2.dtype, copy=False)  # :249
+	assert np.isfinite(p).all() and np.isfinite(gam).all()
+	return [vx, vy, p, gam, alpha, varx, vary]
+
+
+def _auto_batchsize(bsx, bsy, isx, isy, isc, nc, ns, samexy, maxx=500, maxy=500, sizemax=2**30):
+	"""association.py:731-758."""
+	if bsx == 0:
+		bsx = min(int((sizemax - isc * nc * ns) // (2 * isx * ns)), maxx)
+	if bsy == 0 or samexy:
+		bsy = bsx if samexy else min(int((sizemax - isc * nc * ns) // (2 * isy * ns)), maxy)
+	return bsx, bsy
+
+
+def _pool_map(nth, tasks):
+	"""parallel.py:12-74 with dummy=True (thread pool); nth==0 -> cpu_count, nth==1 -> serial."""
+	if nth == 0:
+		nth = os.cpu_count()
+	if nth == 1:
+		return [f(*a, **k) for f, a, k in tasks]
+	with ThreadPool(nth) as pool:
+		return pool.map(lambda t: t[0](*t[1], **t[2]), tasks)
+
+
+def _test4_block(vx, vy, prod, prody, prodyy, na, dimreduce=0, lowmem=False, tol=1E-8):
+	"""association.py:421-576 for dy is not None (the de path): per tested x, every other row of
+	[dx;dc] is a covariate; pseudo-inverse of their Gram matrix; Schur-style partial products."""
+	nx, ny, nc, n, lenx = na
+	p = np.zeros((lenx, ny))
+	vxo = np.zeros((lenx, ))
+	vyo = np.zeros((lenx, ny))
+	gam = np.zeros((lenx, ny))
+	alpha = None if lowmem else np.zeros((lenx, ny, nc))
+	rank = np.zeros((lenx, ny), dtype=int)
+	for i in range(lenx):
+		t0 = [k for k in range(nx + nc) if k != vx + i]  # :523
+		if len(t0) > 0:
+			t1i, r = inv_rank(prod[np.ix_(t0, t0)], tol=tol)  # :527-528
+		else:
+			r = 0
+		rank[i] = r
+		if r == 0:
+			dxx = prod[vx + i, vx + i] / n
+			dyy = prodyy / n
+			dxy = prody[vx + i] / n
+		else:
+			ccx = np.matmul(prod[[vx + i], t0], t1i)
+			dxx = (prod[vx + i, vx + i] - float(np.matmul(ccx, prod[t0, [vx + i]]))) / n  # :539-540
+			ccy = np.matmul(prody[t0].T, t1i)
+			dyy = (prodyy - (ccy.T * prody[t0]).sum(axis=0)) / n  # :542
+			dxy = (prody[vx + i] - np.matmul(ccy, prod[t0, [vx + i]]).ravel()) / n  # :543-544
+		if dxx == 0:
+			dxx = 1
+		vxo[i] = dxx
+		vyo[i] = dyy
+		gam[i] = dxy / dxx
+		if (not lowmem) and r > 0:
+			alpha[i] = (ccy[:, -nc:] - gam[i][:, None] * ccx[-nc:]) if nc > 0 else 0
+		p[i] = (dxy**2) / (dxx * dyy)
+	assert (p >= 0).all() and (p <= 1 + 1E-8).all()
+	dof = n - 1 - rank - dimreduce
+	if (dof <= 0).any():
+		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+	for i in range(lenx):
+		p[i] = pvalues(p[i], dof[i, 0])
+	return [vx, vy, p, gam, alpha, vxo, vyo]
+
+
+def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, **ka):
+	"""association.py:761-1093 for single=0 (any dy) and single=4 (dy is not None)."""
+	samexy = dy is None
+	if samexy:
+		dy = dx
+	nx, ns = dx.shape
+	ny = dy.shape[0]
+	nc = dc.shape[0]
+	if single == 0:
+		bsx, bsy = _auto_batchsize(bsx, bsy, dx.dtype.itemsize, dy.dtype.itemsize, dc.dtype.itemsize, nc, ns, samexy)
+	elif single == 4:
+		bsx, bsy = _auto_batchsize(bsx, bsy, dx.dtype.itemsize, dy.dtype.itemsize, dc.dtype.itemsize, nc, ns, samexy, maxx=10, maxy=500000)
+	else:
+		raise ValueError('Unknown value single={}'.format(single))
+	tiles = itertools.product([(a, min(a + bsx, nx)) for a in range(0, nx, bsx)],
+							  [(b, min(b + bsy, ny)) for b in range(0, ny, bsy)])
+	if samexy:
+		tiles = [t for t in tiles if t[0][0] <= t[1][0]]  # :893-894
+	ka0 = dict(ka, lowmem=lowmem)
+	if single == 0:
+		if nc > 0 and (dc != 0).any():
+			dci, dcr = inv_rank(np.matmul(dc, dc.T))  # :899-900
+		else:
+			dci, dcr = np.zeros((nc, nc)), 0  # reference sets dci=None and crashes for nc>0 (Q11)
+		tasks = [(association_test_1, (x[0], y[0], dx[x[0]:x[1]], dy[y[0]:y[1]], dc, dci, dcr), ka0) for x, y in tiles]
+	else:
+		if samexy:
+			raise NotImplementedError('oracle: single=4 with dy=None not restated')
+		t1 = np.concatenate([dx, dc], axis=0).astype(np.float64)  # :935
+		prod = np.matmul(t1, t1.T)
+		prody = np.matmul(t1, dy.T.astype(np.float64))
+		prodyy = (dy.astype(np.float64)**2).sum(axis=1)
+		tasks = [(_test4_block, (x[0], y[0], prod, prody[:, y[0]:y[1]], prodyy[y[0]:y[1]], [nx, y[1] - y[0], nc, ns, x[1] - x[0]]), ka0)
+				 for x, y in tiles]
+	res = _pool_map(nth, tasks)
+	assert len(res) > 0
+	p = np.ones((nx, ny), dtype=dy.dtype)  # :1005
+	dot = np.zeros((nx, ny), dtype=dy.dtype)
+	alpha = None if lowmem else np.zeros((nx, ny, nc), dtype=dy.dtype)
+	varx = None if samexy else np.zeros((nx, ), dtype=dy.dtype)
+	vary = np.zeros((ny, ) if single == 0 else (nx, ny), dtype=dy.dtype)
+	for r in res:
+		i, j = r[0], r[1]
+		p[i:i + r[2].shape[0], j:j + r[2].shape[1]] = r[2]
+		dot[i:i + r[3].shape[0], j:j + r[3].shape[1]] = r[3]
+		if not lowmem:
+			alpha[i:i + r[4].shape[0], j:j + r[4].shape[1]] = r[4]
+		if not samexy:
+			varx[i:i + r[5].shape[0]] = r[5]
+		if single == 0:
+			vary[j:j + r[6].shape[0]] = r[6]
+		else:
+			vary[i:i + r[6].shape[0], j:j + r[6].shape[1]] = r[6]
+	if samexy:
+		dot = (dot.T * vary).T  # :1039  coefficient -> covariance x~_i.x~_j/n
+		p = np.triu(p, 1)
+		p = p + p.T  # :1050-1051  diagonals exactly 0
+		dot = np.triu(dot, 1)
+		dot = dot + dot.T
+		if not return_dot:
+			dot = (dot.T / vary).T
+	elif return_dot:
+		dot = (dot.T * varx).T  # :1048
+	assert np.isfinite(p).all() and np.isfinite(dot).all() and np.isfinite(vary).all()
+	return (p, dot, alpha, varx, vary)
+
+
+def de(dg, dt, dc, bs=0, **ka):
+	"""de.py:4-132: drop single-valued grouping rows, test, re-inflate with p=1, gamma=0, var=0."""
+	gid = np.array([len(np.unique(x)) > 1 for x in dg], dtype=bool)  # de.py:93
+	p, g, a, vg, vt = association_tests(dg[gid], dt, dc, bsx=bs, bsy=bs, return_dot=False, **ka)
+	ng, nt, nc = dg.shape[0], dt.shape[0], dc.shape[0]
+	P = np.ones((ng, nt), dtype=dt.dtype)
+	P[gid] = p
+	G = np.zeros((ng, nt), dtype=dt.dtype)
+	G[gid] = g
+	A = None
+	if a is not None:
+		A = np.zeros((ng, nt, nc), dtype=dt.dtype)
+		A[gid] = a
+	VG = np.zeros((ng, ), dtype=dt.dtype)
+	VG[gid] = vg
+	VT = np.zeros((ng, nt), dtype=dt.dtype)
+	VT[gid] = vt  # (ny,) broadcasts per kept row for single=0 (Q5)
+	return (P, G, A, VG, VT)
+
+
+def coex(dt, dc, **ka):
+	"""coex.py:46-48."""
+	r = association_tests(dt, None, dc, **ka)
+	return (r[0], r[1], r[4])
+
+
+def pearson_r_t(dot, varx, vary, dof):
+	"""Derived north-star quantities the reference does not return:
+	r = dot/sqrt(var_i var_j) (coex.py:34), t = sign(r) sqrt(dof r^2/(1-r^2))."""
+	r = dot / np.sqrt(np.outer(varx, vary))
+	r2 = np.minimum(r * r, 1.0)
+	with np.errstate(divide='ignore'):
+		t = np.sign(r) * np.sqrt(dof * r2 / (1.0 - r2))
+	return r, t
+
+
+def block_plain_c(dx, dy, dc, dci, dcr, dimreduce=0):
+	"""Plain-C-loop restatement of one tile (nrm_oracle_block) for tiny cases."""
+	lib = ensure_built()
+	f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+	dx, dy, dc, dci = f(dx), f(dy), f(dc), f(dci)
+	nx, n = dx.shape
+	ny, nc = dy.shape[0], dc.shape[0]
+	p = np.empty((nx, ny))
+	g = np.empty((nx, ny))
+	vx = np.empty(nx)
+	vy = np.empty(ny)
+	work = np.empty((nx + ny) * n + (nx + ny) * max(nc, 1))
+	lib.nrm_oracle_block(_dp(dx), _dp(dy), _dp(dc), _dp(dci), nx, ny, nc, n, int(dcr), int(dimreduce), _dp(p), _dp(g), _dp(vx), _dp(vy), _dp(work))
+	return p, g, vx, vy

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the dev container only (the reference lives at /root/reference and never travels):
+
+    PYTHONPATH=/root/reference/src python3 tests/golden/make_golden.py
+
+Each fixture is data only: seeded synthetic inputs plus the outputs the reference
+(normalisr v1.0.0, numpy/scipy versions recorded in meta.json) produced for them.
+Fixture names follow SURVEY.md section 8(c): G1..G7.
+"""
+import gzip
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+warnings.simplefilter('ignore')
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/src'
+sys.path.insert(0, REF)
+
+import scipy  # noqa: E402
+from scipy.stats import beta  # noqa: E402
+import normalisr.normalisr as norm  # noqa: E402
+from normalisr.association import (association_tests, association_test_1, inv_rank)  # noqa: E402
+
+
+def save(name, **ka):
+	path = os.path.join(HERE, name + '.npz')
+	np.savez_compressed(path, **ka)
+	print('{:28s} {:9.1f} KB'.format(name + '.npz', os.path.getsize(path) / 1024))
+
+
+def c1_inputs(seed=1, ngene=500, n=300, ngroup=4):
+	"""Poisson(2) counts -> log1p; dc = [N(0,1); ones]; dg Bernoulli(0.3)."""
+	rng = np.random.default_rng(seed)
+	counts = rng.poisson(2, (ngene, n)).astype(np.uint8)
+	dt = np.log1p(counts.astype(np.float64))
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	dg = (rng.random((ngroup, n)) < 0.3).astype(np.float64)
+	return counts, dt, dc, dg
+
+
+def g1():
+	counts, dt, dc, dg = c1_inputs()
+	dg[2] = 1.  # constant grouping row -> dropped and re-inflated by de (de.py:92-122)
+	out = dict(dt=dt, dc=dc, dg=dg)
+	for lowmem in (True, False):
+		p, g, a, vg, vt = norm.de(dg, dt, dc, lowmem=lowmem)
+		k = 'de_lm{}_'.format(int(lowmem))
+		out.update({k + 'p': p, k + 'gamma': g, k + 'varg': vg, k + 'vart': vt})
+		if a is not None:
+			out[k + 'alpha'] = a
+	ns = 160
+	p, d, v = norm.coex(dt[:ns], dc)
+	out.update(coex_n=ns, coex_p=p, coex_dot=d, coex_var=v)
+	# association_tests raw tuple with return_dot True/False for x!=y
+	p, d, a, vx, vy = association_tests(dg[[0, 1, 3]], dt[:64], dc, return_dot=True)
+	out.update(at_p=p, at_dot=d, at_vx=vx, at_vy=vy)
+	save('G1_c1', **out)
+
+
+def g2():
+	rng = np.random.default_rng(2)
+	n = 240
+	dt = np.log1p(rng.poisson(3, (90, n)).astype(np.float64))
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dg = (rng.random((5, n)) < 0.25).astype(np.float64)
+	out = dict(dt=dt, dc=dc, dg=dg)
+
+	# (a) no covariates
+	dc0 = np.zeros((0, n))
+	p, g, a, vg, vt = norm.de(dg, dt, dc0)
+	out.update(nc0_de_p=p, nc0_de_gamma=g, nc0_de_varg=vg, nc0_de_vart=vt)
+	p, d, v = norm.coex(dt[:40], dc0)
+	out.update(nc0_coex_p=p, nc0_coex_dot=d, nc0_coex_var=v)
+
+	# (b) rank-deficient covariates (duplicate + scaled row) -> rank 3 of 5
+	dcr = np.vstack([dc, dc[0], 2 * dc[1] - dc[0]])
+	mi, r = inv_rank(np.matmul(dcr, dcr.T))
+	p, g, a, vg, vt = norm.de(dg, dt, dcr, lowmem=False)
+	out.update(rd_dc=dcr, rd_rank=r, rd_de_p=p, rd_de_gamma=g, rd_de_alpha=a, rd_de_varg=vg, rd_de_vart=vt)
+	p, d, v = norm.coex(dt[:40], dcr)
+	out.update(rd_coex_p=p, rd_coex_dot=d, rd_coex_var=v)
+
+	# (c) dimreduce=2
+	p, g, a, vg, vt = norm.de(dg, dt, dc, dimreduce=2)
+	out.update(dr2_de_p=p, dr2_de_gamma=g)
+	p, d, v = norm.coex(dt[:40], dc, dimreduce=2)
+	out.update(dr2_coex_p=p)
+
+	# (d) integer grouping matrix
+	dgi = dg.astype(np.int64)
+	p, g, a, vg, vt = norm.de(dgi, dt, dc)
+	out.update(int_de_p=p, int_de_gamma=g, int_de_varg=vg, int_de_vart=vt)
+
+	# (e) uneven tiles
+	p, d, a, vx, vy = association_tests(dg, dt, dc, bsx=2, bsy=13)
+	out.update(tile_at_p=p, tile_at_dot=d, tile_at_vx=vx, tile_at_vy=vy)
+	p, d, a, vx, vy = association_tests(dt[:45], None, dc, bsx=7)
+	out.update(tile_coex_p=p, tile_coex_dot=d, tile_coex_vy=vy)
+
+	# (f) zero-variance gene (all zeros) and a perfectly collinear pair (R^2 -> 1 => p = 0)
+	dz = dt[:30].copy()
+	dz[5] = 0.
+	dz[7] = 3. * dz[6]
+	p, d, v = norm.coex(dz, dc)
+	out.update(zc_dt=dz, zc_coex_p=p, zc_coex_dot=d, zc_coex_var=v)
+	p, g, a, vg, vt = norm.de(dg, dz, dc)
+	out.update(zc_de_p=p, zc_de_gamma=g, zc_de_vart=vt)
+
+	# (g) fp32 inputs for de: reference fp32 result and its fp64 run on the same (fp32-representable) values
+	dt32 = dt.astype(np.float32)
+	dc32 = dc.astype(np.float32)
+	dg32 = dg.astype(np.float32)
+	p, g, a, vg, vt = norm.de(dg32, dt32, dc32)
+	out.update(f32_de_p_ref32=p, f32_de_gamma_ref32=g)
+	p, g, a, vg, vt = norm.de(dg32.astype(np.float64), dt32.astype(np.float64), dc32.astype(np.float64))
+	out.update(f32_de_p=p, f32_de_gamma=g, f32_de_varg=vg, f32_de_vart=vt)
+	p, d, v = norm.coex(dt32[:40].astype(np.float64), dc32.astype(np.float64))
+	out.update(f32_coex_p=p, f32_coex_dot=d, f32_coex_var=v)
+
+	# (h) strong effects: p-values that underflow towards 0 (notebook_de cell 25 shows p==0 in real data)
+	eff = rng.normal(size=(12, 1)) * 2.
+	ds = rng.normal(size=(12, n)) + eff * dg[0]
+	p, g, a, vg, vt = norm.de(dg, ds, dc)
+	out.update(se_dt=ds, se_de_p=p, se_de_gamma=g)
+	save('G2_edge', **out)
+
+
+def g3():
+	"""p-function table: scipy.stats.beta.cdf(1-R2, dof/2, 0.5) (association.py:249)."""
+	dofs = np.array([1, 2, 3, 4, 5, 7, 10, 20, 37, 64, 100, 297, 1000, 9996, 49994, 99979, 499996], dtype=np.float64)
+	r2 = np.concatenate([
+		[0.],
+		10.**np.arange(-300, -12, 24.),
+		10.**np.linspace(-12, -0.001, 190),
+		1 - 10.**np.linspace(-3, -15, 25),
+		np.linspace(0.05, 0.95, 19),
+		[1.],
+	])
+	r2 = np.unique(r2)
+	tab = np.empty((len(dofs), len(r2)))
+	for i, d in enumerate(dofs):
+		tab[i] = beta.cdf(1 - r2, d / 2, 0.5)
+	# independent high-precision cross-check on a subset (mpmath), recorded in meta
+	import mpmath
+	mpmath.mp.dps = 60
+	rng = np.random.default_rng(3)
+	worst = 0.
+	for _ in range(300):
+		i = rng.integers(len(dofs))
+		j = rng.integers(len(r2))
+		if tab[i, j] < 1e-300 or r2[j] == 0:
+			continue
+		x = 1 - mpmath.mpf(float(r2[j]))
+		ref = mpmath.betainc(dofs[i] / 2, 0.5, 0, x, regularized=True)
+		worst = max(worst, abs(float((mpmath.mpf(tab[i, j]) - ref) / ref)))
+	save('G3_ptable', dof=dofs, r2=r2, p=tab, scipy_vs_mpmath_maxrel=worst)
+	return worst
+
+
+def g4():
+	rng = np.random.default_rng(4)
+	out = {}
+	cases = []
+	a = rng.normal(size=(6, 50))
+	cases.append(a @ a.T)  # SPD
+	b = np.vstack([a[:4], a[0] + a[1], 3 * a[2]])
+	cases.append(b @ b.T)  # rank 4 of 6
+	cases.append(np.array([[2.5]]))  # 1x1
+	q, _ = np.linalg.qr(rng.normal(size=(5, 5)))
+	cases.append((q * np.array([1., 1e-3, 2e-8, 0.5e-8, 1e-12])) @ q.T)  # tol-boundary singular values
+	cases.append(np.ones((3, 3)))  # rank 1
+	a21 = rng.normal(size=(21, 400))
+	a21[-1] = 1.
+	cases.append(a21 @ a21.T)
+	for i, m in enumerate(cases):
+		mi, r = inv_rank(m)
+		out['m{}'.format(i)] = m
+		out['mi{}'.format(i)] = mi
+		out['r{}'.format(i)] = r
+	out['ncase'] = len(cases)
+	save('G4_invrank', **out)
+
+
+def g5():
+	rng = np.random.default_rng(5)
+	nx, ny, n = 12, 40, 400
+	dg = (rng.random((nx, n)) < 0.15).astype(np.float64)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dt = rng.normal(size=(ny, n)) + (rng.normal(size=(ny, 3)) @ dg[:3]) * 0.5
+	out = dict(dg=dg, dc=dc, dt=dt)
+	p, g, a, vg, vt = norm.de(dg, dt, dc, single=4, lowmem=False)
+	out.update(s4_p=p, s4_gamma=g, s4_alpha=a, s4_varg=vg, s4_vart=vt)
+	# low-MOI style design for single=1: each cell has at most one grouping in most cells
+	dg1 = np.zeros((6, n))
+	lab = rng.integers(0, 9, n)
+	for i in range(6):
+		dg1[i, lab == i] = 1
+	p, g, a, vg, vt = norm.de(dg1, dt, dc, single=1, lowmem=False)
+	out.update(s1_dg=dg1, s1_p=p, s1_gamma=g, s1_alpha=a, s1_varg=vg, s1_vart=vt)
+	save('G5_single', **out)
+
+
+def g6():
+	"""CLI round trip: tiny TSV inputs and the reference CLI's text outputs."""
+	rng = np.random.default_rng(6)
+	n = 60
+	dt = np.log1p(rng.poisson(2, (14, n)).astype(np.float64))
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	dg = (rng.random((3, n)) < 0.4).astype(np.float64)
+	d = tempfile.mkdtemp()
+	np.savetxt(os.path.join(d, 'g.tsv'), dg, delimiter='\t', fmt='%i')
+	np.savetxt(os.path.join(d, 'e.tsv.gz'), dt, delimiter='\t', fmt='%.8G')
+	np.savetxt(os.path.join(d, 'c.tsv'), dc, delimiter='\t', fmt='%.8G')
+	env = dict(os.environ, PYTHONPATH=REF, OPENBLAS_NUM_THREADS='1')
+	run = lambda *a: subprocess.run([sys.executable, '-W', 'ignore', '-m', 'normalisr'] + list(a), cwd=d, env=env, check=True)
+	run('de', 'g.tsv', 'e.tsv.gz', 'c.tsv', 'pv.tsv', 'lfc.tsv', '--vard_out', 'vard.tsv', '--vart_out', 'vart.tsv', '-n', '1')
+	run('de', '-m', 'covariate', 'g.tsv', 'e.tsv.gz', 'c.tsv', 'pv4.tsv', 'lfc4.tsv', '-n', '1')
+	run('coex', 'e.tsv.gz', 'c.tsv', 'cpv.tsv.gz', '--var_out', 'cvar.tsv', '--dot_out', 'cdot.tsv', '-n', '1', '-d', '1')
+	out = {}
+	for f in sorted(os.listdir(d)):
+		raw = open(os.path.join(d, f), 'rb').read()
+		if f.endswith('.gz'):
+			raw = gzip.decompress(raw)
+		out[f.replace('.', '_')] = np.frombuffer(raw, dtype=np.uint8)
+	save('G6_cli', **out)
+
+
+def g7():
+	"""Block-level association_test_1 on one 64x48x1000 tile (association.py:137-260)."""
+	rng = np.random.default_rng(7)
+	n = 1000
+	lat = rng.normal(size=(1, n))
+	dx = rng.normal(size=(64, n)) + 0.4 * rng.normal(size=(64, 1)) * lat - 3.
+	dy = rng.normal(size=(48, n)) + 0.4 * rng.normal(size=(48, 1)) * lat + 5.
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dci, dcr = inv_rank(np.matmul(dc, dc.T))
+	r = association_test_1(0, 0, dx, dy, dc, dci, dcr, dimreduce=0, lowmem=False)
+	save('G7_block', dx=dx, dy=dy, dc=dc, dci=dci, dcr=dcr, p=r[2], gamma=r[3], alpha=r[4], vx=r[5], vy=r[6])
+
+
+def main():
+	g1()
+	g2()
+	worst = g3()
+	g4()
+	g5()
+	g6()
+	g7()
+	meta = dict(reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
+				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
+	with open(os.path.join(HERE, 'meta.json'), 'w') as f:
+		json.dump(meta, f, indent=1)
+	print(meta)
+
+
+if __name__ == '__main__':
+	main()

@@ -1,0 +1,123 @@
+"""CPU: pin the oracle (oracle/) against the golden vectors generated from the reference."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import relerr
+
+# Tolerances: the oracle restates the same fp64 algorithm; differences come from BLAS/SVD rounding
+# only (reference itself varies ~4e-14 with tile size).  P-values: d ln p/d R2 = -dof/2
+# amplifies those by up to ~1e3 here.
+RT = 1e-9
+
+
+def test_pvalue_table_matches_scipy(golden):
+	g = golden('G3_ptable')
+	dof, r2, ref = g['dof'], g['r2'], g['p']
+	worst = 0.
+	for i, d in enumerate(dof):
+		p = oracle.pvalues(r2, d)
+		normal = ref[i] >= 2.3e-308
+		worst = max(worst, relerr(p[normal], ref[i][normal]))
+		# subnormal/underflow region: absolute agreement
+		assert np.all(np.abs(p[~normal] - ref[i][~normal]) <= 1e-310)
+		assert p[r2 == 0][0] == 1.0 and p[r2 == 1][0] == 0.0
+	# scipy itself is 3.5e-11 off the exact value (mpmath) at dof=1, R2=1e-12; elsewhere both agree to 1e-13
+	assert worst < 1e-10, worst
+
+
+def test_pvalue_clipping():
+	# R2 slightly above 1 -> x < 0 -> cdf clipped to 0 (association.py:248-249, Q15)
+	assert oracle.pvalues(np.array([1 + 5e-9]), 100.)[0] == 0.
+	assert oracle.pvalues(np.array([0.]), 100.)[0] == 1.
+
+
+def test_inv_rank(golden):
+	g = golden('G4_invrank')
+	for i in range(int(g['ncase'])):
+		mi, r = oracle.inv_rank(g['m{}'.format(i)])
+		assert r == int(g['r{}'.format(i)])
+		ref = g['mi{}'.format(i)]
+		assert np.abs(mi - ref).max() <= 1e-9 * np.abs(ref).max()
+	with pytest.raises(ValueError):
+		oracle.inv_rank(np.zeros((2, 3)))
+
+
+def test_block(golden):
+	g = golden('G7_block')
+	r = oracle.association_test_1(0, 0, g['dx'], g['dy'], g['dc'], g['dci'], int(g['dcr']), lowmem=False)
+	assert relerr(r[2], g['p']) < RT
+	assert relerr(r[3], g['gamma'], 1e-14) < RT
+	assert relerr(r[4], g['alpha'], 1e-12) < RT
+	assert relerr(r[5], g['vx']) < 1e-12 and relerr(r[6], g['vy']) < 1e-12
+	# plain C loops agree too (sub-block to keep it quick)
+	p, gam, vx, vy = oracle.block_plain_c(g['dx'][:8], g['dy'][:6], g['dc'], g['dci'], int(g['dcr']))
+	assert relerr(p, g['p'][:8, :6]) < RT and relerr(gam, g['gamma'][:8, :6], 1e-14) < RT
+
+
+def test_c1_de_coex(golden):
+	g = golden('G1_c1')
+	dt, dc, dg = g['dt'], g['dc'], g['dg']
+	for lm in (1, 0):
+		p, gam, a, vg, vt = oracle.de(dg, dt, dc, lowmem=bool(lm))
+		k = 'de_lm{}_'.format(lm)
+		assert relerr(p, g[k + 'p']) < RT
+		assert relerr(gam, g[k + 'gamma'], 1e-14) < RT
+		assert relerr(vg, g[k + 'varg'], 1e-300) < 1e-12 and relerr(vt, g[k + 'vart'], 1e-300) < 1e-12
+		if lm == 0:
+			assert relerr(a, g[k + 'alpha'], 1e-12) < RT
+		else:
+			assert a is None
+		# constant grouping row re-inflated exactly (de.py:107-122)
+		assert (p[2] == 1).all() and (gam[2] == 0).all() and vg[2] == 0 and (vt[2] == 0).all()
+	ns = int(g['coex_n'])
+	p, d, v = oracle.coex(dt[:ns], dc)
+	assert relerr(p, g['coex_p'], 1e-300) < RT and relerr(d, g['coex_dot'], 1e-14) < RT and relerr(v, g['coex_var']) < 1e-12
+	assert (np.diag(p) == 0).all() and (np.diag(d) == 0).all() and (p == p.T).all() and (d == d.T).all()
+	p, d, a, vx, vy = oracle.association_tests(dg[[0, 1, 3]], dt[:64], dc, return_dot=True)
+	assert relerr(p, g['at_p']) < RT and relerr(d, g['at_dot'], 1e-14) < RT
+
+
+def test_edge_cases(golden):
+	g = golden('G2_edge')
+	dt, dc, dg = g['dt'], g['dc'], g['dg']
+	n = dt.shape[1]
+	p, gam, a, vg, vt = oracle.de(dg, dt, np.zeros((0, n)))
+	assert relerr(p, g['nc0_de_p']) < RT and relerr(gam, g['nc0_de_gamma'], 1e-14) < RT
+	p, d, v = oracle.coex(dt[:40], np.zeros((0, n)))
+	assert relerr(p, g['nc0_coex_p'], 1e-300) < RT and relerr(d, g['nc0_coex_dot'], 1e-14) < RT
+	# rank-deficient covariates: integer rank bit-exact
+	mi, r = oracle.inv_rank(g['rd_dc'] @ g['rd_dc'].T)
+	assert r == int(g['rd_rank']) == 3
+	p, gam, a, vg, vt = oracle.de(dg, dt, g['rd_dc'], lowmem=False)
+	assert relerr(p, g['rd_de_p']) < 1e-7 and relerr(gam, g['rd_de_gamma'], 1e-12) < 1e-7
+	p, d, v = oracle.coex(dt[:40], g['rd_dc'])
+	assert relerr(p, g['rd_coex_p'], 1e-300) < 1e-7
+	p, gam, a, vg, vt = oracle.de(dg, dt, dc, dimreduce=2)
+	assert relerr(p, g['dr2_de_p']) < RT
+	p, d, v = oracle.coex(dt[:40], dc, dimreduce=2)
+	assert relerr(p, g['dr2_coex_p'], 1e-300) < RT
+	p, gam, a, vg, vt = oracle.de(dg.astype(np.int64), dt, dc)
+	assert relerr(p, g['int_de_p']) < RT and p.dtype == np.float64
+	p, d, a, vx, vy = oracle.association_tests(dg, dt, dc, bsx=2, bsy=13)
+	assert relerr(p, g['tile_at_p']) < RT and relerr(d, g['tile_at_dot'], 1e-14) < RT
+	p, d, a, vx, vy = oracle.association_tests(dt[:45], None, dc, bsx=7)
+	assert relerr(p, g['tile_coex_p'], 1e-300) < RT and vx is None
+	dz = g['zc_dt']
+	p, d, v = oracle.coex(dz, dc)
+	assert v[5] == 1 and (p[5] == np.where(np.arange(30) == 5, 0, 1)).all() and (d[5] == 0).all()
+	assert p[6, 7] == g['zc_coex_p'][6, 7] == 0.
+	ok = np.ones_like(p, dtype=bool)
+	ok[6, 7] = ok[7, 6] = False
+	assert relerr(p[ok], g['zc_coex_p'][ok], 1e-300) < RT
+	p, gam, a, vg, vt = oracle.de(dg, g['se_dt'], dc)
+	assert relerr(p, g['se_de_p'], 1e-300) < RT
+	assert g['se_de_p'].min() < 1e-20
+
+
+def test_single4(golden):
+	g = golden('G5_single')
+	p, gam, a, vg, vt = oracle.de(g['dg'], g['dt'], g['dc'], single=4, lowmem=False)
+	assert relerr(p, g['s4_p']) < 1e-8 and relerr(gam, g['s4_gamma'], 1e-12) < 1e-8
+	assert relerr(vg, g['s4_varg']) < 1e-10 and relerr(vt, g['s4_vart']) < 1e-10
+	assert relerr(a, g['s4_alpha'], 1e-10) < 1e-8
