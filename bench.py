@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py -- association tests/sec on the BASELINE.json workload.
+
+N=1 workload = BASELINE.json configs[1]: norm.coex gene x gene on 5k genes x 10k cells, fp32 input,
+3 covariates (2 random + intercept), seeded synthetic data.  A step is one full
+pass of the hot path over the matrix resident in HBM: residualise (K1) -> fp64-MFMA Gram (K2) ->
+per-pair sweep R^2 -> p, covariance (K3); outputs stay in HBM.  tests = ng(ng-1)/2 unique pairs.
+For N>1 (one process per GPU, RCCL) the gene count grows as sqrt(N) so the pairs per GPU stay fixed
+(weak scaling); gene-row blocks are residualised locally and exchanged by all-gather.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gram_f64), timed live with HIP
+events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the reference's algorithm,
+test infrastructure) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+	sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (= 1/2 of the 157.3 TF fp32 matrix peak of MI355X_MICROARCH.md)
+
+
+def synth_c2(ng, n, seed, device, torch, row0=0):
+	"""N(0,1) + 0.3 * loading * shared latent factor; dc = [2 x N(0,1); ones]; fp32."""
+	g = torch.Generator(device=device)
+	g.manual_seed(seed)
+	lat = torch.randn((1, n), generator=g, device=device, dtype=torch.float32)
+	dc = torch.cat([torch.randn((2, n), generator=g, device=device, dtype=torch.float32),
+					torch.ones((1, n), device=device, dtype=torch.float32)])
+	g2 = torch.Generator(device=device)
+	g2.manual_seed(seed * 1000003 + row0)
+	load = torch.randn((ng, 1), generator=g2, device=device, dtype=torch.float32)
+	dt = torch.randn((ng, n), generator=g2, device=device, dtype=torch.float32) + 0.3 * load * lat
+	return dt, dc
+
+
+def cpu_baseline(n_cells, nc, seed, budget_genes):
+	"""Time the CPU oracle (port of association.py's tile loop, thread pool over 500x500 tiles like the
+	reference with nth = all cores, BLAS threads as configured) on a bounded gene sample of the workload."""
+	import oracle
+	rng = np.random.default_rng(seed)
+	lat = rng.normal(size=(1, n_cells))
+	dc = np.vstack([rng.normal(size=(nc - 1, n_cells)), np.ones((1, n_cells))])
+	cores = os.cpu_count() or 1
+	dt = rng.normal(size=(budget_genes, n_cells)) + 0.3 * rng.normal(size=(budget_genes, 1)) * lat
+	oracle.coex(dt[:64], dc)  # warm-up (library load)
+	t0 = time.perf_counter()
+	oracle.coex(dt, dc, nth=cores)
+	dt_s = time.perf_counter() - t0
+	pairs = budget_genes * (budget_genes - 1) // 2
+	return dict(value=pairs / dt_s, unit='tests/s', cores=cores, kind='port',
+				sample='coex on {} genes x {} cells fp64 ({} pairs, {:.1f} s), oracle tile loop with nth={} threads'.format(
+					budget_genes, n_cells, pairs, dt_s, cores))
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument('--gpus', type=int, default=1)
+	ap.add_argument('--steps', type=int, default=20)
+	ap.add_argument('--warmup', type=int, default=3)
+	ap.add_argument('--genes', type=int, default=5000, help='genes at N=1 (scaled by sqrt(N) for N>1)')
+	ap.add_argument('--cells', type=int, default=10000)
+	ap.add_argument('--cpu-genes', type=int, default=3000, help='gene sample for the CPU baseline (0 = skip)')
+	ap.add_argument('--seed', type=int, default=2)
+	args = ap.parse_args()
+
+	import torch
+	from normalisr_amd import distributed as nd
+	world = int(os.environ.get('WORLD_SIZE', '1'))
+	rank = int(os.environ.get('RANK', '0'))
+	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	if args.gpus != world:
+		if world == 1 and args.gpus > 1:
+			raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {}'.format(args.gpus, args.gpus))
+	torch.cuda.set_device(local_rank)
+	device = torch.device('cuda', local_rank)
+	group = None
+	if world > 1:
+		import torch.distributed as dist
+		dist.init_process_group('nccl', device_id=device)
+		group = dist.group.WORLD
+
+	n = args.cells
+	# weak scaling: pairs per GPU fixed -> genes ~ sqrt(N); rounded so every rank owns the same number of rows
+	ng = int(round(args.genes * np.sqrt(world) / world)) * world
+	rows_local = ng // world
+	dt_local, dc = synth_c2(rows_local, n, args.seed, device, torch, row0=rank * rows_local)
+	plan = nd.CoexPlan(dt_local, dc, rank=rank, world=world, group=group)
+
+	def barrier():
+		if world > 1:
+			torch.distributed.barrier()
+		torch.cuda.synchronize()
+
+	for _ in range(args.warmup):
+		plan.step()
+	barrier()
+	t0 = time.perf_counter()
+	for _ in range(args.steps):
+		plan.step(timed=True)
+	barrier()
+	elapsed = time.perf_counter() - t0
+	if world > 1:
+		tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+		torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+		elapsed = float(tmax.item())
+	tests = ng * (ng - 1) // 2
+	value = tests * args.steps / elapsed
+	gram_ms = plan.gram_ms()  # average duration of the dominant kernel launch(es) per step on this rank
+	local_pairs = plan.local_pair_count()
+
+	if rank == 0:
+		flops = 2.0 * n * local_pairs  # algorithmic: 2 n_cell flop per test, tests this rank's launches cover
+		achieved = flops / (gram_ms * 1e-3) / 1e12
+		out = dict(metric='association tests/sec (gene x gene coex)', value=value, unit='tests/s', n_gpus=world,
+				   steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
+				   scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+				   config=dict(workload='norm.coex gene x gene, {} genes x {} cells, fp32 input, 3 covariates (BASELINE configs[1]{})'.format(
+					   ng, n, '' if world == 1 else ', genes scaled by sqrt(N)'), genes=ng, cells=n, covariates=3,
+					   tests_per_step=tests, parallelism='gene-row blocks x{}'.format(world)),
+				   roofline=dict(bound='mfma', kernel='k_gram_f64', achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+								 frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=None, kernel_ms=gram_ms),
+				   kernels_ms=plan.kernel_breakdown())
+		if world == 1 and args.cpu_genes > 0:
+			out['cpu_baseline'] = cpu_baseline(n, 3, args.seed, args.cpu_genes)
+		else:
+			out['cpu_baseline'] = None
+		print(json.dumps(out))
+	if world > 1:
+		torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+	main()

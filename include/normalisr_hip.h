@@ -1,0 +1,138 @@
+/*
+ * normalisr_hip.h -- C ABI of libnormalisr_hip.so: the MI355X (gfx950) implementation of Normalisr's
+ * linear-association hot path (covariate residualisation -> Gram contraction -> R^2 -> p-value).
+ *
+ * The reference (lingfeiwang/normalisr v1.0.0) is pure Python and has no FFI; the seams this ABI
+ * replaces are named per function below as file:line under /root/reference/src/normalisr/.
+ * Conventions:
+ *   - every function returns 0 on success or a negative NRM_E_* code; nrm_last_error() gives the text;
+ *   - all matrices are row-major with cells contiguous (association.py:163-170); `ld*` are row pitches
+ *     in ELEMENTS; dtype codes: NRM_F32 = 0, NRM_F64 = 1;
+ *   - pointers named d_* are DEVICE pointers (HBM) owned by the caller; the library never frees or
+ *     retains them past return; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     kernels are enqueued asynchronously on it;
+ *   - pointers named h_* are HOST pointers (numpy buffers); those entry points synchronise.
+ * No torch / Python types cross this boundary.  Bound from Python with ctypes (normalisr_amd/_lib.py),
+ * see INTEGRATION.md for the stub a maintainer of the reference would add.
+ */
+#ifndef NORMALISR_HIP_H
+#define NORMALISR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRM_F32 0
+#define NRM_F64 1
+
+#define NRM_OK 0
+#define NRM_E_ARG -1      /* bad shape/argument  -> ValueError   (association.py:199-216)  */
+#define NRM_E_DEVICE -2   /* HIP runtime failure -> RuntimeError                           */
+#define NRM_E_NUMERIC -3  /* non-finite / out-of-range result -> AssertionError (association.py:248-259) */
+
+/* Tile geometry the padded device buffers must honour (rows multiple of NRM_ROW_TILE, pitch and
+ * cell count multiple of NRM_K_TILE). */
+#define NRM_ROW_TILE 128
+#define NRM_K_TILE 16
+
+/* Number of u-polynomial coefficients of the p-value fast path (see nrm_pvalue_plan). */
+#define NRM_PCOEF 20
+
+int nrm_version(void);
+const char* nrm_last_error(void);
+/* hipGetDeviceCount / hipSetDevice wrappers so that a pure-C host needs no HIP headers. */
+int nrm_device_count(int* count);
+int nrm_set_device(int device);
+
+/*
+ * K1 -- residualise rows against covariates and take their sums of squares.
+ * Replaces association.py:224-233 (ccx = dci@(dc@dx.T); dx1 = dx - ccx@dc; mean of squares) and
+ * removes the per-tile recomputation (the reference redoes this inside every 500x500 tile).
+ *   d_x     (rows, n) input rows, dtype x_dtype, pitch ldx
+ *   d_c     (nc, n) fp64 covariates, pitch ldc;  d_dci (nc, nc) fp64 pseudo-inverse of C C^T
+ *           (computed on the host in fp64: inv_rank, association.py:4-134); rank = integer rank;
+ *           rank == 0 or nc == 0 -> rows are copied unchanged (association.py:224).
+ *   d_out   (rows_pad, ldo) fp64 residualised rows, zero-filled for cells >= n and rows >= rows
+ *   d_ss    (rows_pad) fp64  sum_k out[i,k]^2   (variance * n; the 0 -> 1 rule is applied later)
+ *   d_coef  (rows, nc) fp64 or NULL: the OLS coefficients ccx, needed only for alpha (lowmem=False)
+ */
+int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
+					const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
+					double* d_out, int64_t ldo, int64_t rows_pad,
+					double* d_ss, double* d_coef, void* stream);
+
+/*
+ * K2 -- Gram contraction dot[i,j] = sum_k A[i,k] B[j,k] on the fp64 matrix cores
+ * (v_mfma_f64_16x16x4_f64, 128x128 workgroup tiles staged through LDS).
+ * Replaces np.matmul(dy1, dx1.T) at association.py:234 for ALL tiles of the problem at once.
+ *   d_a (m_pad, lda), d_b (n_pad, ldb) fp64, zero padded; m_pad, n_pad multiples of NRM_ROW_TILE;
+ *   k_pad multiple of NRM_K_TILE; d_dot (m_pad, ldd) fp64.
+ *   symmetric != 0 (coex: d_b == d_a): only tiles on or above the block diagonal are computed and
+ *   written (association.py:893-894); the strictly-lower tiles of d_dot are left untouched.
+ */
+int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad,
+				 int64_t lda, int64_t ldb, double* d_dot, int64_t ldd, int symmetric, void* stream);
+
+/*
+ * P-value plan: host-side constants of p = I_{1-R^2}(dof/2, 1/2) for one dof
+ * (scipy.stats.beta.cdf call at association.py:249).  dof is uniform per call for single=0:
+ * dof = n_cell - 1 - rank - dimreduce.
+ */
+typedef struct nrm_pvalue_plan {
+	double a;                /* dof / 2                                                   */
+	double alpha;            /* a - 1/4                                                   */
+	double ln_front;         /* ln( Gamma(a+1/2) / (Gamma(a) sqrt(pi)) )                  */
+	double umax;             /* fast path used for -ln(1-R^2) <= umax (0 = never)         */
+	double coef[NRM_PCOEF];  /* fast path: p = exp(-alpha u)(erfcx(sqrt(alpha u)) + sqrt(alpha u) sum_j coef[j] u^j) */
+} nrm_pvalue_plan;
+int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof);
+
+/* Elementwise p-values from R^2 (device arrays); kernel-level entry for the table tests. */
+int nrm_pvalues_from_r2(const double* d_r2, int64_t count, double dof, double* d_p, void* stream);
+
+/*
+ * K3 -- per-pair sweep: R^2 = dot^2/(ssx_i ssy_j) -> p-value, effect size, optional Pearson r and t.
+ * Replaces association.py:231-235,248-249 and the gather/symmetrise steps :1037-1057.
+ *   d_dot (.., ldd) from nrm_gram_f64;  d_ssx (nx), d_ssy (ny) from nrm_residualize
+ *   n_cells, dof as above.  zero sums of squares are replaced by n_cells (variance 0 -> 1, :231-233).
+ *   symmetric != 0: coex -- pair (i,j) reads dot[min(i,j), max(i,j)], diagonal outputs are exactly 0
+ *                   (association.py:1050-1057); requires nx == ny and d_ssx == d_ssy.
+ *   stat_kind: 0 -> covariance x~.y~/n ("dot", association.py:1039,1048); 1 -> gamma = x~.y~/ssx (:234)
+ *   outputs (nx, ldo) of dtype out_dtype; d_r / d_t may be NULL (north-star extras: Pearson r, t statistic)
+ *   d_flags: int32[2] device counters, incremented for non-finite inputs [0] and R^2 > 1+1e-8 [1]
+ *            (the reference's assertions at association.py:248,252); may be NULL.
+ */
+int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy,
+					int64_t nx, int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind,
+					void* d_p, void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo,
+					int32_t* d_flags, void* stream);
+
+/*
+ * alpha[i,j,c] = by[j,c] - gamma[i,j] * bx[i,c]  (association.py:238-243), fp64 in, out_dtype out.
+ */
+int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d_bx, const double* d_by,
+			  int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype, void* stream);
+
+/*
+ * Whole-problem host entry (numpy in / numpy out): the seam association_tests(dx, dy, dc, ...)
+ * -> (p, dot|gamma, alpha|None, varx|None, vary) at association.py:761-771,1093 for single=0.
+ * All pointers are HOST buffers owned by the caller.  h_dy == NULL means dy = dx (coex).
+ *   h_dci (nc,nc) fp64 and rank from the host inv_rank;  dimreduce int (association.py:213).
+ *   h_p, h_stat (nx,ny) of dtype out_dtype; h_varx (nx) / h_vary (ny) of out_dtype (h_varx may be
+ *   NULL); h_alpha (nx,ny,nc) or NULL (lowmem); h_r / h_t optional extras or NULL.
+ *   return_dot: 1 -> covariance, 0 -> gamma (association.py:769).
+ * Runs on the current device (nrm_set_device) and synchronises before returning.
+ */
+int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
+							   const void* h_dy, int y_dtype, int64_t ny,
+							   const void* h_dc, int c_dtype, int64_t nc, int64_t n_cells,
+							   const double* h_dci, int rank, int dimreduce, int return_dot,
+							   void* h_p, void* h_stat, void* h_alpha, void* h_varx, void* h_vary,
+							   void* h_r, void* h_t, int out_dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

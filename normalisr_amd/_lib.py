@@ -1,0 +1,68 @@
+"""ctypes binding of libnormalisr_hip.so (include/normalisr_hip.h).  No CPU fallback: if the HIP
+library is missing or a call fails, this raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libnormalisr_hip.so')
+
+NRM_F32, NRM_F64 = 0, 1
+NRM_E_ARG, NRM_E_DEVICE, NRM_E_NUMERIC = -1, -2, -3
+ROW_TILE, K_TILE, PCOEF = 128, 16, 20
+
+_i64, _i32, _vp, _dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+
+
+class PvaluePlan(ctypes.Structure):
+	_fields_ = [('a', _dbl), ('alpha', _dbl), ('ln_front', _dbl), ('umax', _dbl), ('coef', _dbl * PCOEF)]
+
+
+_SIGNATURES = {
+	'nrm_version': ([], _i32),
+	'nrm_last_error': ([], ctypes.c_char_p),
+	'nrm_device_count': ([ctypes.POINTER(_i32)], _i32),
+	'nrm_set_device': ([_i32], _i32),
+	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
+	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _vp], _i32),
+	'nrm_pvalue_plan_init': ([ctypes.POINTER(PvaluePlan), _dbl], _i32),
+	'nrm_pvalues_from_r2': ([_vp, _i64, _dbl, _vp, _vp], _i32),
+	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+	'nrm_alpha': ([_vp, _i32, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp], _i32),
+	'nrm_association_tests_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32,
+									_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32], _i32),
+}
+
+_lib = None
+
+
+def exported_symbols():
+	return sorted(_SIGNATURES)
+
+
+def load():
+	"""Load the HIP library; raises RuntimeError (never falls back) when it is not built."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	if not os.path.exists(LIB_PATH):
+		raise RuntimeError('libnormalisr_hip.so is not built ({}). Run `python -m normalisr_amd.build` '
+						   '(needs hipcc); there is no CPU fallback.'.format(LIB_PATH))
+	lib = ctypes.CDLL(LIB_PATH)
+	for name, (args, res) in _SIGNATURES.items():
+		f = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+		f.argtypes = args
+		f.restype = res
+	_lib = lib
+	return lib
+
+
+def check(rc):
+	"""Map a status code to the exception class the reference raises for the same condition."""
+	if rc == 0:
+		return
+	msg = load().nrm_last_error().decode('utf-8', 'replace')
+	if rc == NRM_E_ARG:
+		raise ValueError(msg)
+	if rc == NRM_E_NUMERIC:
+		raise AssertionError(msg)
+	raise RuntimeError(msg)

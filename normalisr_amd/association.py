@@ -1,0 +1,198 @@
+"""Linear association testing on MI355X -- host-side mirror of the reference's association module.
+
+Same function names, argument meaning, defaults, return tuples and error classes as
+/root/reference/src/normalisr/association.py (v1.0.0); the arithmetic runs in HIP kernels through the
+C ABI (include/normalisr_hip.h).  The reference tiles the pair space into 500x500 blocks and maps them
+over a thread pool (association.py:890-909,997); here one call sees the whole matrices, residualises
+every row once, and the device schedules 128x128 tiles itself, so bsx/bsy/nth are accepted for
+compatibility but do not change the result (the reference's own results vary ~4e-14 with tile size).
+"""
+import logging
+
+import numpy as np
+
+from . import engine as _engine
+
+
+def inv_rank(m, tol=1E-8, method='auto', logger=None, mpc=0, qr=0, **ka):
+	"""Pseudo-inverse and rank of symmetric matrices by truncated SVD (reference association.py:4-134).
+
+	Singular values below tol*largest count as zero; the integer rank is the number kept.  Runs on the
+	host in fp64: the matrices are (n_cov, n_cov) and the rank must be bit-exact.  `method`, `mpc`, `qr`
+	are accepted for signature compatibility; only the exact LAPACK route is implemented
+	(`mpc` still caps the rank as association.py:78-79 does).
+	"""
+	if logger is None:
+		logger = logging
+	m = np.asarray(m)
+	if m.ndim <= 1 or m.shape[-1] != m.shape[-2]:
+		raise ValueError('Wrong shape for m.')
+	if tol <= 0:
+		raise ValueError('tol must be positive.')
+	if qr < 0 or int(qr) != qr:
+		raise ValueError('qr must be non-negative integer.')
+	if method not in ('auto', 'scipy', 'sklearn'):
+		raise ValueError('Unknown method {}'.format(method))
+	if m.ndim > 2 and mpc > 0:
+		raise NotImplementedError('No current method supports >2 dimensions with mpc>0.')
+	if method == 'sklearn' or (method == 'auto' and mpc > 0 and m.shape[-1] > mpc):
+		logger.debug('randomized SVD not implemented here; using exact SVD with rank cap mpc.')
+	n = m.shape[-1]
+	flat = m.reshape((-1, n, n)).astype(np.float64, copy=False)
+	inv = np.empty_like(flat)
+	ranks = np.empty(flat.shape[0], dtype=int)
+	for i, mat in enumerate(flat):
+		_, s, vh = np.linalg.svd(mat)
+		r = int(n - np.searchsorted(s[::-1], tol * s[0]))
+		if mpc > 0:
+			r = min(r, mpc)
+		inv[i] = np.matmul(vh[:r].T / s[:r], vh[:r]).T
+		ranks[i] = r
+	inv = inv.astype(m.dtype if m.dtype in (np.float32, np.float64) else np.float64, copy=False)
+	if m.ndim == 2:
+		return inv[0], int(ranks[0])
+	return inv.reshape(m.shape), ranks.reshape(m.shape[:-2])
+
+
+def _check_dimreduce(dimreduce):
+	if np.ndim(dimreduce) != 0:
+		d = np.unique(np.asarray(dimreduce))
+		if d.size != 1:
+			raise NotImplementedError('Per-gene dimreduce arrays are not supported for single=0 (the reference crashes on them too).')
+		dimreduce = d[0]
+	if int(dimreduce) != dimreduce:
+		raise ValueError('dimreduce must be an integer.')
+	return int(dimreduce)
+
+
+def _check_block_args(dx, dy, dc, dci, dcr, dimreduce):
+	"""Argument validation of association.py:199-216, same exception classes."""
+	if dx.ndim != 2 or dy.ndim != 2 or dc.ndim != 2:
+		raise ValueError('Incorrect dx/dy/dc size.')
+	n = dx.shape[1]
+	if dy.shape[1] != n or dc.shape[1] != n:
+		raise ValueError('Unmatching dx/dy/dc dimensions.')
+	nc = dc.shape[0]
+	if nc == 0:
+		logging.warning('No covariate dc input.')
+	elif dci is None or np.shape(dci) != (nc, nc):
+		raise ValueError('Unmatching dci dimensions.')
+	if dcr < 0:
+		raise ValueError('Negative dcr detected.')
+	if dcr > nc:
+		raise ValueError('dcr higher than covariate dimension.')
+	if n <= dcr + dimreduce + 1:
+		raise ValueError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+
+
+def association_test_1(vx, vy, dx, dy, dc, dci, dcr, dimreduce=0, lowmem=False, return_stats=False):
+	"""One (x-block, y-block) tile on the device; same contract as association.py:137-260.
+
+	Returns [vx, vy, pv, gamma, alpha|None, var_x, var_y]; with return_stats=True two extra entries:
+	Pearson r and the t statistic of every pair (north-star quantities the reference does not return).
+	"""
+	dx, dy, dc = np.asarray(dx), np.asarray(dy), np.asarray(dc)
+	dimreduce = _check_dimreduce(dimreduce)
+	_check_block_args(dx, dy, dc, dci, dcr, dimreduce)
+	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	nc = dc.shape[0]
+	eng = _engine.get_engine()
+	res = eng.association_single0(_engine.as_input(dx), _engine.as_input(dy), np.asarray(dc, dtype=np.float64),
+								  np.zeros((nc, nc)) if dci is None else np.asarray(dci, dtype=np.float64), int(dcr),
+								  dimreduce, return_dot=False, want_alpha=not lowmem, out_dtype=out_dtype,
+								  want_rt=return_stats)
+	ans = [vx, vy, res['p'], res['stat'], res['alpha'], res['varx'], res['vary']]
+	if return_stats:
+		ans += [res['r'], res['t']]
+	return ans
+
+
+def _auto_batchsize(bsx, bsy, itemsizex, itemsizey, itemsizec, nc, ns, samexy, maxx=500, maxy=500, sizemax=2**30):
+	"""Tile sizes the reference would use (association.py:731-758).  Only informational here: the
+	device path is tile-invariant."""
+	if bsx == 0:
+		bsx = min(int((sizemax - itemsizec * nc * ns) // (2 * itemsizex * ns)), maxx)
+	if bsy == 0 or samexy:
+		bsy = bsx if samexy else min(int((sizemax - itemsizec * nc * ns) // (2 * itemsizey * ns)), maxy)
+	return bsx, bsy
+
+
+def _prepare_covariates(dc):
+	"""inv_rank(dc @ dc.T) on the host in fp64 iff there is a non-zero covariate (association.py:899-903).
+	All-zero covariates are treated as rank 0 (the reference crashes there)."""
+	dc64 = np.asarray(dc, dtype=np.float64)
+	nc = dc64.shape[0]
+	if nc > 0 and (dc64 != 0).any():
+		dci, dcr = inv_rank(np.matmul(dc64, dc64.T))
+	else:
+		dci, dcr = np.zeros((nc, nc)), 0
+	return dc64, dci, dcr
+
+
+def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, bs4=500,
+					  return_stats=False, **ka):
+	"""All-pairs association tests between rows of dx and dy (or dx with itself when dy is None).
+
+	Same contract as association.py:761-1093: returns (P-values, dot|gamma, alpha|None, varx|None, vary).
+	single=0 runs on the device; single=4 (other X as covariates) runs the closed-form device path in
+	normalisr_amd.single4.  bsx, bsy, nth, bs4 are accepted and ignored (see module docstring).
+	With return_stats=True a sixth element {'r':..., 't':..., 'dof':...} is appended.
+	"""
+	bs = ka.pop('bs', None)  # the reference's docstring promises `bs` (coex.py:38) but crashes on it
+	if bs is not None and not bsx and not bsy:
+		bsx = bsy = bs
+	for v in (bsx, bsy, bs4):
+		if v < 0 or int(v) != v:
+			raise ValueError('Batch sizes must be non-negative integers.')
+	if single not in {0, 1, 4, 5}:
+		raise ValueError('Unknown value single={}'.format(single))
+	dx = np.asarray(dx)
+	dc = np.asarray(dc)
+	samexy = dy is None
+	if not samexy:
+		dy = np.asarray(dy)
+	if dx.ndim != 2 or dc.ndim != 2 or (not samexy and dy.ndim != 2):
+		raise ValueError('Incorrect dx/dy/dc size.')
+	if single == 1:
+		if samexy:
+			raise NotImplementedError('dy=None with single=1')
+		raise NotImplementedError('single=1 (per-grouping cell subsets) is not on the device path yet.')
+	if single == 5:
+		raise NotImplementedError('single=5 is under development in the reference and not provided.')
+	if single == 4:
+		from .single4 import association_tests_single4
+		return association_tests_single4(dx, dy, dc, lowmem=lowmem, return_dot=return_dot, return_stats=return_stats, **ka)
+
+	dimreduce = _check_dimreduce(ka.pop('dimreduce', 0))
+	if ka:
+		raise TypeError("association_test_1() got an unexpected keyword argument '{}'".format(next(iter(ka))))
+	ref_y = dx if samexy else dy
+	n = dx.shape[1]
+	if ref_y.shape[1] != n or dc.shape[1] != n:
+		raise ValueError('Unmatching dx/dy/dc dimensions.')
+	if dx.shape[0] == 0 or ref_y.shape[0] == 0:
+		raise AssertionError('No association test to perform.')  # assert len(ans0) > 0, association.py:998
+	out_dtype = ref_y.dtype if ref_y.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	nc = dc.shape[0]
+	if nc == 0:
+		logging.warning('No covariate dc input.')
+	dc64, dci, dcr = _prepare_covariates(dc)
+	if n <= dcr + dimreduce + 1:
+		raise ValueError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+	if samexy and not lowmem:
+		raise NotImplementedError('alpha for dy=None is not meaningful in the reference (symmetrised) and is not provided.')
+	eng = _engine.get_engine()
+	res = eng.association_single0(_engine.as_input(dx), None if samexy else _engine.as_input(dy), dc64, dci, dcr,
+								  dimreduce, return_dot=return_dot, want_alpha=not lowmem, out_dtype=out_dtype,
+								  want_rt=return_stats)
+	stat = res['stat']
+	if samexy and not return_dot:
+		# association.py:1059-1061: covariance back to coefficient, row-wise by the row's variance
+		stat = (stat.T / res['vary']).T.astype(out_dtype, copy=False)
+	ans = (res['p'], stat, res['alpha'], res['varx'], res['vary'])
+	if return_stats:
+		ans += (dict(r=res['r'], t=res['t'], dof=res['dof']), )
+	return ans
+
+
+assert __name__ != "__main__"

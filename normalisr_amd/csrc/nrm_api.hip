@@ -1,0 +1,162 @@
+// C ABI glue: error reporting, device selection and the whole-problem host entry
+// (numpy buffers in, numpy buffers out) that stands where association_tests() does
+// (association.py:761-771,1093) for single=0.
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include "nrm_common.h"
+
+static thread_local char g_err[512] = "";
+
+void nrm_set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+extern "C" int nrm_version(void) { return 100; }
+extern "C" const char* nrm_last_error(void) { return g_err; }
+
+extern "C" int nrm_device_count(int* count) {
+	NRM_REQUIRE(count != nullptr, "nrm_device_count: null pointer");
+	NRM_HIP(hipGetDeviceCount(count));
+	return NRM_OK;
+}
+
+extern "C" int nrm_set_device(int device) {
+	NRM_HIP(hipSetDevice(device));
+	return NRM_OK;
+}
+
+namespace {
+struct DevBuf {
+	void* p = nullptr;
+	~DevBuf() {
+		if (p) (void)hipFree(p);
+	}
+	int alloc(size_t bytes) {
+		NRM_HIP(hipMalloc(&p, bytes ? bytes : 16));
+		return NRM_OK;
+	}
+	template <typename T>
+	T* as() {
+		return reinterpret_cast<T*>(p);
+	}
+};
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+inline size_t esize(int dtype) { return dtype == NRM_F64 ? 8 : 4; }
+}  // namespace
+
+#define NRM_TRY(call)        \
+	do {                     \
+		int rc_ = (call);    \
+		if (rc_) return rc_; \
+	} while (0)
+
+extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
+										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
+										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
+										  void* h_vary, void* h_r, void* h_t, int out_dtype) {
+	const bool samexy = (h_dy == nullptr);
+	if (samexy) {
+		ny = nx;
+		y_dtype = x_dtype;
+	}
+	NRM_REQUIRE(h_dx && nx > 0 && ny > 0 && n > 0, "Incorrect dx/dy/dc size.");
+	NRM_REQUIRE(nc >= 0 && (nc == 0 || h_dc), "Incorrect dx/dy/dc size.");
+	NRM_REQUIRE(rank >= 0, "Negative dcr detected.");
+	NRM_REQUIRE(rank <= nc, "dcr higher than covariate dimension.");
+	NRM_REQUIRE(n > (int64_t)rank + dimreduce + 1,
+				"Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.");
+	NRM_REQUIRE(h_p && h_stat && h_vary, "nrm_association_tests_host: null output");
+	const double dof = (double)(n - 1 - rank - dimreduce);
+	hipStream_t st = nullptr;
+	const int64_t kp = round_up(n, NRM_K_TILE), mp = round_up(nx, NRM_ROW_TILE), np_ = round_up(ny, NRM_ROW_TILE);
+
+	DevBuf dx, dy, dc, dci, rx, ry, ssx, ssy, bx, by, dot, flags, op, ostat, oalpha, orr, ot;
+	// covariates as fp64
+	std::vector<double> c64;
+	if (nc > 0) {
+		c64.resize((size_t)nc * n);
+		if (c_dtype == NRM_F64)
+			memcpy(c64.data(), h_dc, c64.size() * 8);
+		else
+			for (size_t i = 0; i < c64.size(); i++) c64[i] = ((const float*)h_dc)[i];
+		NRM_TRY(dc.alloc(c64.size() * 8));
+		NRM_HIP(hipMemcpy(dc.p, c64.data(), c64.size() * 8, hipMemcpyHostToDevice));
+		NRM_TRY(dci.alloc((size_t)nc * nc * 8));
+		NRM_REQUIRE(h_dci != nullptr || rank == 0, "Unmatching dci dimensions.");
+		if (h_dci) NRM_HIP(hipMemcpy(dci.p, h_dci, (size_t)nc * nc * 8, hipMemcpyHostToDevice));
+	}
+	const bool want_alpha = h_alpha != nullptr && nc > 0;
+	NRM_TRY(dx.alloc((size_t)nx * n * esize(x_dtype)));
+	NRM_HIP(hipMemcpy(dx.p, h_dx, (size_t)nx * n * esize(x_dtype), hipMemcpyHostToDevice));
+	NRM_TRY(rx.alloc((size_t)mp * kp * 8));
+	NRM_TRY(ssx.alloc((size_t)mp * 8));
+	if (want_alpha) NRM_TRY(bx.alloc((size_t)nx * nc * 8));
+	if (want_alpha) NRM_HIP(hipMemsetAsync(bx.p, 0, (size_t)nx * nc * 8, st));
+	NRM_TRY(nrm_residualize(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, rx.as<double>(), kp, mp,
+							ssx.as<double>(), want_alpha ? bx.as<double>() : nullptr, st));
+	if (!samexy) {
+		NRM_TRY(dy.alloc((size_t)ny * n * esize(y_dtype)));
+		NRM_HIP(hipMemcpy(dy.p, h_dy, (size_t)ny * n * esize(y_dtype), hipMemcpyHostToDevice));
+		NRM_TRY(ry.alloc((size_t)np_ * kp * 8));
+		NRM_TRY(ssy.alloc((size_t)np_ * 8));
+		if (want_alpha) NRM_TRY(by.alloc((size_t)ny * nc * 8));
+		if (want_alpha) NRM_HIP(hipMemsetAsync(by.p, 0, (size_t)ny * nc * 8, st));
+		NRM_TRY(nrm_residualize(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, ry.as<double>(), kp, np_,
+								ssy.as<double>(), want_alpha ? by.as<double>() : nullptr, st));
+	}
+	const double* A = rx.as<double>();
+	const double* B = samexy ? A : ry.as<double>();
+	const double* sx = ssx.as<double>();
+	const double* sy = samexy ? sx : ssy.as<double>();
+	NRM_TRY(dot.alloc((size_t)mp * np_ * 8));
+	NRM_TRY(nrm_gram_f64(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, st));
+	NRM_TRY(flags.alloc(8));
+	NRM_HIP(hipMemsetAsync(flags.p, 0, 8, st));
+	const size_t ob = (size_t)nx * ny * esize(out_dtype);
+	NRM_TRY(op.alloc(ob));
+	NRM_TRY(ostat.alloc(ob));
+	if (h_r) NRM_TRY(orr.alloc(ob));
+	if (h_t) NRM_TRY(ot.alloc(ob));
+	// coex always converts to covariance (association.py:1037-1039); de keeps gamma unless return_dot
+	const int stat_kind = (samexy || return_dot) ? 0 : 1;
+	NRM_TRY(nrm_assoc_sweep(dot.as<double>(), np_, sx, sy, nx, ny, n, dof, samexy ? 1 : 0, stat_kind, op.p, ostat.p,
+							h_r ? orr.p : nullptr, h_t ? ot.p : nullptr, out_dtype, ny, flags.as<int32_t>(), st));
+	if (want_alpha) {
+		NRM_REQUIRE(!samexy && stat_kind == 1, "alpha is only defined for dy != None with return_dot=False");
+		NRM_TRY(oalpha.alloc(ob * nc));
+		NRM_TRY(nrm_alpha(ostat.p, out_dtype, ny, bx.as<double>(), by.as<double>(), nx, ny, nc, oalpha.p, out_dtype, st));
+	}
+	NRM_HIP(hipStreamSynchronize(st));
+	int32_t hf[2];
+	NRM_HIP(hipMemcpy(hf, flags.p, 8, hipMemcpyDeviceToHost));
+	if (hf[0] || hf[1]) {
+		nrm_set_error("association results failed the reference's assertions (association.py:248,252): %d tiles non-finite, %d tiles with R^2 > 1+1e-8", hf[0], hf[1]);
+		return NRM_E_NUMERIC;
+	}
+	NRM_HIP(hipMemcpy(h_p, op.p, ob, hipMemcpyDeviceToHost));
+	NRM_HIP(hipMemcpy(h_stat, ostat.p, ob, hipMemcpyDeviceToHost));
+	if (h_r) NRM_HIP(hipMemcpy(h_r, orr.p, ob, hipMemcpyDeviceToHost));
+	if (h_t) NRM_HIP(hipMemcpy(h_t, ot.p, ob, hipMemcpyDeviceToHost));
+	if (want_alpha) NRM_HIP(hipMemcpy(h_alpha, oalpha.p, ob * nc, hipMemcpyDeviceToHost));
+	// variances = ss / n with the 0 -> 1 rule (association.py:230-233), cast to the output dtype
+	std::vector<double> hs((size_t)std::max(mp, np_));
+	auto emit_var = [&](const double* d_ss, int64_t cnt, void* h_out) -> int {
+		NRM_HIP(hipMemcpy(hs.data(), d_ss, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+		for (int64_t i = 0; i < cnt; i++) {
+			double v = hs[i] / (double)n;
+			if (v == 0.0) v = 1.0;
+			if (out_dtype == NRM_F64)
+				((double*)h_out)[i] = v;
+			else
+				((float*)h_out)[i] = (float)v;
+		}
+		return NRM_OK;
+	};
+	NRM_TRY(emit_var(sy, ny, h_vary));
+	if (h_varx && !samexy) NRM_TRY(emit_var(sx, nx, h_varx));
+	return NRM_OK;
+}

@@ -1,0 +1,141 @@
+// K1 + K4: residualise expression/design rows against the covariates once per row (the reference
+// redoes this inside every tile: association.py:224-229) and take the row sums of squares
+// (association.py:230-233) in the same pass.  HBM-bound: each input row is read from HBM once (second
+// sweep hits L2), the fp64 residual is written once.
+//
+//   b_i  = (x_i C^T) dci          (association.py:226-227)
+//   x~_i = x_i - b_i C            (association.py:228-229)
+//   ss_i = sum_k x~_ik^2          (= n * variance, association.py:230)
+//
+// One workgroup (256 threads) owns RES_R consecutive rows so that every covariate element fetched
+// from L2 is used RES_R times; covariates are swept in chunks of RES_CB to bound registers.
+#include "nrm_common.h"
+
+#define RES_R 4
+#define RES_CB 8
+#define RES_NC_MAX 256
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
+													  const double* __restrict__ c, int nc, int64_t ldc,
+													  const double* __restrict__ dci, int active,
+													  double* __restrict__ out, int64_t ldo, double* __restrict__ ss,
+													  double* __restrict__ coef) {
+	__shared__ double s_part[4][RES_R * RES_CB];
+	__shared__ double s_a[RES_R][RES_NC_MAX];  // x_i C^T
+	__shared__ double s_b[RES_R][RES_NC_MAX];  // (x_i C^T) dci
+	__shared__ double s_ss[4][RES_R];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int64_t row0 = (int64_t)blockIdx.x * RES_R;
+	const T* xr[RES_R];
+	bool live[RES_R];
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) {
+		live[r] = row0 + r < rows;
+		xr[r] = x + (live[r] ? (row0 + r) : 0) * ldx;
+	}
+
+	if (active) {
+		// phase A: a[r][cc] = sum_k x[r][k] C[cc][k]
+		for (int c0 = 0; c0 < nc; c0 += RES_CB) {
+			double acc[RES_R][RES_CB];
+#pragma unroll
+			for (int r = 0; r < RES_R; r++)
+#pragma unroll
+				for (int q = 0; q < RES_CB; q++) acc[r][q] = 0.0;
+			for (int64_t k = tid; k < n; k += 256) {
+				double xv[RES_R];
+#pragma unroll
+				for (int r = 0; r < RES_R; r++) xv[r] = live[r] ? (double)xr[r][k] : 0.0;
+#pragma unroll
+				for (int q = 0; q < RES_CB; q++) {
+					double cv = (c0 + q < nc) ? c[(int64_t)(c0 + q) * ldc + k] : 0.0;
+#pragma unroll
+					for (int r = 0; r < RES_R; r++) acc[r][q] = fma(xv[r], cv, acc[r][q]);
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < RES_R; r++)
+#pragma unroll
+				for (int q = 0; q < RES_CB; q++) {
+					double v = wave_sum(acc[r][q]);
+					if (lane == 0) s_part[wid][r * RES_CB + q] = v;
+				}
+			__syncthreads();
+			if (tid < RES_R * RES_CB) {
+				int r = tid / RES_CB, q = tid % RES_CB;
+				if (c0 + q < nc) s_a[r][c0 + q] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+			}
+			__syncthreads();
+		}
+		// b = a dci   (dci symmetric; association.py:226 applies dci on the left of dc@dx.T)
+		for (int i = tid; i < RES_R * nc; i += 256) {
+			int r = i / nc, q = i % nc;
+			double v = 0.0;
+			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], s_a[r][e], v);
+			s_b[r][q] = v;
+			if (coef && live[r]) coef[(row0 + r) * nc + q] = v;
+		}
+		__syncthreads();
+	}
+
+	// phase B: residual, zero padding, sum of squares
+	double sq[RES_R];
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) sq[r] = 0.0;
+	for (int64_t k = tid; k < ldo; k += 256) {
+		double v[RES_R];
+#pragma unroll
+		for (int r = 0; r < RES_R; r++) v[r] = (live[r] && k < n) ? (double)xr[r][k] : 0.0;
+		if (active && k < n) {
+			for (int q = 0; q < nc; q++) {
+				double cv = c[(int64_t)q * ldc + k];
+#pragma unroll
+				for (int r = 0; r < RES_R; r++) v[r] = fma(-s_b[r][q], cv, v[r]);
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < RES_R; r++) {
+			if (!live[r]) v[r] = 0.0;
+			out[(row0 + r) * ldo + k] = v[r];
+			sq[r] = fma(v[r], v[r], sq[r]);
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) {
+		double v = wave_sum(sq[r]);
+		if (lane == 0) s_ss[wid][r] = v;
+	}
+	__syncthreads();
+	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
+}
+
+extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c,
+							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
+							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
+	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
+	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
+	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
+	NRM_REQUIRE(rank >= 0 && rank <= nc, "dcr higher than covariate dimension.");
+	NRM_REQUIRE(rows_pad >= rows && rows_pad % RES_R == 0, "nrm_residualize: rows_pad must cover rows and be a multiple of %d", RES_R);
+	NRM_REQUIRE(ldo >= n, "nrm_residualize: output pitch smaller than cell count");
+	NRM_REQUIRE(d_out && d_ss, "nrm_residualize: null output");
+	if (rows_pad == 0) return NRM_OK;
+	NRM_REQUIRE(d_x || rows == 0, "nrm_residualize: null input");
+	int active = (rank > 0 && nc > 0) ? 1 : 0;
+	NRM_REQUIRE(!active || (d_c && d_dci && ldc >= n), "Unmatching dx/dy/dc dimensions.");
+	dim3 grid((unsigned)(rows_pad / RES_R));
+	if (x_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_residualize<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)d_x, rows, n, ldx, d_c,
+						   (int)nc, ldc, d_dci, active, d_out, ldo, d_ss, d_coef);
+	else
+		hipLaunchKernelGGL(k_residualize<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, rows, n, ldx, d_c,
+						   (int)nc, ldc, d_dci, active, d_out, ldo, d_ss, d_coef);
+	return nrm_check_launch("k_residualize");
+}

@@ -1,0 +1,237 @@
+// K3: per-pair sweep (R^2 -> p, effect size, Pearson r, t) and the p-value plan.
+// Reference lines restated: association.py:231-235 (variance 0->1, gamma, R^2), :248-249 (range
+// assertion, beta.cdf), :1037-1057 (coef->dot conversion, symmetrise, zero diagonal).
+#include <cmath>
+#include <cstring>
+#include "nrm_pvalue.h"
+
+// ---- host: plan -------------------------------------------------------------------------------
+
+// Taylor coefficients h_k of sqrt((s/2)/sinh(s/2)) = sum_k h_k s^(2k)
+static const double kH[] = {1.0,
+							-0.02083333333333333333333,
+							0.000390625,
+							-0.000007879670965608465608466,
+							1.696766579172178130511e-7,
+							-3.805064191721906565657e-9,
+							8.748377596315407304061e-11,
+							-2.044523359411973817584e-12,
+							4.833351797967704408319e-14,
+							-1.152434101767385923873e-15,
+							2.766052043599370042286e-17};
+
+// ln( Gamma(a+1/2)/Gamma(a) ): recurrence up to a >= 24, then the asymptotic series (DLMF 5.11.13).
+static double ln_gamma_ratio_half(double a) {
+	double shift = 0.0;
+	while (a < 24.0) {
+		shift += std::log(a / (a + 0.5));
+		a += 1.0;
+	}
+	double i = 1.0 / a, i2 = i * i;
+	double s = i * (-1.0 / 8 + i2 * (1.0 / 192 + i2 * (-1.0 / 640 + i2 * (17.0 / 14336 + i2 * (-31.0 / 18432 + i2 * (691.0 / 180224))))));
+	return 0.5 * std::log(a) + s + shift;
+}
+
+extern "C" int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof) {
+	NRM_REQUIRE(plan != nullptr, "nrm_pvalue_plan_init: null plan");
+	NRM_REQUIRE(dof > 0, "Insufficient number of cells: dof = %g must be positive", dof);
+	const int K = NRM_PCOEF / 2;  // series terms k = 0..K
+	double a = 0.5 * dof;
+	plan->a = a;
+	plan->alpha = a - 0.25;
+	plan->ln_front = ln_gamma_ratio_half(a) - 0.57236494292470008707;  // - ln(pi)/2
+	for (int j = 0; j < NRM_PCOEF; j++) plan->coef[j] = 0.0;
+	if (a < 8.0) {
+		plan->umax = 0.0;  // asymptotic series in 1/alpha not accurate enough: continued fraction only
+		return NRM_OK;
+	}
+	plan->umax = 1.5;
+	double al = plan->alpha;
+	// S = sum_k h_k alpha^-2k c'_2k,  c'_m = prod_{i<m} (i + 1/2)
+	long double S = 0;
+	for (int k = 0; k <= K; k++) {
+		long double cp = 1;
+		for (int i = 0; i < 2 * k; i++) cp *= (i + 0.5L);
+		S += (long double)kH[k] * powl(al, -2 * k) * cp;
+	}
+	// coef_j = (1/(S sqrt(pi))) sum_{k: 2k > j} h_k alpha^(j-2k) prod_{i=j+1}^{2k-1} (i + 1/2)
+	for (int j = 0; j < NRM_PCOEF; j++) {
+		long double c = 0;
+		for (int k = 1; k <= K; k++) {
+			int m = 2 * k;
+			if (j >= m) continue;
+			long double pr = 1;
+			for (int i = j + 1; i < m; i++) pr *= (i + 0.5L);
+			c += (long double)kH[k] * powl(al, j - m) * pr;
+		}
+		plan->coef[j] = (double)(c / (S * 1.7724538509055160272981674833411L));
+	}
+	return NRM_OK;
+}
+
+static PvalPlan to_dev(const nrm_pvalue_plan& p) {
+	PvalPlan d;
+	d.a = p.a;
+	d.alpha = p.alpha;
+	d.ln_front = p.ln_front;
+	d.umax = p.umax;
+	for (int j = 0; j < NRM_PCOEF; j++) d.coef[j] = p.coef[j];
+	return d;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_pvalues_from_r2(const double* __restrict__ r2, int64_t count, PvalPlan pl,
+														  double* __restrict__ p) {
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < count; i += stride) p[i] = nrm_pvalue(r2[i], pl);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_out(void* base, int64_t idx, double v) {
+	reinterpret_cast<T*>(base)[idx] = (T)v;
+}
+
+// One workgroup = one 64x64 tile of the (nx, ny) output.  The source tile of dot is staged through LDS
+// so that the mirrored half of a symmetric (coex) problem is read coalesced and transposed on chip.
+#define SW_T 64
+template <typename OutT>
+__global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ dot, int64_t ldd,
+													  const double* __restrict__ ssx, const double* __restrict__ ssy,
+													  int64_t nx, int64_t ny, double ncells, double dof, int symmetric,
+													  int stat_kind, PvalPlan pl, void* __restrict__ p_out,
+													  void* __restrict__ stat_out, void* __restrict__ r_out,
+													  void* __restrict__ t_out, int64_t ldo, int32_t* __restrict__ flags) {
+	__shared__ double tile[SW_T][SW_T + 1];
+	__shared__ double sx[SW_T], sy[SW_T];
+	const int bi = blockIdx.y, bj = blockIdx.x;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+	// source tile: for coex always from the upper triangle (association.py:1050-1057)
+	const bool mirror = symmetric && bi > bj;
+	const int si = mirror ? bj : bi, sj = mirror ? bi : bj;
+	for (int r = ty; r < SW_T; r += 4) {
+		int64_t gi = (int64_t)si * SW_T + r, gj = (int64_t)sj * SW_T + tx;
+		int64_t lim_i = mirror ? ny : nx, lim_j = mirror ? nx : ny;
+		tile[r][tx] = (gi < lim_i && gj < lim_j) ? dot[gi * ldd + gj] : 0.0;
+	}
+	if (threadIdx.x < SW_T) {
+		int64_t gi = (int64_t)bi * SW_T + threadIdx.x;
+		double v = gi < nx ? ssx[gi] : 1.0;
+		sx[threadIdx.x] = (v == 0.0) ? ncells : v;  // variance 0 -> 1  (association.py:231)
+	} else if (threadIdx.x < 2 * SW_T) {
+		int t = threadIdx.x - SW_T;
+		int64_t gj = (int64_t)bj * SW_T + t;
+		double v = gj < ny ? ssy[gj] : 1.0;
+		sy[t] = (v == 0.0) ? ncells : v;  // association.py:233
+	}
+	__syncthreads();
+	int bad_nf = 0, bad_rng = 0;
+	const int64_t gj = (int64_t)bj * SW_T + tx;
+	for (int r = ty; r < SW_T; r += 4) {
+		const int64_t gi = (int64_t)bi * SW_T + r;
+		if (gi >= nx || gj >= ny) continue;
+		double d;
+		if (!symmetric)
+			d = tile[r][tx];
+		else if (mirror)
+			d = tile[tx][r];
+		else if (bi == bj)
+			d = (r <= tx) ? tile[r][tx] : tile[tx][r];
+		else
+			d = tile[r][tx];
+		const double vx = sx[r], vy = sy[tx];
+		double r2 = (d * d) / (vx * vy);  // = gamma^2 vx / vy  (association.py:235)
+		double p, stat, rr, tt;
+		if (symmetric && gi == gj) {
+			p = 0.0;  // triu(.,1) + transpose leaves exact zeros on the diagonal (Q1)
+			stat = 0.0;
+			rr = 0.0;
+			tt = 0.0;
+		} else {
+			if (!isfinite(r2) || !isfinite(vx) || !isfinite(vy)) bad_nf = 1;
+			if (r2 > 1.0 + 1e-8) bad_rng = 1;  // association.py:248
+			p = nrm_pvalue(r2, pl);
+			stat = stat_kind ? d / vx : d / ncells;
+			rr = d / sqrt(vx * vy);
+			double rc = fmin(r2, 1.0);
+			tt = copysign(sqrt(dof * rc / (1.0 - rc)), d);
+		}
+		const int64_t o = gi * ldo + gj;
+		store_out<OutT>(p_out, o, p);
+		store_out<OutT>(stat_out, o, stat);
+		if (r_out) store_out<OutT>(r_out, o, rr);
+		if (t_out) store_out<OutT>(t_out, o, tt);
+	}
+	if (flags) {
+		if (bad_nf) atomicAdd(&flags[0], 1);
+		if (bad_rng) atomicAdd(&flags[1], 1);
+	}
+}
+
+template <typename GT, typename OutT>
+__global__ void __launch_bounds__(256) k_alpha(const GT* __restrict__ gamma, int64_t ldg, const double* __restrict__ bx,
+												const double* __restrict__ by, int64_t nx, int64_t ny, int64_t nc,
+												OutT* __restrict__ alpha) {
+	int64_t total = nx * ny * nc;
+	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < total; i += stride) {
+		int64_t c = i % nc, ij = i / nc;
+		int64_t j = ij % ny, x = ij / ny;
+		alpha[i] = (OutT)(by[j * nc + c] - (double)gamma[x * ldg + j] * bx[x * nc + c]);  // association.py:238-243
+	}
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------
+
+extern "C" int nrm_pvalues_from_r2(const double* d_r2, int64_t count, double dof, double* d_p, void* stream) {
+	nrm_pvalue_plan plan;
+	int rc = nrm_pvalue_plan_init(&plan, dof);
+	if (rc) return rc;
+	if (count <= 0) return NRM_OK;
+	NRM_REQUIRE(d_r2 && d_p, "nrm_pvalues_from_r2: null pointer");
+	int grid = (int)((count + 255) / 256);
+	if (grid > 4096) grid = 4096;
+	hipLaunchKernelGGL(k_pvalues_from_r2, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_r2, count, to_dev(plan), d_p);
+	return nrm_check_launch("k_pvalues_from_r2");
+}
+
+extern "C" int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t nx,
+							   int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind, void* d_p,
+							   void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo, int32_t* d_flags,
+							   void* stream) {
+	NRM_REQUIRE(nx >= 0 && ny >= 0 && n_cells > 0, "nrm_assoc_sweep: bad sizes");
+	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_assoc_sweep: bad out_dtype");
+	NRM_REQUIRE(!symmetric || nx == ny, "nrm_assoc_sweep: symmetric needs nx == ny");
+	nrm_pvalue_plan plan;
+	int rc = nrm_pvalue_plan_init(&plan, dof);
+	if (rc) return rc;
+	if (nx == 0 || ny == 0) return NRM_OK;
+	NRM_REQUIRE(d_dot && d_ssx && d_ssy && d_p && d_stat, "nrm_assoc_sweep: null pointer");
+	NRM_REQUIRE(ldo >= ny && ldd >= ny, "nrm_assoc_sweep: pitch smaller than row length");
+	dim3 grid((unsigned)((ny + SW_T - 1) / SW_T), (unsigned)((nx + SW_T - 1) / SW_T));
+	if (out_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_assoc_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
+						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags);
+	else
+		hipLaunchKernelGGL(k_assoc_sweep<float>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
+						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags);
+	return nrm_check_launch("k_assoc_sweep");
+}
+
+extern "C" int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d_bx, const double* d_by,
+						 int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype, void* stream) {
+	NRM_REQUIRE(gamma_dtype == out_dtype, "nrm_alpha: gamma and alpha dtypes must match");
+	if (nx * ny * nc == 0) return NRM_OK;
+	int64_t total = nx * ny * nc;
+	int grid = (int)((total + 255) / 256);
+	if (grid > 8192) grid = 8192;
+	if (out_dtype == NRM_F64)
+		hipLaunchKernelGGL((k_alpha<double, double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double*)d_gamma,
+						   ldg, d_bx, d_by, nx, ny, nc, (double*)d_alpha);
+	else
+		hipLaunchKernelGGL((k_alpha<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)d_gamma, ldg,
+						   d_bx, d_by, nx, ny, nc, (float*)d_alpha);
+	return nrm_check_launch("k_alpha");
+}

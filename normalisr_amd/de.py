@@ -1,0 +1,51 @@
+"""Differential expression: all genes against all groupings (mirror of the reference's de module)."""
+import numpy as np
+
+from .association import association_tests
+
+
+def _varying_rows(dg):
+	"""Rows with more than one distinct value (de.py:93 uses len(np.unique(x)) > 1; NaNs compare equal there)."""
+	first = dg[:, :1]
+	diff = dg != first
+	if dg.dtype.kind == 'f':
+		diff &= ~(np.isnan(dg) & np.isnan(first))
+	return diff.any(axis=1)
+
+
+def de(dg, dt, dc, bs=0, **ka):
+	"""Differential expression of every gene (rows of dt) against every grouping (rows of dg) with
+	covariates dc: Y = gamma*X + alpha*C + eps, H0: gamma = 0.  Same contract as reference de.py:4-132.
+
+	Returns (P-values (n_group,n_gene), gamma (n_group,n_gene), alpha (n_group,n_gene,n_cov)|None,
+	varg (n_group,), vart (n_group,n_gene)).  Keyword arguments single, lowmem, nth, dimreduce, tol, ...
+	are passed to association_tests.  Single-valued grouping rows are not tested and come back with
+	p=1, gamma=0, alpha=0, varg=0, vart=0 (de.py:107-122).
+	"""
+	dg0 = np.asarray(dg)
+	dt = np.asarray(dt)
+	dc = np.asarray(dc)
+	if dg0.ndim != 2 or dt.ndim != 2 or dc.ndim != 2:
+		raise ValueError('Incorrect dx/dy/dc size.')
+	gid = _varying_rows(dg0)
+	nt, nc, ng0 = dt.shape[0], dc.shape[0], dg0.shape[0]
+	odt = dt.dtype if dt.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	p, gam, alpha, varg, vart = association_tests(dg0[gid], dt, dc, bsx=bs, bsy=bs, return_dot=False, **ka)
+	P = np.ones((ng0, nt), dtype=odt)
+	P[gid] = p
+	G = np.zeros((ng0, nt), dtype=odt)
+	G[gid] = gam
+	A = None
+	if alpha is not None:
+		A = np.zeros((ng0, nt, nc), dtype=odt)
+		A[gid] = alpha
+	VG = np.zeros((ng0, ), dtype=odt)
+	VG[gid] = varg
+	VT = np.zeros((ng0, nt), dtype=odt)
+	VT[gid] = vart  # (n_gene,) for single=0 broadcasts to every tested row
+	assert np.isfinite(P).all() and np.isfinite(G).all() and np.isfinite(VG).all() and np.isfinite(VT).all()
+	assert (P >= 0).all() and (P <= 1).all() and (VG >= 0).all() and (VT >= 0).all()
+	return (P, G, A, VG, VT)
+
+
+assert __name__ != "__main__"

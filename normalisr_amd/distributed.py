@@ -1,0 +1,228 @@
+"""Multi-GPU sharding of the pair space: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI).  The reference's only parallelism is a thread-pool map over independent (x-block, y-block)
+tiles (association.py:890-909,997; parallel.py:12-74); here the same independence is used across GPUs.
+
+coex (dy=None): gene-row block b lives on rank b.  Each rank residualises its own block (covariates are
+tiny and replicated), then ONE exchange step -- an all-gather of the residualised blocks and their sums
+of squares -- after which rank b contracts block pairs (b, b+k mod N), k = 0..floor(N/2); for even N
+the k = N/2 pair is shared half/half by its two owners.  Every unordered block pair is computed exactly
+once (association.py:893-894 keeps x0 <= y0 the same way).  K (cells) is never split across GPUs, so
+there is no all-reduce.  xGMI is point-to-point: an all-gather in which every GPU pushes its shard to its
+7 peers at once uses all links in parallel (shard bytes / ~153 GB/s).
+
+de (dy given): gene rows of Y are sharded, the (few) design rows X are residualised redundantly on every
+rank -- no collective at all (see DePlan).
+"""
+import numpy as np
+
+from ._lib import ROW_TILE, K_TILE
+
+
+def _round_up(v, m):
+	return (v + m - 1) // m * m
+
+
+def block_pair_schedule(rank, world, rows_pad):
+	"""Block pairs rank `rank` contracts: list of (bi, bj, row_lo, row_hi, symmetric).
+	Rows [row_lo, row_hi) of block bi (padded row indices, multiples of ROW_TILE) against all of block bj."""
+	sched = [(rank, rank, 0, rows_pad, True)]
+	for k in range(1, (world - 1) // 2 + 1):
+		sched.append((rank, (rank + k) % world, 0, rows_pad, False))
+	if world % 2 == 0 and world > 1:
+		other = (rank + world // 2) % world
+		lo, hi = min(rank, other), max(rank, other)
+		half = _round_up(rows_pad // 2, ROW_TILE)
+		if rank == lo:
+			sched.append((lo, hi, 0, half, False))
+		elif half < rows_pad:
+			sched.append((lo, hi, half, rows_pad, False))
+	return sched
+
+
+def schedule_covers_all_pairs(world, rows_pad):
+	"""Host-side invariant used by the tests: every unordered block pair (and every row of it) exactly once."""
+	seen = {}
+	for r in range(world):
+		for bi, bj, lo, hi, sym in block_pair_schedule(r, world, rows_pad):
+			key = (min(bi, bj), max(bi, bj))
+			assert (bi <= bj) or not sym
+			seen.setdefault(key, []).append((bi, bj, lo, hi))
+	for a in range(world):
+		for b in range(a, world):
+			parts = sorted(seen.get((a, b), []), key=lambda t: t[2])
+			assert parts, (a, b)
+			assert len({(p[0], p[1]) for p in parts}) == 1, 'mixed orientation'
+			assert parts[0][2] == 0 and parts[-1][3] == rows_pad
+			for p, q in zip(parts, parts[1:]):
+				assert p[3] == q[2]
+	return True
+
+
+class HipBackend:
+	"""Block operations on the local GPU through the C ABI (normalisr_amd.engine)."""
+
+	def __init__(self, device):
+		from .engine import get_engine
+		self.eng = get_engine(device)
+		self.torch = self.eng.torch
+
+	def covariates(self, dc):
+		"""dc: (nc, n) device or host array -> replicated fp64 device covariates, pseudo-inverse, rank."""
+		from .association import _prepare_covariates
+		dc_h = dc.detach().cpu().numpy() if hasattr(dc, 'detach') else np.asarray(dc)
+		dc64, dci, dcr = _prepare_covariates(dc_h)
+		d_c, d_dci = self.eng.covariates(dc64, dci)
+		return d_c, d_dci, dcr
+
+	def residualize(self, x, cov, rows_pad):
+		d_c, d_dci, dcr = cov
+		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad)
+		return r.data, r.ss
+
+	def gram(self, a, b, symmetric):
+		from .engine import Residualized
+		return self.eng.gram(Residualized(a.shape[0], a.shape[1], a, None, None), Residualized(b.shape[0], b.shape[1], b, None, None), symmetric)
+
+	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
+		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags)
+		return p, stat, flags
+
+	def empty(self, shape):
+		return self.torch.empty(shape, dtype=self.torch.float64, device=self.eng.device)
+
+	def event(self):
+		return self.torch.cuda.Event(enable_timing=True)
+
+	def sync(self):
+		self.torch.cuda.synchronize(self.eng.device)
+
+
+class CoexPlan:
+	"""Sharded coex over `world` ranks; world == 1 is the plain single-GPU path.
+
+	dt_local: this rank's gene rows (rows_local, n) already on the device (or host for a host backend);
+	every rank must own the same number of rows.  dc: (nc, n) covariates (replicated).
+	step() runs one full pass and leaves the outputs of this rank's block pairs in self.outputs:
+	list of dict(bi, bj, row_lo, nx, ny, symmetric, p, stat)."""
+
+	def __init__(self, dt_local, dc, rank=0, world=1, group=None, backend=None, dimreduce=0, out_dtype=None):
+		self.rank, self.world, self.group = rank, world, group
+		self.be = backend if backend is not None else HipBackend(dt_local.device.index)
+		self.x = dt_local
+		self.rows, self.n = dt_local.shape
+		self.rows_pad = _round_up(max(self.rows, 1), ROW_TILE)
+		self.k_pad = _round_up(self.n, K_TILE)
+		self.cov = self.be.covariates(dc)
+		self.dof = self.n - 1 - self.cov[2] - dimreduce
+		if self.dof <= 0:
+			raise ValueError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+		if out_dtype is None:
+			out_dtype = np.float32 if 'float32' in str(dt_local.dtype) else np.float64
+		self.out_dtype = out_dtype
+		self.sched = block_pair_schedule(rank, world, self.rows_pad)
+		self.outputs = []
+		self.flags = None
+		self._ev = dict(residualize=[], exchange=[], gram=[], sweep=[])
+		if world > 1:
+			self.all_data = self.be.empty((world * self.rows_pad, self.k_pad))
+			self.all_ss = self.be.empty((world * self.rows_pad, ))
+
+	def _timed(self, name, timed, fn):
+		if not timed:
+			return fn()
+		e0, e1 = self.be.event(), self.be.event()
+		e0.record()
+		out = fn()
+		e1.record()
+		self._ev[name].append((e0, e1))
+		return out
+
+	def _exchange(self, data, ss):
+		import torch.distributed as dist
+		if dist.get_backend(self.group) == 'nccl':
+			dist.all_gather_into_tensor(self.all_data, data, group=self.group)
+			dist.all_gather_into_tensor(self.all_ss, ss, group=self.group)
+		else:
+			dist.all_gather(list(self.all_data.view(self.world, self.rows_pad, self.k_pad).unbind(0)), data, group=self.group)
+			dist.all_gather(list(self.all_ss.view(self.world, self.rows_pad).unbind(0)), ss, group=self.group)
+
+	def block(self, b):
+		if self.world == 1:
+			return self._data, self._ss
+		return (self.all_data[b * self.rows_pad:(b + 1) * self.rows_pad], self.all_ss[b * self.rows_pad:(b + 1) * self.rows_pad])
+
+	def step(self, timed=False):
+		data, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
+		self._data, self._ss = data, ss
+		if self.world > 1:
+			self._timed('exchange', timed, lambda: self._exchange(data, ss))
+		outs = []
+		for bi, bj, lo, hi, sym in self.sched:
+			a, ssa = self.block(bi)
+			b, ssb = self.block(bj)
+			a, ssa = a[lo:hi], ssa[lo:hi]
+			dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym))
+			nx = max(0, min(hi, self.rows) - lo)
+			ny = self.rows
+			if nx == 0:
+				continue
+			p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
+			outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
+		self.outputs = outs
+		return outs
+
+	# ---- accounting for bench.py -----------------------------------------------------------------
+	def local_pair_count(self):
+		"""Unique unordered gene pairs covered by this rank's Gram launches."""
+		cnt = 0
+		for bi, bj, lo, hi, sym in self.sched:
+			nx = max(0, min(hi, self.rows) - lo)
+			cnt += nx * (nx - 1) // 2 if sym else nx * self.rows
+		return cnt
+
+	def _avg_ms(self, name):
+		ev = self._ev[name]
+		if not ev:
+			return 0.0
+		self.be.sync()
+		per_step = max(1, len(self._ev['residualize']))
+		return sum(a.elapsed_time(b) for a, b in ev) / per_step
+
+	def gram_ms(self):
+		return self._avg_ms('gram')
+
+	def kernel_breakdown(self):
+		return {k: round(self._avg_ms(k), 4) for k in self._ev}
+
+	# ---- assembly (validation / numpy out) -------------------------------------------------------
+	def assemble(self, to_numpy):
+		"""Gather every rank's output blocks on rank 0 and build the full symmetric (p, dot) matrices with
+		zero diagonals.  to_numpy converts a backend array to numpy.  Returns (p, dot, var) on rank 0, None elsewhere."""
+		mine = [dict(bi=o['bi'], bj=o['bj'], row_lo=o['row_lo'], symmetric=o['symmetric'], p=to_numpy(o['p']), stat=to_numpy(o['stat']))
+				for o in self.outputs]
+		var = to_numpy(self._ss)[:self.rows] / float(self.n)
+		var[var == 0] = 1
+		if self.world > 1:
+			import torch.distributed as dist
+			gathered = [None] * self.world if self.rank == 0 else None
+			dist.gather_object((mine, var), gathered, dst=0, group=self.group)
+			if self.rank != 0:
+				return None
+		else:
+			gathered = [(mine, var)]
+		ng = self.world * self.rows
+		P = np.zeros((ng, ng), dtype=self.out_dtype)
+		D = np.zeros((ng, ng), dtype=self.out_dtype)
+		V = np.concatenate([g[1] for g in gathered]).astype(self.out_dtype)
+		R = self.rows
+		for blocks, _ in gathered:
+			for o in blocks:
+				r0 = o['bi'] * R + o['row_lo']
+				c0 = o['bj'] * R
+				nx, ny = o['p'].shape
+				P[r0:r0 + nx, c0:c0 + ny] = o['p']
+				D[r0:r0 + nx, c0:c0 + ny] = o['stat']
+				if not o['symmetric']:
+					P[c0:c0 + ny, r0:r0 + nx] = o['p'].T
+					D[c0:c0 + ny, r0:r0 + nx] = o['stat'].T
+		return P, D, V

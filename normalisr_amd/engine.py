@@ -1,0 +1,181 @@
+"""Device orchestration of the association hot path: numpy in -> HBM -> HIP kernels (through the C ABI
+of libnormalisr_hip.so) -> numpy out.  torch is used only as plumbing: device memory, the current HIP
+stream and (in normalisr_amd.distributed) RCCL collectives.  There is no CPU fallback here.
+
+Data layout in HBM:
+  residualised rows   fp64 [rows_pad][k_pad]   rows_pad % 128 == 0, k_pad % 16 == 0, zero padded
+  sums of squares     fp64 [rows_pad]
+  dot                 fp64 [m_pad][n_pad]
+  outputs p / stat    out dtype [nx][ny]
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import NRM_F32, NRM_F64, ROW_TILE, K_TILE
+
+
+def _torch():
+	import torch
+	if not torch.cuda.is_available():
+		raise RuntimeError('normalisr_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback.')
+	return torch
+
+
+def _round_up(v, m):
+	return (v + m - 1) // m * m
+
+
+def _code(dtype):
+	return NRM_F64 if np.dtype(dtype) == np.float64 else NRM_F32
+
+
+def as_input(a):
+	"""C-contiguous fp32/fp64 view or copy of a 2-D array (ints and other floats -> fp64)."""
+	a = np.asarray(a)
+	if a.dtype not in (np.float32, np.float64):
+		a = a.astype(np.float64)
+	return np.ascontiguousarray(a)
+
+
+class Residualized:
+	"""Residualised rows resident in HBM, plus their sums of squares and OLS coefficients."""
+
+	def __init__(self, rows, n, data, ss, coef):
+		self.rows, self.n = rows, n
+		self.data, self.ss, self.coef = data, ss, coef
+		self.rows_pad, self.k_pad = data.shape
+
+
+class Engine:
+	def __init__(self, device=None):
+		torch = _torch()
+		self.torch = torch
+		self.lib = _lib.load()
+		self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+
+	def _stream(self):
+		return self.torch.cuda.current_stream(self.device).cuda_stream
+
+	def upload(self, a, dtype=None):
+		t = self.torch.from_numpy(np.ascontiguousarray(a))
+		if dtype is not None:
+			t = t.to(dtype)
+		return t.to(self.device, non_blocking=False)
+
+	def covariates(self, dc, dci):
+		"""fp64 covariates and pseudo-inverse on the device (replicated; tiny)."""
+		torch = self.torch
+		nc = dc.shape[0]
+		if nc == 0:
+			return None, None
+		return self.upload(np.asarray(dc, dtype=np.float64)), self.upload(np.asarray(dci, dtype=np.float64).reshape(nc, nc))
+
+	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None):
+		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n)."""
+		torch = self.torch
+		with torch.cuda.device(self.device):
+			if isinstance(x, np.ndarray):
+				x = self.upload(as_input(x))
+			rows, n = x.shape
+			nc = 0 if d_c is None else d_c.shape[0]
+			rp = _round_up(max(rows, 1), ROW_TILE) if rows_pad is None else rows_pad
+			kp = _round_up(n, K_TILE)
+			out = torch.empty((rp, kp), dtype=torch.float64, device=self.device)
+			ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
+			coef = torch.zeros((rows, nc), dtype=torch.float64, device=self.device) if want_coef else None
+			_lib.check(self.lib.nrm_residualize(
+				x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
+				0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
+				0 if d_dci is None else d_dci.data_ptr(), int(rank),
+				out.data_ptr(), kp, rp, ss.data_ptr(), 0 if coef is None else coef.data_ptr(), self._stream()))
+		return Residualized(rows, n, out, ss, coef)
+
+	def gram(self, a, b, symmetric):
+		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T on the fp64 matrix cores."""
+		torch = self.torch
+		with torch.cuda.device(self.device):
+			dot = torch.empty((a.rows_pad, b.rows_pad), dtype=torch.float64, device=self.device)
+			_lib.check(self.lib.nrm_gram_f64(a.data.data_ptr(), b.data.data_ptr(), a.rows_pad, b.rows_pad, a.k_pad,
+											 a.data.stride(0), b.data.stride(0), dot.data_ptr(), dot.stride(0),
+											 1 if symmetric else 0, self._stream()))
+		return dot
+
+	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None):
+		"""K3: p, stat (covariance or gamma) and optionally Pearson r and t for every pair."""
+		torch = self.torch
+		tdt = torch.float64 if np.dtype(out_dtype) == np.float64 else torch.float32
+		with torch.cuda.device(self.device):
+			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
+			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
+			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
+			t = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
+			if flags is None:
+				flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+			_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), ssx.data_ptr(), ssy.data_ptr(), nx, ny,
+												int(n_cells), float(dof), 1 if symmetric else 0, int(stat_kind),
+												p.data_ptr(), stat.data_ptr(), 0 if r is None else r.data_ptr(),
+												0 if t is None else t.data_ptr(), _code(out_dtype), max(ny, 1),
+												flags.data_ptr(), self._stream()))
+		return p, stat, r, t, flags
+
+	def alpha(self, gamma, bx, by, nc):
+		torch = self.torch
+		nx, ny = gamma.shape
+		with torch.cuda.device(self.device):
+			out = torch.empty((nx, ny, nc), dtype=gamma.dtype, device=self.device)
+			code = NRM_F64 if gamma.dtype == torch.float64 else NRM_F32
+			_lib.check(self.lib.nrm_alpha(gamma.data_ptr(), code, gamma.stride(0), bx.data_ptr(), by.data_ptr(), nx, ny, nc,
+										  out.data_ptr(), code, self._stream()))
+		return out
+
+	@staticmethod
+	def check_flags(flags):
+		f = flags.cpu().numpy()
+		if f[0] or f[1]:
+			raise AssertionError('association results failed the reference assertions (association.py:248,252): '
+								 '{} tiles with non-finite values, {} tiles with R^2 > 1+1e-8'.format(int(f[0]), int(f[1])))
+
+	def variances(self, ss, count, n_cells, out_dtype):
+		"""ss/n with the variance 0 -> 1 substitution (association.py:230-233)."""
+		v = ss[:count].cpu().numpy() / float(n_cells)
+		v[v == 0] = 1
+		return v.astype(out_dtype, copy=False)
+
+	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False):
+		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric)."""
+		samexy = dy is None
+		nx, n = dx.shape
+		ny = nx if samexy else dy.shape[0]
+		nc = dc.shape[0]
+		dof = n - 1 - rank - dimreduce
+		d_c, d_dci = self.covariates(dc, dci)
+		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
+		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
+		dot = self.gram(rx, ry, samexy)
+		stat_kind = 0 if (samexy or return_dot) else 1
+		p, stat, r, t, flags = self.sweep(dot, rx.ss, ry.ss, nx, ny, n, dof, samexy, stat_kind, out_dtype, want_rt)
+		alpha = None
+		if want_alpha:
+			if nc > 0 and not samexy and stat_kind == 1:
+				alpha = self.alpha(stat, rx.coef, ry.coef, nc).cpu().numpy()
+			else:
+				alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
+		self.check_flags(flags)
+		res = dict(p=p.cpu().numpy(), stat=stat.cpu().numpy(), alpha=alpha,
+				   varx=None if samexy else self.variances(rx.ss, nx, n, out_dtype),
+				   vary=self.variances(ry.ss, ny, n, out_dtype), dof=dof)
+		if want_rt:
+			res['r'] = r.cpu().numpy()
+			res['t'] = t.cpu().numpy()
+		return res
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+	torch = _torch()
+	idx = torch.cuda.current_device() if device is None else int(device)
+	if idx not in _engines:
+		_engines[idx] = Engine(idx)
+	return _engines[idx]

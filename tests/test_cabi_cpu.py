@@ -1,0 +1,97 @@
+"""CPU-only checks of the boundary: the C-ABI library loads, exports what include/normalisr_hip.h
+declares, its host-side p-value plan is right, and the Python mirror validates arguments like the
+reference does.  No kernels are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, relerr
+from normalisr_amd import _lib
+
+
+def test_library_exports_declared_symbols():
+	hdr = open(os.path.join(ROOT, 'include', 'normalisr_hip.h')).read()
+	declared = set(re.findall(r'\b(nrm_[a-z0-9_]+)\s*\(', hdr))
+	assert len(declared) >= 10
+	lib = ctypes.CDLL(_lib.LIB_PATH)
+	for name in declared:
+		assert hasattr(lib, name), name
+	assert declared == set(_lib.exported_symbols())
+	assert _lib.load().nrm_version() >= 100
+
+
+def _plan(dof):
+	plan = _lib.PvaluePlan()
+	_lib.check(_lib.load().nrm_pvalue_plan_init(ctypes.byref(plan), float(dof)))
+	return plan
+
+
+def test_pvalue_plan_matches_oracle():
+	from scipy.special import erfcx  # numpy stand-in for the device formula, host-side check only
+	for dof in (16., 37., 297., 9996., 99979., 499996.):
+		plan = _plan(dof)
+		assert plan.a == dof / 2 and plan.umax == 1.5
+		u = np.concatenate([[0.], np.geomspace(1e-12, 1.5, 200)])
+		u = u[plan.alpha * u < 700]
+		r2 = -np.expm1(-u)
+		x = 1 - r2
+		w = 1 - x
+		uu = -np.log1p(-w)
+		z = plan.alpha * uu
+		poly = np.polyval(np.array(plan.coef[:])[::-1], uu)
+		p = np.exp(-z) * (erfcx(np.sqrt(z)) + np.sqrt(z) * poly)
+		ref = oracle.pvalues(r2, dof)
+		assert relerr(p, ref) < 2e-12, dof
+	small = _plan(5.)
+	assert small.umax == 0.  # continued fraction only
+	lnf = small.ln_front
+	from math import lgamma, log, pi
+	assert abs(lnf - (lgamma(3.0) - lgamma(2.5) - 0.5 * log(pi))) < 1e-14
+	with pytest.raises(ValueError):
+		_plan(0.)
+
+
+def test_argument_validation_before_device():
+	from normalisr_amd.association import association_tests, inv_rank
+	x = np.zeros((3, 10))
+	c = np.ones((1, 10))
+	with pytest.raises(ValueError):
+		association_tests(x, None, c, single=7)
+	with pytest.raises(ValueError):
+		association_tests(x, np.zeros((2, 9)), c)
+	with pytest.raises(ValueError):
+		association_tests(x[:, :2], None, c[:, :2])  # n <= rank + 1
+	with pytest.raises(NotImplementedError):
+		association_tests(x, None, c, single=1)
+	with pytest.raises(TypeError):
+		association_tests(x, None, c, bogus=1)
+	with pytest.raises(ValueError):
+		inv_rank(np.zeros((2, 3)))
+	with pytest.raises(ValueError):
+		inv_rank(np.eye(2), tol=0)
+
+
+def test_inv_rank_matches_golden(golden):
+	from normalisr_amd.association import inv_rank
+	g = golden('G4_invrank')
+	for i in range(int(g['ncase'])):
+		mi, r = inv_rank(g['m{}'.format(i)])
+		assert r == int(g['r{}'.format(i)]) and isinstance(r, int)
+		ref = g['mi{}'.format(i)]
+		assert np.abs(mi - ref).max() <= 1e-9 * np.abs(ref).max()
+	m3 = np.stack([g['m0'], g['m0'] * 2])
+	mi, r = inv_rank(m3)
+	assert mi.shape == m3.shape and (r == int(g['r0'])).all()
+
+
+def test_missing_device_fails_loudly():
+	import torch
+	if torch.cuda.is_available():
+		pytest.skip('GPU present')
+	import normalisr_amd.normalisr as norm
+	with pytest.raises(RuntimeError):
+		norm.coex(np.random.default_rng(0).normal(size=(4, 30)), np.ones((1, 30)))

@@ -1,0 +1,275 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors generated from the reference.  Tolerances (BASELINE.json north_star): integers/zeros/shapes
+bit-exact; Pearson r, t and p within 1e-6 relative.  A pure relative bound is meaningless where the
+true value is ~0 (r of an uncorrelated pair) or subnormal (p < 2.3e-308), so each comparison carries
+an explicit absolute floor, stated at the call site."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6  # north-star tolerance on r, t, p
+R_FLOOR = 1e-12  # |r| below this is rounding noise of an fp64 dot product over <=1e5 cells
+P_TINY = 2.3e-308  # below: subnormal, compared absolutely
+
+
+def close(a, b, rtol=RTOL, floor=0.):
+	return relerr(a, b, floor) < rtol
+
+
+def p_close(p, ref, rtol=RTOL):
+	p, ref = np.asarray(p, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+	normal = ref >= P_TINY
+	ok = relerr(p[normal], ref[normal]) < rtol if normal.any() else True
+	return ok and np.all(np.abs(p[~normal] - ref[~normal]) <= 1e-307)
+
+
+@pytest.fixture(scope='module')
+def norm():
+	import normalisr_amd.normalisr as norm
+	return norm
+
+
+@pytest.fixture(scope='module')
+def eng():
+	from normalisr_amd.engine import get_engine
+	return get_engine()
+
+
+def test_pvalue_kernel_table(golden, eng):
+	"""K3 arithmetic alone against scipy's table (G3) and the oracle, all dof regimes incl. dof < 16."""
+	import torch
+	from normalisr_amd import _lib
+	g = golden('G3_ptable')
+	dof, r2, ref = g['dof'], g['r2'], g['p']
+	d_r2 = torch.from_numpy(r2).cuda()
+	d_p = torch.empty_like(d_r2)
+	worst = 0.
+	for i, d in enumerate(dof):
+		_lib.check(eng.lib.nrm_pvalues_from_r2(d_r2.data_ptr(), r2.size, float(d), d_p.data_ptr(), 0))
+		torch.cuda.synchronize()
+		p = d_p.cpu().numpy()
+		normal = ref[i] >= P_TINY
+		worst = max(worst, relerr(p[normal], ref[i][normal]))
+		assert np.all(np.abs(p[~normal] - ref[i][~normal]) <= 1e-307)
+		assert p[r2 == 0][0] == 1.0 and p[r2 == 1][0] == 0.0
+		assert relerr(p[normal], oracle.pvalues(r2, d)[normal]) < 1e-9
+	assert worst < 1e-9, worst  # far inside the 1e-6 north-star bound
+	# R^2 a hair above 1 (rounding) clips to p = 0; NaN propagates
+	x = torch.tensor([1 + 5e-9, float('nan'), 0.5], dtype=torch.float64).cuda()
+	o = torch.empty_like(x)
+	_lib.check(eng.lib.nrm_pvalues_from_r2(x.data_ptr(), 3, 100., o.data_ptr(), 0))
+	o = o.cpu().numpy()
+	assert o[0] == 0. and np.isnan(o[1]) and 0 < o[2] < 1
+
+
+def test_gram_kernel_layout(eng):
+	"""K2 alone with exact small-integer data and asymmetric operands (catches row/col swaps of the MFMA maps)."""
+	import torch
+	from normalisr_amd.engine import Residualized
+	rng = np.random.default_rng(11)
+	a = rng.integers(-3, 4, (256, 48)).astype(np.float64)
+	b = rng.integers(-3, 4, (128, 48)).astype(np.float64)
+	A = Residualized(256, 48, torch.from_numpy(a).cuda(), None, None)
+	B = Residualized(128, 48, torch.from_numpy(b).cuda(), None, None)
+	dot = eng.gram(A, B, False).cpu().numpy()
+	assert np.array_equal(dot, a @ b.T)
+	dot = eng.gram(A, A, True).cpu().numpy()
+	ref = a @ a.T
+	assert np.array_equal(dot[:128], ref[:128]) and np.array_equal(dot[128:, 128:], ref[128:, 128:])
+
+
+def test_block_g7(golden):
+	from normalisr_amd.association import association_test_1
+	g = golden('G7_block')
+	r = association_test_1(3, 5, g['dx'], g['dy'], g['dc'], g['dci'], int(g['dcr']), lowmem=False, return_stats=True)
+	assert r[0] == 3 and r[1] == 5
+	assert p_close(r[2], g['p']) and close(r[3], g['gamma'], floor=1e-12) and close(r[4], g['alpha'], floor=1e-10)
+	assert close(r[5], g['vx'], 1e-12) and close(r[6], g['vy'], 1e-12)
+	dof = 1000 - 1 - int(g['dcr'])
+	rr, tt = oracle.pearson_r_t((g['gamma'].T * g['vx']).T, g['vx'], g['vy'], dof)
+	assert close(r[7], rr, floor=R_FLOOR) and close(r[8], tt, floor=1e-9)
+
+
+def test_c1_de_coex_golden(golden, norm):
+	g = golden('G1_c1')
+	dt, dc, dg = g['dt'], g['dc'], g['dg']
+	for lm in (1, 0):
+		p, gam, a, vg, vt = norm.de(dg, dt, dc, lowmem=bool(lm))
+		k = 'de_lm{}_'.format(lm)
+		assert p.shape == (4, 500) and p.dtype == np.float64
+		assert p_close(p, g[k + 'p']) and close(gam, g[k + 'gamma'], floor=1e-12)
+		assert close(vg, g[k + 'varg'], 1e-12, 1e-300) and close(vt, g[k + 'vart'], 1e-12, 1e-300)
+		assert (a is None) if lm else close(a, g[k + 'alpha'], floor=1e-10)
+		# constant grouping row re-inflated exactly (de.py:107-122)
+		assert (p[2] == 1).all() and (gam[2] == 0).all() and vg[2] == 0 and (vt[2] == 0).all()
+	ns = int(g['coex_n'])
+	p, d, v = norm.coex(dt[:ns], dc)
+	assert p_close(p, g['coex_p']) and close(d, g['coex_dot'], floor=1e-13) and close(v, g['coex_var'], 1e-12)
+	# bit-exact structure: zero diagonals and exact symmetry (association.py:1050-1057)
+	assert (np.diag(p) == 0).all() and (np.diag(d) == 0).all() and (p == p.T).all() and (d == d.T).all()
+	from normalisr_amd.association import association_tests
+	p, d, a, vx, vy = association_tests(dg[[0, 1, 3]], dt[:64], dc, return_dot=True)
+	assert p_close(p, g['at_p']) and close(d, g['at_dot'], floor=1e-13) and close(vx, g['at_vx'], 1e-12) and a is None
+
+
+def test_edge_cases_golden(golden, norm):
+	from normalisr_amd.association import association_tests
+	g = golden('G2_edge')
+	dt, dc, dg = g['dt'], g['dc'], g['dg']
+	n = dt.shape[1]
+	p, gam, a, vg, vt = norm.de(dg, dt, np.zeros((0, n)))
+	assert p_close(p, g['nc0_de_p']) and close(gam, g['nc0_de_gamma'], floor=1e-12) and close(vt, g['nc0_de_vart'], 1e-12)
+	p, d, v = norm.coex(dt[:40], np.zeros((0, n)))
+	assert p_close(p, g['nc0_coex_p']) and close(d, g['nc0_coex_dot'], floor=1e-13)
+	p, gam, a, vg, vt = norm.de(dg, dt, g['rd_dc'], lowmem=False)  # rank 3 of 5
+	assert p_close(p, g['rd_de_p']) and close(gam, g['rd_de_gamma'], floor=1e-12) and close(vt, g['rd_de_vart'], 1e-9)
+	p, d, v = norm.coex(dt[:40], g['rd_dc'])
+	assert p_close(p, g['rd_coex_p']) and close(v, g['rd_coex_var'], 1e-9)
+	p, gam, a, vg, vt = norm.de(dg, dt, dc, dimreduce=2)
+	assert p_close(p, g['dr2_de_p'])
+	p, d, v = norm.coex(dt[:40], dc, dimreduce=2)
+	assert p_close(p, g['dr2_coex_p'])
+	p, gam, a, vg, vt = norm.de(dg.astype(np.int64), dt, dc)
+	assert p_close(p, g['int_de_p']) and p.dtype == np.float64 and close(vg, g['int_de_varg'], 1e-12)
+	p, d, a, vx, vy = association_tests(dg, dt, dc, bsx=2, bsy=13)
+	assert p_close(p, g['tile_at_p']) and close(d, g['tile_at_dot'], floor=1e-13)
+	p, d, a, vx, vy = association_tests(dt[:45], None, dc, bsx=7)
+	assert p_close(p, g['tile_coex_p']) and vx is None and close(vy, g['tile_coex_vy'], 1e-12)
+	p, d, v = norm.coex(dt[:45], dc, bs=7)  # `bs` alias accepted (the reference crashes here)
+	assert p_close(p, g['tile_coex_p'])
+	# zero-variance gene: variance reported as 1, p = 1, dot = 0 (association.py:231-233)
+	dz = g['zc_dt']
+	p, d, v = norm.coex(dz, dc)
+	assert v[5] == 1 and (p[5] == np.where(np.arange(30) == 5, 0, 1)).all() and (d[5] == 0).all()
+	assert p[6, 7] == 0. and p[7, 6] == 0.  # collinear pair: R^2 -> 1 => p = 0
+	ok = np.ones_like(p, dtype=bool)
+	ok[6, 7] = ok[7, 6] = False
+	assert p_close(p[ok], g['zc_coex_p'][ok])
+	p, gam, a, vg, vt = norm.de(dg, dz, dc)
+	assert p_close(p, g['zc_de_p']) and close(vt, g['zc_de_vart'], 1e-12, 1e-300)
+	# fp32 inputs: oracle = reference run in fp64 on the same fp32-representable values
+	dt32, dc32, dg32 = dt.astype(np.float32), dc.astype(np.float32), dg.astype(np.float32)
+	p, gam, a, vg, vt = norm.de(dg32, dt32, dc32)
+	assert p.dtype == np.float32 and gam.dtype == np.float32 and vt.dtype == np.float32
+	assert close(p, g['f32_de_p'], 1e-6, 1e-38) and close(gam, g['f32_de_gamma'], 1e-6, 1e-7)
+	p, d, v = norm.coex(dt32[:40], dc32)
+	assert p.dtype == np.float32 and close(p, g['f32_coex_p'], 1e-6, 1e-38) and close(v, g['f32_coex_var'], 1e-6)
+	# strong effects: tiny p-values keep their relative accuracy
+	p, gam, a, vg, vt = norm.de(dg, g['se_dt'], dc)
+	assert p_close(p, g['se_de_p']) and g['se_de_p'].min() < 1e-20
+
+
+def _synthetic(seed, nx, ny, n, nc, dtype=np.float64):
+	rng = np.random.default_rng(seed)
+	lat = rng.normal(size=(2, n))
+	dy = rng.normal(size=(ny, n)) + 0.3 * rng.normal(size=(ny, 2)) @ lat + rng.normal(size=(ny, 1)) * 3
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))]) if nc else np.zeros((0, n))
+	dx = None
+	if nx:
+		dx = (rng.random((nx, n)) < 0.2).astype(np.float64) + 0.1 * lat[:1]
+	cast = lambda a: None if a is None else a.astype(dtype)
+	return cast(dx), cast(dy), cast(dc)
+
+
+@pytest.mark.parametrize('ng,n,nc', [(300, 1000, 3), (517, 2049, 4), (129, 333, 1), (64, 5000, 0)])
+def test_coex_vs_oracle_seeded(norm, ng, n, nc):
+	from normalisr_amd.association import association_tests
+	_, dt, dc = _synthetic(100 + ng, 0, ng, n, nc)
+	p, d, a, vx, v, st = association_tests(dt, None, dc, return_stats=True)
+	po, do, vo = oracle.coex(dt, dc)
+	assert p_close(p, po) and close(d, do, floor=1e-13) and close(v, vo, 1e-12)
+	assert (np.diag(p) == 0).all() and (p == p.T).all() and (d == d.T).all()
+	dof = st['dof']
+	assert dof == n - 1 - min(nc, np.linalg.matrix_rank(dc) if nc else 0)
+	rr, tt = oracle.pearson_r_t(do, vo, vo, dof)
+	off = ~np.eye(ng, dtype=bool)
+	assert close(st['r'][off], rr[off], floor=R_FLOOR) and close(st['t'][off], tt[off], floor=1e-9)
+
+
+@pytest.mark.parametrize('nx,ny,n,nc', [(5, 700, 1500, 3), (130, 260, 800, 2), (1, 1000, 4097, 20)])
+def test_de_vs_oracle_seeded(norm, nx, ny, n, nc):
+	dg, dt, dc = _synthetic(200 + nx, nx, ny, n, nc)
+	p, gam, al, vg, vt = norm.de(dg, dt, dc, lowmem=False)
+	po, go, ao, vgo, vto = oracle.de(dg, dt, dc, lowmem=False)
+	assert p_close(p, po) and close(gam, go, floor=1e-12) and close(al, ao, floor=1e-9)
+	assert close(vg, vgo, 1e-12) and close(vt, vto, 1e-12)
+
+
+def test_fp32_inputs_vs_fp64_oracle(norm):
+	dg, dt, dc = _synthetic(7, 3, 400, 3000, 3, np.float32)
+	p, gam, al, vg, vt = norm.de(dg, dt, dc)
+	po, go, ao, vgo, vto = oracle.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
+	assert p.dtype == np.float32
+	# fp64 arithmetic inside, one final rounding to fp32 (6e-8): bound 1e-6 with fp32 floors
+	assert close(p, po, 1e-6, 1e-38) and close(gam, go, 1e-6, 1e-7) and close(vt, vto, 1e-6)
+
+
+def test_host_entry_numpy_in_out(eng):
+	"""nrm_association_tests_host: the whole-problem C entry without any torch plumbing."""
+	from normalisr_amd import _lib
+	dg, dt, dc = _synthetic(9, 6, 150, 700, 3)
+	dci, rank = oracle.inv_rank(dc @ dc.T)
+	nx, ny, n, nc = 6, 150, 700, 3
+	p = np.empty((nx, ny))
+	gam = np.empty((nx, ny))
+	al = np.empty((nx, ny, nc))
+	vx = np.empty(nx)
+	vy = np.empty(ny)
+	r = np.empty((nx, ny))
+	t = np.empty((nx, ny))
+	vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+	_lib.check(eng.lib.nrm_association_tests_host(vp(dg), 1, nx, vp(dt), 1, ny, vp(dc), 1, nc, n, vp(dci), rank, 0, 0,
+												  vp(p), vp(gam), vp(al), vp(vx), vp(vy), vp(r), vp(t), 1))
+	po, go, ao, vxo, vyo = oracle.association_tests(dg, dt, dc, lowmem=False, return_dot=False)
+	assert p_close(p, po) and close(gam, go, floor=1e-12) and close(al, ao, floor=1e-9)
+	assert close(vx, vxo, 1e-12) and close(vy, vyo, 1e-12)
+	# coex through the same entry (dy = NULL), fp32 in/out
+	dt32 = dt[:90].astype(np.float32)
+	p32 = np.empty((90, 90), dtype=np.float32)
+	d32 = np.empty((90, 90), dtype=np.float32)
+	v32 = np.empty(90, dtype=np.float32)
+	_lib.check(eng.lib.nrm_association_tests_host(vp(dt32), 0, 90, None, 0, 0, vp(dc), 1, nc, n, vp(dci), rank, 0, 1,
+												  vp(p32), vp(d32), None, None, vp(v32), None, None, 0))
+	po, do, vo = oracle.coex(dt32.astype(np.float64), dc)
+	assert close(p32, po, 1e-6, 1e-38) and close(d32, do, 1e-6, 1e-7) and (np.diag(p32) == 0).all()
+	# error mapping: too few cells -> ValueError like association.py:213-216
+	with pytest.raises(ValueError):
+		_lib.check(eng.lib.nrm_association_tests_host(vp(dg), 1, nx, vp(dt), 1, ny, vp(dc), 1, nc, 4, vp(dci), rank, 0, 0,
+													  vp(p), vp(gam), None, vp(vx), vp(vy), None, None, 1))
+
+
+def test_nonfinite_input_raises_assertion(norm):
+	_, dt, dc = _synthetic(5, 0, 70, 300, 2)
+	dt[3, 7] = np.nan
+	with pytest.raises(AssertionError):  # association.py:248,252
+		norm.coex(dt, dc)
+
+
+def test_full_size_c2_properties(norm):
+	"""BASELINE config 2 (coex 5k genes x 10k cells, fp32 in): size-independent properties plus a
+	sampled comparison against the oracle on the sampled genes."""
+	rng = np.random.default_rng(2)
+	ng, n = 5000, 10000
+	lat = rng.normal(size=(1, n)).astype(np.float32)
+	dt = rng.normal(size=(ng, n)).astype(np.float32) + 0.3 * rng.normal(size=(ng, 1)).astype(np.float32) * lat
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))]).astype(np.float32)
+	p, d, v = norm.coex(dt, dc)
+	assert p.shape == (ng, ng) and p.dtype == np.float32 and v.shape == (ng, )
+	assert (np.diag(p) == 0).all() and (np.diag(d) == 0).all()
+	assert (p == p.T).all() and (d == d.T).all()
+	assert (p >= 0).all() and (p <= 1).all() and np.isfinite(d).all() and (v > 0).all()
+	idx = np.sort(rng.choice(ng, 48, replace=False))
+	po, do, vo = oracle.coex(dt[idx].astype(np.float64), dc.astype(np.float64))
+	sub = np.ix_(idx, idx)
+	assert close(p[sub], po, 1e-6, 1e-38) and close(d[sub], do, 1e-6, 1e-7) and close(v[idx], vo, 1e-6)
+	# linearity: scaling a gene leaves p unchanged and scales dot
+	dt2 = dt[idx].copy()
+	dt2[0] *= 4
+	p2, d2, v2 = norm.coex(dt2, dc)
+	assert close(p2, p[sub], 1e-5, 1e-38) and close(d2[0, 1:], 4 * d[sub][0, 1:], 1e-5, 1e-7)
