@@ -41,23 +41,39 @@ def synth_c2(ng, n, seed, device, torch, row0=0):
 	return dt, dc
 
 
-def cpu_baseline(n_cells, nc, seed, budget_genes):
-	"""Time the CPU oracle (port of association.py's tile loop, thread pool over 500x500 tiles like the
-	reference with nth = all cores, BLAS threads as configured) on a bounded gene sample of the workload."""
+def cpu_baseline_worker(ng, n_cells, nc, seed, min_seconds):
+	"""Runs in a child process started with BLAS threads pinned to 1 (the reference launcher's convention,
+	bin/normalisr:3) and times the CPU oracle's tile loop with nth = all cores on the full workload."""
 	import oracle
 	rng = np.random.default_rng(seed)
 	lat = rng.normal(size=(1, n_cells))
 	dc = np.vstack([rng.normal(size=(nc - 1, n_cells)), np.ones((1, n_cells))])
 	cores = os.cpu_count() or 1
-	dt = rng.normal(size=(budget_genes, n_cells)) + 0.3 * rng.normal(size=(budget_genes, 1)) * lat
+	dt = rng.normal(size=(ng, n_cells)) + 0.3 * rng.normal(size=(ng, 1)) * lat
 	oracle.coex(dt[:64], dc)  # warm-up (library load)
-	t0 = time.perf_counter()
-	oracle.coex(dt, dc, nth=cores)
-	dt_s = time.perf_counter() - t0
-	pairs = budget_genes * (budget_genes - 1) // 2
-	return dict(value=pairs / dt_s, unit='tests/s', cores=cores, kind='port',
-				sample='coex on {} genes x {} cells fp64 ({} pairs, {:.1f} s), oracle tile loop with nth={} threads'.format(
-					budget_genes, n_cells, pairs, dt_s, cores))
+	reps, t0 = 0, time.perf_counter()
+	while True:
+		oracle.coex(dt, dc, nth=cores)
+		reps += 1
+		el = time.perf_counter() - t0
+		if el >= min_seconds or reps >= 50:
+			break
+	pairs = ng * (ng - 1) // 2
+	print(json.dumps(dict(value=pairs * reps / el, unit='tests/s', cores=cores, kind='port',
+						  sample='{} pass(es) of coex on {} genes x {} cells fp64 ({} pairs each) in {:.1f} s; CPU oracle tile loop '
+						  '(500x500 tiles, per-tile residualisation as association.py:224-249), thread pool nth={}, BLAS threads=1'.format(
+							  reps, ng, n_cells, pairs, el, cores))))
+
+
+def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0):
+	import subprocess
+	env = dict(os.environ)
+	for k in ('OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS', 'OMP_NUM_THREADS'):
+		env[k] = '1'
+	env['HIP_VISIBLE_DEVICES'] = ''
+	r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(ng), str(n_cells), str(nc), str(seed), str(min_seconds)],
+					   env=env, stdout=subprocess.PIPE, text=True, timeout=600)
+	return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def main():
@@ -67,15 +83,25 @@ def main():
 	ap.add_argument('--warmup', type=int, default=3)
 	ap.add_argument('--genes', type=int, default=5000, help='genes at N=1 (scaled by sqrt(N) for N>1)')
 	ap.add_argument('--cells', type=int, default=10000)
-	ap.add_argument('--cpu-genes', type=int, default=3000, help='gene sample for the CPU baseline (0 = skip)')
+	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
+	ap.add_argument('--cpu-worker', nargs=5, default=None, help=argparse.SUPPRESS)
 	ap.add_argument('--seed', type=int, default=2)
 	args = ap.parse_args()
+	if args.cpu_worker:
+		w = args.cpu_worker
+		cpu_baseline_worker(int(w[0]), int(w[1]), int(w[2]), int(w[3]), float(w[4]))
+		return
 
-	import torch
-	from normalisr_amd import distributed as nd
 	world = int(os.environ.get('WORLD_SIZE', '1'))
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	cpu = None
+	if world == 1 and args.cpu_seconds > 0:
+		# CPU baseline first, in a child process, before this process touches the GPU
+		cpu = cpu_baseline(int(round(args.genes)), args.cells, 3, args.seed, args.cpu_seconds)
+
+	import torch
+	from normalisr_amd import distributed as nd
 	if args.gpus != world:
 		if world == 1 and args.gpus > 1:
 			raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {}'.format(args.gpus, args.gpus))
@@ -128,10 +154,7 @@ def main():
 				   roofline=dict(bound='mfma', kernel='k_gram_f64', achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
 								 frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=None, kernel_ms=gram_ms),
 				   kernels_ms=plan.kernel_breakdown())
-		if world == 1 and args.cpu_genes > 0:
-			out['cpu_baseline'] = cpu_baseline(n, 3, args.seed, args.cpu_genes)
-		else:
-			out['cpu_baseline'] = None
+		out['cpu_baseline'] = cpu
 		print(json.dumps(out))
 	if world > 1:
 		torch.distributed.destroy_process_group()

@@ -47,6 +47,13 @@ def load():
 	if not os.path.exists(LIB_PATH):
 		raise RuntimeError('libnormalisr_hip.so is not built ({}). Run `python -m normalisr_amd.build` '
 						   '(needs hipcc); there is no CPU fallback.'.format(LIB_PATH))
+	# One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  If it is
+	# loaded first our DT_NEEDED entry binds to it; the other order would load /opt/rocm's copy next to
+	# torch's and the second runtime finds no device.  torch is the plumbing for device memory anyway.
+	try:
+		import torch  # noqa: F401
+	except ImportError:
+		pass
 	lib = ctypes.CDLL(LIB_PATH)
 	for name, (args, res) in _SIGNATURES.items():
 		f = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
