@@ -6,16 +6,22 @@
 //
 // Geometry (MFMA-bound; 2*n_cell flop per pair):
 //   workgroup tile 128 x 128, 256 threads = 4 waves as 2(M) x 2(N); each wave owns 64 x 64 = 4 x 4 MFMA
-//   tiles (64 fp64 accumulators per lane).  K is consumed in slabs of GK = 16 cells staged through a
-//   double-buffered LDS image [row][k] with an 18-element pitch: with 144-byte rows the 16 rows a
-//   ds_read_b64 wave-instruction touches per half-wave land on 16 distinct 4-bank groups (conflict-free),
-//   and every 16-byte staging store stays 16-byte aligned.
+//   tiles (64 fp64 accumulators per lane, kept in VGPRs: with AGPR accumulators this instruction issues
+//   at half rate on MI355X, tools/mfma_peak.hip).  K is consumed in slabs of GK = 16 cells staged through
+//   a double-buffered LDS image [row][k] with an 18-element pitch: 144-byte rows keep every 16-byte
+//   staging store aligned and spread the 16 rows of an operand read over the banks.
 //   MFMA operand maps (f64 16x16x4): lane l supplies A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15];
 //   it receives D[row = (l >> 4) + 4 q][col = l & 15] in accumulator element q.
-//   Global -> register -> LDS staging: next slab's loads are issued before the MFMA block of the current
-//   slab and stored to the other LDS buffer after it (one barrier per slab); two workgroups per CU
-//   (74 KB LDS each) cover each other's barrier bubbles.
-//   Symmetric (coex) launches only enumerate tiles on or above the block diagonal (association.py:893-894).
+//   Global -> register -> LDS staging: the next slab's loads are issued before the MFMA block of the
+//   current slab and stored to the other LDS buffer after it (one barrier per slab); two workgroups per
+//   CU (74 KB LDS each) cover each other's barrier bubbles.
+//
+// Scheduling (persistent, "data-parallel + stream-K"): the launch is 2 workgroups per CU.  Whole waves of
+// tiles are processed tile-per-workgroup with all workgroups in K-lockstep (operand slabs shared through
+// L2); the tiles of the last partial wave are cut along K into equal unit ranges so every workgroup
+// finishes together (820 tiles on 512 slots would otherwise idle 20 % of the chip).  Tile pieces that do
+// not cover the whole K range are combined with fp64 atomic adds into the zero-initialised output.
+// Symmetric (coex) launches only enumerate tiles on or above the block diagonal (association.py:893-894).
 #include "nrm_common.h"
 
 #define GM 128
@@ -25,39 +31,40 @@
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void gram_tile_coords(int symmetric, int ntn, int& ti, int& tj) {
+__device__ __forceinline__ void gram_tile_coords(int t, int symmetric, int ntn, int& ti, int& tj) {
 	if (!symmetric) {
-		ti = blockIdx.y;
-		tj = blockIdx.x;
+		ti = t / ntn;
+		tj = t - ti * ntn;
 		return;
 	}
 	// linear index over the upper triangle, row by row: row i holds tiles (i, i..ntn-1)
-	int b = blockIdx.x;
 	int i = 0, len = ntn;
-	while (b >= len) {
-		b -= len;
+	while (t >= len) {
+		t -= len;
 		i++;
 		len--;
 	}
 	ti = i;
-	tj = i + b;
+	tj = i + t;
 }
 
-__global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ A, const double* __restrict__ B, int64_t lda,
-													  int64_t ldb, int nk, double* __restrict__ C, int64_t ldc, int symmetric,
-													  int ntn) {
-	__shared__ __attribute__((aligned(16))) double lds[2][2][GM * GP];  // [buffer][A|B][row*GP + k]
-	int ti, tj;
-	gram_tile_coords(symmetric, ntn, ti, tj);
+// One tile piece: k-tiles [kt0, kt1) of tile (ti, tj).  atomic != 0 -> accumulate into C, else store.
+__device__ __forceinline__ void gram_piece(const double* __restrict__ A, const double* __restrict__ B, int64_t lda, int64_t ldb,
+										   double* __restrict__ C, int64_t ldc, int ti, int tj, int kt0, int kt1, int atomic,
+										   double* lds /* [2][2][GM*GP] */) {
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int wm = wid >> 1, wn = wid & 1;
 	const int l15 = lane & 15, lg = lane >> 4;
-
 	// staging map: 8 consecutive lanes cover one 128-byte row slab; 4 passes of 32 rows
 	const int srow = tid >> 3, scol = (tid & 7) * 2;
-	const double* ga = A + ((int64_t)ti * GM + srow) * lda + scol;
-	const double* gb = B + ((int64_t)tj * GN + srow) * ldb + scol;
+	const double* ga = A + ((int64_t)ti * GM + srow) * lda + scol + (int64_t)kt0 * GK;
+	const double* gb = B + ((int64_t)tj * GN + srow) * ldb + scol + (int64_t)kt0 * GK;
 	const int soff = srow * GP + scol;
+	const int nk = kt1 - kt0;
+	double* ldsA0 = lds;
+	double* ldsB0 = lds + GM * GP;
+	double* ldsA1 = lds + 2 * GM * GP;
+	double* ldsB1 = lds + 3 * GM * GP;
 
 	d2_t ra[4], rb[4];
 #pragma unroll
@@ -67,8 +74,8 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 	}
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
-		*reinterpret_cast<d2_t*>(&lds[0][0][soff + j * 32 * GP]) = ra[j];
-		*reinterpret_cast<d2_t*>(&lds[0][1][soff + j * 32 * GP]) = rb[j];
+		*reinterpret_cast<d2_t*>(&ldsA0[soff + j * 32 * GP]) = ra[j];
+		*reinterpret_cast<d2_t*>(&ldsB0[soff + j * 32 * GP]) = rb[j];
 	}
 	__syncthreads();
 
@@ -92,8 +99,8 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 				rb[j] = *reinterpret_cast<const d2_t*>(gb + (int64_t)j * 32 * ldb + ko);
 			}
 		}
-		const double* la = &lds[cur][0][aoff];
-		const double* lb = &lds[cur][1][boff];
+		const double* la = (cur ? ldsA1 : ldsA0) + aoff;
+		const double* lb = (cur ? ldsB1 : ldsB0) + boff;
 #pragma unroll
 		for (int kk = 0; kk < GK / 4; kk++) {
 			double fa[4], fb[4];
@@ -108,10 +115,12 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 				for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
 		}
 		if (more) {
+			double* wa = cur ? ldsA0 : ldsA1;
+			double* wb = cur ? ldsB0 : ldsB1;
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
-				*reinterpret_cast<d2_t*>(&lds[cur ^ 1][0][soff + j * 32 * GP]) = ra[j];
-				*reinterpret_cast<d2_t*>(&lds[cur ^ 1][1][soff + j * 32 * GP]) = rb[j];
+				*reinterpret_cast<d2_t*>(&wa[soff + j * 32 * GP]) = ra[j];
+				*reinterpret_cast<d2_t*>(&wb[soff + j * 32 * GP]) = rb[j];
 			}
 		}
 		__syncthreads();
@@ -119,13 +128,67 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 
 	// epilogue: lane l holds D[row = lg + 4 q][col = l15] of each 16x16 tile
 	double* cbase = C + ((int64_t)ti * GM + wm * 64) * ldc + (int64_t)tj * GN + wn * 64;
+	if (atomic) {
 #pragma unroll
-	for (int i = 0; i < 4; i++)
+		for (int i = 0; i < 4; i++)
 #pragma unroll
-		for (int j = 0; j < 4; j++)
+			for (int j = 0; j < 4; j++)
 #pragma unroll
-			for (int q = 0; q < 4; q++) cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15] = acc[i][j][q];
+				for (int q = 0; q < 4; q++) unsafeAtomicAdd(&cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15], acc[i][j][q]);
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+#pragma unroll
+				for (int q = 0; q < 4; q++) cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15] = acc[i][j][q];
+	}
 }
+
+struct GramSched {
+	int ntn;        // tiles per row of the tile grid (N direction)
+	int nkt;        // k-tiles (slabs of GK cells)
+	int tiles_dp;   // tiles processed whole, one per workgroup per wave
+	int tiles_sk;   // tiles of the tail, cut into unit ranges
+	int units_per_wg;
+	int nwg;        // persistent workgroups (multiple of 8)
+};
+
+__global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ A, const double* __restrict__ B, int64_t lda,
+													  int64_t ldb, double* __restrict__ C, int64_t ldc, int symmetric, GramSched s) {
+	__shared__ __attribute__((aligned(16))) double lds[2 * 2 * GM * GP];
+	// workgroups that share an XCD (same blockIdx % 8) take consecutive tiles so that operand panels are shared in its L2
+	const int per_xcd = s.nwg >> 3;
+	const int p = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+	int t_dp = p;
+	int64_t u = (int64_t)p * s.units_per_wg;
+	const int64_t total = (int64_t)s.tiles_sk * s.nkt;
+	int64_t uend = u + s.units_per_wg;
+	if (uend > total) uend = total;
+	for (;;) {  // one call site for gram_piece: whole tiles first, then this workgroup's share of the tail
+		int t, k0, k1;
+		if (t_dp < s.tiles_dp) {
+			t = t_dp;
+			k0 = 0;
+			k1 = s.nkt;
+			t_dp += s.nwg;
+		} else if (u < uend) {
+			const int ts = (int)(u / s.nkt);
+			k0 = (int)(u - (int64_t)ts * s.nkt);
+			int64_t k1l = k0 + (uend - u);
+			k1 = k1l > s.nkt ? s.nkt : (int)k1l;
+			t = s.tiles_dp + ts;
+			u += k1 - k0;
+		} else {
+			break;
+		}
+		int ti, tj;
+		gram_tile_coords(t, symmetric, s.ntn, ti, tj);
+		gram_piece(A, B, lda, ldb, C, ldc, ti, tj, k0, k1, !(k0 == 0 && k1 == s.nkt), lds);
+	}
+}
+
+static int g_num_cu = 0;
 
 extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,
 							int64_t ldb, double* d_dot, int64_t ldd, int symmetric, void* stream) {
@@ -137,13 +200,29 @@ extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad,
 	if (m_pad == 0 || n_pad == 0) return NRM_OK;
 	NRM_REQUIRE(d_a && d_b && d_dot, "nrm_gram_f64: null pointer");
 	NRM_REQUIRE(((uintptr_t)d_a % 16 == 0) && ((uintptr_t)d_b % 16 == 0), "nrm_gram_f64: operands must be 16-byte aligned");
-	int ntm = (int)(m_pad / GM), ntn = (int)(n_pad / GN);
-	dim3 grid;
-	if (symmetric)
-		grid = dim3((unsigned)((int64_t)ntn * (ntn + 1) / 2));
-	else
-		grid = dim3((unsigned)ntn, (unsigned)ntm);
-	hipLaunchKernelGGL(k_gram_f64, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, lda, ldb, (int)(k_pad / GK), d_dot, ldd,
-					   symmetric, ntn);
+	if (g_num_cu == 0) {
+		int dev = 0;
+		NRM_HIP(hipGetDevice(&dev));
+		NRM_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+		if (g_num_cu <= 0) g_num_cu = 256;
+	}
+	const int64_t ntm = m_pad / GM, ntn = n_pad / GN;
+	const int64_t tiles = symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn;
+	NRM_REQUIRE(tiles < (1LL << 30) && k_pad / GK < (1LL << 30), "nrm_gram_f64: problem too large for one launch");
+	GramSched s;
+	s.ntn = (int)ntn;
+	s.nkt = (int)(k_pad / GK);
+	s.nwg = 2 * g_num_cu;
+	s.nwg -= s.nwg % 8;
+	const int64_t waves = tiles / s.nwg, rem = tiles - waves * s.nwg;
+	int64_t sk = rem;
+	if (rem > 0 && rem < s.nwg / 4 && waves >= 1) sk = rem + s.nwg;  // keep every stream-K share >= ~1 tile
+	s.tiles_sk = (int)sk;
+	s.tiles_dp = (int)(tiles - sk);
+	const int64_t units = sk * s.nkt;
+	s.units_per_wg = (int)((units + s.nwg - 1) / s.nwg);
+	if (sk > 0 && (s.units_per_wg % s.nkt) != 0)  // some tile pieces are combined atomically: the output must start from zero
+		NRM_HIP(hipMemsetAsync(d_dot, 0, (size_t)m_pad * ldd * sizeof(double), (hipStream_t)stream));
+	hipLaunchKernelGGL(k_gram_f64, dim3((unsigned)s.nwg), dim3(256), 0, (hipStream_t)stream, d_a, d_b, lda, ldb, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_f64");
 }
