@@ -86,6 +86,7 @@ def main():
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
 	ap.add_argument('--cpu-worker', nargs=5, default=None, help=argparse.SUPPRESS)
 	ap.add_argument('--seed', type=int, default=2)
+	ap.add_argument('--e2e', type=int, default=2, help='repetitions of the numpy-in/numpy-out end-to-end timing (0 = skip)')
 	args = ap.parse_args()
 	if args.cpu_worker:
 		w = args.cpu_worker
@@ -141,6 +142,18 @@ def main():
 	value = tests * args.steps / elapsed
 	gram_ms = plan.gram_ms()  # average duration of the dominant kernel launch(es) per step on this rank
 	local_pairs = plan.local_pair_count()
+	e2e = None
+	if world == 1 and args.e2e > 0:
+		# numpy in -> numpy out through the drop-in API (H2D + kernels + D2H over PCIe); reported beside `value`, never as it
+		import normalisr_amd.normalisr as norm
+		h_dt, h_dc = dt_local.cpu().numpy(), dc.cpu().numpy()
+		norm.coex(h_dt[:256], h_dc)
+		ts = []
+		for _ in range(args.e2e):
+			t1 = time.perf_counter()
+			norm.coex(h_dt, h_dc)
+			ts.append(time.perf_counter() - t1)
+		e2e = dict(seconds=min(ts), tests_per_s=ng * (ng - 1) // 2 / min(ts), note='norm.coex(numpy fp32) -> numpy, pageable host memory, PCIe inclusive')
 
 	if rank == 0:
 		flops = 2.0 * n * local_pairs  # algorithmic: 2 n_cell flop per test, tests this rank's launches cover
@@ -155,6 +168,7 @@ def main():
 								 frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=None, kernel_ms=gram_ms),
 				   kernels_ms=plan.kernel_breakdown())
 		out['cpu_baseline'] = cpu
+		out['end_to_end_pcie'] = e2e
 		print(json.dumps(out))
 	if world > 1:
 		torch.distributed.destroy_process_group()

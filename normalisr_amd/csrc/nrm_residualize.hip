@@ -116,6 +116,172 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
 }
 
+// Vectorised variant: every lane moves 4 consecutive cells per step (16-byte loads of fp32 input, 32-byte
+// loads/stores of fp64 covariates and residuals), so one wave-instruction covers 1-2 KiB of a row.
+// Needs 16-byte aligned rows: ldx % (16/sizeof(T)) == 0, ldc % 2 == 0, ldo % 4 == 0.
+template <typename T>
+struct Vec4Load;
+template <>
+struct Vec4Load<float> {
+	static __device__ __forceinline__ void ld(const float* p, double (&v)[4]) {
+		float4 t = *reinterpret_cast<const float4*>(p);
+		v[0] = t.x;
+		v[1] = t.y;
+		v[2] = t.z;
+		v[3] = t.w;
+	}
+};
+template <>
+struct Vec4Load<double> {
+	static __device__ __forceinline__ void ld(const double* p, double (&v)[4]) {
+		double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+		v[0] = a.x;
+		v[1] = a.y;
+		v[2] = b.x;
+		v[3] = b.y;
+	}
+};
+
+template <typename T, int CB>
+__global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
+														 const double* __restrict__ c, int nc, int64_t ldc,
+														 const double* __restrict__ dci, int active, double* __restrict__ out,
+														 int64_t ldo, double* __restrict__ ss, double* __restrict__ coef) {
+	__shared__ double s_part[4][RES_R * CB];
+	__shared__ double s_a[RES_R][RES_NC_MAX];
+	__shared__ double s_b[RES_R][RES_NC_MAX];
+	__shared__ double s_ss[4][RES_R];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int64_t row0 = (int64_t)blockIdx.x * RES_R;
+	const int64_t n4 = n & ~(int64_t)3;
+	const T* xr[RES_R];
+	bool live[RES_R];
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) {
+		live[r] = row0 + r < rows;
+		xr[r] = x + (live[r] ? (row0 + r) : 0) * ldx;
+	}
+	if (active) {
+		for (int c0 = 0; c0 < nc; c0 += CB) {
+			double acc[RES_R][CB];
+#pragma unroll
+			for (int r = 0; r < RES_R; r++)
+#pragma unroll
+				for (int q = 0; q < CB; q++) acc[r][q] = 0.0;
+			for (int64_t k = (int64_t)tid * 4; k < n4; k += 1024) {
+				double xv[RES_R][4];
+#pragma unroll
+				for (int r = 0; r < RES_R; r++) Vec4Load<T>::ld(xr[r] + k, xv[r]);
+#pragma unroll
+				for (int q = 0; q < CB; q++) {
+					if (c0 + q < nc) {
+						double cv[4];
+						Vec4Load<double>::ld(c + (int64_t)(c0 + q) * ldc + k, cv);
+#pragma unroll
+						for (int r = 0; r < RES_R; r++)
+#pragma unroll
+							for (int i = 0; i < 4; i++) acc[r][q] = fma(xv[r][i], cv[i], acc[r][q]);
+					}
+				}
+			}
+			for (int64_t k = n4 + tid; k < n; k += 256) {  // tail cells when n % 4 != 0
+#pragma unroll
+				for (int q = 0; q < CB; q++) {
+					if (c0 + q < nc) {
+						double cv = c[(int64_t)(c0 + q) * ldc + k];
+#pragma unroll
+						for (int r = 0; r < RES_R; r++) acc[r][q] = fma((double)xr[r][k], cv, acc[r][q]);
+					}
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < RES_R; r++)
+#pragma unroll
+				for (int q = 0; q < CB; q++) {
+					double v = wave_sum(live[r] ? acc[r][q] : 0.0);
+					if (lane == 0) s_part[wid][r * CB + q] = v;
+				}
+			__syncthreads();
+			if (tid < RES_R * CB) {
+				int r = tid / CB, q = tid % CB;
+				if (c0 + q < nc) s_a[r][c0 + q] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+			}
+			__syncthreads();
+		}
+		for (int i = tid; i < RES_R * nc; i += 256) {
+			int r = i / nc, q = i % nc;
+			double v = 0.0;
+			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], s_a[r][e], v);
+			s_b[r][q] = v;
+			if (coef && live[r]) coef[(row0 + r) * nc + q] = v;
+		}
+		__syncthreads();
+	}
+	double sq[RES_R];
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) sq[r] = 0.0;
+	for (int64_t k = (int64_t)tid * 4; k < ldo; k += 1024) {
+		double v[RES_R][4];
+		if (k < n4) {
+#pragma unroll
+			for (int r = 0; r < RES_R; r++) Vec4Load<T>::ld(xr[r] + k, v[r]);
+			if (active) {
+				for (int q = 0; q < nc; q++) {
+					double cv[4];
+					Vec4Load<double>::ld(c + (int64_t)q * ldc + k, cv);
+#pragma unroll
+					for (int r = 0; r < RES_R; r++)
+#pragma unroll
+						for (int i = 0; i < 4; i++) v[r][i] = fma(-s_b[r][q], cv[i], v[r][i]);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int64_t kk = k + i;
+#pragma unroll
+				for (int r = 0; r < RES_R; r++) v[r][i] = (kk < n) ? (double)xr[r][kk] : 0.0;
+				if (active && kk < n) {
+					for (int q = 0; q < nc; q++) {
+						double cv = c[(int64_t)q * ldc + kk];
+#pragma unroll
+						for (int r = 0; r < RES_R; r++) v[r][i] = fma(-s_b[r][q], cv, v[r][i]);
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < RES_R; r++) {
+			if (!live[r]) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
+			double* o = out + (row0 + r) * ldo + k;
+			*reinterpret_cast<double2*>(o) = make_double2(v[r][0], v[r][1]);
+			*reinterpret_cast<double2*>(o + 2) = make_double2(v[r][2], v[r][3]);
+#pragma unroll
+			for (int i = 0; i < 4; i++) sq[r] = fma(v[r][i], v[r][i], sq[r]);
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) {
+		double v = wave_sum(sq[r]);
+		if (lane == 0) s_ss[wid][r] = v;
+	}
+	__syncthreads();
+	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
+}
+
+template <typename T>
+static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, int64_t ldx, const double* c, int nc, int64_t ldc,
+							   const double* dci, int active, double* out, int64_t ldo, int64_t rows_pad, double* ss, double* coef,
+							   hipStream_t st) {
+	dim3 grid((unsigned)(rows_pad / RES_R));
+	if (!vec)
+		hipLaunchKernelGGL(k_residualize<T>, grid, dim3(256), 0, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+	else if (nc <= 4)
+		hipLaunchKernelGGL((k_residualize_v4<T, 4>), grid, dim3(256), 0, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+	else
+		hipLaunchKernelGGL((k_residualize_v4<T, 8>), grid, dim3(256), 0, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+}
+
 extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c,
 							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
 							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
@@ -130,12 +296,14 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 	NRM_REQUIRE(d_x || rows == 0, "nrm_residualize: null input");
 	int active = (rank > 0 && nc > 0) ? 1 : 0;
 	NRM_REQUIRE(!active || (d_c && d_dci && ldc >= n), "Unmatching dx/dy/dc dimensions.");
-	dim3 grid((unsigned)(rows_pad / RES_R));
+	const int64_t xa = 16 / (x_dtype == NRM_F64 ? 8 : 4);
+	const bool vec = (ldx % xa == 0) && ((uintptr_t)d_x % 16 == 0) && (ldo % 4 == 0) && ((uintptr_t)d_out % 16 == 0) &&
+					 (!active || (ldc % 2 == 0 && (uintptr_t)d_c % 16 == 0));
 	if (x_dtype == NRM_F64)
-		hipLaunchKernelGGL(k_residualize<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)d_x, rows, n, ldx, d_c,
-						   (int)nc, ldc, d_dci, active, d_out, ldo, d_ss, d_coef);
+		launch_residualize<double>(vec, (const double*)d_x, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, d_out, ldo, rows_pad, d_ss, d_coef,
+								   (hipStream_t)stream);
 	else
-		hipLaunchKernelGGL(k_residualize<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_x, rows, n, ldx, d_c,
-						   (int)nc, ldc, d_dci, active, d_out, ldo, d_ss, d_coef);
+		launch_residualize<float>(vec, (const float*)d_x, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, d_out, ldo, rows_pad, d_ss, d_coef,
+								  (hipStream_t)stream);
 	return nrm_check_launch("k_residualize");
 }

@@ -169,6 +169,90 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 	}
 }
 
+// Symmetric (coex) sweep over the upper triangle of 64x64 tiles only: every p-value is computed once and
+// written twice (direct and mirrored through an LDS transpose), halving the special-function work.
+template <typename OutT>
+__global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ss,
+														  int64_t ng, int nb, double ncells, PvalPlan pl, OutT* __restrict__ p_out,
+														  OutT* __restrict__ stat_out, int64_t ldo, int32_t* __restrict__ flags) {
+	__shared__ double tile[SW_T][SW_T + 1];
+	__shared__ double sx[SW_T], sy[SW_T];
+	int b = blockIdx.x, bi = 0, len = nb;
+	while (b >= len) {
+		b -= len;
+		bi++;
+		len--;
+	}
+	const int bj = bi + b;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	for (int r = ty; r < SW_T; r += 4) {
+		int64_t gi = (int64_t)bi * SW_T + r, gj = (int64_t)bj * SW_T + tx;
+		tile[r][tx] = (gi < ng && gj < ng) ? dot[gi * ldd + gj] : 0.0;
+	}
+	if (threadIdx.x < SW_T) {
+		int64_t gi = (int64_t)bi * SW_T + threadIdx.x;
+		double v = gi < ng ? ss[gi] : 1.0;
+		sx[threadIdx.x] = (v == 0.0) ? ncells : v;
+	} else if (threadIdx.x < 2 * SW_T) {
+		int t = threadIdx.x - SW_T;
+		int64_t gj = (int64_t)bj * SW_T + t;
+		double v = gj < ng ? ss[gj] : 1.0;
+		sy[t] = (v == 0.0) ? ncells : v;
+	}
+	__syncthreads();
+	int bad_nf = 0, bad_rng = 0;
+	const int64_t gj = (int64_t)bj * SW_T + tx;
+	double pv[SW_T / 4], sv[SW_T / 4];
+#pragma unroll
+	for (int i = 0; i < SW_T / 4; i++) {
+		const int r = ty + 4 * i;
+		const int64_t gi = (int64_t)bi * SW_T + r;
+		double d = (bi == bj && r > tx) ? tile[tx][r] : tile[r][tx];
+		const double vx = sx[r], vy = sy[tx];
+		const double r2 = (d * d) / (vx * vy);
+		double p = 0.0, st = 0.0;
+		if (gi < ng && gj < ng && gi != gj) {
+			if (!isfinite(r2) || !isfinite(vx) || !isfinite(vy)) bad_nf = 1;
+			if (r2 > 1.0 + 1e-8) bad_rng = 1;
+			p = nrm_pvalue(r2, pl);
+			st = d / ncells;
+		}
+		pv[i] = p;
+		sv[i] = st;
+		if (gi < ng && gj < ng) {
+			p_out[gi * ldo + gj] = (OutT)p;
+			stat_out[gi * ldo + gj] = (OutT)st;
+		}
+	}
+	if (bi != bj) {
+		const int64_t oj = (int64_t)bi * SW_T + tx;  // mirrored block: rows of block bj, columns of block bi
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = pv[i];
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < SW_T / 4; i++) {
+			const int r = ty + 4 * i;
+			const int64_t oi = (int64_t)bj * SW_T + r;
+			if (oi < ng && oj < ng) p_out[oi * ldo + oj] = (OutT)tile[tx][r];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = sv[i];
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < SW_T / 4; i++) {
+			const int r = ty + 4 * i;
+			const int64_t oi = (int64_t)bj * SW_T + r;
+			if (oi < ng && oj < ng) stat_out[oi * ldo + oj] = (OutT)tile[tx][r];
+		}
+	}
+	if (flags) {
+		if (bad_nf) atomicAdd(&flags[0], 1);
+		if (bad_rng) atomicAdd(&flags[1], 1);
+	}
+}
+
 template <typename GT, typename OutT>
 __global__ void __launch_bounds__(256) k_alpha(const GT* __restrict__ gamma, int64_t ldg, const double* __restrict__ bx,
 												const double* __restrict__ by, int64_t nx, int64_t ny, int64_t nc,
@@ -210,6 +294,17 @@ extern "C" int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d
 	if (nx == 0 || ny == 0) return NRM_OK;
 	NRM_REQUIRE(d_dot && d_ssx && d_ssy && d_p && d_stat, "nrm_assoc_sweep: null pointer");
 	NRM_REQUIRE(ldo >= ny && ldd >= ny, "nrm_assoc_sweep: pitch smaller than row length");
+	if (symmetric && !d_r && !d_t && stat_kind == 0) {
+		const int64_t nb = (nx + SW_T - 1) / SW_T;
+		dim3 g((unsigned)(nb * (nb + 1) / 2));
+		if (out_dtype == NRM_F64)
+			hipLaunchKernelGGL(k_assoc_sweep_sym<double>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
+							   (double)n_cells, to_dev(plan), (double*)d_p, (double*)d_stat, ldo, d_flags);
+		else
+			hipLaunchKernelGGL(k_assoc_sweep_sym<float>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
+							   (double)n_cells, to_dev(plan), (float*)d_p, (float*)d_stat, ldo, d_flags);
+		return nrm_check_launch("k_assoc_sweep_sym");
+	}
 	dim3 grid((unsigned)((ny + SW_T - 1) / SW_T), (unsigned)((nx + SW_T - 1) / SW_T));
 	if (out_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_assoc_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
