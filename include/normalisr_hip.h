@@ -116,6 +116,21 @@ int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d
 			  int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype, void* stream);
 
 /*
+ * single=4 sweep (competition-aware DE, association.py:421-576 in closed form).
+ * Inputs from one multiple regression of every gene on A = [dx; dc] (m = nx + nc rows):
+ *   d_bt  (ny, ldb) fp64: Bt[y,k] = coefficient of row k of A for gene y      (B = (A A^T)^-1 A Y^T)
+ *   d_pt  (ny, ldb) fp64: Pt[y,k] = A_k . y                                   (prody^T, association.py:952-967)
+ *   d_yy  (ny) fp64: sum_k y^2 (association.py:968);  d_dxx (nx) fp64: 1/(n (AA^T)^-1_ii) = variance of x_i
+ *   unexplained by all other rows (association.py:539-540).
+ * Outputs (nx, ldo) of out_dtype: p, gamma (association.py:550) or gamma*varx when return_dot, vary (:548).
+ * dof = n - 1 - (m - 1) - dimreduce is uniform for full-rank A A^T.  d_work: ny doubles of scratch.
+ */
+int nrm_single4_sweep(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
+					  int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot,
+					  void* d_p, void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags,
+					  void* stream);
+
+/*
  * Whole-problem host entry (numpy in / numpy out): the seam association_tests(dx, dy, dc, ...)
  * -> (p, dot|gamma, alpha|None, varx|None, vary) at association.py:761-771,1093 for single=0.
  * All pointers are HOST buffers owned by the caller.  h_dy == NULL means dy = dx (coex).

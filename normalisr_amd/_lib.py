@@ -27,6 +27,7 @@ _SIGNATURES = {
 	'nrm_pvalue_plan_init': ([ctypes.POINTER(PvaluePlan), _dbl], _i32),
 	'nrm_pvalues_from_r2': ([_vp, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+	'nrm_single4_sweep': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
 	'nrm_alpha': ([_vp, _i32, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp], _i32),
 	'nrm_association_tests_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32,
 									_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32], _i32),

@@ -273,3 +273,62 @@ def test_full_size_c2_properties(norm):
 	dt2[0] *= 4
 	p2, d2, v2 = norm.coex(dt2, dc)
 	assert close(p2, p[sub], 1e-5, 1e-38) and close(d2[0, 1:], 4 * d[sub][0, 1:], 1e-5, 1e-7)
+
+
+def test_single4_golden_and_oracle(golden, norm):
+	"""single=4 (other groupings as covariates): closed-form device path vs the reference's per-grouping SVD loop."""
+	g = golden('G5_single')
+	p, gam, a, vg, vt = norm.de(g['dg'], g['dt'], g['dc'], single=4, lowmem=False)
+	assert p.shape == (12, 40) and vt.shape == (12, 40) and a.shape == (12, 40, 3)
+	assert p_close(p, g['s4_p']) and close(gam, g['s4_gamma'], floor=1e-12) and close(a, g['s4_alpha'], floor=1e-10)
+	assert close(vg, g['s4_varg'], 1e-9) and close(vt, g['s4_vart'], 1e-9)
+	# larger seeded case with a constant grouping row (dropped by de) and return_dot through association_tests
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(31)
+	nx, ny, n = 70, 300, 2500
+	dg = (rng.random((nx, n)) < 0.05).astype(np.float64)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dt = rng.normal(size=(ny, n)) + (rng.normal(size=(ny, 8)) @ dg[:8]) * 0.7
+	p, d, a, vx, vy = association_tests(dg, dt, dc, single=4, return_dot=True)
+	po, do, ao, vxo, vyo = oracle.association_tests(dg, dt, dc, single=4, return_dot=True)
+	assert p_close(p, po) and close(d, do, floor=1e-12) and close(vx, vxo, 1e-9) and close(vy, vyo, 1e-9) and a is None
+	assert po.min() < 1e-30
+	# rank-deficient design (duplicated grouping): per-grouping ranks differ -> host fallback on device Gram matrices
+	dg2 = np.vstack([dg[:6], dg[0]])
+	p, gam, a, vg, vt = norm.de(dg2, dt[:50], dc, single=4)
+	po, go, ao, vgo, vto = oracle.de(dg2, dt[:50], dc, single=4)
+	assert p_close(p, po, 1e-5) and close(gam, go, 1e-5, 1e-10)
+
+
+def test_cli_round_trip_golden(golden, tmp_path):
+	"""`normalisr de|coex` on the TSV fixtures of G6: text outputs equal to the reference CLI's up to the
+	'%.8G' print precision."""
+	import gzip
+	from normalisr_amd.__main__ import main
+	g = golden('G6_cli')
+	files = {k: bytes(g[k]) for k in g.files}
+	for name in ('g_tsv', 'e_tsv_gz', 'c_tsv'):
+		raw = files[name]
+		fn = tmp_path / name.replace('_tsv', '.tsv').replace('_gz', '.gz')
+		fn.write_bytes(gzip.compress(raw) if name.endswith('gz') else raw)
+	cwd = str(tmp_path)
+	import os
+	old = os.getcwd()
+	os.chdir(cwd)
+	try:
+		assert main(['de', 'g.tsv', 'e.tsv.gz', 'c.tsv', 'pv.tsv', 'lfc.tsv', '--vard_out', 'vard.tsv', '--vart_out', 'vart.tsv', '-n', '1']) == 0
+		assert main(['de', '-m', 'covariate', 'g.tsv', 'e.tsv.gz', 'c.tsv', 'pv4.tsv', 'lfc4.tsv', '-n', '1']) == 0
+		assert main(['coex', 'e.tsv.gz', 'c.tsv', 'cpv.tsv.gz', '--var_out', 'cvar.tsv', '--dot_out', 'cdot.tsv', '-n', '1', '-d', '1', '-b', '5']) == 0
+		assert main(['de', 'g.tsv', 'e.tsv.gz', 'c.tsv', 'pv2.tsv', 'lfc2.tsv', '--clfc_out', 'clfc.tsv']) == 0  # crashes in the reference (Q9)
+	finally:
+		os.chdir(old)
+	load = lambda raw: np.loadtxt(raw.decode().splitlines(), delimiter='\t', ndmin=2)
+	for mine, ref in (('pv.tsv', 'pv_tsv'), ('lfc.tsv', 'lfc_tsv'), ('vard.tsv', 'vard_tsv'), ('vart.tsv', 'vart_tsv'),
+					  ('pv4.tsv', 'pv4_tsv'), ('lfc4.tsv', 'lfc4_tsv'), ('cpv.tsv.gz', 'cpv_tsv_gz'), ('cvar.tsv', 'cvar_tsv'),
+					  ('cdot.tsv', 'cdot_tsv')):
+		got = np.loadtxt(str(tmp_path / mine), delimiter='\t', ndmin=2)
+		exp = load(files[ref])
+		assert got.shape == exp.shape, mine
+		assert relerr(got, exp, 1e-12) < 2e-7, mine  # '%.8G' keeps 8 significant digits
+	assert np.loadtxt(str(tmp_path / 'clfc.tsv'), delimiter='\t', ndmin=2).shape == (3, 14 * 2)
+	assert main([]) == 1
