@@ -31,21 +31,44 @@
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void gram_tile_coords(int t, int symmetric, int ntn, int& ti, int& tj) {
-	if (!symmetric) {
-		ti = t / ntn;
-		tj = t - ti * ntn;
-		return;
+// Tile order: the tile grid is cut into 8x8 super-blocks that are visited one after another (row-major
+// inside a super-block).  64 consecutive tiles -- what the 64 co-resident workgroups of one XCD process at
+// the same time -- therefore touch 8 A panels and 8 B panels instead of 1 + 64, and those slabs are shared
+// through the XCD's L2 while the workgroups advance through K in lockstep.  Symmetric launches keep only
+// super-blocks and tiles on or above the diagonal (association.py:893-894).
+#define GSB 8
+__device__ __forceinline__ void gram_tile_coords(int t, int symmetric, int ntm, int ntn, int& ti, int& tj) {
+	const int nbm = (ntm + GSB - 1) / GSB, nbn = (ntn + GSB - 1) / GSB;
+	for (int bi = 0; bi < nbm; bi++) {
+		const int h = min(GSB, ntm - bi * GSB);
+		for (int bj = symmetric ? bi : 0; bj < nbn; bj++) {
+			const int w = min(GSB, ntn - bj * GSB);
+			const bool diag = symmetric && bi == bj;
+			const int cnt = diag ? h * (h + 1) / 2 : h * w;
+			if (t < cnt) {
+				int li, lj;
+				if (!diag) {
+					li = t / w;
+					lj = t - li * w;
+				} else {
+					li = 0;
+					int len = h;
+					while (t >= len) {
+						t -= len;
+						li++;
+						len--;
+					}
+					lj = li + t;
+				}
+				ti = bi * GSB + li;
+				tj = bj * GSB + lj;
+				return;
+			}
+			t -= cnt;
+		}
 	}
-	// linear index over the upper triangle, row by row: row i holds tiles (i, i..ntn-1)
-	int i = 0, len = ntn;
-	while (t >= len) {
-		t -= len;
-		i++;
-		len--;
-	}
-	ti = i;
-	tj = i + t;
+	ti = 0;
+	tj = 0;
 }
 
 // One tile piece: k-tiles [kt0, kt1) of tile (ti, tj).  atomic != 0 -> accumulate into C, else store.
@@ -146,7 +169,7 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 }
 
 struct GramSched {
-	int ntn;        // tiles per row of the tile grid (N direction)
+	int ntm, ntn;   // tile grid (M, N)
 	int nkt;        // k-tiles (slabs of GK cells)
 	int tiles_dp;   // tiles processed whole, one per workgroup per wave
 	int tiles_sk;   // tiles of the tail, cut into unit ranges
@@ -183,7 +206,7 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 			break;
 		}
 		int ti, tj;
-		gram_tile_coords(t, symmetric, s.ntn, ti, tj);
+		gram_tile_coords(t, symmetric, s.ntm, s.ntn, ti, tj);
 		gram_piece(A, B, lda, ldb, C, ldc, ti, tj, k0, k1, !(k0 == 0 && k1 == s.nkt), lds);
 	}
 }
@@ -210,6 +233,7 @@ extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad,
 	const int64_t tiles = symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn;
 	NRM_REQUIRE(tiles < (1LL << 30) && k_pad / GK < (1LL << 30), "nrm_gram_f64: problem too large for one launch");
 	GramSched s;
+	s.ntm = (int)ntm;
 	s.ntn = (int)ntn;
 	s.nkt = (int)(k_pad / GK);
 	s.nwg = 2 * g_num_cu;

@@ -332,3 +332,57 @@ def test_cli_round_trip_golden(golden, tmp_path):
 		assert relerr(got, exp, 1e-12) < 2e-7, mine  # '%.8G' keeps 8 significant digits
 	assert np.loadtxt(str(tmp_path / 'clfc.tsv'), delimiter='\t', ndmin=2).shape == (3, 14 * 2)
 	assert main([]) == 1
+
+
+def _sharded_worker(rank, world, port, q):
+	import os
+	import sys
+	import torch
+	import torch.distributed as dist
+	from conftest import ROOT
+	sys.path.insert(0, ROOT)
+	from normalisr_amd.distributed import CoexPlan
+	dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
+	torch.cuda.set_device(0)
+	rng = np.random.default_rng(77)
+	ng, n = 150 * world, 700
+	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(np.float32)
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(np.float32)
+	R = ng // world
+	plan = CoexPlan(torch.from_numpy(dt[rank * R:(rank + 1) * R]).cuda(), torch.from_numpy(dc).cuda(), rank=rank, world=world,
+					group=dist.group.WORLD)
+	plan.step()
+	res = plan.assemble(lambda t: t.detach().cpu().numpy())
+	if rank == 0:
+		q.put(res)
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
+	"""The N>1 path with the real HIP backend: `world` processes share this box's single GPU and exchange
+	residual blocks over gloo (RCCL needs one GPU per rank); result must equal the single-process oracle."""
+	import socket
+	import torch.multiprocessing as mp
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	ctx = mp.get_context('spawn')
+	q = ctx.Queue()
+	procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+	for p in procs:
+		p.start()
+	P, D, V = q.get(timeout=300)
+	for p in procs:
+		p.join(timeout=120)
+		assert p.exitcode == 0
+	rng = np.random.default_rng(77)
+	ng, n = 150 * world, 700
+	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(np.float32)
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(np.float32)
+	po, do, vo = oracle.coex(dt.astype(np.float64), dc.astype(np.float64))
+	assert P.dtype == np.float32
+	assert close(P, po, 1e-6, 1e-38) and close(D, do, 1e-6, 1e-7) and close(V, vo, 1e-6)
+	assert (np.diag(P) == 0).all() and (P == P.T).all() and (D == D.T).all()

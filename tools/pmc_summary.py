@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs (separate FETCH_SIZE / WRITE_SIZE passes) per kernel.
+
+    python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE [more dirs] > profiles/rNN_pmc_c2.json
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
+on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced stream, so it is doubled for kernels
+whose loads are that wide (K2, vectorised K1, K3's 8 B/lane tile reads are left uncorrected and flagged)."""
+import glob
+import json
+import os
+import sys
+
+import pandas as pd
+
+WIDE = {'k_gram_f64': True, 'k_residualize_v4': True, 'k_assoc_sweep_sym': False, 'k_assoc_sweep': False, 'k_residualize': False}
+
+
+def main(dirs):
+	rows = []
+	for d in dirs:
+		for f in glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True):
+			df = pd.read_csv(f)
+			df['kernel'] = df['Kernel_Name'].str.extract(r'\b(k_[a-z0-9_]+)')
+			rows.append(df[df['kernel'].notna()])
+	df = pd.concat(rows)
+	mean = df.groupby(['kernel', 'Counter_Name'])['Counter_Value'].mean().unstack()
+	out = {}
+	for k, r in mean.iterrows():
+		e = {c: float(v) for c, v in r.items() if v == v}
+		if 'FETCH_SIZE' in e:
+			e['fetch_bytes_raw'] = e['FETCH_SIZE'] * 1024
+			e['fetch_bytes'] = e['fetch_bytes_raw'] * (2 if WIDE.get(k, False) else 1)
+			e['fetch_corrected_x2'] = bool(WIDE.get(k, False))
+		if 'WRITE_SIZE' in e:
+			e['write_bytes'] = e['WRITE_SIZE'] * 1024
+		if 'fetch_bytes' in e and 'write_bytes' in e:
+			e['hbm_bytes_per_launch'] = e['fetch_bytes'] + e['write_bytes']
+		out[k] = e
+	json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+	main(sys.argv[1:])
