@@ -77,6 +77,58 @@ def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0):
 	return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def bench_de(args, torch, nd, world, rank, device):
+	"""Extra measurements on the de shapes of BASELINE configs[2] (1 x 20k x 100k, 20 covariates: HBM-bound streaming
+	path) and configs[3] (1k gRNAs x 15k genes x 50k cells: MFMA-bound general path); gene rows sharded over ranks."""
+	if args.workload == 'de_c3':
+		nx, ny, n, nc, seed = 1, 20000, 100000, 20, 3
+	else:
+		nx, ny, n, nc, seed = 1000, 15000, 50000, 5, 4
+	ny_local = ny // world
+	g = torch.Generator(device=device)
+	g.manual_seed(seed)
+	dc = torch.cat([torch.randn((nc - 1, n), generator=g, device=device, dtype=torch.float32), torch.ones((1, n), device=device, dtype=torch.float32)])
+	p1 = 0.5 if nx == 1 else 0.01
+	dx = (torch.rand((nx, n), generator=g, device=device) < p1).to(torch.float32)
+	g2 = torch.Generator(device=device)
+	g2.manual_seed(seed * 7919 + rank)
+	dy = torch.randn((ny_local, n), generator=g2, device=device, dtype=torch.float32)
+	dy[:16] += 0.2 * dx[0]
+	plan = nd.DePlan(dx, dy, dc, rank=rank, world=world)
+
+	def barrier():
+		if world > 1:
+			torch.distributed.barrier()
+		torch.cuda.synchronize()
+	for _ in range(args.warmup):
+		plan.step()
+	barrier()
+	t0 = time.perf_counter()
+	for _ in range(args.steps):
+		plan.step(timed=True)
+	barrier()
+	elapsed = time.perf_counter() - t0
+	if world > 1:
+		tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+		torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+		elapsed = float(tmax.item())
+	tests = nx * ny_local * world
+	if rank == 0:
+		ms = plan.step_ms()
+		if plan.streaming():
+			byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
+			roof = dict(bound='hbm', kernel='k_gram_skinny + sweep (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=8000.0, unit='GB/s',
+						frac=byts / (ms * 1e-3) / 8e12, traffic=None, step_ms=ms)
+		else:
+			fl = 2.0 * n * nx * ny_local
+			roof = dict(bound='mfma', kernel='k_gram_f64 (whole step)', achieved=fl / (ms * 1e-3) / 1e12, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+						frac=fl / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, traffic=None, step_ms=ms)
+		print(json.dumps(dict(metric='association tests/sec (de)', value=tests * args.steps / elapsed, unit='tests/s', n_gpus=world, steps=args.steps,
+							  warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='strong', vs_baseline=None,
+							  dtype='f64', data='synthetic', config=dict(workload='norm.de {} x {} genes x {} cells, fp32 input, {} covariates'.format(nx, ny, n, nc),
+							  parallelism='gene rows of Y x{}'.format(world)), roofline=roof, cpu_baseline=None)))
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--gpus', type=int, default=1)
@@ -86,6 +138,8 @@ def main():
 	ap.add_argument('--cells', type=int, default=10000)
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
 	ap.add_argument('--cpu-worker', nargs=5, default=None, help=argparse.SUPPRESS)
+	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4'],
+					help='coex_c2 = BASELINE configs[1] (the headline line); de_c3 / de_c4 = configs[2] / configs[3] shapes (extra measurements)')
 	ap.add_argument('--seed', type=int, default=2)
 	ap.add_argument('--e2e', type=int, default=2, help='repetitions of the numpy-in/numpy-out end-to-end timing (0 = skip)')
 	args = ap.parse_args()
@@ -114,6 +168,12 @@ def main():
 		import torch.distributed as dist
 		dist.init_process_group('nccl', device_id=device)
 		group = dist.group.WORLD
+
+	if args.workload != 'coex_c2':
+		bench_de(args, torch, nd, world, rank, device)
+		if world > 1:
+			torch.distributed.destroy_process_group()
+		return
 
 	n = args.cells
 	# weak scaling: pairs per GPU fixed -> genes ~ sqrt(N); rounded so every rank owns the same number of rows

@@ -116,6 +116,27 @@ int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d
 			  int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype, void* stream);
 
 /*
+ * K2s + sweep -- streaming path for de with few design rows (nx + nc <= 32): HBM-bound, every expression
+ * value is read once, raw (fp32/fp64), never materialised as an fp64 residual (see csrc/nrm_gram_skinny.hip).
+ *   nrm_gram_skinny:  G[y,:] = sum_k Y[y,k] Z[:,k] (rows_pad, 32) and ss[y] = sum_k Y[y,k]^2, with
+ *       d_z (32, ldz) fp64 = [C (nc rows); X~ (nx rows, residualised by nrm_residualize); zero rows],
+ *       zero padded to k_pad cells (multiple of 32).  d_a rows must be 16-byte aligned (lda % (16/itemsize) == 0).
+ *   nrm_de_small_sweep: |y~|^2 = ss - (y C^T) dci (C y^T), y~.x~ = y.x~  ->  R^2, p, gamma|cov (association.py:226-235,249);
+ *       d_ssy (ny) receives |y~|^2; d_by (ny, nc) or NULL receives the OLS coefficients ccy (for alpha).
+ */
+/* Residualise <= 32 rows with the work spread along the cells (used for the design rows of the streaming path):
+ * d_ga (rows, 32) holds x C^T in its first nc columns (from nrm_gram_skinny against Z = [C; 0]); out (rows, ldo) fp64,
+ * zero padded up to ldo; d_ss (rows) sums of squares; d_coef (rows, nc) or NULL the OLS coefficients. */
+int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
+						 int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
+						 double* d_ss, double* d_coef, void* stream);
+int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64_t n, int64_t lda, const double* d_z, int64_t ldz,
+					int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, void* stream);
+int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
+					   int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,
+					   void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags, void* stream);
+
+/*
  * single=4 sweep (competition-aware DE, association.py:421-576 in closed form).
  * Inputs from one multiple regression of every gene on A = [dx; dc] (m = nx + nc rows):
  *   d_bt  (ny, ldb) fp64: Bt[y,k] = coefficient of row k of A for gene y      (B = (A A^T)^-1 A Y^T)

@@ -307,3 +307,63 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 								  (hipStream_t)stream);
 	return nrm_check_launch("k_residualize");
 }
+
+// Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS
+// products a = x C^T come from nrm_gram_skinny (G matrix, 32 columns); every workgroup rebuilds b = a dci in
+// LDS (tiny) and applies x~ = x - b C to its 1024-cell slab for all rows; sums of squares by atomics.
+#define RW_ROWS 32
+template <typename T>
+__global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ x, int rows, int64_t n, int64_t ldx,
+														   const double* __restrict__ c, int nc, int64_t ldc,
+														   const double* __restrict__ ga /* (rows, 32) */, const double* __restrict__ dci,
+														   int active, double* __restrict__ out, int64_t ldo, double* __restrict__ ss,
+														   double* __restrict__ coef) {
+	__shared__ double s_b[RW_ROWS][RW_ROWS];
+	const int tid = threadIdx.x, lane = tid & 63;
+	if (active) {
+		for (int i = tid; i < rows * nc; i += 256) {
+			const int r = i / nc, q = i % nc;
+			double v = 0.0;
+			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], ga[r * 32 + e], v);
+			s_b[r][q] = v;
+			if (coef && blockIdx.x == 0) coef[r * nc + q] = v;
+		}
+		__syncthreads();
+	}
+	const int64_t k0 = (int64_t)blockIdx.x * 1024;
+	for (int r = 0; r < rows; r++) {
+		double sq = 0.0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int64_t k = k0 + tid + 256 * j;
+			if (k >= ldo) continue;
+			double v = (k < n) ? (double)x[(int64_t)r * ldx + k] : 0.0;
+			if (active && k < n)
+				for (int q = 0; q < nc; q++) v = fma(-s_b[r][q], c[(int64_t)q * ldc + k], v);
+			out[(int64_t)r * ldo + k] = v;
+			sq = fma(v, v, sq);
+		}
+		sq = wave_sum(sq);
+		if (lane == 0) unsafeAtomicAdd(&ss[r], sq);
+	}
+}
+
+extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
+									int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
+									double* d_ss, double* d_coef, void* stream) {
+	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize_wide: bad dtype");
+	NRM_REQUIRE(rows > 0 && rows <= RW_ROWS && nc >= 0 && nc <= RW_ROWS, "nrm_residualize_wide: at most %d rows and covariates", RW_ROWS);
+	NRM_REQUIRE(n > 0 && ldx >= n && ldo >= n && d_x && d_out && d_ss, "Incorrect dx/dy/dc size.");
+	const int active = (rank > 0 && nc > 0) ? 1 : 0;
+	NRM_REQUIRE(!active || (d_c && d_ga && d_dci && ldc >= n), "Unmatching dx/dy/dc dimensions.");
+	hipStream_t st = (hipStream_t)stream;
+	NRM_HIP(hipMemsetAsync(d_ss, 0, (size_t)rows * sizeof(double), st));
+	dim3 grid((unsigned)((ldo + 1023) / 1024));
+	if (x_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_residualize_wide<double>, grid, dim3(256), 0, st, (const double*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
+						   d_dci, active, d_out, ldo, d_ss, d_coef);
+	else
+		hipLaunchKernelGGL(k_residualize_wide<float>, grid, dim3(256), 0, st, (const float*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
+						   d_dci, active, d_out, ldo, d_ss, d_coef);
+	return nrm_check_launch("k_residualize_wide");
+}

@@ -253,6 +253,67 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 	}
 }
 
+// Sweep for the streaming de path (nrm_gram_skinny): one thread per gene.  G[y] = [y C^T (nc) | y X~^T (nx) | 0...],
+// ssraw[y] = |y|^2.  |y~|^2 = |y|^2 - a dci a^T with a = y C^T (association.py:226-230 expanded), y~.x~ = y.x~.
+#define DS_NZ 32
+template <typename OutT>
+__global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict__ G, const double* __restrict__ ssraw,
+														 const double* __restrict__ dci, int nc, int rank_pos,
+														 const double* __restrict__ ssx, int nx, int64_t ny, double ncells, double dof,
+														 int stat_kind, PvalPlan pl, OutT* __restrict__ p_out, OutT* __restrict__ stat_out,
+														 OutT* __restrict__ r_out, OutT* __restrict__ t_out, int64_t ldo,
+														 double* __restrict__ ssy_out, double* __restrict__ by_out,
+														 int32_t* __restrict__ flags) {
+	const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (y >= ny) return;
+	double g[DS_NZ];
+#pragma unroll
+	for (int c = 0; c < DS_NZ; c++) g[c] = G[y * DS_NZ + c];
+	double q = 0.0;
+	if (rank_pos) {
+#pragma unroll
+		for (int c = 0; c < DS_NZ; c++) {
+			if (c < nc) {
+				double b = 0.0;
+#pragma unroll
+				for (int e = 0; e < DS_NZ; e++)
+					if (e < nc) b = fma(dci[c * nc + e], g[e], b);
+				q = fma(g[c], b, q);
+				if (by_out) by_out[y * nc + c] = b;
+			}
+		}
+	}
+	double sy = ssraw[y] - q;
+	if (sy < 0.0) sy = 0.0;
+	ssy_out[y] = sy;
+	const double vy = (sy == 0.0) ? ncells : sy;  // variance 0 -> 1 (association.py:233)
+	int bad_nf = 0, bad_rng = 0;
+#pragma unroll
+	for (int c = 0; c < DS_NZ; c++) {
+		const int x = c - nc;
+		if (x >= 0 && x < nx) {
+			const double d = g[c];
+			double vx = ssx[x];
+			if (vx == 0.0) vx = ncells;
+			const double r2 = (d * d) / (vx * vy);
+			if (!isfinite(r2) || !isfinite(vy)) bad_nf = 1;
+			if (r2 > 1.0 + 1e-8) bad_rng = 1;
+			const int64_t o = (int64_t)x * ldo + y;
+			p_out[o] = (OutT)nrm_pvalue(r2, pl);
+			stat_out[o] = (OutT)(stat_kind ? d / vx : d / ncells);
+			if (r_out) r_out[o] = (OutT)(d / sqrt(vx * vy));
+			if (t_out) {
+				const double rc = fmin(r2, 1.0);
+				t_out[o] = (OutT)copysign(sqrt(dof * rc / (1.0 - rc)), d);
+			}
+		}
+	}
+	if (flags) {
+		if (bad_nf) atomicAdd(&flags[0], 1);
+		if (bad_rng) atomicAdd(&flags[1], 1);
+	}
+}
+
 template <typename GT, typename OutT>
 __global__ void __launch_bounds__(256) k_alpha(const GT* __restrict__ gamma, int64_t ldg, const double* __restrict__ bx,
 												const double* __restrict__ by, int64_t nx, int64_t ny, int64_t nc,
@@ -329,4 +390,27 @@ extern "C" int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, cons
 		hipLaunchKernelGGL((k_alpha<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)d_gamma, ldg,
 						   d_bx, d_by, nx, ny, nc, (float*)d_alpha);
 	return nrm_check_launch("k_alpha");
+}
+
+extern "C" int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
+								  int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,
+								  void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags, void* stream) {
+	NRM_REQUIRE(nx > 0 && ny > 0 && nc >= 0 && nx + nc <= DS_NZ, "nrm_de_small_sweep: needs nx + nc <= %d", DS_NZ);
+	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_de_small_sweep: bad out_dtype");
+	NRM_REQUIRE(d_g && d_ssraw && d_ssx && d_p && d_stat && d_ssy && ldo >= ny, "nrm_de_small_sweep: null pointer or small pitch");
+	NRM_REQUIRE(!(rank > 0 && nc > 0) || d_dci, "Unmatching dci dimensions.");
+	nrm_pvalue_plan plan;
+	int rc = nrm_pvalue_plan_init(&plan, dof);
+	if (rc) return rc;
+	const int rank_pos = (rank > 0 && nc > 0) ? 1 : 0;
+	dim3 grid((unsigned)((ny + 255) / 256));
+	if (out_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_de_small_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_g, d_ssraw, d_dci, (int)nc, rank_pos, d_ssx,
+						   (int)nx, ny, (double)n_cells, dof, stat_kind, to_dev(plan), (double*)d_p, (double*)d_stat, (double*)d_r,
+						   (double*)d_t, ldo, d_ssy, d_by, d_flags);
+	else
+		hipLaunchKernelGGL(k_de_small_sweep<float>, grid, dim3(256), 0, (hipStream_t)stream, d_g, d_ssraw, d_dci, (int)nc, rank_pos, d_ssx,
+						   (int)nx, ny, (double)n_cells, dof, stat_kind, to_dev(plan), (float*)d_p, (float*)d_stat, (float*)d_r,
+						   (float*)d_t, ldo, d_ssy, d_by, d_flags);
+	return nrm_check_launch("k_de_small_sweep");
 }

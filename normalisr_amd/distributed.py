@@ -122,6 +122,7 @@ class CoexPlan:
 		self.sched = block_pair_schedule(rank, world, self.rows_pad)
 		self.outputs = []
 		self.flags = None
+		self._pending = []
 		self._ev = dict(residualize=[], exchange=[], gram=[], sweep=[])
 		if world > 1:
 			self.all_data = self.be.empty((world * self.rows_pad, self.k_pad))
@@ -138,26 +139,35 @@ class CoexPlan:
 		return out
 
 	def _exchange(self, data, ss):
+		"""Start the all-gather of residual blocks and sums of squares; returns handles to wait on (RCCL runs it on its
+		own stream, so the diagonal block pair -- local data only -- is contracted while the shards travel over xGMI)."""
 		import torch.distributed as dist
 		if dist.get_backend(self.group) == 'nccl':
-			dist.all_gather_into_tensor(self.all_data, data, group=self.group)
-			dist.all_gather_into_tensor(self.all_ss, ss, group=self.group)
-		else:
-			dist.all_gather(list(self.all_data.view(self.world, self.rows_pad, self.k_pad).unbind(0)), data, group=self.group)
-			dist.all_gather(list(self.all_ss.view(self.world, self.rows_pad).unbind(0)), ss, group=self.group)
+			return [dist.all_gather_into_tensor(self.all_data, data, group=self.group, async_op=True),
+					dist.all_gather_into_tensor(self.all_ss, ss, group=self.group, async_op=True)]
+		dist.all_gather(list(self.all_data.view(self.world, self.rows_pad, self.k_pad).unbind(0)), data, group=self.group)
+		dist.all_gather(list(self.all_ss.view(self.world, self.rows_pad).unbind(0)), ss, group=self.group)
+		return []
 
 	def block(self, b):
-		if self.world == 1:
-			return self._data, self._ss
+		if self.world == 1 or (b == self.rank and self._pending):
+			return self._data, self._ss  # own block: local buffers (valid before the exchange has landed)
 		return (self.all_data[b * self.rows_pad:(b + 1) * self.rows_pad], self.all_ss[b * self.rows_pad:(b + 1) * self.rows_pad])
 
 	def step(self, timed=False):
 		data, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
 		self._data, self._ss = data, ss
+		self._pending = []
 		if self.world > 1:
-			self._timed('exchange', timed, lambda: self._exchange(data, ss))
+			self._pending = self._exchange(data, ss)
 		outs = []
 		for bi, bj, lo, hi, sym in self.sched:
+			if self._pending and not (bi == self.rank and bj == self.rank):
+				def wait():
+					for w in self._pending:
+						w.wait()
+				self._timed('exchange', timed, wait)  # time the part of the exchange that compute did not hide
+				self._pending = []
 			a, ssa = self.block(bi)
 			b, ssb = self.block(bj)
 			a, ssa = a[lo:hi], ssa[lo:hi]
@@ -168,6 +178,9 @@ class CoexPlan:
 				continue
 			p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
 			outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
+		for w in self._pending:
+			w.wait()
+		self._pending = []
 		self.outputs = outs
 		return outs
 
@@ -226,3 +239,46 @@ class CoexPlan:
 					P[c0:c0 + ny, r0:r0 + nx] = o['p'].T
 					D[c0:c0 + ny, r0:r0 + nx] = o['stat'].T
 		return P, D, V
+
+
+class DePlan:
+	"""Sharded de (dy given): rank r owns a block of gene rows of Y; the design rows X and the covariates are
+	replicated and residualised redundantly, so there is NO collective on the data path (outputs are disjoint
+	column blocks of the (n_x, n_y) result).  step() leaves this rank's (p, gamma, varx, vary) in self.result."""
+
+	def __init__(self, dx, dy_local, dc, rank=0, world=1, dimreduce=0, return_dot=False, device=None):
+		from .association import _prepare_covariates
+		from .engine import get_engine
+		self.rank, self.world = rank, world
+		self.eng = get_engine(device)
+		self.dx, self.dy = dx, dy_local
+		dc_h = dc.detach().cpu().numpy() if hasattr(dc, 'detach') else np.asarray(dc)
+		self.dc64, self.dci, self.dcr = _prepare_covariates(dc_h)
+		self.dimreduce, self.return_dot = dimreduce, return_dot
+		self.out_dtype = np.float32 if 'float32' in str(dy_local.dtype) else np.float64
+		self.nx, self.n = dx.shape
+		self.ny = dy_local.shape[0]
+		if self.n <= self.dcr + dimreduce + 1:
+			raise ValueError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+		self.cov = self.eng.covariates(self.dc64, self.dci)  # resident on the device across steps
+		self.result = None
+		self._ev = []
+
+	def step(self, timed=False):
+		torch = self.eng.torch
+		if timed:
+			e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+			e0.record()
+		self.result = self.eng.association_single0(self.dx, self.dy, self.dc64, self.dci, self.dcr, self.dimreduce,
+												   return_dot=self.return_dot, want_alpha=False, out_dtype=self.out_dtype, cov=self.cov)
+		if timed:
+			e1.record()
+			self._ev.append((e0, e1))
+		return self.result
+
+	def step_ms(self):
+		self.eng.torch.cuda.synchronize()
+		return sum(a.elapsed_time(b) for a, b in self._ev) / max(1, len(self._ev))
+
+	def streaming(self):
+		return self.eng.de_streaming_ok(self.dx, self.dy, self.dc64)

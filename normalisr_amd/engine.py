@@ -141,14 +141,94 @@ class Engine:
 		v[v == 0] = 1
 		return v.astype(out_dtype, copy=False)
 
-	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False):
-		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric)."""
+	def de_streaming_ok(self, dx, dy, dc):
+		"""The streaming path (K2s) applies to de with few design rows and 16-byte aligned expression rows."""
+		import os
+		mode = os.environ.get('NRM_DE_PATH', 'auto')
+		if dy is None or mode == 'general':
+			return False
+		ok = dx.shape[0] + dc.shape[0] <= 32 and (dy.shape[1] * dy.dtype.itemsize) % 16 == 0
+		if mode == 'streaming' and not ok:
+			raise ValueError('NRM_DE_PATH=streaming needs nx + nc <= 32 and 16-byte aligned rows')
+		return ok
+
+	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None):
+		"""de with nx + nc <= 32: stream the raw expression rows once (HBM-bound), see csrc/nrm_gram_skinny.hip."""
+		torch = self.torch
+		nx, n = dx.shape
+		ny, nc = dy.shape[0], dc.shape[0]
+		dof = n - 1 - rank - dimreduce
+		tdt = torch.float64 if np.dtype(out_dtype) == np.float64 else torch.float32
+		with torch.cuda.device(self.device):
+			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
+			# design rows: a = x C^T through the streaming Gram (all CUs), then x~ = x - (a dci) C spread along the cells
+			k32 = _round_up(n, 32)
+			z = torch.zeros((32, k32), dtype=torch.float64, device=self.device)
+			if nc:
+				z[:nc, :n] = d_c
+			xd = dx if not isinstance(dx, np.ndarray) else self.upload(as_input(dx))
+			xcode = NRM_F64 if xd.dtype == torch.float64 else NRM_F32
+			gx = torch.empty((ROW_TILE, 32), dtype=torch.float64, device=self.device)
+			ssx_raw = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
+			active = rank > 0 and nc > 0
+			if active:
+				if (xd.stride(0) * xd.element_size()) % 16 == 0:
+					_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
+														ssx_raw.data_ptr(), ROW_TILE, self._stream()))
+				else:
+					gx[:nx, :nc] = xd.to(torch.float64) @ d_c.T  # unaligned design rows: tiny product, plumbing
+			xt = torch.zeros((nx, k32), dtype=torch.float64, device=self.device)
+			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
+			coefx = torch.zeros((nx, nc), dtype=torch.float64, device=self.device) if want_alpha else None
+			_lib.check(self.lib.nrm_residualize_wide(xd.data_ptr(), xcode, nx, n, xd.stride(0), 0 if d_c is None else d_c.data_ptr(), nc,
+													 0 if d_c is None else d_c.stride(0), gx.data_ptr(), 0 if d_dci is None else d_dci.data_ptr(),
+													 int(rank), xt.data_ptr(), k32, ssx.data_ptr(), 0 if coefx is None else coefx.data_ptr(),
+													 self._stream()))
+			rx = Residualized(nx, n, xt, ssx, coefx)
+			z[nc:nc + nx] = xt
+			y = dy if not isinstance(dy, np.ndarray) else self.upload(dy)
+			ny_pad = _round_up(ny, ROW_TILE)
+			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
+			ssraw = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
+			_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), NRM_F64 if y.dtype == torch.float64 else NRM_F32, ny, n, y.stride(0),
+												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, self._stream()))
+			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
+			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
+			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
+			t = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
+			ssy = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
+			by = torch.zeros((ny, nc), dtype=torch.float64, device=self.device) if (want_alpha and nc) else None
+			flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+			stat_kind = 0 if return_dot else 1
+			_lib.check(self.lib.nrm_de_small_sweep(g.data_ptr(), ssraw.data_ptr(), 0 if d_dci is None else d_dci.data_ptr(), nc, int(rank),
+												   rx.ss.data_ptr(), nx, ny, n, float(dof), stat_kind, p.data_ptr(), stat.data_ptr(),
+												   0 if r is None else r.data_ptr(), 0 if t is None else t.data_ptr(), _code(out_dtype),
+												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), self._stream()))
+			alpha = None
+			if want_alpha:
+				if nc > 0 and stat_kind == 1:
+					alpha = self.alpha(stat, rx.coef, by, nc).cpu().numpy()
+				else:
+					alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
+			self.check_flags(flags)
+			res = dict(p=p.cpu().numpy(), stat=stat.cpu().numpy(), alpha=alpha, varx=self.variances(rx.ss, nx, n, out_dtype),
+					   vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
+			if want_rt:
+				res['r'] = r.cpu().numpy()
+				res['t'] = t.cpu().numpy()
+		return res
+
+	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None):
+		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric).
+		cov: optional (d_c, d_dci) already on the device (repeated calls with the same covariates)."""
 		samexy = dy is None
+		if self.de_streaming_ok(dx, dy, dc):
+			return self.association_de_streaming(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov)
 		nx, n = dx.shape
 		ny = nx if samexy else dy.shape[0]
 		nc = dc.shape[0]
 		dof = n - 1 - rank - dimreduce
-		d_c, d_dci = self.covariates(dc, dci)
+		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
 		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
 		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
 		dot = self.gram(rx, ry, samexy)

@@ -35,6 +35,14 @@ def norm():
 	return norm
 
 
+@pytest.fixture(params=['auto', 'general'])
+def de_path(request, monkeypatch):
+	"""de runs either through the streaming kernel (K2s, picked automatically for nx + nc <= 32) or the general
+	K1 -> K2 -> K3 path; both must meet the same parity bar."""
+	monkeypatch.setenv('NRM_DE_PATH', request.param)
+	return request.param
+
+
 @pytest.fixture(scope='module')
 def eng():
 	from normalisr_amd.engine import get_engine
@@ -84,7 +92,7 @@ def test_gram_kernel_layout(eng):
 	assert np.array_equal(dot[:128], ref[:128]) and np.array_equal(dot[128:, 128:], ref[128:, 128:])
 
 
-def test_block_g7(golden):
+def test_block_g7(golden, de_path):
 	from normalisr_amd.association import association_test_1
 	g = golden('G7_block')
 	r = association_test_1(3, 5, g['dx'], g['dy'], g['dc'], g['dci'], int(g['dcr']), lowmem=False, return_stats=True)
@@ -96,7 +104,7 @@ def test_block_g7(golden):
 	assert close(r[7], rr, floor=R_FLOOR) and close(r[8], tt, floor=1e-9)
 
 
-def test_c1_de_coex_golden(golden, norm):
+def test_c1_de_coex_golden(golden, norm, de_path):
 	g = golden('G1_c1')
 	dt, dc, dg = g['dt'], g['dc'], g['dg']
 	for lm in (1, 0):
@@ -118,7 +126,7 @@ def test_c1_de_coex_golden(golden, norm):
 	assert p_close(p, g['at_p']) and close(d, g['at_dot'], floor=1e-13) and close(vx, g['at_vx'], 1e-12) and a is None
 
 
-def test_edge_cases_golden(golden, norm):
+def test_edge_cases_golden(golden, norm, de_path):
 	from normalisr_amd.association import association_tests
 	g = golden('G2_edge')
 	dt, dc, dg = g['dt'], g['dc'], g['dg']
@@ -192,8 +200,8 @@ def test_coex_vs_oracle_seeded(norm, ng, n, nc):
 	assert close(st['r'][off], rr[off], floor=R_FLOOR) and close(st['t'][off], tt[off], floor=1e-9)
 
 
-@pytest.mark.parametrize('nx,ny,n,nc', [(5, 700, 1500, 3), (130, 260, 800, 2), (1, 1000, 4097, 20)])
-def test_de_vs_oracle_seeded(norm, nx, ny, n, nc):
+@pytest.mark.parametrize('nx,ny,n,nc', [(5, 700, 1500, 3), (130, 260, 800, 2), (1, 1000, 4097, 20), (2, 777, 4100, 20), (12, 300, 10000, 0)])
+def test_de_vs_oracle_seeded(norm, de_path, nx, ny, n, nc):
 	dg, dt, dc = _synthetic(200 + nx, nx, ny, n, nc)
 	p, gam, al, vg, vt = norm.de(dg, dt, dc, lowmem=False)
 	po, go, ao, vgo, vto = oracle.de(dg, dt, dc, lowmem=False)
@@ -201,7 +209,7 @@ def test_de_vs_oracle_seeded(norm, nx, ny, n, nc):
 	assert close(vg, vgo, 1e-12) and close(vt, vto, 1e-12)
 
 
-def test_fp32_inputs_vs_fp64_oracle(norm):
+def test_fp32_inputs_vs_fp64_oracle(norm, de_path):
 	dg, dt, dc = _synthetic(7, 3, 400, 3000, 3, np.float32)
 	p, gam, al, vg, vt = norm.de(dg, dt, dc)
 	po, go, ao, vgo, vto = oracle.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
