@@ -70,10 +70,14 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
  *   d_a (m_pad, lda), d_b (n_pad, ldb) fp64, zero padded; m_pad, n_pad multiples of NRM_ROW_TILE;
  *   k_pad multiple of NRM_K_TILE; d_dot (m_pad, ldd) fp64.
  *   symmetric != 0 (coex: d_b == d_a): only tiles on or above the block diagonal are computed and
- *   written (association.py:893-894); the strictly-lower tiles of d_dot are left untouched.
+ *   written (association.py:893-894); the strictly-lower tiles of d_dot are left untouched, and inside
+ *   diagonal tiles only 16x16 sub-blocks on or above the diagonal are guaranteed.
+ *   m_rows, n_rows: valid (unpadded) row counts (0 = all): 16-row sub-blocks that are pure padding are skipped
+ *   and their outputs left unwritten.
  */
 int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad,
-				 int64_t lda, int64_t ldb, double* d_dot, int64_t ldd, int symmetric, void* stream);
+				 int64_t lda, int64_t ldb, double* d_dot, int64_t ldd, int symmetric,
+				 int64_t m_rows, int64_t n_rows, void* stream);
 
 /*
  * P-value plan: host-side constants of p = I_{1-R^2}(dof/2, 1/2) for one dof

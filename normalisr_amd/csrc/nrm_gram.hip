@@ -74,6 +74,7 @@ __device__ __forceinline__ void gram_tile_coords(int t, int symmetric, int ntm, 
 // One tile piece: k-tiles [kt0, kt1) of tile (ti, tj).  atomic != 0 -> accumulate into C, else store.
 __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const double* __restrict__ B, int64_t lda, int64_t ldb,
 										   double* __restrict__ C, int64_t ldc, int ti, int tj, int kt0, int kt1, int atomic,
+										   const unsigned need /* bit i*4+j: this wave's 16x16 sub-block (i,j) is wanted */,
 										   double* lds /* [2][2][GM*GP] */) {
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int wm = wid >> 1, wn = wid & 1;
@@ -124,6 +125,8 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 		}
 		const double* la = (cur ? ldsA1 : ldsA0) + aoff;
 		const double* lb = (cur ? ldsB1 : ldsB0) + boff;
+		// (predicating individual MFMAs on `need` was measured: the 16 scalar branches per k-step cost 3 % on full tiles,
+		//  more than the 5 % of padded / mirrored sub-blocks they save on 80 of 820 tiles -- so the loop stays branch-free)
 #pragma unroll
 		for (int kk = 0; kk < GK / 4; kk++) {
 			double fa[4], fb[4];
@@ -135,7 +138,8 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 #pragma unroll
 			for (int i = 0; i < 4; i++)
 #pragma unroll
-				for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+				for (int j = 0; j < 4; j++)
+					acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
 		}
 		if (more) {
 			double* wa = cur ? ldsA0 : ldsA1;
@@ -157,18 +161,21 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 #pragma unroll
-				for (int q = 0; q < 4; q++) unsafeAtomicAdd(&cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15], acc[i][j][q]);
+				for (int q = 0; q < 4; q++)
+					if (need & (1u << (i * 4 + j))) unsafeAtomicAdd(&cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15], acc[i][j][q]);
 	} else {
 #pragma unroll
 		for (int i = 0; i < 4; i++)
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 #pragma unroll
-				for (int q = 0; q < 4; q++) cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15] = acc[i][j][q];
+				for (int q = 0; q < 4; q++)
+					if (need & (1u << (i * 4 + j))) cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15] = acc[i][j][q];
 	}
 }
 
 struct GramSched {
+	int m_rows, n_rows;  // valid (unpadded) rows of A and B
 	int ntm, ntn;   // tile grid (M, N)
 	int nkt;        // k-tiles (slabs of GK cells)
 	int tiles_dp;   // tiles processed whole, one per workgroup per wave
@@ -207,14 +214,28 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 		}
 		int ti, tj;
 		gram_tile_coords(t, symmetric, s.ntm, s.ntn, ti, tj);
-		gram_piece(A, B, lda, ldb, C, ldc, ti, tj, k0, k1, !(k0 == 0 && k1 == s.nkt), lds);
+		// which of this wave's 4x4 sub-blocks are wanted: rows/columns inside the matrix and, on diagonal tiles of a
+		// symmetric problem, not strictly below the diagonal (K3 only reads dot[min(i,j)][max(i,j)])
+		unsigned need = 0;
+		{
+			const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
+			const int r0 = ti * GM + wm * 64, c0 = tj * GN + wn * 64;
+			const bool diag = symmetric && ti == tj;
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					if (r0 + i * 16 < s.m_rows && c0 + j * 16 < s.n_rows && (!diag || c0 + j * 16 >= r0 + i * 16)) need |= 1u << (i * 4 + j);
+			need = __builtin_amdgcn_readfirstlane(need);
+		}
+		gram_piece(A, B, lda, ldb, C, ldc, ti, tj, k0, k1, !(k0 == 0 && k1 == s.nkt), need, lds);
 	}
 }
 
 static int g_num_cu = 0;
 
 extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,
-							int64_t ldb, double* d_dot, int64_t ldd, int symmetric, void* stream) {
+							int64_t ldb, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, void* stream) {
 	NRM_REQUIRE(m_pad >= 0 && n_pad >= 0 && k_pad > 0, "nrm_gram_f64: bad sizes");
 	NRM_REQUIRE(m_pad % GM == 0 && n_pad % GN == 0 && k_pad % GK == 0, "nrm_gram_f64: sizes must be padded to %d/%d/%d", GM, GN, GK);
 	NRM_REQUIRE(lda >= k_pad && ldb >= k_pad && ldd >= n_pad, "nrm_gram_f64: pitch too small");
@@ -233,6 +254,8 @@ extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad,
 	const int64_t tiles = symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn;
 	NRM_REQUIRE(tiles < (1LL << 30) && k_pad / GK < (1LL << 30), "nrm_gram_f64: problem too large for one launch");
 	GramSched s;
+	s.m_rows = (int)((m_rows > 0 && m_rows < m_pad) ? m_rows : m_pad);
+	s.n_rows = (int)((n_rows > 0 && n_rows < n_pad) ? n_rows : n_pad);
 	s.ntm = (int)ntm;
 	s.ntn = (int)ntn;
 	s.nkt = (int)(k_pad / GK);

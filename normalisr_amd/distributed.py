@@ -79,9 +79,10 @@ class HipBackend:
 		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad)
 		return r.data, r.ss
 
-	def gram(self, a, b, symmetric):
+	def gram(self, a, b, symmetric, rows_a=None, rows_b=None):
 		from .engine import Residualized
-		return self.eng.gram(Residualized(a.shape[0], a.shape[1], a, None, None), Residualized(b.shape[0], b.shape[1], b, None, None), symmetric)
+		return self.eng.gram(Residualized(a.shape[0] if rows_a is None else rows_a, a.shape[1], a, None, None),
+							 Residualized(b.shape[0] if rows_b is None else rows_b, b.shape[1], b, None, None), symmetric)
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
 		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags)
@@ -171,11 +172,11 @@ class CoexPlan:
 			a, ssa = self.block(bi)
 			b, ssb = self.block(bj)
 			a, ssa = a[lo:hi], ssa[lo:hi]
-			dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym))
 			nx = max(0, min(hi, self.rows) - lo)
 			ny = self.rows
 			if nx == 0:
 				continue
+			dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym, nx, ny))
 			p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
 			outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
 		for w in self._pending:

@@ -97,7 +97,7 @@ class Engine:
 			dot = torch.empty((a.rows_pad, b.rows_pad), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_gram_f64(a.data.data_ptr(), b.data.data_ptr(), a.rows_pad, b.rows_pad, a.k_pad,
 											 a.data.stride(0), b.data.stride(0), dot.data_ptr(), dot.stride(0),
-											 1 if symmetric else 0, self._stream()))
+											 1 if symmetric else 0, int(a.rows), int(b.rows), self._stream()))
 		return dot
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None):

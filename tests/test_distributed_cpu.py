@@ -49,7 +49,7 @@ class OracleBackend:
 		out[:x.shape[0], :x.shape[1]] = r
 		return self.torch.from_numpy(out), self.torch.from_numpy((out**2).sum(axis=1))
 
-	def gram(self, a, b, symmetric):
+	def gram(self, a, b, symmetric, rows_a=None, rows_b=None):
 		return self.torch.from_numpy(a.numpy() @ b.numpy().T)
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
