@@ -124,7 +124,7 @@ int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d
  * value is read once, raw (fp32/fp64), never materialised as an fp64 residual (see csrc/nrm_gram_skinny.hip).
  *   nrm_gram_skinny:  G[y,:] = sum_k Y[y,k] Z[:,k] (rows_pad, 32) and ss[y] = sum_k Y[y,k]^2, with
  *       d_z (32, ldz) fp64 = [C (nc rows); X~ (nx rows, residualised by nrm_residualize); zero rows],
- *       zero padded to k_pad cells (multiple of 32).  d_a rows must be 16-byte aligned (lda % (16/itemsize) == 0).
+ *       zero padded to k_pad cells (multiple of 128); rows_pad multiple of 256.  d_a rows must be 16-byte aligned (lda % (16/itemsize) == 0).
  *   nrm_de_small_sweep: |y~|^2 = ss - (y C^T) dci (C y^T), y~.x~ = y.x~  ->  R^2, p, gamma|cov (association.py:226-235,249);
  *       d_ssy (ny) receives |y~|^2; d_by (ny, nc) or NULL receives the OLS coefficients ccy (for alpha).
  */

@@ -8,16 +8,25 @@
 // from which the per-pair sweep (k_de_small_sweep) recovers, without ever forming y~:
 //     y~ . x~ = y . x~                      (x~ is orthogonal to C)           association.py:234
 //     |y~|^2  = |y|^2 - (y C^T) dci (C y^T)                                   association.py:229-230
-// Algorithmic HBM bytes: itemsize * n per expression row (+ Z from L2).  Geometry: workgroup = 128 rows x
-// 32 Z-rows, 4 waves stacked along the rows (each 32 x 32 = 2 x 2 MFMA tiles), K slabs of 32 cells staged
-// global -> registers -> LDS (fp32 converted on the way); persistent DP + stream-K schedule as in K2 so that
-// 157 row tiles still fill 256 CUs; all pieces are combined with fp64 atomics into zeroed G / ss.
+// Algorithmic HBM bytes: itemsize * n per expression row (+ Z from L2).
+//
+// Geometry: a wave owns 64 expression rows (4 MFMA row tiles) x NT*16 Z rows.  The Y operand goes from
+// global memory STRAIGHT into the MFMA A-operand layout -- no LDS round trip, no barrier: for a slab of 16
+// cells lane (r = l & 15, g = l >> 4) loads the 4 consecutive cells 4g..4g+3 of row r (one 16-byte load for
+// fp32), and MFMA step s = 0..3 consumes cell 4g+s; a dot product does not care about the order of its
+// terms as long as the Z operand uses the same permutation (it does: lane (z, g) reads cells 4g..4g+3 of Z
+// row z from LDS).  Slabs are prefetched 4 (fp32) / 2 (fp64) deep in registers to cover HBM latency; one wave per SIMD
+// with the whole 512-entry register file (accumulators forced into VGPRs: -amdgpu-mfma-vgpr-form, AGPR accumulators
+// halve the fp64 MFMA rate).  Z (tiny, shared
+// by every wave) is staged through LDS in chunks of 128 cells, double buffered, one barrier per chunk.
+// Persistent DP + stream-K schedule as in K2 so that 79 row tiles still fill 256 CUs; pieces are combined
+// with fp64 atomics into zeroed G / ss.
 #include "nrm_common.h"
 
-#define SKM 128
-#define SKN 32
-#define SKK 32
-#define SKP 34  // LDS pitch in doubles (272 B): 16-byte aligned rows, 16 rows of an operand read on distinct banks
+#define SKM 256      // rows per workgroup tile (4 waves x 64)
+#define SKN 32       // columns of G
+#define SKC 128      // cells per Z chunk in LDS
+#define SKP (SKC + 2)  // LDS pitch in doubles: 16-byte aligned, rows 16 bytes apart modulo the bank row
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -26,44 +35,36 @@ struct SkinnySched {
 };
 
 template <typename T>
-__device__ __forceinline__ void load4(const T* p, bool full, int64_t k, int64_t n, double (&v)[4]);
+struct Slab;  // 4 consecutive cells of one row, as loaded (rows are readable and zero up to a multiple of 16 cells)
 template <>
-__device__ __forceinline__ void load4<float>(const float* p, bool full, int64_t k, int64_t n, double (&v)[4]) {
-	if (full) {
-		float4 t = *reinterpret_cast<const float4*>(p + k);
-		v[0] = t.x;
-		v[1] = t.y;
-		v[2] = t.z;
-		v[3] = t.w;
-	} else {
-#pragma unroll
-		for (int i = 0; i < 4; i++) v[i] = (k + i < n) ? (double)p[k + i] : 0.0;
-	}
-}
+struct Slab<float> {
+	float4 v;
+	__device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+	__device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+	__device__ __forceinline__ double get(int s) const { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+};
 template <>
-__device__ __forceinline__ void load4<double>(const double* p, bool full, int64_t k, int64_t n, double (&v)[4]) {
-	if (full) {
-		d2_t a = *reinterpret_cast<const d2_t*>(p + k), b = *reinterpret_cast<const d2_t*>(p + k + 2);
-		v[0] = a[0];
-		v[1] = a[1];
-		v[2] = b[0];
-		v[3] = b[1];
-	} else {
-#pragma unroll
-		for (int i = 0; i < 4; i++) v[i] = (k + i < n) ? p[k + i] : 0.0;
+struct Slab<double> {
+	d2_t a, b;
+	__device__ __forceinline__ void load(const double* p) {
+		a = *reinterpret_cast<const d2_t*>(p);
+		b = *reinterpret_cast<const d2_t*>(p + 2);
 	}
-}
+	__device__ __forceinline__ void zero() {
+		a = (d2_t){0.0, 0.0};
+		b = a;
+	}
+	__device__ __forceinline__ double get(int s) const { return s == 0 ? a[0] : s == 1 ? a[1] : s == 2 ? b[0] : b[1]; }
+};
 
-template <typename T>
-__global__ void __launch_bounds__(256, 3) k_gram_skinny(const T* __restrict__ A, int64_t rows, int64_t n, int64_t lda,
+// NT = number of 16-row Z tiles actually used (1 when nx + nc <= 16: half the MFMA work)
+template <typename T, int NT>
+__global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A, int64_t rows, int64_t n16, int64_t lda,
 														 const double* __restrict__ Z, int64_t ldz, double* __restrict__ G,
 														 double* __restrict__ ss, SkinnySched s) {
-	__shared__ __attribute__((aligned(16))) double lds[(SKM + SKN) * SKP];
-	double* ldsA = lds;
-	double* ldsZ = lds + SKM * SKP;
+	__shared__ __attribute__((aligned(16))) double lds[2][NT * 16 * SKP];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int l15 = lane & 15, lg = lane >> 4;
-	const int srow = tid >> 3, scol = (tid & 7) * 4;
 	const int per_xcd = s.nwg >> 3;
 	const int p = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
 	int t_dp = p;
@@ -72,96 +73,125 @@ __global__ void __launch_bounds__(256, 3) k_gram_skinny(const T* __restrict__ A,
 	int64_t uend = u + s.units_per_wg;
 	if (uend > total) uend = total;
 	for (;;) {
-		int t, k0, k1;
+		int t, c0, c1;  // tile, chunk range [c0, c1) in units of SKC cells
 		if (t_dp < s.tiles_dp) {
 			t = t_dp;
-			k0 = 0;
-			k1 = s.nkt;
+			c0 = 0;
+			c1 = s.nkt;
 			t_dp += s.nwg;
 		} else if (u < uend) {
 			const int ts = (int)(u / s.nkt);
-			k0 = (int)(u - (int64_t)ts * s.nkt);
-			int64_t k1l = k0 + (uend - u);
-			k1 = k1l > s.nkt ? s.nkt : (int)k1l;
+			c0 = (int)(u - (int64_t)ts * s.nkt);
+			int64_t c1l = c0 + (uend - u);
+			c1 = c1l > s.nkt ? s.nkt : (int)c1l;
 			t = s.tiles_dp + ts;
-			u += k1 - k0;
+			u += c1 - c0;
 		} else {
 			break;
 		}
-		// ---- one piece: rows [t*128, +128), k-tiles [k0, k1) ----
+		// ---- one piece: rows [t*256 + wid*64, +64) of this wave, cells [c0*128, c1*128) ----
+		// rows past the end are clamped to row 0: their products land in padding rows of G / ss that nobody reads
 		const T* arow[4];
-		bool alive[4];
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const int64_t r = (int64_t)t * SKM + srow + 32 * j;
-			alive[j] = r < rows;
-			arow[j] = A + (alive[j] ? r : 0) * lda;
+		for (int i = 0; i < 4; i++) {
+			const int64_t r = (int64_t)t * SKM + wid * 64 + i * 16 + l15;
+			arow[i] = A + (r < rows ? r : 0) * lda + 4 * lg;
 		}
-		const double* zrow = Z + (int64_t)srow * ldz;
-		double ra[4][4], rz[4], sq[4] = {0.0, 0.0, 0.0, 0.0};
-		d4_t acc[2][2];
+		d4_t acc[4][NT];
 #pragma unroll
-		for (int i = 0; i < 2; i++)
+		for (int i = 0; i < 4; i++)
 #pragma unroll
-			for (int j = 0; j < 2; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-		{
-			const int64_t k = (int64_t)k0 * SKK + scol;
-			const bool full = k + 3 < n;
+			for (int j = 0; j < NT; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+		double sq[4] = {0.0, 0.0, 0.0, 0.0};
+		const int64_t kbeg = (int64_t)c0 * SKC;
+		constexpr int DEPTH = sizeof(T) == 4 ? 4 : 2;  // slabs (16 cells) in flight per wave: 16 KB per wave, 64 KB per CU
+		Slab<T> pre[DEPTH][4];
 #pragma unroll
-			for (int j = 0; j < 4; j++) load4<T>(arow[j], full, k, n, ra[j]);
-			load4<double>(zrow, true, k, 0, rz);
+		for (int d = 0; d < DEPTH; d++) {
+			const int64_t k = kbeg + (int64_t)d * 16;
+			if (k < n16) {
+#pragma unroll
+				for (int i = 0; i < 4; i++) pre[d][i].load(arow[i] + k);
+			} else {
+#pragma unroll
+				for (int i = 0; i < 4; i++) pre[d][i].zero();
+			}
 		}
-		for (int kt = k0; kt < k1; kt++) {
-			__syncthreads();  // previous slab fully consumed
+		// Z chunk: NT*16 rows x 128 cells; thread -> row tid/8 (+16 per pass), 16 consecutive cells: one base address, immediates
+		const double* zsrc = Z + (int64_t)(tid >> 3) * ldz + (tid & 7) * 16;
+		const int zdst = (tid >> 3) * SKP + (tid & 7) * 16;
+		auto stage_z = [&](int buf, int64_t k0) {
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				if (!alive[j]) ra[j][0] = ra[j][1] = ra[j][2] = ra[j][3] = 0.0;
+			for (int pass = 0; pass < NT * 16 / 32; pass++) {
+				const double* src = zsrc + (int64_t)pass * 32 * ldz + k0;
+				double* dst = &lds[buf][zdst + pass * 32 * SKP];
 #pragma unroll
-				for (int i = 0; i < 4; i++) sq[j] = fma(ra[j][i], ra[j][i], sq[j]);
-				double* d = &ldsA[(srow + 32 * j) * SKP + scol];
-				*reinterpret_cast<d2_t*>(d) = (d2_t){ra[j][0], ra[j][1]};
-				*reinterpret_cast<d2_t*>(d + 2) = (d2_t){ra[j][2], ra[j][3]};
+				for (int q = 0; q < 8; q++) *reinterpret_cast<d2_t*>(dst + 2 * q) = *reinterpret_cast<const d2_t*>(src + 2 * q);
 			}
-			{
-				double* d = &ldsZ[srow * SKP + scol];
-				*reinterpret_cast<d2_t*>(d) = (d2_t){rz[0], rz[1]};
-				*reinterpret_cast<d2_t*>(d + 2) = (d2_t){rz[2], rz[3]};
-			}
-			__syncthreads();
-			if (kt + 1 < k1) {  // prefetch the next slab while this one is contracted
-				const int64_t k = (int64_t)(kt + 1) * SKK + scol;
-				const bool full = k + 3 < n;
+		};
+		__syncthreads();  // previous piece done with LDS
+		stage_z(0, kbeg);
+		__syncthreads();
+		for (int c = c0; c < c1; c++) {
+			const int buf = (c - c0) & 1;
+			if (c + 1 < c1) stage_z(buf ^ 1, (int64_t)(c + 1) * SKC);
+			const double* zl = &lds[buf][l15 * SKP + 4 * lg];
+			const int64_t kc = (int64_t)c * SKC;
+#pragma unroll 1
+			for (int h = 0; h < SKC / 16 / DEPTH; h++) {
 #pragma unroll
-				for (int j = 0; j < 4; j++) load4<T>(arow[j], full, k, n, ra[j]);
-				load4<double>(zrow, true, k, 0, rz);
-			}
-			const double* la = &ldsA[(wid * 32 + l15) * SKP + lg];
-			const double* lz = &ldsZ[l15 * SKP + lg];
+				for (int q = 0; q < DEPTH; q++) {
+					const int sl = h * DEPTH + q;
+					__builtin_amdgcn_sched_barrier(0);  // keep each slab's LDS reads next to its MFMAs (register budget)
+					Slab<T> cur[4];
 #pragma unroll
-			for (int kk = 0; kk < SKK / 4; kk++) {
-				const double a0 = la[kk * 4], a1 = la[16 * SKP + kk * 4];
-				const double z0 = lz[kk * 4], z1 = lz[16 * SKP + kk * 4];
-				acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, z0, acc[0][0], 0, 0, 0);
-				acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, z1, acc[0][1], 0, 0, 0);
-				acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, z0, acc[1][0], 0, 0, 0);
-				acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, z1, acc[1][1], 0, 0, 0);
+					for (int i = 0; i < 4; i++) cur[i] = pre[q][i];
+					// refill this slot with the slab DEPTH ahead (still inside this piece and inside the padded rows)
+					const int64_t kn = kc + (int64_t)(sl + DEPTH) * 16;
+					if (kn < n16 && kn < (int64_t)c1 * SKC) {
+#pragma unroll
+						for (int i = 0; i < 4; i++) pre[q][i].load(arow[i] + kn);
+					} else {
+#pragma unroll
+						for (int i = 0; i < 4; i++) pre[q][i].zero();
+					}
+					double zf[NT][4];
+#pragma unroll
+					for (int j = 0; j < NT; j++) {
+						const d2_t z01 = *reinterpret_cast<const d2_t*>(zl + j * 16 * SKP + sl * 16);
+						const d2_t z23 = *reinterpret_cast<const d2_t*>(zl + j * 16 * SKP + sl * 16 + 2);
+						zf[j][0] = z01[0];
+						zf[j][1] = z01[1];
+						zf[j][2] = z23[0];
+						zf[j][3] = z23[1];
+					}
+#pragma unroll
+					for (int st = 0; st < 4; st++)
+#pragma unroll
+						for (int i = 0; i < 4; i++) {
+							const double a = cur[i].get(st);
+							sq[i] = fma(a, a, sq[i]);
+#pragma unroll
+							for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zf[j][st], acc[i][j], 0, 0, 0);
+						}
+				}
 			}
+			__syncthreads();  // next chunk staged, this buffer free
 		}
 		// combine: G and ss start from zero (memset by the launcher)
-		double* gbase = G + ((int64_t)t * SKM + wid * 32) * SKN;
+		double* gbase = G + ((int64_t)t * SKM + wid * 64) * SKN;
 #pragma unroll
-		for (int i = 0; i < 2; i++)
+		for (int i = 0; i < 4; i++)
 #pragma unroll
-			for (int j = 0; j < 2; j++)
+			for (int j = 0; j < NT; j++)
 #pragma unroll
 				for (int q = 0; q < 4; q++) unsafeAtomicAdd(&gbase[(int64_t)(i * 16 + lg + 4 * q) * SKN + j * 16 + l15], acc[i][j][q]);
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			double v = sq[j];
-			v += __shfl_xor(v, 1, 64);
-			v += __shfl_xor(v, 2, 64);
-			v += __shfl_xor(v, 4, 64);
-			if ((tid & 7) == 0) unsafeAtomicAdd(&ss[(int64_t)t * SKM + srow + 32 * j], v);
+		for (int i = 0; i < 4; i++) {
+			double v = sq[i];
+			v += __shfl_xor(v, 16, 64);
+			v += __shfl_xor(v, 32, 64);
+			if (lg == 0) unsafeAtomicAdd(&ss[(int64_t)t * SKM + wid * 64 + i * 16 + l15], v);
 		}
 	}
 }
@@ -172,7 +202,9 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 							   int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, void* stream) {
 	NRM_REQUIRE(a_dtype == NRM_F32 || a_dtype == NRM_F64, "nrm_gram_skinny: bad dtype");
 	NRM_REQUIRE(rows > 0 && n > 0 && lda >= n, "Incorrect dx/dy/dc size.");
-	NRM_REQUIRE(k_pad >= n && k_pad % SKK == 0 && ldz >= k_pad && ldz % 2 == 0, "nrm_gram_skinny: Z must be padded to a multiple of %d cells", SKK);
+	const int64_t n16 = (n + 15) / 16 * 16;
+	NRM_REQUIRE(lda >= n16, "nrm_gram_skinny: rows must be readable (and zero) up to a multiple of 16 cells: lda >= %lld", (long long)n16);
+	NRM_REQUIRE(k_pad >= n && k_pad % SKC == 0 && ldz >= k_pad && ldz % 2 == 0, "nrm_gram_skinny: Z must be padded to a multiple of %d cells", SKC);
 	NRM_REQUIRE(rows_pad >= rows && rows_pad % SKM == 0, "nrm_gram_skinny: rows_pad must be a multiple of %d", SKM);
 	NRM_REQUIRE(d_a && d_z && d_g && d_ss, "nrm_gram_skinny: null pointer");
 	const int64_t al = 16 / (a_dtype == NRM_F64 ? 8 : 4);
@@ -188,8 +220,8 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 	NRM_HIP(hipMemsetAsync(d_ss, 0, (size_t)rows_pad * sizeof(double), st));
 	SkinnySched s;
 	const int64_t tiles = rows_pad / SKM;
-	s.nkt = (int)(k_pad / SKK);
-	s.nwg = 3 * g_num_cu_s;
+	s.nkt = (int)(k_pad / SKC);
+	s.nwg = 2 * g_num_cu_s;
 	s.nwg -= s.nwg % 8;
 	const int64_t waves = tiles / s.nwg, rem = tiles - waves * s.nwg;
 	int64_t sk = rem;
@@ -198,8 +230,8 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 	s.tiles_dp = (int)(tiles - sk);
 	s.units_per_wg = (int)((sk * s.nkt + s.nwg - 1) / s.nwg);
 	if (a_dtype == NRM_F64)
-		hipLaunchKernelGGL(k_gram_skinny<double>, dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n, lda, d_z, ldz, d_g, d_ss, s);
+		hipLaunchKernelGGL((k_gram_skinny<double, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
 	else
-		hipLaunchKernelGGL(k_gram_skinny<float>, dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n, lda, d_z, ldz, d_g, d_ss, s);
+		hipLaunchKernelGGL((k_gram_skinny<float, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
 	return nrm_check_launch("k_gram_skinny");
 }

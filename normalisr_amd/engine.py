@@ -141,15 +141,34 @@ class Engine:
 		v[v == 0] = 1
 		return v.astype(out_dtype, copy=False)
 
+	def _rows_padded16(self, a):
+		"""Device copy of a (rows, n) matrix whose rows are readable and zero up to a multiple of 16 cells (K2s streams
+		16-cell slabs without bounds checks).  No copy when n is already a multiple of 16 and the array is on the device."""
+		torch = self.torch
+		rows, n = a.shape
+		n16 = _round_up(n, 16)
+		if isinstance(a, np.ndarray):
+			t = torch.from_numpy(np.ascontiguousarray(a))
+			if n16 == n:
+				return t.to(self.device)
+			buf = torch.zeros((rows, n16), dtype=t.dtype, device=self.device)
+			buf[:, :n] = t.to(self.device)
+			return buf[:, :n]
+		if n16 == n and a.stride(1) == 1 and a.stride(0) % 4 == 0:
+			return a
+		buf = torch.zeros((rows, n16), dtype=a.dtype, device=self.device)
+		buf[:, :n] = a
+		return buf[:, :n]
+
 	def de_streaming_ok(self, dx, dy, dc):
 		"""The streaming path (K2s) applies to de with few design rows and 16-byte aligned expression rows."""
 		import os
 		mode = os.environ.get('NRM_DE_PATH', 'auto')
 		if dy is None or mode == 'general':
 			return False
-		ok = dx.shape[0] + dc.shape[0] <= 32 and (dy.shape[1] * dy.dtype.itemsize) % 16 == 0
+		ok = dx.shape[0] + dc.shape[0] <= 32
 		if mode == 'streaming' and not ok:
-			raise ValueError('NRM_DE_PATH=streaming needs nx + nc <= 32 and 16-byte aligned rows')
+			raise ValueError('NRM_DE_PATH=streaming needs nx + nc <= 32')
 		return ok
 
 	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None):
@@ -162,21 +181,18 @@ class Engine:
 		with torch.cuda.device(self.device):
 			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
 			# design rows: a = x C^T through the streaming Gram (all CUs), then x~ = x - (a dci) C spread along the cells
-			k32 = _round_up(n, 32)
+			k32 = _round_up(n, 128)
 			z = torch.zeros((32, k32), dtype=torch.float64, device=self.device)
 			if nc:
 				z[:nc, :n] = d_c
-			xd = dx if not isinstance(dx, np.ndarray) else self.upload(as_input(dx))
+			xd = self._rows_padded16(as_input(dx) if isinstance(dx, np.ndarray) else dx)
 			xcode = NRM_F64 if xd.dtype == torch.float64 else NRM_F32
-			gx = torch.empty((ROW_TILE, 32), dtype=torch.float64, device=self.device)
-			ssx_raw = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
+			gx = torch.empty((256, 32), dtype=torch.float64, device=self.device)
+			ssx_raw = torch.empty((256, ), dtype=torch.float64, device=self.device)
 			active = rank > 0 and nc > 0
 			if active:
-				if (xd.stride(0) * xd.element_size()) % 16 == 0:
-					_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
-														ssx_raw.data_ptr(), ROW_TILE, self._stream()))
-				else:
-					gx[:nx, :nc] = xd.to(torch.float64) @ d_c.T  # unaligned design rows: tiny product, plumbing
+				_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
+													ssx_raw.data_ptr(), 256, self._stream()))
 			xt = torch.zeros((nx, k32), dtype=torch.float64, device=self.device)
 			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
 			coefx = torch.zeros((nx, nc), dtype=torch.float64, device=self.device) if want_alpha else None
@@ -186,8 +202,8 @@ class Engine:
 													 self._stream()))
 			rx = Residualized(nx, n, xt, ssx, coefx)
 			z[nc:nc + nx] = xt
-			y = dy if not isinstance(dy, np.ndarray) else self.upload(dy)
-			ny_pad = _round_up(ny, ROW_TILE)
+			y = self._rows_padded16(dy)
+			ny_pad = _round_up(ny, 256)
 			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
 			ssraw = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), NRM_F64 if y.dtype == torch.float64 else NRM_F32, ny, n, y.stride(0),

@@ -400,3 +400,55 @@ def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
 	assert P.dtype == np.float32
 	assert close(P, po, 1e-6, 1e-38) and close(D, do, 1e-6, 1e-7) and close(V, vo, 1e-6)
 	assert (np.diag(P) == 0).all() and (P == P.T).all() and (D == D.T).all()
+
+
+def test_randomised_shapes_vs_oracle(norm):
+	"""Seeded sweep over awkward shapes (cells not a multiple of the K tile, single rows, many covariates, rank-deficient
+	covariates, mixed dtypes) through de and coex, both de paths; every case against the oracle."""
+	import os
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(2026)
+	cases = []
+	for _ in range(28):
+		nx = int(rng.choice([1, 2, 3, 17, 40]))
+		ny = int(rng.choice([1, 5, 63, 129, 300]))
+		n = int(rng.choice([40, 97, 256, 1001, 2048, 3333]))
+		nc = int(rng.choice([0, 1, 2, 7, 19, 33]))
+		if n <= nc + 3:
+			continue
+		cases.append((nx, ny, n, nc, bool(rng.integers(2)), bool(rng.integers(2)), int(rng.integers(1 << 30))))
+	assert len(cases) > 20
+	for nx, ny, n, nc, f32, dup, seed in cases:
+		r = np.random.default_rng(seed)
+		lat = r.normal(size=(1, n))
+		dy = r.normal(size=(ny, n)) * r.uniform(0.5, 3, (ny, 1)) + 0.4 * r.normal(size=(ny, 1)) * lat + r.normal(size=(ny, 1)) * 4
+		dx = (r.random((nx, n)) < 0.3).astype(np.float64) + 0.05 * lat
+		dc = np.vstack([r.normal(size=(nc - 1, n)), np.ones((1, n))]) if nc else np.zeros((0, n))
+		if dup and nc >= 3:
+			dc[1] = dc[0] * 2  # rank deficient
+		if f32:
+			dy, dx, dc = dy.astype(np.float32), dx.astype(np.float32), dc.astype(np.float32)
+		up = lambda a: a.astype(np.float64)
+		po, go, ao, vxo, vyo = oracle.association_tests(up(dx), up(dy), up(dc), return_dot=False, lowmem=False)
+		tol = dict(rtol=1e-6, floor=1e-38) if f32 else dict(rtol=RTOL, floor=0.)
+		for path in ('auto', 'general'):
+			os.environ['NRM_DE_PATH'] = path
+			try:
+				p, g, a, vx, vy = association_tests(dx, dy, dc, return_dot=False, lowmem=False)
+			finally:
+				os.environ.pop('NRM_DE_PATH', None)
+			tag = (nx, ny, n, nc, f32, dup, path)
+			if f32:
+				assert close(p, po, 1e-6, 1e-38), tag
+				assert close(g, go, 1e-6, 1e-6) and close(vy, vyo, 1e-6) and close(vx, vxo, 1e-6), tag
+			else:
+				assert p_close(p, po), tag
+				assert close(g, go, floor=1e-11) and close(vy, vyo, 1e-9) and close(vx, vxo, 1e-9) and close(a, ao, 1e-6, 1e-8), tag
+		if ny > 1:
+			p, d, v = norm.coex(dy, dc)
+			pc, dcov, vc = oracle.coex(up(dy), up(dc))
+			if f32:
+				assert close(p, pc, 1e-6, 1e-38) and close(d, dcov, 1e-6, 1e-6), (ny, n, nc, f32, dup)
+			else:
+				assert p_close(p, pc) and close(d, dcov, floor=1e-12), (ny, n, nc, f32, dup)
+			assert (np.diag(p) == 0).all() and (p == p.T).all()
