@@ -161,12 +161,18 @@ def main():
 	if args.gpus != world:
 		if world == 1 and args.gpus > 1:
 			raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {}'.format(args.gpus, args.gpus))
+	backend = os.environ.get('NRM_DIST_BACKEND', 'nccl')  # 'gloo' + NRM_SHARE_GPU=1: functional test of the N>1 path on a 1-GPU box
+	if os.environ.get('NRM_SHARE_GPU') == '1':
+		local_rank = 0
 	torch.cuda.set_device(local_rank)
 	device = torch.device('cuda', local_rank)
 	group = None
 	if world > 1:
 		import torch.distributed as dist
-		dist.init_process_group('nccl', device_id=device)
+		if backend == 'nccl':
+			dist.init_process_group('nccl', device_id=device)
+		else:
+			dist.init_process_group(backend)
 		group = dist.group.WORLD
 
 	if args.workload != 'coex_c2':
@@ -196,7 +202,7 @@ def main():
 	barrier()
 	elapsed = time.perf_counter() - t0
 	if world > 1:
-		tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+		tmax = torch.tensor([elapsed], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
 		torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
 		elapsed = float(tmax.item())
 	tests = ng * (ng - 1) // 2
