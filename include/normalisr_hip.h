@@ -156,6 +156,18 @@ int nrm_single4_sweep(const double* d_bt, const double* d_pt, int64_t ldb, const
 					  void* stream);
 
 /*
+ * single=1 sweep (every grouping tested on its own subset of cells, association.py:263-390).
+ *   d_g  (ny, ldg): Gram of the expression rows with the masked rows W_i = [1_Si C (nc rows); 1_Si x_i], i = 0..nx-1,
+ *        column i*(nc+1)+c;  d_g2 (ny, ldg2): Gram of the squared expression rows with the masks 1_Si.
+ *   d_info (nx, info_pitch) fp64 per grouping: [ns_i, vx_i, the 24 doubles of struct nrm_pvalue_plan, ccx_i (nc), M_i^+ (nc*nc)]
+ *        prepared on the host (inv_rank of C_S C_S^T stays on the host: integer rank).
+ * Outputs (nx, ldo): p, gamma (or gamma*vx when return_dot), vary; d_alpha (nx, ny, nc) or NULL.
+ */
+int nrm_single1_sweep(const double* d_g, int64_t ldg, const double* d_g2, int64_t ldg2, const double* d_info, int64_t info_pitch,
+					  int64_t nc, int64_t nx, int64_t ny, int return_dot, void* d_p, void* d_stat, void* d_vary, void* d_alpha,
+					  int out_dtype, int64_t ldo, int32_t* d_flags, void* stream);
+
+/*
  * Whole-problem host entry (numpy in / numpy out): the seam association_tests(dx, dy, dc, ...)
  * -> (p, dot|gamma, alpha|None, varx|None, vary) at association.py:761-771,1093 for single=0.
  * All pointers are HOST buffers owned by the caller.  h_dy == NULL means dy = dx (coex).

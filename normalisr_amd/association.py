@@ -134,8 +134,8 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 	"""All-pairs association tests between rows of dx and dy (or dx with itself when dy is None).
 
 	Same contract as association.py:761-1093: returns (P-values, dot|gamma, alpha|None, varx|None, vary).
-	single=0 runs on the device; single=4 (other X as covariates) runs the closed-form device path in
-	normalisr_amd.single4.  bsx, bsy, nth, bs4 are accepted and ignored (see module docstring).
+	single=0 runs on the device; single=1 (per-grouping cell subsets) and single=4 (other X as covariates) run the
+	closed-form device paths in normalisr_amd.single1 / .single4.  bsx, bsy, nth, bs4 are accepted and ignored (see module docstring).
 	With return_stats=True a sixth element {'r':..., 't':..., 'dof':...} is appended.
 	"""
 	bs = ka.pop('bs', None)  # the reference's docstring promises `bs` (coex.py:38) but crashes on it (SURVEY Q8)
@@ -156,7 +156,8 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 	if single == 1:
 		if samexy:
 			raise NotImplementedError('dy=None with single=1')
-		raise NotImplementedError('single=1 (per-grouping cell subsets) is not on the device path yet.')
+		from .single1 import association_tests_single1
+		return association_tests_single1(dx, dy, dc, lowmem=lowmem, return_dot=return_dot, return_stats=return_stats, **ka)
 	if single == 5:
 		raise NotImplementedError('single=5 is under development in the reference and not provided.')
 	if single == 4:

@@ -1,0 +1,138 @@
+"""single=1: each grouping is tested only on cells that carry no OTHER grouping (low-MOI CRISPR screens).
+
+Reference: association.py:911-925 builds sselectx[i,k] = (dx[i,k] == sum_j dx[j,k]) and association_test_2
+(:263-390) loops over groupings: subset the cells, pseudo-invert the subset's covariate Gram matrix, residualise
+x_i and every gene on the subset, R^2, p with dof_i = ns_i - 1 - rank_i - dimreduce.
+
+Device formulation: all per-(grouping, gene) quantities are bilinear in the gene's expression row, so the whole
+loop collapses into two Gram contractions on the fp64 matrix cores (K2),
+
+    G  = Y  W^T,   W_i = [1_Si * C (nc rows); 1_Si * x_i]      and      G2 = (Y*Y) S^T,  S_i = 1_Si,
+
+a tiny host step per grouping (inv_rank of C_S C_S^T: the rank is an integer and stays on the host) and one
+sweep kernel (csrc/nrm_single1.hip).  Groupings are processed in chunks to bound the size of W.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from . import _lib
+from . import engine as _engine
+from ._lib import ROW_TILE, PvaluePlan
+from .association import inv_rank
+
+
+def _round_up(v, m):
+	return (v + m - 1) // m * m
+
+
+def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, chunk=256, **ka):
+	"""Device path of association_tests(..., single=1); returns (p, gamma|dot, alpha|None, varx (n_x,), vary (n_x,n_y))."""
+	if ka:
+		raise TypeError("association_test_2() got an unexpected keyword argument '{}'".format(next(iter(ka))))
+	if dy is None:
+		raise NotImplementedError('dy=None with single=1')  # association.py:912
+	if return_stats:
+		raise NotImplementedError('return_stats is only available for single=0.')
+	if np.ndim(dimreduce) != 0:
+		d = np.unique(np.asarray(dimreduce))
+		if d.size != 1:
+			raise NotImplementedError('Per-gene dimreduce arrays are not supported on the device path.')
+		dimreduce = d[0]
+	dimreduce = int(dimreduce)
+	dx, dy, dc = np.asarray(dx), np.asarray(dy), np.asarray(dc)
+	nx, n = dx.shape
+	ny, nc = dy.shape[0], dc.shape[0]
+	if dy.shape[1] != n or dc.shape[1] != n:
+		raise ValueError('Unmatching dx/dy/dc dimensions.')
+	if nc == 0:
+		logging.warning('No covariate dc input.')
+	if nc > 31:
+		raise NotImplementedError('single=1 on the device supports at most 31 covariates.')
+	assert dx.max() == 1  # association.py:914
+	x64 = dx.astype(np.float64)
+	sel = x64 == x64.sum(axis=0)  # association.py:915-916
+	selx = np.where(sel, x64, np.nan)
+	assert ((np.nanmax(selx, axis=1) - np.nanmin(selx, axis=1)) > 0).all()  # >1 distinct value among the selected cells (:917-918)
+	ns = sel.sum(axis=1)
+	c64 = np.asarray(dc, dtype=np.float64)
+	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	eng = _engine.get_engine()
+	torch = eng.torch
+	tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+	nw = nc + 1
+	with torch.cuda.device(eng.device):
+		ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
+		y2 = Residualized_sq(ry, eng)
+		d_c = eng.upload(c64) if nc else None
+		p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+		stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+		vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+		alpha = None if lowmem else torch.zeros((nx, ny, nc), dtype=tdt, device=eng.device)
+		flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
+		varx = np.empty(nx)
+		pitch = 26 + nc + nc * nc
+		kp = ry.k_pad
+		for i0 in range(0, nx, chunk):
+			i1 = min(nx, i0 + chunk)
+			m = i1 - i0
+			d_sel = eng.upload(sel[i0:i1].astype(np.float64))  # (m, n)
+			d_x = eng.upload(x64[i0:i1])
+			wrows = _round_up(m * nw, ROW_TILE)
+			w = torch.zeros((wrows, kp), dtype=torch.float64, device=eng.device)
+			wv = w[:m * nw].view(m, nw, kp)
+			if nc:
+				wv[:, :nc, :n] = d_sel[:, None, :] * d_c[None, :, :]
+			wv[:, nc, :n] = d_sel * d_x
+			srows = _round_up(m, ROW_TILE)
+			s = torch.zeros((srows, kp), dtype=torch.float64, device=eng.device)
+			s[:m, :n] = d_sel
+			W = _engine.Residualized(m * nw, n, w, None, None)
+			S = _engine.Residualized(m, n, s, None, None)
+			g = eng.gram(ry, W, False)   # (ny_pad, wrows): y . (1_S C), y . (1_S x)
+			g2 = eng.gram(y2, S, False)  # (ny_pad, srows): |y_S|^2
+			# grouping-side statistics: M_i = C_S C_S^T, xC_i = C_S x_S, xx_i = |x_S|^2 (tiny; W against [C; x] rows)
+			if nc:
+				mc = torch.einsum('icn,dn->icd', wv[:, :nc, :n], d_c).cpu().numpy()       # (m, nc, nc)
+				xc = torch.einsum('in,dn->id', wv[:, nc, :n], d_c).cpu().numpy()          # (m, nc)
+			xx = (wv[:, nc, :n] * d_x).sum(dim=1).cpu().numpy()
+			info = np.zeros((m, pitch))
+			for j in range(m):
+				i = i0 + j
+				r = 0
+				ccx = np.zeros(nc)
+				mi = np.zeros((nc, nc))
+				if nc:
+					mi, r = inv_rank(mc[j])  # association.py:350-351
+					if r > 0:
+						ccx = mi @ xc[j]
+					else:
+						mi = np.zeros((nc, nc))
+				vxx = (xx[j] - (xc[j] @ ccx if nc else 0.0)) / ns[i]
+				if vxx == 0:
+					vxx = 1  # association.py:362-364
+				varx[i] = vxx
+				dof = ns[i] - 1 - r - dimreduce
+				if dof <= 0:
+					raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+				plan = PvaluePlan()
+				_lib.check(eng.lib.nrm_pvalue_plan_init(ctypes.byref(plan), float(dof)))
+				info[j, 0], info[j, 1] = ns[i], vxx
+				info[j, 2:6] = plan.a, plan.alpha, plan.ln_front, plan.umax
+				info[j, 6:26] = plan.coef[:]
+				info[j, 26:26 + nc] = ccx
+				info[j, 26 + nc:] = np.asarray(mi, dtype=np.float64).ravel()
+			d_info = eng.upload(info)
+			code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
+			_lib.check(eng.lib.nrm_single1_sweep(g.data_ptr(), g.stride(0), g2.data_ptr(), g2.stride(0), d_info.data_ptr(), pitch, nc, m, ny,
+												 1 if return_dot else 0, p[i0:i1].data_ptr(), stat[i0:i1].data_ptr(), vary[i0:i1].data_ptr(),
+												 0 if alpha is None else alpha[i0:i1].data_ptr(), code, ny, flags.data_ptr(), eng._stream()))
+		eng.check_flags(flags)
+		return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), varx.astype(out_dtype),
+				eng.download(vary))
+
+
+def Residualized_sq(ry, eng):
+	"""Element-wise square of the padded fp64 expression matrix (operand of the |y_S|^2 contraction)."""
+	return _engine.Residualized(ry.rows, ry.n, ry.data * ry.data, None, None)

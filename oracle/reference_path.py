@@ -184,15 +184,60 @@ def _test4_block(vx, vy, prod, prody, prodyy, na, dimreduce=0, lowmem=False, tol
 	return [vx, vy, p, gam, alpha, vxo, vyo]
 
 
+def _test2_block(vx, vy, dx, dy, dc, sselectx, dimreduce=0, lowmem=False):
+	"""association.py:263-390: like association_test_1 but every x uses its own subset of cells."""
+	nx, n = dx.shape
+	ny, nc = dy.shape[0], dc.shape[0]
+	p = np.zeros((nx, ny))
+	vxo = np.zeros((nx, ))
+	vyo = np.zeros((nx, ny))
+	gam = np.zeros((nx, ny))
+	alpha = None if lowmem else np.zeros((nx, ny, nc))
+	rank = np.zeros((nx, ny), dtype=int)
+	for i in range(nx):
+		t1 = np.nonzero(sselectx[i])[0]  # :341
+		ns = len(t1)
+		if len(np.unique(dx[i, t1])) < 2:
+			continue
+		x1 = dx[i, t1].astype(np.float64)
+		y1 = dy[:, t1].astype(np.float64)
+		r = 0
+		if nc > 0:
+			c1 = dc[:, t1].astype(np.float64)
+			ci, r = inv_rank(np.matmul(c1, c1.T))  # :350-351
+		rank[i] = r
+		if r > 0:
+			ccx = np.matmul(ci, np.matmul(c1, x1.T)).T
+			ccy = np.matmul(ci, np.matmul(c1, y1.T)).T
+			x1 = x1 - np.matmul(ccx, c1)
+			y1 = y1 - np.matmul(ccy, c1)
+		v = (x1**2).mean()
+		if v == 0:
+			v = 1
+		vxo[i] = v
+		vyo[i] = (y1**2).mean(axis=1)
+		gam[i] = np.matmul(x1, y1.T).ravel() / (ns * v)  # :367
+		if (not lowmem) and r > 0:
+			alpha[i] = ccy - gam[i][:, None] * ccx.ravel()
+		p[i] = (gam[i]**2) * v / vyo[i]
+	assert (p >= 0).all() and (p <= 1 + 1E-8).all()
+	dof = (sselectx.sum(axis=1) - 1 - rank.T - dimreduce).T  # :374
+	if (dof <= 0).any():
+		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+	for i in range(nx):
+		p[i] = pvalues(p[i], dof[i, 0])
+	return [vx, vy, p, gam, alpha, vxo, vyo]
+
+
 def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, **ka):
-	"""association.py:761-1093 for single=0 (any dy) and single=4 (dy is not None)."""
+	"""association.py:761-1093 for single=0 (any dy), single=1 and single=4 (dy is not None)."""
 	samexy = dy is None
 	if samexy:
 		dy = dx
 	nx, ns = dx.shape
 	ny = dy.shape[0]
 	nc = dc.shape[0]
-	if single == 0:
+	if single in (0, 1):
 		bsx, bsy = _auto_batchsize(bsx, bsy, dx.dtype.itemsize, dy.dtype.itemsize, dc.dtype.itemsize, nc, ns, samexy)
 	elif single == 4:
 		bsx, bsy = _auto_batchsize(bsx, bsy, dx.dtype.itemsize, dy.dtype.itemsize, dc.dtype.itemsize, nc, ns, samexy, maxx=10, maxy=500000)
@@ -209,6 +254,14 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		else:
 			dci, dcr = np.zeros((nc, nc)), 0  # reference sets dci=None and crashes for nc>0 (Q11)
 		tasks = [(association_test_1, (x[0], y[0], dx[x[0]:x[1]], dy[y[0]:y[1]], dc, dci, dcr), ka0) for x, y in tiles]
+	elif single == 1:
+		if samexy:
+			raise NotImplementedError('dy=None with single=1')  # :912
+		assert dx.max() == 1  # :914
+		sel = dx == dx.sum(axis=0)  # :915-916: a cell counts for x_i iff no OTHER grouping is present in it
+		for i in range(nx):
+			assert len(np.unique(dx[i, sel[i]])) > 1  # :917-918
+		tasks = [(_test2_block, (x[0], y[0], dx[x[0]:x[1]], dy[y[0]:y[1]], dc, sel[x[0]:x[1]]), ka0) for x, y in tiles]
 	else:
 		if samexy:
 			raise NotImplementedError('oracle: single=4 with dy=None not restated')

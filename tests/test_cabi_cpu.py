@@ -66,7 +66,9 @@ def test_argument_validation_before_device():
 	with pytest.raises(ValueError):
 		association_tests(x[:, :2], None, c[:, :2])  # n <= rank + 1
 	with pytest.raises(NotImplementedError):
-		association_tests(x, None, c, single=1)
+		association_tests(x, None, c, single=1)  # dy=None with single=1 (association.py:912)
+	with pytest.raises(NotImplementedError):
+		association_tests(x, None, c, single=5)
 	with pytest.raises(TypeError):
 		association_tests(x, None, c, bogus=1)
 	with pytest.raises(ValueError):

@@ -452,3 +452,30 @@ def test_randomised_shapes_vs_oracle(norm):
 			else:
 				assert p_close(p, pc) and close(d, dcov, floor=1e-12), (ny, n, nc, f32, dup)
 			assert (np.diag(p) == 0).all() and (p == p.T).all()
+
+
+def test_single1_golden_and_oracle(golden, norm):
+	"""single=1 (each grouping on the cells that carry no other grouping): two Gram contractions + sweep vs the
+	reference's per-grouping loop (association.py:263-390)."""
+	g = golden('G5_single')
+	p, gam, a, vg, vt = norm.de(g['s1_dg'], g['dt'], g['dc'], single=1, lowmem=False)
+	assert p.shape == (6, 40) and vt.shape == (6, 40) and a.shape == (6, 40, 3)
+	assert p_close(p, g['s1_p']) and close(gam, g['s1_gamma'], floor=1e-12) and close(a, g['s1_alpha'], floor=1e-10)
+	assert close(vg, g['s1_varg'], 1e-9) and close(vt, g['s1_vart'], 1e-9)
+	# larger seeded low-MOI design, fp32 expression, chunked groupings, return_dot
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(41)
+	nx, ny, n = 300, 200, 6000
+	lab = rng.integers(0, nx + 60, n)  # labels >= nx: cells without any grouping
+	dg = np.zeros((nx, n))
+	dg[lab[lab < nx], np.nonzero(lab < nx)[0]] = 1
+	extra = rng.choice(n, 400, replace=False)  # some doubly-infected cells: excluded for both groupings
+	dg[rng.integers(0, nx, 400), extra] = 1
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dt = (rng.normal(size=(ny, n)) + (rng.normal(size=(ny, 10)) @ dg[:10]) * 1.5).astype(np.float32)
+	p, d, a, vx, vy = association_tests(dg, dt, dc, single=1, return_dot=True)
+	po, do, ao, vxo, vyo = oracle.association_tests(dg, dt.astype(np.float64), dc, single=1, return_dot=True)
+	assert p.dtype == np.float32 and p.shape == (nx, ny) and a is None
+	assert close(p, po, 1e-6, 1e-38) and close(d, do, 1e-6, 1e-7) and close(vx, vxo, 1e-6) and close(vy, vyo, 1e-6)
+	with pytest.raises(AssertionError):  # a grouping that is constant on its own cells (association.py:917-918)
+		association_tests(np.vstack([dg[:3], np.zeros((1, n))]), dt[:5], dc, single=1)

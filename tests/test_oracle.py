@@ -121,3 +121,11 @@ def test_single4(golden):
 	assert relerr(p, g['s4_p']) < 1e-8 and relerr(gam, g['s4_gamma'], 1e-12) < 1e-8
 	assert relerr(vg, g['s4_varg']) < 1e-10 and relerr(vt, g['s4_vart']) < 1e-10
 	assert relerr(a, g['s4_alpha'], 1e-10) < 1e-8
+
+
+def test_single1(golden):
+	g = golden('G5_single')
+	p, gam, a, vg, vt = oracle.de(g['s1_dg'], g['dt'], g['dc'], single=1, lowmem=False)
+	assert relerr(p, g['s1_p']) < 1e-8 and relerr(gam, g['s1_gamma'], 1e-12) < 1e-8
+	assert relerr(vg, g['s1_varg']) < 1e-10 and relerr(vt, g['s1_vart']) < 1e-10
+	assert relerr(a, g['s1_alpha'], 1e-10) < 1e-8
