@@ -183,6 +183,8 @@ struct GramSched {
 	int ntm, ntn;   // tile grid (M, N)
 	int nkt;        // k-tiles (slabs of GK cells)
 	int tiles_dp;   // tiles processed whole, one per workgroup per wave
+	int tiles_al;   // tiles cut into `parts` equal K ranges, one range per workgroup (K-aligned: slabs still shared in L2)
+	int parts;
 	int tiles_sk;   // tiles of the tail, cut into unit ranges
 	int units_per_wg;
 	int nwg;        // persistent workgroups (multiple of 8)
@@ -195,6 +197,7 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 	const int per_xcd = s.nwg >> 3;
 	const int p = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
 	int t_dp = p;
+	bool al_todo = p < s.tiles_al * s.parts;
 	int64_t u = (int64_t)p * s.units_per_wg;
 	const int64_t total = (int64_t)s.tiles_sk * s.nkt;
 	int64_t uend = u + s.units_per_wg;
@@ -206,12 +209,18 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 			k0 = 0;
 			k1 = s.nkt;
 			t_dp += s.nwg;
+		} else if (al_todo) {
+			al_todo = false;
+			const int ta = p / s.parts, part = p - ta * s.parts;
+			t = s.tiles_dp + ta;
+			k0 = (int)((int64_t)s.nkt * part / s.parts);
+			k1 = (int)((int64_t)s.nkt * (part + 1) / s.parts);
 		} else if (u < uend) {
 			const int ts = (int)(u / s.nkt);
 			k0 = (int)(u - (int64_t)ts * s.nkt);
 			int64_t k1l = k0 + (uend - u);
 			k1 = k1l > s.nkt ? s.nkt : (int)k1l;
-			t = s.tiles_dp + ts;
+			t = s.tiles_dp + s.tiles_al + ts;
 			u += k1 - k0;
 		} else {
 			break;
@@ -265,14 +274,26 @@ extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad,
 	s.nkt = (int)(k_pad / GK);
 	s.nwg = 2 * g_num_cu;
 	s.nwg -= s.nwg % 8;
+	// three phases, every workgroup does the same amount of work in each:
+	//  1. whole tiles, one per workgroup per wave (K-lockstep, plain stores);
+	//  2. of the remaining rem < nwg tiles, nwg/parts tiles are cut into `parts` equal K ranges (still K-aligned within a
+	//     part, so workgroups of an XCD keep sharing slabs through L2);
+	//  3. the rest is cut into equal unit ranges (stream-K; different K offsets, no sharing -- kept small).
 	const int64_t waves = tiles / s.nwg, rem = tiles - waves * s.nwg;
-	int64_t sk = rem;
-	if (rem > 0 && rem < s.nwg / 4 && waves >= 1) sk = rem + s.nwg;  // keep every stream-K share >= ~1 tile
+	s.tiles_dp = (int)(waves * s.nwg);
+	s.parts = 1;
+	s.tiles_al = 0;
+	for (int parts = 2; parts <= 8 && s.nkt >= 8 * parts; parts *= 2)
+		if (rem >= s.nwg / parts) {
+			s.parts = parts;
+			s.tiles_al = s.nwg / parts;
+			break;
+		}
+	int64_t sk = rem - s.tiles_al;
 	s.tiles_sk = (int)sk;
-	s.tiles_dp = (int)(tiles - sk);
 	const int64_t units = sk * s.nkt;
 	s.units_per_wg = (int)((units + s.nwg - 1) / s.nwg);
-	if (sk > 0 && (s.units_per_wg % s.nkt) != 0)  // some tile pieces are combined atomically: the output must start from zero
+	if (s.tiles_al > 0 || (sk > 0 && (s.units_per_wg % s.nkt) != 0))  // tile pieces are combined atomically: the output must start from zero
 		NRM_HIP(hipMemsetAsync(d_dot, 0, (size_t)m_pad * ldd * sizeof(double), (hipStream_t)stream));
 	hipLaunchKernelGGL(k_gram_f64, dim3((unsigned)s.nwg), dim3(256), 0, (hipStream_t)stream, d_a, d_b, lda, ldb, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_f64");
