@@ -168,6 +168,15 @@ int nrm_single1_sweep(const double* d_g, int64_t ldg, const double* d_g2, int64_
 					  int out_dtype, int64_t ldo, int32_t* d_flags, void* stream);
 
 /*
+ * binnet -- binarise a (ng, ng) co-expression P-value matrix at a per-row Benjamini-Hochberg q-value cutoff
+ * (reference binnet.py:134-173 with bh :77-131; the consumer of coex's p-matrix).  d_out (ng, ldo) bytes 0/1, diagonal 0;
+ * *d_total receives the number of selected entries (0 -> the reference raises "Empty binary network");
+ * d_flags[0] counts rows with entries outside [0,1] / non-finite (reference assertions :151-152).
+ */
+int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp, double qcut, unsigned char* d_out, int64_t ldo,
+			   unsigned long long* d_total, int32_t* d_flags, void* stream);
+
+/*
  * Whole-problem host entry (numpy in / numpy out): the seam association_tests(dx, dy, dc, ...)
  * -> (p, dot|gamma, alpha|None, varx|None, vary) at association.py:761-771,1093 for single=0.
  * All pointers are HOST buffers owned by the caller.  h_dy == NULL means dy = dx (coex).

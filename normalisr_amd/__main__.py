@@ -1,6 +1,6 @@
 """`python -m normalisr_amd <cmd>` / `normalisr <cmd>`: command line of the association hot path.
 Same sub-commands, positionals and flags as the reference CLI for `de` (__main__.py:358-436) and
-`coex` (:442-492), global -v (:14-17), help on stderr + exit 1 without arguments (:649-651)."""
+`coex` (:442-492) and `binnet` (:498-509), global -v (:14-17), help on stderr + exit 1 without arguments (:649-651)."""
 import argparse
 import logging
 import sys
@@ -38,6 +38,10 @@ def build_parser():
 	p.add_argument('--var_out', dest='var_out', action='store', help='Output variance of each gene unexplained by covariates, TSV.')
 	p.add_argument('--dot_out', dest='dot_out', action='store',
 				   help='Output covariance of gene pairs after covariate removal (inner product / cell count), TSV. Pearson R = dot/sqrt(var_i var_j).')
+	p = sub.add_parser('binnet', help='Binarize P-value co-expression network.')
+	p.add_argument('pv_in', help='Input P-value matrix of gene pairwise co-expression (genes x genes), TSV.')
+	p.add_argument('net_out', help='Output binary co-expression network (genes x genes, 0/1), TSV.')
+	p.add_argument('qcut', type=float, help='Q-value cutoff for binary network.')
 	return p0
 
 

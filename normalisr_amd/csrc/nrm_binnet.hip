@@ -1,0 +1,126 @@
+// binnet: binarise a co-expression P-value matrix at a per-row Benjamini-Hochberg q-value cutoff
+// (reference binnet.py:134-173, bh at :77-131) -- the consumer of the coex p-matrix, kept on the device so
+// that a 30k x 30k p-matrix never has to cross PCIe.  HBM-bound: the matrix is read from HBM once (a row
+// stays in L2 for the handful of counting passes), one byte per entry is written.
+//
+// No sort.  For row i with m = ng-1 off-diagonal entries the reference computes, for each distinct value v with
+// rank c_v = #{p <= v}:  q_v = v / (c_v / m)  (arithmetic in the matrix dtype), takes the running minimum from
+// the top, and keeps entries with q <= qcut.  That is exactly { p <= tau* },  tau* = max{ v : q_v <= qcut }.
+// tau* is found with counting passes: k <- #{p <= qcut (1+d) k / m} started from above converges to the
+// largest k for which ANY element of rank > k fails the test even with a relative slack d >> rounding error,
+// so only the few distinct values just below that bound need the reference's exact floating-point test.
+#include "nrm_common.h"
+
+template <typename T>
+struct BnRow {
+	const T* p;
+	int64_t ng;
+	int64_t self;  // diagonal index to skip
+};
+
+__device__ __forceinline__ double bn_block_sum(double v, double* sm) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+	__syncthreads();
+	return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ double bn_block_max(double v, double* sm) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+	__syncthreads();
+	return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
+template <typename T>
+__device__ __forceinline__ int64_t bn_count_le(const BnRow<T>& r, double x, double* sm) {
+	double c = 0;
+	for (int64_t j = threadIdx.x; j < r.ng; j += 256)
+		if (j != r.self && (double)r.p[j] <= x) c += 1.0;
+	return (int64_t)bn_block_sum(c, sm);
+}
+template <typename T>
+__device__ __forceinline__ double bn_max_le(const BnRow<T>& r, double x, double* sm) {
+	double v = -1.0;
+	for (int64_t j = threadIdx.x; j < r.ng; j += 256) {
+		const double pj = (double)r.p[j];
+		if (j != r.self && pj <= x) v = fmax(v, pj);
+	}
+	return bn_block_max(v, sm);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, int64_t ng, int64_t ldp, double qcut, unsigned char* __restrict__ out,
+													 int64_t ldo, unsigned long long* __restrict__ total, int32_t* __restrict__ flags) {
+	__shared__ double sm[4];
+	const int64_t i = blockIdx.x;
+	BnRow<T> r{p + i * ldp, ng, i};
+	const double m = (double)(ng - 1);
+	const T qc = (T)qcut;  // the reference compares in the matrix dtype (numpy weak-scalar promotion)
+	const double slack = sizeof(T) == 4 ? 1e-5 : 1e-12;
+	// validity (binnet.py:151-152): finite and inside [0,1]
+	{
+		double bad = 0;
+		for (int64_t j = threadIdx.x; j < ng; j += 256) {
+			const double v = (double)r.p[j];
+			if (!(v >= 0.0 && v <= 1.0)) bad += 1.0;
+		}
+		if (bn_block_sum(bad, sm) > 0 && threadIdx.x == 0) atomicAdd(&flags[0], 1);
+	}
+	double x = 2.0;       // every entry is a candidate
+	double tau = -1.0;    // tau*: nothing selected yet
+	for (int guard = 0; guard < 1000000; guard++) {
+		// skip everything that fails the test even with slack: largest fixed point of k <- #{p <= min(x, qcut (1+slack) k/m)}
+		int64_t k = bn_count_le(r, x, sm);
+		while (k > 0) {
+			const double bound = fmin(x, qcut * (1.0 + slack) * (double)k / m);
+			const int64_t c = bn_count_le(r, bound, sm);
+			if (c == k) {
+				x = bound;
+				break;
+			}
+			k = c;
+		}
+		if (k == 0) break;
+		const double v = bn_max_le(r, x, sm);
+		if (v < 0.0) break;
+		const int64_t c = bn_count_le(r, v, sm);
+		// the reference's arithmetic, in the matrix dtype: w = c/m, q = v/w, clipped to [0,1]  (binnet.py:121-125)
+		const T w = (T)c / (T)(ng - 1);
+		T q = (T)v / w;
+		if (!isfinite((double)q)) q = (T)1;
+		q = q > (T)1 ? (T)1 : (q < (T)0 ? (T)0 : q);
+		if (q <= qc) {
+			tau = v;
+			break;
+		}
+		x = nextafter(v, -1.0);  // v fails: continue strictly below it
+	}
+	double cnt = 0;
+	unsigned char* o = out + i * ldo;
+	for (int64_t j = threadIdx.x; j < ng; j += 256) {
+		const unsigned char b = (j != i && (double)r.p[j] <= tau) ? 1 : 0;
+		o[j] = b;
+		cnt += b;
+	}
+	cnt = bn_block_sum(cnt, sm);
+	if (threadIdx.x == 0 && cnt > 0) atomicAdd(total, (unsigned long long)cnt);
+}
+
+extern "C" int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp, double qcut, unsigned char* d_out, int64_t ldo,
+						  unsigned long long* d_total, int32_t* d_flags, void* stream) {
+	NRM_REQUIRE(p_dtype == NRM_F32 || p_dtype == NRM_F64, "nrm_binnet: bad dtype");
+	NRM_REQUIRE(ng > 1 && ldp >= ng && ldo >= ng, "Wrong shape of net or namet.");
+	NRM_REQUIRE(qcut > 0 && qcut < 1, "Q-value cutoff must be between 0 and 1.");
+	NRM_REQUIRE(d_p && d_out && d_total && d_flags, "nrm_binnet: null pointer");
+	hipStream_t st = (hipStream_t)stream;
+	NRM_HIP(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
+	if (p_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_binnet_rows<double>, dim3((unsigned)ng), dim3(256), 0, st, (const double*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags);
+	else
+		hipLaunchKernelGGL(k_binnet_rows<float>, dim3((unsigned)ng), dim3(256), 0, st, (const float*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags);
+	return nrm_check_launch("k_binnet_rows");
+}

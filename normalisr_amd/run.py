@@ -81,4 +81,13 @@ def coex(args):
 		file_write_tsv(args['var_out'], ans[2])
 
 
+def binnet(args):
+	from .binnet import binnet as binnet_func
+	net = file_read_tsv(args['pv_in'])
+	logging.debug('Start calculation.')
+	ans = binnet_func(net, args['qcut'])
+	logging.debug('Finish calculation.')
+	file_write_tsv(args['net_out'], ans.astype('u1', copy=False), fmt=fmt_int)
+
+
 assert __name__ != "__main__"

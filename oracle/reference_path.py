@@ -354,3 +354,42 @@ def block_plain_c(dx, dy, dc, dci, dcr, dimreduce=0):
 	work = np.empty((nx + ny) * n + (nx + ny) * max(nc, 1))
 	lib.nrm_oracle_block(_dp(dx), _dp(dy), _dp(dc), _dp(dci), nx, ny, nc, n, int(dcr), int(dimreduce), _dp(p), _dp(g), _dp(vx), _dp(vy), _dp(work))
 	return p, g, vx, vy
+
+
+def bh(pv, weight=None):
+	"""Benjamini-Hochberg q-values with ties and optional weights (binnet.py:77-131): unique p-values u with cumulative
+	weight fraction w_u; q_u = min_{v >= u} clip(p_v / w_v, 0, 1); arithmetic in pv.dtype as the reference does."""
+	pv = np.asarray(pv)
+	assert pv.ndim == 1 and pv.size > 0
+	assert np.isfinite(pv).all() and pv.min() >= 0 and pv.max() <= 1
+	wt = np.ones(pv.size) if weight is None else np.asarray(weight)
+	u, ids = np.unique(pv, return_inverse=True)
+	w = np.zeros(u.size, dtype=pv.dtype)
+	np.add.at(w, ids, wt.astype(pv.dtype))  # sequential accumulation like the loop at binnet.py:118-119
+	w = np.cumsum(w)
+	w /= w[-1]
+	with np.errstate(divide='ignore', invalid='ignore'):
+		q = u / w
+	q[~np.isfinite(q)] = 1
+	q = np.clip(q, 0, 1)
+	q = np.minimum.accumulate(q[::-1])[::-1]  # binnet.py:126-127
+	return q[ids].astype(pv.dtype, copy=False)
+
+
+def binnet(net, qcut):
+	"""binnet.py:134-173: per-row BH q-values over the off-diagonal entries, thresholded at qcut; diagonal False."""
+	net = np.asarray(net)
+	assert net.ndim == 2 and np.isfinite(net).all() and net.min() >= 0 and net.max() <= 1
+	nt = net.shape[0]
+	if net.shape[1] != nt or nt <= 1:
+		raise ValueError('Wrong shape of net or namet.')
+	if qcut <= 0 or qcut >= 1:
+		raise ValueError('Q-value cutoff must be between 0 and 1.')
+	out = np.zeros((nt, nt), dtype=bool)
+	off = ~np.eye(nt, dtype=bool)
+	for i in range(nt):
+		q = bh(net[i, off[i]])
+		out[i, off[i]] = q <= qcut
+	if out.sum() == 0:
+		raise RuntimeError('Empty binary network.')
+	return out

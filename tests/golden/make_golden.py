@@ -247,6 +247,37 @@ def g7():
 	save('G7_block', dx=dx, dy=dy, dc=dc, dci=dci, dcr=dcr, p=r[2], gamma=r[3], alpha=r[4], vx=r[5], vy=r[6])
 
 
+def g8():
+	"""binnet / bh (binnet.py:77-173): per-row Benjamini-Hochberg q-values of a coex p-matrix, thresholded."""
+	from normalisr.binnet import binnet, bh
+	rng = np.random.default_rng(8)
+	n = 500
+	lat = rng.normal(size=(3, n))
+	dt = rng.normal(size=(150, n)) + (rng.normal(size=(150, 3)) * (rng.random((150, 3)) < 0.3)) @ lat
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	p, d, v = norm.coex(dt, dc)
+	out = dict(p=p)
+	for q in (0.05, 0.2, 0.5):
+		out['net_q{}'.format(int(q * 100))] = binnet(p, q)
+	p32 = p.astype(np.float32)
+	out['p32'] = p32
+	for q in (0.05, 0.3):
+		out['net32_q{}'.format(int(q * 100))] = binnet(p32, q)
+	# tie-heavy p-values (quantised) and exact boundary cases
+	pt = np.round(rng.random((60, 60))**3, 2)
+	pt = np.triu(pt, 1) + np.triu(pt, 1).T
+	out['pt'] = pt
+	out['nett_q10'] = binnet(pt, 0.1)
+	out['nett_q25'] = binnet(pt, 0.25)
+	vec = np.concatenate([rng.random(200)**4, [0., 0., 1., 1., 0.5, 0.5]])
+	out['bh_in'] = vec
+	out['bh_out'] = bh(vec)
+	w = rng.random(vec.size) + 0.1
+	out['bh_w'] = w
+	out['bh_wout'] = bh(vec, weight=w)
+	save('G8_binnet', **out)
+
+
 def main():
 	g1()
 	g2()
@@ -255,6 +286,7 @@ def main():
 	g5()
 	g6()
 	g7()
+	g8()
 	meta = dict(reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:

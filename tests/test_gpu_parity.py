@@ -479,3 +479,37 @@ def test_single1_golden_and_oracle(golden, norm):
 	assert close(p, po, 1e-6, 1e-38) and close(d, do, 1e-6, 1e-7) and close(vx, vxo, 1e-6) and close(vy, vyo, 1e-6)
 	with pytest.raises(AssertionError):  # a grouping that is constant on its own cells (association.py:917-918)
 		association_tests(np.vstack([dg[:3], np.zeros((1, n))]), dt[:5], dc, single=1)
+
+
+def test_binnet_golden_and_oracle(golden, norm):
+	"""binnet on the device (per-row BH threshold by counting passes, no sort): booleans bit-exact vs the reference."""
+	g = golden('G8_binnet')
+	for k, q in (('net_q5', 0.05), ('net_q20', 0.2), ('net_q50', 0.5)):
+		assert np.array_equal(norm.binnet(g['p'], q), g[k])
+	for k, q in (('net32_q5', 0.05), ('net32_q30', 0.3)):
+		assert np.array_equal(norm.binnet(g['p32'], q), g[k])
+	for k, q in (('nett_q10', 0.1), ('nett_q25', 0.25)):
+		assert np.array_equal(norm.binnet(g['pt'], q), g[k])  # tie-heavy, values on exact boundaries
+	# coex -> binnet pipeline on seeded data (p-matrix from the device), fp64 and fp32, several cutoffs
+	rng = np.random.default_rng(88)
+	n, ng = 800, 700
+	lat = rng.normal(size=(4, n))
+	dt = rng.normal(size=(ng, n)) + (rng.normal(size=(ng, 4)) * (rng.random((ng, 4)) < 0.2)) @ lat
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	for dtype in (np.float64, np.float32):
+		p = norm.coex(dt.astype(dtype), dc.astype(dtype))[0]
+		for q in (0.01, 0.1, 0.37):
+			net = norm.binnet(p, q)
+			assert net.dtype == bool and not net.diagonal().any()
+			assert np.array_equal(net, oracle.binnet(p, q)), (dtype, q)
+	# heavy ties + zeros + ones; boundary-hugging cutoffs
+	pt = np.round(rng.random((300, 300))**4, 3)
+	pt = np.triu(pt, 1) + np.triu(pt, 1).T
+	for q in (0.003, 0.05, 0.25, 0.9):
+		assert np.array_equal(norm.binnet(pt, q), oracle.binnet(pt, q)), q
+	with pytest.raises(RuntimeError):
+		norm.binnet(np.ones((20, 20)), 0.01)  # nothing survives: "Empty binary network."
+	with pytest.raises(ValueError):
+		norm.binnet(np.ones((20, 20)), 1.5)
+	with pytest.raises(AssertionError):
+		norm.binnet(np.full((20, 20), 1.5), 0.1)

@@ -129,3 +129,15 @@ def test_single1(golden):
 	assert relerr(p, g['s1_p']) < 1e-8 and relerr(gam, g['s1_gamma'], 1e-12) < 1e-8
 	assert relerr(vg, g['s1_varg']) < 1e-10 and relerr(vt, g['s1_vart']) < 1e-10
 	assert relerr(a, g['s1_alpha'], 1e-10) < 1e-8
+
+
+def test_binnet_bh(golden):
+	g = golden('G8_binnet')
+	for k, q in (('net_q5', 0.05), ('net_q20', 0.2), ('net_q50', 0.5)):
+		assert np.array_equal(oracle.binnet(g['p'], q), g[k])  # booleans: bit-exact
+	for k, q in (('net32_q5', 0.05), ('net32_q30', 0.3)):
+		assert np.array_equal(oracle.binnet(g['p32'], q), g[k])
+	for k, q in (('nett_q10', 0.1), ('nett_q25', 0.25)):
+		assert np.array_equal(oracle.binnet(g['pt'], q), g[k])  # tie-heavy
+	assert np.array_equal(oracle.bh(g['bh_in']), g['bh_out'])
+	assert relerr(oracle.bh(g['bh_in'], weight=g['bh_w']), g['bh_wout'], 1e-300) < 1e-13
