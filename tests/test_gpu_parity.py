@@ -345,6 +345,14 @@ def test_cli_round_trip_golden(golden, tmp_path):
 		assert got.shape == exp.shape, mine
 		assert relerr(got, exp, 1e-12) < 2e-7, mine  # '%.8G' keeps 8 significant digits
 	assert np.loadtxt(str(tmp_path / 'clfc.tsv'), delimiter='\t', ndmin=2).shape == (3, 14 * 2)
+	# coex -> binnet through files (run.py:313-321 writes '%i')
+	os.chdir(cwd)
+	try:
+		assert main(['binnet', 'cpv.tsv.gz', 'net.tsv', '0.5']) == 0
+	finally:
+		os.chdir(old)
+	net = np.loadtxt(str(tmp_path / 'net.tsv'), delimiter='\t', ndmin=2)
+	assert np.array_equal(net.astype(bool), oracle.binnet(load(files['cpv_tsv_gz']), 0.5))
 	assert main([]) == 1
 
 
