@@ -125,9 +125,16 @@ class CoexPlan:
 		self.flags = None
 		self._pending = []
 		self._ev = dict(residualize=[], exchange=[], gram=[], sweep=[])
+		# what travels over xGMI: the fp64 residual blocks, or -- when the input is narrower than fp64 -- the raw input
+		# blocks (half the bytes for fp32; partner blocks are then residualised again locally, K1 is HBM-cheap)
+		self.exchange_raw = world > 1 and backend is None and 'float32' in str(dt_local.dtype)
 		if world > 1:
-			self.all_data = self.be.empty((world * self.rows_pad, self.k_pad))
-			self.all_ss = self.be.empty((world * self.rows_pad, ))
+			if self.exchange_raw:
+				self.all_x = self.be.torch.empty((world * self.rows, self.n), dtype=dt_local.dtype, device=dt_local.device)
+				self._blocks = {}
+			else:
+				self.all_data = self.be.empty((world * self.rows_pad, self.k_pad))
+				self.all_ss = self.be.empty((world * self.rows_pad, ))
 
 	def _timed(self, name, timed, fn):
 		if not timed:
@@ -143,7 +150,14 @@ class CoexPlan:
 		"""Start the all-gather of residual blocks and sums of squares; returns handles to wait on (RCCL runs it on its
 		own stream, so the diagonal block pair -- local data only -- is contracted while the shards travel over xGMI)."""
 		import torch.distributed as dist
-		if dist.get_backend(self.group) == 'nccl':
+		nccl = dist.get_backend(self.group) == 'nccl'
+		if self.exchange_raw:
+			self._blocks = {}
+			if nccl:
+				return [dist.all_gather_into_tensor(self.all_x, self.x, group=self.group, async_op=True)]
+			dist.all_gather(list(self.all_x.view(self.world, self.rows, self.n).unbind(0)), self.x.contiguous(), group=self.group)
+			return []
+		if nccl:
 			return [dist.all_gather_into_tensor(self.all_data, data, group=self.group, async_op=True),
 					dist.all_gather_into_tensor(self.all_ss, ss, group=self.group, async_op=True)]
 		dist.all_gather(list(self.all_data.view(self.world, self.rows_pad, self.k_pad).unbind(0)), data, group=self.group)
@@ -151,8 +165,12 @@ class CoexPlan:
 		return []
 
 	def block(self, b):
-		if self.world == 1 or (b == self.rank and self._pending):
+		if self.world == 1 or b == self.rank:
 			return self._data, self._ss  # own block: local buffers (valid before the exchange has landed)
+		if self.exchange_raw:
+			if b not in self._blocks:  # partner block arrived raw: residualise it here (once per step)
+				self._blocks[b] = self.be.residualize(self.all_x[b * self.rows:(b + 1) * self.rows], self.cov, self.rows_pad)
+			return self._blocks[b]
 		return (self.all_data[b * self.rows_pad:(b + 1) * self.rows_pad], self.all_ss[b * self.rows_pad:(b + 1) * self.rows_pad])
 
 	def step(self, timed=False):
