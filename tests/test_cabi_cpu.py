@@ -97,3 +97,33 @@ def test_missing_device_fails_loudly():
 	import normalisr_amd.normalisr as norm
 	with pytest.raises(RuntimeError):
 		norm.coex(np.random.default_rng(0).normal(size=(4, 30)), np.ones((1, 30)))
+
+
+def test_cli_matrix_io_text_and_binary(tmp_path):
+	"""run.file_read_tsv / file_write_tsv: reference text format ('%.8G', gzip by suffix, 1-D -> (1,n)) and the .npy extension."""
+	from normalisr_amd import run
+	a = np.random.default_rng(0).normal(size=(3, 5))
+	for name in ('a.tsv', 'a.tsv.gz'):
+		f = str(tmp_path / name)
+		run.file_write_tsv(f, a)
+		b = run.file_read_tsv(f)
+		assert b.shape == a.shape and np.allclose(a, b, rtol=1e-7)
+	f = str(tmp_path / 'v.tsv')
+	run.file_write_tsv(f, a[0])
+	assert run.file_read_tsv(f).shape == (5, 1) or run.file_read_tsv(f).shape == (1, 5)
+	f = str(tmp_path / 'a.npy')
+	run.file_write_tsv(f, a.astype(np.float32))
+	b = run.file_read_tsv(f)
+	assert b.dtype == np.float32 and np.array_equal(b, a.astype(np.float32))
+	f = str(tmp_path / 'v.npy')
+	run.file_write_tsv(f, a[0])
+	assert run.file_read_tsv(f).shape == (1, 5)
+	# CLI parser: same sub-commands / flags as the reference for the association path
+	from normalisr_amd.__main__ import build_parser
+	p = build_parser()
+	ns = vars(p.parse_args(['de', 'g', 'e', 'c', 'pv', 'lfc', '-m', 'covariate', '-n', '2', '-b', '100', '-d', '1', '--vard_out', 'x']))
+	assert ns['cmd'] == 'de' and ns['method'] == 'covariate' and ns['nth'] == 2 and ns['bs'] == 100 and ns['dimr'] == 1 and ns['vard_out'] == 'x'
+	ns = vars(p.parse_args(['coex', 'e', 'c', 'pv', '--dot_out', 'd']))
+	assert ns['cmd'] == 'coex' and ns['nth'] == 0 and ns['dot_out'] == 'd' and ns['var_out'] is None
+	ns = vars(p.parse_args(['binnet', 'pv', 'net', '0.05']))
+	assert ns['cmd'] == 'binnet' and ns['qcut'] == 0.05
