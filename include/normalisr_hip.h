@@ -177,6 +177,19 @@ int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp, double qcu
 			   unsigned long long* d_total, int32_t* d_flags, void* stream);
 
 /*
+ * normvar (reference norm.py:131-289): per-gene weighted covariate removal, e_gk = w_k^wt_g.
+ *   nrm_normvar_weights: U = e^2, V = e^2 * y  (fp64, (rows_pad, ldo), zero padded) for the two Gram contractions
+ *       M_g = U P^T (P = products C_c*C_c') and a_g = V C^T on nrm_gram_f64;  s1 = sum_k y e, s2 = sum_k (y e)^2.
+ *       d_lnw (n) = ln w, d_wt (rows) = wt.
+ *   nrm_normvar_apply:   out_gk = scale_g * e_gk * (y_gk - sum_c b_gc C_ck),  b_g = M_g^+ a_g from the host (integer rank).
+ */
+int nrm_normvar_weights(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
+						double* d_u, double* d_v, int64_t ldo, int64_t rows_pad, double* d_s1, double* d_s2, void* stream);
+int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
+					  const double* d_c, int64_t nc, int64_t ldc, const double* d_b, const double* d_scale, void* d_out, int out_dtype,
+					  int64_t ldo, void* stream);
+
+/*
  * Whole-problem host entry (numpy in / numpy out): the seam association_tests(dx, dy, dc, ...)
  * -> (p, dot|gamma, alpha|None, varx|None, vary) at association.py:761-771,1093 for single=0.
  * All pointers are HOST buffers owned by the caller.  h_dy == NULL means dy = dx (coex).

@@ -4,7 +4,7 @@ reference's src/ directory."""
 import importlib
 import sys
 
-__all__ = ['association', 'binnet', 'coex', 'de', 'normalisr', 'parallel', 'run']
+__all__ = ['association', 'binnet', 'coex', 'de', 'norm', 'normalisr', 'parallel', 'run']
 for _m in __all__:
 	sys.modules[__name__ + '.' + _m] = importlib.import_module('normalisr_amd.' + _m)
 	globals()[_m] = sys.modules[__name__ + '.' + _m]

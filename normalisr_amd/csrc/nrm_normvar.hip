@@ -1,0 +1,135 @@
+// normvar (reference norm.py:131-289): variance normalisation with PER-GENE weighted covariates -- the step right
+// before de/coex in the Normalisr pipeline.  Gene g is scaled by e_gk = w_k^wt_g and the covariates C * e_g are
+// removed from it: a different (nc x nc) OLS per gene.  The reference loops over genes; here
+//     M_g = sum_k e_gk^2 C_k C_k^T   and   a_g = sum_k e_gk^2 y_gk C_k
+// are rows of two Gram contractions on the fp64 matrix cores (K2): U P^T and V C^T with U = e^2, V = e^2 y and
+// P = the nc(nc+1)/2 products C_c * C_c'.  This file holds the two HBM-bound element-wise passes around them.
+#include "nrm_common.h"
+
+#define NV_R 4
+
+__device__ __forceinline__ double nv_wave_sum(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+
+// pass 1: U = e^2, V = e^2 y (fp64, zero padded), s1 = sum y e, s2 = sum (y e)^2      (norm.py:244-249)
+template <typename T>
+__global__ void __launch_bounds__(256) k_nv_weights(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy,
+													const double* __restrict__ lnw, const double* __restrict__ wt, double* __restrict__ U,
+													double* __restrict__ V, int64_t ldo, double* __restrict__ s1, double* __restrict__ s2) {
+	__shared__ double sm[4][2 * NV_R];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int64_t row0 = (int64_t)blockIdx.x * NV_R;
+	double a1[NV_R], a2[NV_R], ex[NV_R];
+	bool live[NV_R];
+#pragma unroll
+	for (int r = 0; r < NV_R; r++) {
+		live[r] = row0 + r < rows;
+		ex[r] = live[r] ? wt[row0 + r] : 0.0;
+		a1[r] = a2[r] = 0.0;
+	}
+	for (int64_t k = tid; k < ldo; k += 256) {
+		const double lw = k < n ? lnw[k] : 0.0;
+#pragma unroll
+		for (int r = 0; r < NV_R; r++) {
+			double u = 0.0, v = 0.0;
+			if (live[r] && k < n) {
+				const double e = ex[r] == 0.0 ? 1.0 : exp(ex[r] * lw);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
+				const double yv = (double)y[(row0 + r) * ldy + k];
+				const double yp = yv * e;
+				u = e * e;
+				v = u * yv;
+				a1[r] += yp;
+				a2[r] = fma(yp, yp, a2[r]);
+			}
+			U[(row0 + r) * ldo + k] = u;
+			V[(row0 + r) * ldo + k] = v;
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < NV_R; r++) {
+		const double x1 = nv_wave_sum(a1[r]), x2 = nv_wave_sum(a2[r]);
+		if (lane == 0) {
+			sm[wid][2 * r] = x1;
+			sm[wid][2 * r + 1] = x2;
+		}
+	}
+	__syncthreads();
+	if (tid < NV_R) {
+		s1[row0 + tid] = sm[0][2 * tid] + sm[1][2 * tid] + sm[2][2 * tid] + sm[3][2 * tid];
+		s2[row0 + tid] = sm[0][2 * tid + 1] + sm[1][2 * tid + 1] + sm[2][2 * tid + 1] + sm[3][2 * tid + 1];
+	}
+}
+
+// pass 2: out = scale_g * e_gk * (y_gk - sum_c b_gc C_ck)      (norm.py:157 per gene, :259)
+template <typename T, typename OutT>
+__global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy, const double* __restrict__ lnw,
+												  const double* __restrict__ wt, const double* __restrict__ c, int nc, int64_t ldc,
+												  const double* __restrict__ b, const double* __restrict__ scale, OutT* __restrict__ out,
+												  int64_t ldo) {
+	__shared__ double s_b[NV_R][64];
+	const int tid = threadIdx.x;
+	const int64_t row0 = (int64_t)blockIdx.x * NV_R;
+	for (int i = tid; i < NV_R * nc; i += 256) {
+		const int r = i / nc, q = i % nc;
+		s_b[r][q] = row0 + r < rows ? b[(row0 + r) * nc + q] : 0.0;
+	}
+	__syncthreads();
+	double ex[NV_R], sc[NV_R];
+#pragma unroll
+	for (int r = 0; r < NV_R; r++) {
+		const bool live = row0 + r < rows;
+		ex[r] = live ? wt[row0 + r] : 0.0;
+		sc[r] = live ? scale[row0 + r] : 0.0;
+	}
+	for (int64_t k = tid; k < n; k += 256) {
+		const double lw = lnw[k];
+		double fit[NV_R];
+#pragma unroll
+		for (int r = 0; r < NV_R; r++) fit[r] = 0.0;
+		for (int q = 0; q < nc; q++) {
+			const double cv = c[(int64_t)q * ldc + k];
+#pragma unroll
+			for (int r = 0; r < NV_R; r++) fit[r] = fma(s_b[r][q], cv, fit[r]);
+		}
+#pragma unroll
+		for (int r = 0; r < NV_R; r++) {
+			if (row0 + r < rows) {
+				const double e = ex[r] == 0.0 ? 1.0 : exp(ex[r] * lw);
+				out[(row0 + r) * ldo + k] = (OutT)(sc[r] * e * ((double)y[(row0 + r) * ldy + k] - fit[r]));
+			}
+		}
+	}
+}
+
+extern "C" int nrm_normvar_weights(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
+								   double* d_u, double* d_v, int64_t ldo, int64_t rows_pad, double* d_s1, double* d_s2, void* stream) {
+	NRM_REQUIRE(y_dtype == NRM_F32 || y_dtype == NRM_F64, "nrm_normvar_weights: bad dtype");
+	NRM_REQUIRE(rows > 0 && n > 0 && ldy >= n && ldo >= n && rows_pad >= rows && rows_pad % NV_R == 0, "Unmatched gene or cell counts.");
+	NRM_REQUIRE(d_y && d_lnw && d_wt && d_u && d_v && d_s1 && d_s2, "nrm_normvar_weights: null pointer");
+	dim3 grid((unsigned)(rows_pad / NV_R));
+	if (y_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_nv_weights<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)d_y, rows, n, ldy, d_lnw, d_wt, d_u, d_v, ldo, d_s1, d_s2);
+	else
+		hipLaunchKernelGGL(k_nv_weights<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_y, rows, n, ldy, d_lnw, d_wt, d_u, d_v, ldo, d_s1, d_s2);
+	return nrm_check_launch("k_nv_weights");
+}
+
+extern "C" int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
+								 const double* d_c, int64_t nc, int64_t ldc, const double* d_b, const double* d_scale, void* d_out, int out_dtype,
+								 int64_t ldo, void* stream) {
+	NRM_REQUIRE((y_dtype == NRM_F32 || y_dtype == NRM_F64) && (out_dtype == NRM_F32 || out_dtype == NRM_F64), "nrm_normvar_apply: bad dtype");
+	NRM_REQUIRE(rows > 0 && n > 0 && ldy >= n && ldo >= n && nc > 0 && nc <= 64 && ldc >= n, "Unmatched gene or cell counts.");
+	NRM_REQUIRE(d_y && d_lnw && d_wt && d_c && d_b && d_scale && d_out, "nrm_normvar_apply: null pointer");
+	dim3 grid((unsigned)((rows + NV_R - 1) / NV_R));
+	hipStream_t st = (hipStream_t)stream;
+#define NV_LAUNCH(TY, TO) hipLaunchKernelGGL((k_nv_apply<TY, TO>), grid, dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, (int)nc, ldc, d_b, d_scale, (TO*)d_out, ldo)
+	if (y_dtype == NRM_F64 && out_dtype == NRM_F64) NV_LAUNCH(double, double);
+	else if (y_dtype == NRM_F64) NV_LAUNCH(double, float);
+	else if (out_dtype == NRM_F64) NV_LAUNCH(float, double);
+	else NV_LAUNCH(float, float);
+#undef NV_LAUNCH
+	return nrm_check_launch("k_nv_apply");
+}

@@ -1,0 +1,147 @@
+"""Variance normalisation (mirror of the reference's norm.normvar / normvar1, norm.py:131-289) on the device.
+
+normvar multiplies gene g by w**wt[g] and removes the covariates dc * w**wt[g] from it -- a different small OLS
+per gene.  The reference loops over genes (one (n_cov, n_cov) SVD and two skinny matmuls each); here the per-gene
+Gram matrices and moment vectors are rows of two Gram contractions on the fp64 matrix cores,
+    M_g = sum_k e_gk^2 C_k C_k^T = (U P^T)_g        a_g = sum_k e_gk^2 y_gk C_k = (V C^T)_g ,
+with U = e^2, V = e^2 y, P = the pairwise products of covariate rows; the pseudo-inverses (integer ranks) are a
+batched SVD on the host, and two HBM-bound element-wise kernels (csrc/nrm_normvar.hip) do the rest.
+Only normvar / normvar1 are provided from the reference's norm module (normcov, compute_var are out of scope)."""
+import numpy as np
+
+from . import _lib
+from . import engine as _engine
+from ._lib import ROW_TILE, K_TILE
+from .association import inv_rank
+
+
+def _round_up(v, m):
+	return (v + m - 1) // m * m
+
+
+def normvar1(dt, dc, w2=None):
+	"""Remove covariates from every row of dt (norm.py:131-163).  w2 (n_gene, n_cell): row g uses dc * w2[g]."""
+	dt, dc = np.asarray(dt), np.asarray(dc)
+	if w2 is not None:
+		raise NotImplementedError('normvar1 with explicit per-gene weights: use normvar (weights of the form w**wt).')
+	dc64 = np.asarray(dc, dtype=np.float64)
+	mi, r = inv_rank(np.matmul(dc64, dc64.T))
+	if r <= 0:
+		raise RuntimeError('Zero-rank covariates found.')
+	eng = _engine.get_engine()
+	d_c, d_mi = eng.covariates(dc64, mi)
+	res = eng.residualize(_engine.as_input(dt), d_c, d_mi, r)
+	out = eng.download(res.data[:dt.shape[0], :dt.shape[1]].contiguous())
+	assert np.isfinite(out).all()
+	return out.astype(np.result_type(dt.dtype, dc.dtype, np.float32), copy=False)
+
+
+def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, normmean=False, tol=1E-8):
+	"""Mean and variance normalisation, same contract as reference norm.py:166-289: returns [dtn, dcn] (+ [dextran]).
+	nth and bs are accepted for compatibility and ignored."""
+	dt, dc, w, wt = np.asarray(dt), np.asarray(dc), np.asarray(w), np.asarray(wt)
+	if any(x.ndim != 2 for x in (dt, dc)):
+		raise ValueError('dt and dc should have 2 dimensions.')
+	if any(x.ndim != 1 for x in (w, wt)):
+		raise ValueError('w and wt should have 1 dimension.')
+	nt, ns = dt.shape
+	nc = dc.shape[0]
+	if nc == 0:
+		raise ValueError('No covariates.')
+	if dc.shape[1] != ns or w.shape[0] != ns or wt.shape[0] != nt:
+		raise ValueError('Unmatched gene or cell counts.')
+	if dextra is not None:
+		dextra = np.asarray(dextra)
+		if dextra.ndim != 2 or dextra.shape[0] == 0 or dextra.shape[1] != ns:
+			raise ValueError('Unmatched shape or size for dextra.')
+	if w.min() <= 0:
+		raise ValueError('w must be positive.')
+	if wt.min() < 0:
+		raise ValueError('wt must be non-negative.')
+	if cat not in (0, 1, 2):
+		raise ValueError('Invalid cat value.')
+	if nc > 63:
+		raise NotImplementedError('normvar on the device supports at most 63 covariates.')
+	out_dtype = np.result_type(dt.dtype, dc.dtype, w.dtype, wt.dtype, np.float32)
+	out_dtype = np.dtype(np.float32) if out_dtype == np.float32 else np.dtype(np.float64)
+	eng = _engine.get_engine()
+	torch = eng.torch
+	c64 = np.asarray(dc, dtype=np.float64)
+	npair = nc * (nc + 1) // 2
+	iu = np.triu_indices(nc)
+	with torch.cuda.device(eng.device):
+		y = eng.upload(_engine.as_input(dt))
+		ycode = _lib.NRM_F64 if y.dtype == torch.float64 else _lib.NRM_F32
+		d_lnw = eng.upload(np.log(np.asarray(w, dtype=np.float64)))
+		d_wt = eng.upload(np.asarray(wt, dtype=np.float64))
+		d_c = eng.upload(c64)
+		rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
+		u = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
+		v = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
+		s1 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
+		s2 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
+		_lib.check(eng.lib.nrm_normvar_weights(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), u.data_ptr(),
+											   v.data_ptr(), kp, rp, s1.data_ptr(), s2.data_ptr(), eng._stream()))
+		# operands of the two Gram contractions: P = pairwise products of covariate rows, C itself
+		pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+		pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
+		cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+		cp[:nc, :ns] = d_c
+		R = _engine.Residualized
+		gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
+		ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
+		# per-gene pseudo-inverse on the host: batched SVD, rank rule of inv_rank (association.py:77)
+		m = np.zeros((nt, nc, nc))
+		m[:, iu[0], iu[1]] = gm
+		m[:, iu[1], iu[0]] = gm
+		_, sv, vh = np.linalg.svd(m)
+		keep = sv >= tol * sv[:, :1]
+		if (keep.sum(axis=1) <= 0).any():
+			raise RuntimeError('Zero-rank covariates found.')
+		with np.errstate(divide='ignore'):
+			inv_s = np.where(keep, 1.0 / sv, 0.0)
+		b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)  # b_g = M_g^+ a_g
+		scale = np.ones(nt)
+		if keepvar:
+			mean = s1[:nt].cpu().numpy() / ns
+			dv = np.sqrt(np.maximum(s2[:nt].cpu().numpy() / ns - mean * mean, 0.0))  # norm.py:248-249
+			dv2 = np.sqrt(np.maximum(s2[:nt].cpu().numpy() - np.einsum('gc,gc->g', ga, b), 0.0) / ns)  # |y' - P y'|^2 = |y'|^2 - a.b
+			with np.errstate(divide='ignore', invalid='ignore'):
+				scale = (dv / dv2)**np.asarray(wt, dtype=np.float64)  # norm.py:259
+		tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+		out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
+		d_b, d_scale = eng.upload(b), eng.upload(scale)
+		_lib.check(eng.lib.nrm_normvar_apply(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), d_c.data_ptr(), nc,
+											 d_c.stride(0), d_b.data_ptr(), d_scale.data_ptr(), out.data_ptr(),
+											 _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, eng._stream()))
+		# covariates: continuous rows (and the intercept for cat=1) are scaled by w (norm.py:261-273)
+		w64 = np.asarray(w, dtype=np.float64)
+		if cat == 2:
+			dcn = dc * w
+		else:
+			dcn = dc.copy()
+			t0 = ((dc != 0) & (dc != 1)).any(axis=1)
+			if cat == 1:
+				t0 |= (dc == 1).all(axis=1)
+			dcn = dcn.astype(np.result_type(dc.dtype, w.dtype), copy=False)
+			dcn[t0] = dc[t0] * w
+		if normmean:
+			dcn64 = np.asarray(dcn, dtype=np.float64)
+			mi, r = inv_rank(np.matmul(dcn64, dcn64.T))
+			if r <= 0:
+				raise RuntimeError('Zero-rank covariates found.')
+			cov = eng.covariates(dcn64, mi)
+			res = eng.residualize(out, cov[0], cov[1], r)
+			out = res.data[:nt, :ns].to(tdt).contiguous()
+		dtn = eng.download(out)
+	assert np.isfinite(dtn).all() and np.isfinite(dcn).all()
+	ans = [dtn, dcn]
+	if dextra is not None:
+		dextran = dextra * w
+		assert np.isfinite(dextran).all()
+		ans.append(dextran)
+	del w64
+	return ans
+
+
+assert __name__ != "__main__"

@@ -1,11 +1,12 @@
 """User API facade: `import normalisr_amd.normalisr as norm` (reference normalisr.py:3-9).
-Only the linear-association hot path (de, coex) and its direct consumer binnet are provided; the reference's pre/post-processing
-steps (qc_reads, lcpm, normcov, normvar, gotop, ...) are outside this build's scope."""
+Only the linear-association hot path (de, coex) its direct consumer binnet and its direct producer normvar are provided; the reference's pre/post-processing
+steps (qc_reads, lcpm, normcov, gotop, ...) are outside this build's scope."""
 from .de import de
 from .coex import coex
 from .binnet import binnet
+from .norm import normvar
 
-_OUT_OF_SCOPE = ('qc_reads', 'qc_outlier', 'lcpm', 'scaling_factor', 'normcov', 'compute_var', 'normvar', 'gotop', 'pccovt')
+_OUT_OF_SCOPE = ('qc_reads', 'qc_outlier', 'lcpm', 'scaling_factor', 'normcov', 'compute_var', 'gotop', 'pccovt')
 
 
 def __getattr__(name):

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _lib
 from . import engine as _engine
-from ._lib import ROW_TILE
+
 
 
 def _round_up(v, m):

@@ -5,4 +5,4 @@ the product (normalisr_amd/) never does.  See oracle/normalisr_oracle.c and orac
 """
 from .reference_path import (  # noqa: F401
 	ensure_built, pvalues, beta_cdf_half, inv_rank, association_test_1, association_tests, de, coex,
-	block_plain_c, pearson_r_t, bh, binnet)
+	block_plain_c, pearson_r_t, bh, binnet, normvar, normvar1)

@@ -393,3 +393,56 @@ def binnet(net, qcut):
 	if out.sum() == 0:
 		raise RuntimeError('Empty binary network.')
 	return out
+
+
+def normvar1(dt, dc, w2=None):
+	"""norm.py:131-163: remove covariates from every row; with w2 each row g uses its own covariates dc * w2[g]."""
+	if w2 is not None:
+		return np.concatenate([normvar1(dt[[g]], dc * w2[g]) for g in range(dt.shape[0])], axis=0)
+	mi, r = inv_rank(np.matmul(dc, dc.T))
+	if r <= 0:
+		raise RuntimeError('Zero-rank covariates found.')
+	return dt - np.matmul(dc.T, np.matmul(mi, np.matmul(dc, dt.T))).T
+
+
+def normvar(dt, dc, w, wt, dextra=None, cat=1, keepvar=True, normmean=False, **ka):
+	"""norm.py:166-289: variance normalisation. Gene g is multiplied by w**wt[g], covariates dc * w**wt[g] are
+	removed per gene, the variance is optionally restored, covariates (and dextra) are scaled by w."""
+	if any(x.ndim != 2 for x in (dt, dc)):
+		raise ValueError('dt and dc should have 2 dimensions.')
+	if any(x.ndim != 1 for x in (w, wt)):
+		raise ValueError('w and wt should have 1 dimension.')
+	nt, ns = dt.shape
+	if dc.shape[0] == 0:
+		raise ValueError('No covariates.')
+	if dc.shape[1] != ns or w.shape[0] != ns or wt.shape[0] != nt:
+		raise ValueError('Unmatched gene or cell counts.')
+	if w.min() <= 0:
+		raise ValueError('w must be positive.')
+	if wt.min() < 0:
+		raise ValueError('wt must be non-negative.')
+	w2 = (np.repeat([w], nt, axis=0).T**wt).T  # :244
+	w2[wt == 0] = 1
+	dt = dt * w2
+	if keepvar:
+		dv = np.sqrt(((dt.T - dt.mean(axis=1))**2).mean(axis=0))  # :248-249
+	dtn = normvar1(dt, dc, w2=w2)
+	if keepvar:
+		dv2 = np.sqrt((dtn**2).mean(axis=1))
+		dtn = (dtn.T * ((dv / dv2)**wt)).T  # :259
+	if cat == 2:
+		dcn = dc * w
+	elif cat in (0, 1):
+		dcn = dc.copy()
+		t0 = ((dc != 0) & (dc != 1)).any(axis=1)
+		if cat == 1:
+			t0 |= (dc == 1).all(axis=1)  # the intercept is scaled too
+		dcn[t0] = dc[t0] * w
+	else:
+		raise ValueError('Invalid cat value.')
+	if normmean:
+		dtn = normvar1(dtn, dcn)
+	ans = [dtn, dcn]
+	if dextra is not None:
+		ans.append(dextra * w)
+	return ans

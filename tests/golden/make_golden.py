@@ -278,6 +278,27 @@ def g8():
 	save('G8_binnet', **out)
 
 
+def g9():
+	"""normvar (norm.py:166-289): per-gene weighted covariate removal, the step right before de/coex."""
+	from normalisr.norm import normvar
+	rng = np.random.default_rng(9)
+	ng, n = 60, 350
+	dt = rng.normal(size=(ng, n)) * rng.uniform(0.5, 2, (ng, 1)) - 8 + 0.8 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))
+	dc = np.vstack([rng.normal(size=(2, n)), (rng.random((1, n)) < 0.4).astype(float), np.ones((1, n))])
+	w = np.exp(0.3 * rng.normal(size=n))
+	wt = rng.uniform(0, 1.2, ng)
+	wt[[3, 17]] = 0.
+	dextra = rng.normal(size=(2, n))
+	out = dict(dt=dt, dc=dc, w=w, wt=wt, dextra=dextra)
+	r = normvar(dt, dc, w, wt)
+	out.update(a_dtn=r[0], a_dcn=r[1])
+	r = normvar(dt, dc, w, wt, dextra=dextra, cat=2, keepvar=False, normmean=True)
+	out.update(b_dtn=r[0], b_dcn=r[1], b_dex=r[2])
+	r = normvar(dt, dc, w, wt, cat=0, bs=7)
+	out.update(c_dtn=r[0], c_dcn=r[1])
+	save('G9_normvar', **out)
+
+
 def main():
 	g1()
 	g2()
@@ -287,6 +308,7 @@ def main():
 	g6()
 	g7()
 	g8()
+	g9()
 	meta = dict(reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:

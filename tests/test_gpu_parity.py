@@ -521,3 +521,31 @@ def test_binnet_golden_and_oracle(golden, norm):
 		norm.binnet(np.ones((20, 20)), 1.5)
 	with pytest.raises(AssertionError):
 		norm.binnet(np.full((20, 20), 1.5), 0.1)
+
+
+def test_normvar_golden_and_oracle(golden, norm):
+	"""normvar on the device (per-gene weighted OLS as two Gram contractions) vs the reference's per-gene loop."""
+	g = golden('G9_normvar')
+	dt, dc, w, wt = g['dt'], g['dc'], g['w'], g['wt']
+	r = norm.normvar(dt, dc, w, wt)
+	assert len(r) == 2 and r[0].dtype == np.float64
+	assert close(r[0], g['a_dtn'], 1e-6, 1e-9) and np.array_equal(r[1], g['a_dcn'])
+	r = norm.normvar(dt, dc, w, wt, dextra=g['dextra'], cat=2, keepvar=False, normmean=True)
+	assert close(r[0], g['b_dtn'], 1e-6, 1e-9) and np.array_equal(r[1], g['b_dcn']) and np.array_equal(r[2], g['b_dex'])
+	r = norm.normvar(dt, dc, w, wt, cat=0, bs=7, nth=3)
+	assert close(r[0], g['c_dtn'], 1e-6, 1e-9) and np.array_equal(r[1], g['c_dcn'])
+	# larger seeded case, fp32 expression, 12 covariates; normalised output feeds de exactly like the reference pipeline
+	rng = np.random.default_rng(99)
+	ng, n, nc = 700, 3000, 12
+	dt = (rng.normal(size=(ng, n)) * rng.uniform(0.5, 2, (ng, 1)) - 9).astype(np.float32)
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+	w = np.exp(0.25 * rng.normal(size=n))
+	wt = rng.uniform(0, 1.5, ng)
+	wt[::50] = 0
+	got = norm.normvar(dt, dc, w, wt)
+	ref = oracle.normvar(dt.astype(np.float64), dc, w, wt)
+	assert got[0].dtype == np.float64 and close(got[0], ref[0], 1e-6, 1e-8) and np.array_equal(got[1], ref[1])
+	with pytest.raises(ValueError):
+		norm.normvar(dt, dc, -w, wt)
+	with pytest.raises(ValueError):
+		norm.normvar(dt, dc[:0], w, wt)

@@ -141,3 +141,14 @@ def test_binnet_bh(golden):
 		assert np.array_equal(oracle.binnet(g['pt'], q), g[k])  # tie-heavy
 	assert np.array_equal(oracle.bh(g['bh_in']), g['bh_out'])
 	assert relerr(oracle.bh(g['bh_in'], weight=g['bh_w']), g['bh_wout'], 1e-300) < 1e-13
+
+
+def test_normvar(golden):
+	g = golden('G9_normvar')
+	dt, dc, w, wt = g['dt'], g['dc'], g['w'], g['wt']
+	r = oracle.normvar(dt, dc, w, wt)
+	assert relerr(r[0], g['a_dtn'], 1e-12) < 1e-9 and np.array_equal(r[1], g['a_dcn'])
+	r = oracle.normvar(dt, dc, w, wt, dextra=g['dextra'], cat=2, keepvar=False, normmean=True)
+	assert relerr(r[0], g['b_dtn'], 1e-12) < 1e-9 and np.array_equal(r[1], g['b_dcn']) and np.array_equal(r[2], g['b_dex'])
+	r = oracle.normvar(dt, dc, w, wt, cat=0)
+	assert relerr(r[0], g['c_dtn'], 1e-12) < 1e-9 and np.array_equal(r[1], g['c_dcn'])
