@@ -1,6 +1,6 @@
 """`python -m normalisr_amd <cmd>` / `normalisr <cmd>`: command line of the association hot path.
 Same sub-commands, positionals and flags as the reference CLI for `de` (__main__.py:358-436) and
-`coex` (:442-492) and `binnet` (:498-509), global -v (:14-17), help on stderr + exit 1 without arguments (:649-651)."""
+`coex` (:442-492), `binnet` (:498-509) and `normvar` (:311-352), global -v (:14-17), help on stderr + exit 1 without arguments (:649-651)."""
 import argparse
 import logging
 import sys
@@ -38,6 +38,16 @@ def build_parser():
 	p.add_argument('--var_out', dest='var_out', action='store', help='Output variance of each gene unexplained by covariates, TSV.')
 	p.add_argument('--dot_out', dest='dot_out', action='store',
 				   help='Output covariance of gene pairs after covariate removal (inner product / cell count), TSV. Pearson R = dot/sqrt(var_i var_j).')
+	p = sub.add_parser('normvar', help='Normalize variances of gene expressions and covariates.')
+	p.add_argument('lcpm_in', help='Input Bayesian logCPM matrix (genes x cells), TSV.')
+	p.add_argument('weights_in', help='Input vector of the fitted weight of each cell, TSV.')
+	p.add_argument('cov_in', help='Input covariate matrix (covariates x cells), TSV.')
+	p.add_argument('scale_in', help='Input vector of the variance-normalisation scaling factor of each gene, TSV.')
+	p.add_argument('exp_out', help='Output normalized expression matrix, same format as lcpm_in.')
+	p.add_argument('cov_out', help='Output normalized covariate matrix.')
+	p.add_argument('-n', dest='nth', action='store', type=int, default='0', help='Number of CPU cores (kept for compatibility; ignored).')
+	p.add_argument('-b', dest='bs', action='store', type=int, help='Batch size (kept for compatibility; ignored).')
+
 	p = sub.add_parser('binnet', help='Binarize P-value co-expression network.')
 	p.add_argument('pv_in', help='Input P-value matrix of gene pairwise co-expression (genes x genes), TSV.')
 	p.add_argument('net_out', help='Output binary co-expression network (genes x genes, 0/1), TSV.')

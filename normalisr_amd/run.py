@@ -91,6 +91,24 @@ def coex(args):
 		file_write_tsv(args['var_out'], ans[2])
 
 
+def normvar(args):
+	from .norm import normvar as normvar_func
+	dt = file_read_tsv(args['lcpm_in'])
+	dc = file_read_tsv(args['cov_in'])
+	dmult = file_read_tsv(args['weights_in']).ravel()
+	dw = file_read_tsv(args['scale_in']).ravel()
+	ka = dict()
+	if args.get('nth') is not None:
+		ka['nth'] = args['nth']
+	if args.get('bs') is not None:
+		ka['bs'] = args['bs']
+	logging.debug('Start calculation.')
+	ans = normvar_func(dt, dc, dmult, dw, **ka)
+	logging.debug('Finish calculation.')
+	file_write_tsv(args['exp_out'], ans[0])
+	file_write_tsv(args['cov_out'], ans[1])
+
+
 def binnet(args):
 	from .binnet import binnet as binnet_func
 	net = file_read_tsv(args['pv_in'])
