@@ -38,6 +38,8 @@ def inv_rank(m, tol=1E-8, method='auto', logger=None, mpc=0, qr=0, **ka):
 	if method == 'sklearn' or (method == 'auto' and mpc > 0 and m.shape[-1] > mpc):
 		logger.debug('randomized SVD not implemented here; using exact SVD with rank cap mpc.')
 	n = m.shape[-1]
+	if not np.isfinite(m).all():
+		raise ValueError('array must not contain infs or NaNs')  # scipy.linalg.svd(check_finite=True) in the reference
 	flat = m.reshape((-1, n, n)).astype(np.float64, copy=False)
 	inv = np.empty_like(flat)
 	ranks = np.empty(flat.shape[0], dtype=int)

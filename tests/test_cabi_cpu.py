@@ -75,6 +75,8 @@ def test_argument_validation_before_device():
 		inv_rank(np.zeros((2, 3)))
 	with pytest.raises(ValueError):
 		inv_rank(np.eye(2), tol=0)
+	with pytest.raises(ValueError):
+		inv_rank(np.array([[1., np.nan], [np.nan, 1.]]))
 
 
 def test_inv_rank_matches_golden(golden):
