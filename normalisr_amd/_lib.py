@@ -53,8 +53,12 @@ def load():
 	if _lib is not None:
 		return _lib
 	if not os.path.exists(LIB_PATH):
-		raise RuntimeError('libnormalisr_hip.so is not built ({}). Run `python -m normalisr_amd.build` '
-						   '(needs hipcc); there is no CPU fallback.'.format(LIB_PATH))
+		try:  # build in-tree once if a ROCm toolchain is present; never fall back to a CPU path
+			from . import build as _build
+			_build.build()
+		except Exception as e:
+			raise RuntimeError('libnormalisr_hip.so is not built ({}) and building it failed: {}. Run `python -m normalisr_amd.build` '
+							   '(needs hipcc); there is no CPU fallback.'.format(LIB_PATH, e))
 	# One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  If it is
 	# loaded first our DT_NEEDED entry binds to it; the other order would load /opt/rocm's copy next to
 	# torch's and the second runtime finds no device.  torch is the plumbing for device memory anyway.
