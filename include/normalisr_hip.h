@@ -77,7 +77,10 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
  */
 int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad,
 				 int64_t lda, int64_t ldb, double* d_dot, int64_t ldd, int symmetric,
-				 int64_t m_rows, int64_t n_rows, void* stream);
+				 int64_t m_rows, int64_t n_rows, void* d_work, void* stream);
+/* Size of the device scratch nrm_gram_f64 needs in d_work (partial tiles of the stream-K tail; summed in a fixed
+ * order, so results are bitwise reproducible).  Independent of the problem size. */
+int64_t nrm_gram_workspace_bytes(void);
 
 /*
  * P-value plan: host-side constants of p = I_{1-R^2}(dof/2, 1/2) for one dof

@@ -23,7 +23,8 @@ _SIGNATURES = {
 	'nrm_device_count': ([ctypes.POINTER(_i32)], _i32),
 	'nrm_set_device': ([_i32], _i32),
 	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
-	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp], _i32),
+	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp], _i32),
+	'nrm_gram_workspace_bytes': ([], _i64),
 	'nrm_pvalue_plan_init': ([ctypes.POINTER(PvaluePlan), _dbl], _i32),
 	'nrm_pvalues_from_r2': ([_vp, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),

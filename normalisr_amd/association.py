@@ -132,13 +132,14 @@ def _prepare_covariates(dc):
 
 
 def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, bs4=500,
-					  return_stats=False, **ka):
+					  return_stats=False, device_out=False, **ka):
 	"""All-pairs association tests between rows of dx and dy (or dx with itself when dy is None).
 
 	Same contract as association.py:761-1093: returns (P-values, dot|gamma, alpha|None, varx|None, vary).
 	single=0 runs on the device; single=1 (per-grouping cell subsets) and single=4 (other X as covariates) run the
 	closed-form device paths in normalisr_amd.single1 / .single4.  bsx, bsy, nth, bs4 are accepted and ignored (see module docstring).
-	With return_stats=True a sixth element {'r':..., 't':..., 'dof':...} is appended.
+	With return_stats=True a sixth element {'r':..., 't':..., 'dof':...} is appended.  With device_out=True (single=0 only)
+	the two (n_x, n_y) matrices are returned as torch tensors resident in HBM (e.g. to feed binnet without crossing PCIe).
 	"""
 	bs = ka.pop('bs', None)  # the reference's docstring promises `bs` (coex.py:38) but crashes on it (SURVEY Q8)
 	if bs is not None and not bsx and not bsy:
@@ -187,8 +188,10 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 	eng = _engine.get_engine()
 	res = eng.association_single0(_engine.as_input(dx), None if samexy else _engine.as_input(dy), dc64, dci, dcr,
 								  dimreduce, return_dot=return_dot, want_alpha=not lowmem, out_dtype=out_dtype,
-								  want_rt=return_stats)
+								  want_rt=return_stats, device_out=device_out and not return_stats)
 	stat = res['stat']
+	if device_out and samexy and not return_dot:
+		raise NotImplementedError('device_out with dy=None and return_dot=False')
 	if samexy and not return_dot:
 		# association.py:1059-1061: covariance back to coefficient, row-wise by the row's variance
 		stat = (stat.T / res['vary']).T.astype(out_dtype, copy=False)

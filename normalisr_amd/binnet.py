@@ -58,10 +58,13 @@ def bh(pv, weight=None):
 
 def binnet(net, qcut):
 	"""Binarise a symmetric co-expression P-value matrix: per-row BH q-values over the off-diagonal entries,
-	thresholded at qcut (binnet.py:134-173).  Returns a boolean (n_gene, n_gene) matrix, diagonal False."""
+	thresholded at qcut (binnet.py:134-173).  Returns a boolean (n_gene, n_gene) matrix, diagonal False.
+	A torch CUDA tensor is accepted (and then returned) so that coex -> binnet can stay in HBM."""
 	from . import _lib
 	from . import engine as _engine
-	net = np.asarray(net)
+	on_device = hasattr(net, 'is_cuda') and net.is_cuda  # torch tensor already in HBM (e.g. coex(..., device_out=True)[0])
+	if not on_device:
+		net = np.asarray(net)
 	assert net.ndim == 2
 	nt = net.shape[0]
 	if net.shape[1] != nt or nt <= 1:
@@ -71,7 +74,9 @@ def binnet(net, qcut):
 	eng = _engine.get_engine()
 	torch = eng.torch
 	with torch.cuda.device(eng.device):
-		d_p = eng.upload(_engine.as_input(net))
+		d_p = net.contiguous() if on_device else eng.upload(_engine.as_input(net))
+		if d_p.dtype not in (torch.float32, torch.float64):
+			d_p = d_p.to(torch.float64)
 		out = torch.empty((nt, nt), dtype=torch.uint8, device=eng.device)
 		total = torch.zeros(1, dtype=torch.int64, device=eng.device)
 		flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
@@ -81,7 +86,7 @@ def binnet(net, qcut):
 			raise AssertionError('P-values must be finite and within [0,1] (binnet.py:151-152).')
 		if int(total.item()) == 0:
 			raise RuntimeError('Empty binary network.')
-		return eng.download(out).astype(bool, copy=False)
+		return out.to(torch.bool) if on_device else eng.download(out).astype(bool, copy=False)
 
 
 assert __name__ != "__main__"

@@ -113,7 +113,9 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	const double* sx = ssx.as<double>();
 	const double* sy = samexy ? sx : ssy.as<double>();
 	NRM_TRY(dot.alloc((size_t)mp * np_ * 8));
-	NRM_TRY(nrm_gram_f64(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, st));
+	DevBuf gwork;
+	NRM_TRY(gwork.alloc((size_t)nrm_gram_workspace_bytes()));
+	NRM_TRY(nrm_gram_f64(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, gwork.p, st));
 	NRM_TRY(flags.alloc(8));
 	NRM_HIP(hipMemsetAsync(flags.p, 0, 8, st));
 	const size_t ob = (size_t)nx * ny * esize(out_dtype);

@@ -20,7 +20,8 @@
 // tiles are processed tile-per-workgroup with all workgroups in K-lockstep (operand slabs shared through
 // L2); the tiles of the last partial wave are cut along K into equal unit ranges so every workgroup
 // finishes together (820 tiles on 512 slots would otherwise idle 20 % of the chip).  Tile pieces that do
-// not cover the whole K range are combined with fp64 atomic adds into the zero-initialised output.
+// not cover the whole K range are written to workspace slabs and summed per tile in a fixed order by a small
+// fix-up kernel (deterministic: no atomics).
 // Symmetric (coex) launches only enumerate tiles on or above the block diagonal (association.py:893-894).
 #include "nrm_common.h"
 
@@ -71,9 +72,9 @@ __device__ __forceinline__ void gram_tile_coords(int t, int symmetric, int ntm, 
 	tj = 0;
 }
 
-// One tile piece: k-tiles [kt0, kt1) of tile (ti, tj).  atomic != 0 -> accumulate into C, else store.
+// One tile piece: k-tiles [kt0, kt1) of tile (ti, tj).  slab != null -> partial piece, stored to its workspace slab.
 __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const double* __restrict__ B, int64_t lda, int64_t ldb,
-										   double* __restrict__ C, int64_t ldc, int ti, int tj, int kt0, int kt1, int atomic,
+										   double* __restrict__ C, int64_t ldc, int ti, int tj, int kt0, int kt1, double* __restrict__ slab,
 										   const unsigned need /* bit i*4+j: this wave's 16x16 sub-block (i,j) is wanted */,
 										   double* lds /* [2][2][GM*GP] */) {
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -157,25 +158,25 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 		__syncthreads();
 	}
 
-	// epilogue: lane l holds D[row = lg + 4 q][col = l15] of each 16x16 tile
-	double* cbase = C + ((int64_t)ti * GM + wm * 64) * ldc + (int64_t)tj * GN + wn * 64;
-	if (atomic) {
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-#pragma unroll
-			for (int j = 0; j < 4; j++)
-#pragma unroll
-				for (int q = 0; q < 4; q++)
-					if (need & (1u << (i * 4 + j))) unsafeAtomicAdd(&cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15], acc[i][j][q]);
+	// epilogue: lane l holds D[row = lg + 4 q][col = l15] of each 16x16 tile.  A piece that covers the whole K range goes
+	// straight to C; a partial piece goes to its own 128x128 slab of the workspace and k_gram_fixup adds the slabs of a
+	// tile in a fixed order (no atomics: results are bitwise reproducible from run to run).
+	double* cbase;
+	int64_t pitch;
+	if (slab) {
+		cbase = slab + (wm * 64) * GN + wn * 64;
+		pitch = GN;
 	} else {
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-#pragma unroll
-			for (int j = 0; j < 4; j++)
-#pragma unroll
-				for (int q = 0; q < 4; q++)
-					if (need & (1u << (i * 4 + j))) cbase[(int64_t)(i * 16 + lg + 4 * q) * ldc + j * 16 + l15] = acc[i][j][q];
+		cbase = C + ((int64_t)ti * GM + wm * 64) * ldc + (int64_t)tj * GN + wn * 64;
+		pitch = ldc;
 	}
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				if (slab || (need & (1u << (i * 4 + j)))) cbase[(int64_t)(i * 16 + lg + 4 * q) * pitch + j * 16 + l15] = acc[i][j][q];
 }
 
 struct GramSched {
@@ -188,6 +189,7 @@ struct GramSched {
 	int tiles_sk;   // tiles of the tail, cut into unit ranges
 	int units_per_wg;
 	int nwg;        // persistent workgroups (multiple of 8)
+	double* work;   // slabs of partial pieces: [tiles_al*parts] then [2 per workgroup]
 };
 
 __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ A, const double* __restrict__ B, int64_t lda,
@@ -202,8 +204,10 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 	const int64_t total = (int64_t)s.tiles_sk * s.nkt;
 	int64_t uend = u + s.units_per_wg;
 	if (uend > total) uend = total;
+	int sk_piece = 0;
 	for (;;) {  // one call site for gram_piece: whole tiles first, then this workgroup's share of the tail
 		int t, k0, k1;
+		double* slab = nullptr;
 		if (t_dp < s.tiles_dp) {
 			t = t_dp;
 			k0 = 0;
@@ -215,6 +219,7 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 			t = s.tiles_dp + ta;
 			k0 = (int)((int64_t)s.nkt * part / s.parts);
 			k1 = (int)((int64_t)s.nkt * (part + 1) / s.parts);
+			slab = s.work + (int64_t)p * (GM * GN);
 		} else if (u < uend) {
 			const int ts = (int)(u / s.nkt);
 			k0 = (int)(u - (int64_t)ts * s.nkt);
@@ -222,6 +227,8 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 			k1 = k1l > s.nkt ? s.nkt : (int)k1l;
 			t = s.tiles_dp + s.tiles_al + ts;
 			u += k1 - k0;
+			if (!(k0 == 0 && k1 == s.nkt)) slab = s.work + ((int64_t)s.tiles_al * s.parts + 2 * p + sk_piece) * (GM * GN);
+			sk_piece++;
 		} else {
 			break;
 		}
@@ -241,18 +248,71 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 					if (r0 + i * 16 < s.m_rows && c0 + j * 16 < s.n_rows && (!diag || c0 + j * 16 >= r0 + i * 16)) need |= 1u << (i * 4 + j);
 			need = __builtin_amdgcn_readfirstlane(need);
 		}
-		gram_piece(A, B, lda, ldb, C, ldc, ti, tj, k0, k1, !(k0 == 0 && k1 == s.nkt), need, lds);
+		gram_piece(A, B, lda, ldb, C, ldc, ti, tj, k0, k1, slab, need, lds);
+	}
+}
+
+// Adds the slabs of every split tile in a fixed order and writes the tile of C.  One workgroup per split tile.
+__global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int64_t ldc, int symmetric, GramSched s) {
+	const int b = blockIdx.x;
+	int ti, tj;
+	int first, count;       // slab range (aligned tiles) or workgroup range (stream-K tiles)
+	const double* base;
+	if (b < s.tiles_al) {
+		gram_tile_coords(s.tiles_dp + b, symmetric, s.ntm, s.ntn, ti, tj);
+		base = s.work + (int64_t)b * s.parts * (GM * GN);
+		first = 0;
+		count = s.parts;
+	} else {
+		const int ts = b - s.tiles_al;
+		gram_tile_coords(s.tiles_dp + s.tiles_al + ts, symmetric, s.ntm, s.ntn, ti, tj);
+		const int64_t u0 = (int64_t)ts * s.nkt, u1 = u0 + s.nkt;
+		first = (int)(u0 / s.units_per_wg);
+		int last = (int)((u1 - 1) / s.units_per_wg);
+		if (last > s.nwg - 1) last = s.nwg - 1;
+		count = last - first + 1;
+		if (count == 1 && (int64_t)first * s.units_per_wg <= u0 && (int64_t)(first + 1) * s.units_per_wg >= u1) return;  // stored whole
+		base = s.work + (int64_t)s.tiles_al * s.parts * (GM * GN);
+	}
+	// blockIdx.y selects 16 of the tile's 128 rows: 8 workgroups per tile keep enough loads in flight
+	double* ct = C + (int64_t)ti * GM * ldc + (int64_t)tj * GN;
+	const int e0 = blockIdx.y * (16 * GN);
+	for (int e = e0 + threadIdx.x * 2; e < e0 + 16 * GN; e += 512) {
+		d2_t acc = (d2_t){0.0, 0.0};
+		if (b < s.tiles_al) {
+			for (int q = 0; q < count; q++) acc += *reinterpret_cast<const d2_t*>(base + (int64_t)q * (GM * GN) + e);
+		} else {
+			const int ts = b - s.tiles_al;
+			for (int q = 0; q < count; q++) {
+				const int p = first + q;
+				// this workgroup's first stream-K piece lies in tile floor(p U / nkt); a second piece (if any) in the next tile
+				const int local = ((int64_t)p * s.units_per_wg / s.nkt) == ts ? 0 : 1;
+				acc += *reinterpret_cast<const d2_t*>(base + ((int64_t)2 * p + local) * (GM * GN) + e);
+			}
+		}
+		*reinterpret_cast<d2_t*>(ct + (int64_t)(e / GN) * ldc + (e % GN)) = acc;
 	}
 }
 
 static int g_num_cu = 0;
 
+extern "C" int64_t nrm_gram_workspace_bytes(void) {
+	if (g_num_cu == 0) {
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cu <= 0)
+			g_num_cu = 256;
+	}
+	// at most nwg/2 aligned tiles x 2 parts (= nwg slabs for any parts) plus two stream-K slabs per workgroup
+	return (int64_t)3 * (2 * g_num_cu) * GM * GN * (int64_t)sizeof(double);
+}
+
 extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,
-							int64_t ldb, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, void* stream) {
+							int64_t ldb, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, void* d_work,
+							void* stream) {
 	NRM_REQUIRE(m_pad >= 0 && n_pad >= 0 && k_pad > 0, "nrm_gram_f64: bad sizes");
 	NRM_REQUIRE(m_pad % GM == 0 && n_pad % GN == 0 && k_pad % GK == 0, "nrm_gram_f64: sizes must be padded to %d/%d/%d", GM, GN, GK);
 	NRM_REQUIRE(lda >= k_pad && ldb >= k_pad && ldd >= n_pad, "nrm_gram_f64: pitch too small");
-	NRM_REQUIRE(lda % 2 == 0 && ldb % 2 == 0, "nrm_gram_f64: operand pitches must be even (16-byte rows)");
+	NRM_REQUIRE(lda % 2 == 0 && ldb % 2 == 0 && ldd % 2 == 0, "nrm_gram_f64: pitches must be even (16-byte rows)");
 	NRM_REQUIRE(!symmetric || m_pad == n_pad, "nrm_gram_f64: symmetric needs square output");
 	if (m_pad == 0 || n_pad == 0) return NRM_OK;
 	NRM_REQUIRE(d_a && d_b && d_dot, "nrm_gram_f64: null pointer");
@@ -293,8 +353,10 @@ extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad,
 	s.tiles_sk = (int)sk;
 	const int64_t units = sk * s.nkt;
 	s.units_per_wg = (int)((units + s.nwg - 1) / s.nwg);
-	if (s.tiles_al > 0 || (sk > 0 && (s.units_per_wg % s.nkt) != 0))  // tile pieces are combined atomically: the output must start from zero
-		NRM_HIP(hipMemsetAsync(d_dot, 0, (size_t)m_pad * ldd * sizeof(double), (hipStream_t)stream));
+	NRM_REQUIRE(d_work != nullptr, "nrm_gram_f64: workspace of nrm_gram_workspace_bytes() bytes required");
+	s.work = (double*)d_work;
 	hipLaunchKernelGGL(k_gram_f64, dim3((unsigned)s.nwg), dim3(256), 0, (hipStream_t)stream, d_a, d_b, lda, ldb, d_dot, ldd, symmetric, s);
+	if (s.tiles_al + s.tiles_sk > 0)
+		hipLaunchKernelGGL(k_gram_fixup, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_f64");
 }

@@ -52,6 +52,7 @@ class Engine:
 		self.torch = torch
 		self.lib = _lib.load()
 		self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+		self._gram_work = None
 
 	def _stream(self):
 		return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -106,9 +107,11 @@ class Engine:
 		torch = self.torch
 		with torch.cuda.device(self.device):
 			dot = torch.empty((a.rows_pad, b.rows_pad), dtype=torch.float64, device=self.device)
+			if self._gram_work is None:
+				self._gram_work = torch.empty((int(self.lib.nrm_gram_workspace_bytes()) // 8, ), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_gram_f64(a.data.data_ptr(), b.data.data_ptr(), a.rows_pad, b.rows_pad, a.k_pad,
 											 a.data.stride(0), b.data.stride(0), dot.data_ptr(), dot.stride(0),
-											 1 if symmetric else 0, int(a.rows), int(b.rows), self._stream()))
+											 1 if symmetric else 0, int(a.rows), int(b.rows), self._gram_work.data_ptr(), self._stream()))
 		return dot
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None):
@@ -245,7 +248,8 @@ class Engine:
 				res['t'] = t.cpu().numpy()
 		return res
 
-	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None):
+	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
+							device_out=False):
 		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric).
 		cov: optional (d_c, d_dci) already on the device (repeated calls with the same covariates)."""
 		samexy = dy is None
@@ -268,7 +272,8 @@ class Engine:
 			else:
 				alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
 		self.check_flags(flags)
-		res = dict(p=self.download(p), stat=self.download(stat), alpha=alpha,
+		keep = (lambda t: t) if device_out else self.download  # device_out: p / stat stay in HBM (torch tensors) for a device pipeline
+		res = dict(p=keep(p), stat=keep(stat), alpha=alpha,
 				   varx=None if samexy else self.variances(rx.ss, nx, n, out_dtype),
 				   vary=self.variances(ry.ss, ny, n, out_dtype), dof=dof)
 		if want_rt:

@@ -510,6 +510,11 @@ def test_binnet_golden_and_oracle(golden, norm):
 			net = norm.binnet(p, q)
 			assert net.dtype == bool and not net.diagonal().any()
 			assert np.array_equal(net, oracle.binnet(p, q)), (dtype, q)
+	# device pipeline: the p-matrix never leaves HBM
+	pd, dd, vd = norm.coex(dt, dc, device_out=True)
+	assert pd.is_cuda and np.array_equal(pd.cpu().numpy(), norm.coex(dt, dc)[0])
+	netd = norm.binnet(pd, 0.1)
+	assert netd.is_cuda and np.array_equal(netd.cpu().numpy(), oracle.binnet(pd.cpu().numpy(), 0.1))
 	# heavy ties + zeros + ones; boundary-hugging cutoffs
 	pt = np.round(rng.random((300, 300))**4, 3)
 	pt = np.triu(pt, 1) + np.triu(pt, 1).T
