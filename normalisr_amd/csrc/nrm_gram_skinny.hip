@@ -19,8 +19,8 @@
 // with the whole 512-entry register file (accumulators forced into VGPRs: -amdgpu-mfma-vgpr-form, AGPR accumulators
 // halve the fp64 MFMA rate).  Z (tiny, shared
 // by every wave) is staged through LDS in chunks of 128 cells, double buffered, one barrier per chunk.
-// Persistent DP + stream-K schedule as in K2 so that 79 row tiles still fill 256 CUs; pieces are combined
-// with fp64 atomics into zeroed G / ss.
+// Persistent DP + stream-K schedule as in K2 so that 79 row tiles still fill 256 CUs; partial pieces go to
+// workspace slabs and are summed in a fixed order (k_skinny_fixup): bitwise reproducible, no atomics.
 #include "nrm_common.h"
 
 #define SKM 256      // rows per workgroup tile (4 waves x 64)
@@ -32,7 +32,9 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 
 struct SkinnySched {
 	int nkt, tiles_dp, tiles_sk, units_per_wg, nwg;
+	double* work;  // per partial piece: a (256 x 32) slab of G followed by 256 sums of squares; two pieces per workgroup
 };
+#define SK_SLAB (SKM * SKN + SKM)
 
 template <typename T>
 struct Slab;  // 4 consecutive cells of one row, as loaded (rows are readable and zero up to a multiple of 16 cells)
@@ -72,8 +74,10 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 	const int64_t total = (int64_t)s.tiles_sk * s.nkt;
 	int64_t uend = u + s.units_per_wg;
 	if (uend > total) uend = total;
+	int sk_piece = 0;
 	for (;;) {
 		int t, c0, c1;  // tile, chunk range [c0, c1) in units of SKC cells
+		double* slab = nullptr;
 		if (t_dp < s.tiles_dp) {
 			t = t_dp;
 			c0 = 0;
@@ -86,6 +90,8 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 			c1 = c1l > s.nkt ? s.nkt : (int)c1l;
 			t = s.tiles_dp + ts;
 			u += c1 - c0;
+			if (!(c0 == 0 && c1 == s.nkt)) slab = s.work + ((int64_t)2 * p + sk_piece) * SK_SLAB;
+			sk_piece++;
 		} else {
 			break;
 		}
@@ -178,28 +184,67 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 			}
 			__syncthreads();  // next chunk staged, this buffer free
 		}
-		// combine: G and ss start from zero (memset by the launcher)
-		double* gbase = G + ((int64_t)t * SKM + wid * 64) * SKN;
+		// a piece covering all cells writes G / ss directly; partial pieces write their slab, summed in fixed order by k_skinny_fixup
+		double* gbase = slab ? slab + (wid * 64) * SKN : G + ((int64_t)t * SKM + wid * 64) * SKN;
+		double* sbase = slab ? slab + SKM * SKN + wid * 64 : ss + (int64_t)t * SKM + wid * 64;
 #pragma unroll
 		for (int i = 0; i < 4; i++)
 #pragma unroll
 			for (int j = 0; j < NT; j++)
 #pragma unroll
-				for (int q = 0; q < 4; q++) unsafeAtomicAdd(&gbase[(int64_t)(i * 16 + lg + 4 * q) * SKN + j * 16 + l15], acc[i][j][q]);
+				for (int q = 0; q < 4; q++) gbase[(int64_t)(i * 16 + lg + 4 * q) * SKN + j * 16 + l15] = acc[i][j][q];
+		if (NT < 2) {
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+#pragma unroll
+				for (int q = 0; q < 4; q++) gbase[(int64_t)(i * 16 + lg + 4 * q) * SKN + 16 + l15] = 0.0;
+		}
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
 			double v = sq[i];
 			v += __shfl_xor(v, 16, 64);
 			v += __shfl_xor(v, 32, 64);
-			if (lg == 0) unsafeAtomicAdd(&ss[(int64_t)t * SKM + wid * 64 + i * 16 + l15], v);
+			if (lg == 0) sbase[i * 16 + l15] = v;
 		}
 	}
 }
 
+// Sum the slabs of every split row tile in workgroup order (deterministic) into G and ss.  blockIdx.y selects a
+// 256-element chunk of the slab so that enough loads are in flight.
+__global__ void __launch_bounds__(256) k_skinny_fixup(double* __restrict__ G, double* __restrict__ ss, SkinnySched s) {
+	const int ts = blockIdx.x;
+	const int64_t u0 = (int64_t)ts * s.nkt, u1 = u0 + s.nkt;
+	const int first = (int)(u0 / s.units_per_wg);
+	int last = (int)((u1 - 1) / s.units_per_wg);
+	if (last > s.nwg - 1) last = s.nwg - 1;
+	if (first == last && (int64_t)first * s.units_per_wg <= u0 && (int64_t)(first + 1) * s.units_per_wg >= u1) return;  // written whole
+	const int64_t t = s.tiles_dp + ts;
+	const int e = blockIdx.y * 256 + threadIdx.x;
+	if (e >= SK_SLAB) return;
+	double acc = 0.0;
+	for (int p = first; p <= last; p++) {
+		const int local = ((int64_t)p * s.units_per_wg / s.nkt) == ts ? 0 : 1;
+		acc += s.work[((int64_t)2 * p + local) * SK_SLAB + e];
+	}
+	if (e < SKM * SKN)
+		G[t * SKM * SKN + e] = acc;
+	else
+		ss[t * SKM + (e - SKM * SKN)] = acc;
+}
+
 static int g_num_cu_s = 0;
 
+extern "C" int64_t nrm_gram_skinny_workspace_bytes(void) {
+	if (g_num_cu_s == 0) {
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_num_cu_s, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cu_s <= 0)
+			g_num_cu_s = 256;
+	}
+	return (int64_t)2 * (2 * g_num_cu_s) * SK_SLAB * (int64_t)sizeof(double);
+}
+
 extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64_t n, int64_t lda, const double* d_z, int64_t ldz,
-							   int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, void* stream) {
+							   int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, void* d_work, void* stream) {
 	NRM_REQUIRE(a_dtype == NRM_F32 || a_dtype == NRM_F64, "nrm_gram_skinny: bad dtype");
 	NRM_REQUIRE(rows > 0 && n > 0 && lda >= n, "Incorrect dx/dy/dc size.");
 	const int64_t n16 = (n + 15) / 16 * 16;
@@ -216,16 +261,15 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 		NRM_HIP(hipDeviceGetAttribute(&g_num_cu_s, hipDeviceAttributeMultiprocessorCount, dev));
 		if (g_num_cu_s <= 0) g_num_cu_s = 256;
 	}
-	NRM_HIP(hipMemsetAsync(d_g, 0, (size_t)rows_pad * SKN * sizeof(double), st));
-	NRM_HIP(hipMemsetAsync(d_ss, 0, (size_t)rows_pad * sizeof(double), st));
+	NRM_REQUIRE(d_work != nullptr, "nrm_gram_skinny: workspace of nrm_gram_skinny_workspace_bytes() bytes required");
 	SkinnySched s;
+	s.work = (double*)d_work;
 	const int64_t tiles = rows_pad / SKM;
 	s.nkt = (int)(k_pad / SKC);
 	s.nwg = 2 * g_num_cu_s;
 	s.nwg -= s.nwg % 8;
 	const int64_t waves = tiles / s.nwg, rem = tiles - waves * s.nwg;
-	int64_t sk = rem;
-	if (rem > 0 && rem < s.nwg / 4 && waves >= 1) sk = rem + s.nwg;
+	const int64_t sk = rem;  // < nwg, so a workgroup's unit range spans at most two tiles (two slabs per workgroup)
 	s.tiles_sk = (int)sk;
 	s.tiles_dp = (int)(tiles - sk);
 	s.units_per_wg = (int)((sk * s.nkt + s.nwg - 1) / s.nwg);
@@ -233,5 +277,6 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 		hipLaunchKernelGGL((k_gram_skinny<double, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
 	else
 		hipLaunchKernelGGL((k_gram_skinny<float, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+	if (s.tiles_sk > 0) hipLaunchKernelGGL(k_skinny_fixup, dim3((unsigned)s.tiles_sk, (SK_SLAB + 255) / 256), dim3(256), 0, st, d_g, d_ss, s);
 	return nrm_check_launch("k_gram_skinny");
 }

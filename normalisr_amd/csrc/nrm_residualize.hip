@@ -316,9 +316,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ x, int rows, int64_t n, int64_t ldx,
 														   const double* __restrict__ c, int nc, int64_t ldc,
 														   const double* __restrict__ ga /* (rows, 32) */, const double* __restrict__ dci,
-														   int active, double* __restrict__ out, int64_t ldo, double* __restrict__ ss,
+														   int active, double* __restrict__ out, int64_t ldo, double* __restrict__ ss_part,
 														   double* __restrict__ coef) {
 	__shared__ double s_b[RW_ROWS][RW_ROWS];
+	__shared__ double s_w[4];
 	const int tid = threadIdx.x, lane = tid & 63;
 	if (active) {
 		for (int i = tid; i < rows * nc; i += 256) {
@@ -343,27 +344,40 @@ __global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ 
 			out[(int64_t)r * ldo + k] = v;
 			sq = fma(v, v, sq);
 		}
+		// per-block partial sums (no atomics: k_rw_sum adds them in block order, bitwise reproducible)
 		sq = wave_sum(sq);
-		if (lane == 0) unsafeAtomicAdd(&ss[r], sq);
+		__syncthreads();
+		if (lane == 0) s_w[tid >> 6] = sq;
+		__syncthreads();
+		if (tid == 0) ss_part[(int64_t)blockIdx.x * RW_ROWS + r] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 	}
+}
+
+__global__ void __launch_bounds__(64) k_rw_sum(const double* __restrict__ part, int nblocks, int rows, double* __restrict__ ss) {
+	const int r = threadIdx.x;
+	if (r >= rows) return;
+	double acc = 0.0;
+	for (int b = 0; b < nblocks; b++) acc += part[(int64_t)b * RW_ROWS + r];
+	ss[r] = acc;
 }
 
 extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 									int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
-									double* d_ss, double* d_coef, void* stream) {
+									double* d_ss, double* d_coef, double* d_work, void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize_wide: bad dtype");
 	NRM_REQUIRE(rows > 0 && rows <= RW_ROWS && nc >= 0 && nc <= RW_ROWS, "nrm_residualize_wide: at most %d rows and covariates", RW_ROWS);
 	NRM_REQUIRE(n > 0 && ldx >= n && ldo >= n && d_x && d_out && d_ss, "Incorrect dx/dy/dc size.");
 	const int active = (rank > 0 && nc > 0) ? 1 : 0;
 	NRM_REQUIRE(!active || (d_c && d_ga && d_dci && ldc >= n), "Unmatching dx/dy/dc dimensions.");
 	hipStream_t st = (hipStream_t)stream;
-	NRM_HIP(hipMemsetAsync(d_ss, 0, (size_t)rows * sizeof(double), st));
+	NRM_REQUIRE(d_work != nullptr, "nrm_residualize_wide: d_work must hold 32 * ceil(ldo / 1024) doubles");
 	dim3 grid((unsigned)((ldo + 1023) / 1024));
 	if (x_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_residualize_wide<double>, grid, dim3(256), 0, st, (const double*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
-						   d_dci, active, d_out, ldo, d_ss, d_coef);
+						   d_dci, active, d_out, ldo, d_work, d_coef);
 	else
 		hipLaunchKernelGGL(k_residualize_wide<float>, grid, dim3(256), 0, st, (const float*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
-						   d_dci, active, d_out, ldo, d_ss, d_coef);
+						   d_dci, active, d_out, ldo, d_work, d_coef);
+	hipLaunchKernelGGL(k_rw_sum, dim3(1), dim3(64), 0, st, d_work, (int)grid.x, (int)rows, d_ss);
 	return nrm_check_launch("k_residualize_wide");
 }

@@ -53,6 +53,7 @@ class Engine:
 		self.lib = _lib.load()
 		self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
 		self._gram_work = None
+		self._skinny_ws = None
 
 	def _stream(self):
 		return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -155,6 +156,11 @@ class Engine:
 		v[v == 0] = 1
 		return v.astype(out_dtype, copy=False)
 
+	def _skinny_work(self):
+		if self._skinny_ws is None:
+			self._skinny_ws = self.torch.empty((int(self.lib.nrm_gram_skinny_workspace_bytes()) // 8, ), dtype=self.torch.float64, device=self.device)
+		return self._skinny_ws
+
 	def _rows_padded16(self, a):
 		"""Device copy of a (rows, n) matrix whose rows are readable and zero up to a multiple of 16 cells (K2s streams
 		16-cell slabs without bounds checks).  No copy when n is already a multiple of 16 and the array is on the device."""
@@ -206,14 +212,15 @@ class Engine:
 			active = rank > 0 and nc > 0
 			if active:
 				_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
-													ssx_raw.data_ptr(), 256, self._stream()))
+													ssx_raw.data_ptr(), 256, self._skinny_work().data_ptr(), self._stream()))
 			xt = torch.zeros((nx, k32), dtype=torch.float64, device=self.device)
+			rw_work = torch.empty((32 * ((k32 + 1023) // 1024), ), dtype=torch.float64, device=self.device)
 			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
 			coefx = torch.zeros((nx, nc), dtype=torch.float64, device=self.device) if want_alpha else None
 			_lib.check(self.lib.nrm_residualize_wide(xd.data_ptr(), xcode, nx, n, xd.stride(0), 0 if d_c is None else d_c.data_ptr(), nc,
 													 0 if d_c is None else d_c.stride(0), gx.data_ptr(), 0 if d_dci is None else d_dci.data_ptr(),
 													 int(rank), xt.data_ptr(), k32, ssx.data_ptr(), 0 if coefx is None else coefx.data_ptr(),
-													 self._stream()))
+													 rw_work.data_ptr(), self._stream()))
 			rx = Residualized(nx, n, xt, ssx, coefx)
 			z[nc:nc + nx] = xt
 			y = self._rows_padded16(dy)
@@ -221,7 +228,7 @@ class Engine:
 			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
 			ssraw = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), NRM_F64 if y.dtype == torch.float64 else NRM_F32, ny, n, y.stride(0),
-												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, self._stream()))
+												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, self._skinny_work().data_ptr(), self._stream()))
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None

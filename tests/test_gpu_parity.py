@@ -554,3 +554,18 @@ def test_normvar_golden_and_oracle(golden, norm):
 		norm.normvar(dt, dc, -w, wt)
 	with pytest.raises(ValueError):
 		norm.normvar(dt, dc[:0], w, wt)
+
+
+def test_bitwise_reproducible(norm, de_path):
+	"""No atomics on the result path: repeated calls return bit-identical p-values (stream-K partial tiles are summed
+	in a fixed order).  Matters downstream: binnet thresholds compare p-values exactly."""
+	rng = np.random.default_rng(123)
+	dt = rng.normal(size=(900, 2000)) + 0.4 * rng.normal(size=(900, 1)) * rng.normal(size=(1, 2000))
+	dc = np.vstack([rng.normal(size=(2, 2000)), np.ones((1, 2000))])
+	dg = (rng.random((6, 2000)) < 0.3).astype(float)
+	a = norm.coex(dt, dc)
+	b = norm.coex(dt, dc)
+	assert all(np.array_equal(x, y) for x, y in zip(a, b))
+	a = norm.de(dg, dt, dc)
+	b = norm.de(dg, dt, dc)
+	assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[4], b[4])
