@@ -569,3 +569,28 @@ def test_bitwise_reproducible(norm, de_path):
 	a = norm.de(dg, dt, dc)
 	b = norm.de(dg, dt, dc)
 	assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[4], b[4])
+
+
+def test_large_cell_counts_vs_oracle(norm):
+	"""BASELINE configs[2]/[3] regimes at reduced gene counts but full cell counts (p is most sensitive to the dot product
+	at large dof): streaming path at 100k cells / 20 covariates, general path at 50k cells with 256 groupings."""
+	rng = np.random.default_rng(303)
+	n, nc, ny = 100000, 20, 1500
+	dc = np.vstack([rng.standard_normal((nc - 1, n)), np.ones((1, n))]).astype(np.float32)
+	dg = (rng.random((1, n)) < 0.5).astype(np.float32)
+	dt = rng.standard_normal((ny, n), dtype=np.float32) * 1.3 - 7
+	dt[:40] += np.linspace(0.002, 0.08, 40, dtype=np.float32)[:, None] * dg[0]
+	p, gam, a, vg, vt = norm.de(dg, dt, dc)
+	po, go, ao, vgo, vto = oracle.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
+	assert po.min() < 1e-20 and po.max() > 0.5
+	assert close(p, po, 1e-6, 1e-38) and close(gam, go, 1e-6, 1e-7) and close(vt, vto, 1e-6)
+	# same data in fp64: the north-star tolerance without the final fp32 rounding
+	p, gam, a, vg, vt = norm.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
+	assert p_close(p, po) and close(gam, go, floor=1e-12)
+	n, nx, ny, nc = 50000, 256, 900, 5
+	dc = np.vstack([rng.standard_normal((nc - 1, n)), np.ones((1, n))])
+	dg = (rng.random((nx, n)) < 0.01).astype(np.float64)
+	dt = rng.standard_normal((ny, n)) + 0.5 * (rng.standard_normal((ny, 6)) @ dg[:6])
+	p, gam, a, vg, vt = norm.de(dg, dt, dc)
+	po, go, ao, vgo, vto = oracle.de(dg, dt, dc)
+	assert p_close(p, po) and close(gam, go, floor=1e-12) and close(vg, vgo, 1e-10) and close(vt, vto, 1e-10)
