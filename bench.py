@@ -81,7 +81,7 @@ def bench_de(args, torch, nd, world, rank, device):
 	"""Extra measurements on the de shapes of BASELINE configs[2] (1 x 20k x 100k, 20 covariates: HBM-bound streaming
 	path) and configs[3] (1k gRNAs x 15k genes x 50k cells: MFMA-bound general path); gene rows sharded over ranks."""
 	if args.workload == 'de_c3':
-		nx, ny, n, nc, seed = 1, 20000, 100000, 20, 3
+		nx, ny, n, nc, seed = 1, 20000, 100000, args.covariates, 3
 	else:
 		nx, ny, n, nc, seed = 1000, 15000, 50000, 5, 4
 	ny_local = ny // world
@@ -140,6 +140,7 @@ def main():
 	ap.add_argument('--cpu-worker', nargs=5, default=None, help=argparse.SUPPRESS)
 	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4'],
 					help='coex_c2 = BASELINE configs[1] (the headline line); de_c3 / de_c4 = configs[2] / configs[3] shapes (extra measurements)')
+	ap.add_argument('--covariates', type=int, default=20, help='covariates of the de_c3 workload (<= 15 selects the half-width streaming kernel)')
 	ap.add_argument('--seed', type=int, default=2)
 	ap.add_argument('--e2e', type=int, default=2, help='repetitions of the numpy-in/numpy-out end-to-end timing (0 = skip)')
 	args = ap.parse_args()

@@ -138,7 +138,8 @@ int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, 
 						 int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
 						 double* d_ss, double* d_coef, double* d_work /* 32 * ceil(ldo/1024) doubles */, void* stream);
 int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64_t n, int64_t lda, const double* d_z, int64_t ldz,
-					int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, void* d_work, void* stream);
+					int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, int64_t nz /* used rows of Z (<= 32); <= 16 selects the half-width variant */,
+					void* d_work, void* stream);
 int64_t nrm_gram_skinny_workspace_bytes(void);  /* scratch for d_work (deterministic combination of partial pieces) */
 int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
 					   int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,

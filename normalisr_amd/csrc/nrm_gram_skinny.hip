@@ -127,10 +127,9 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 		const double* zsrc = Z + (int64_t)(tid >> 3) * ldz + (tid & 7) * 16;
 		const int zdst = (tid >> 3) * SKP + (tid & 7) * 16;
 		auto stage_z = [&](int buf, int64_t k0) {
-#pragma unroll
-			for (int pass = 0; pass < NT * 16 / 32; pass++) {
-				const double* src = zsrc + (int64_t)pass * 32 * ldz + k0;
-				double* dst = &lds[buf][zdst + pass * 32 * SKP];
+			if ((tid >> 3) < NT * 16) {  // NT = 1: only the first 16 Z rows exist in LDS
+				const double* src = zsrc + k0;
+				double* dst = &lds[buf][zdst];
 #pragma unroll
 				for (int q = 0; q < 8; q++) *reinterpret_cast<d2_t*>(dst + 2 * q) = *reinterpret_cast<const d2_t*>(src + 2 * q);
 			}
@@ -244,7 +243,7 @@ extern "C" int64_t nrm_gram_skinny_workspace_bytes(void) {
 }
 
 extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64_t n, int64_t lda, const double* d_z, int64_t ldz,
-							   int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, void* d_work, void* stream) {
+							   int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, int64_t nz, void* d_work, void* stream) {
 	NRM_REQUIRE(a_dtype == NRM_F32 || a_dtype == NRM_F64, "nrm_gram_skinny: bad dtype");
 	NRM_REQUIRE(rows > 0 && n > 0 && lda >= n, "Incorrect dx/dy/dc size.");
 	const int64_t n16 = (n + 15) / 16 * 16;
@@ -273,10 +272,19 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 	s.tiles_sk = (int)sk;
 	s.tiles_dp = (int)(tiles - sk);
 	s.units_per_wg = (int)((sk * s.nkt + s.nwg - 1) / s.nwg);
-	if (a_dtype == NRM_F64)
-		hipLaunchKernelGGL((k_gram_skinny<double, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
-	else
-		hipLaunchKernelGGL((k_gram_skinny<float, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+	// nz <= 16 used Z rows: one MFMA column tile instead of two (half the matrix-core work: the pass becomes HBM-bound)
+	const bool one = nz > 0 && nz <= 16;
+	if (a_dtype == NRM_F64) {
+		if (one)
+			hipLaunchKernelGGL((k_gram_skinny<double, 1>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+		else
+			hipLaunchKernelGGL((k_gram_skinny<double, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+	} else {
+		if (one)
+			hipLaunchKernelGGL((k_gram_skinny<float, 1>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+		else
+			hipLaunchKernelGGL((k_gram_skinny<float, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+	}
 	if (s.tiles_sk > 0) hipLaunchKernelGGL(k_skinny_fixup, dim3((unsigned)s.tiles_sk, (SK_SLAB + 255) / 256), dim3(256), 0, st, d_g, d_ss, s);
 	return nrm_check_launch("k_gram_skinny");
 }

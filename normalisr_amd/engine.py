@@ -212,7 +212,7 @@ class Engine:
 			active = rank > 0 and nc > 0
 			if active:
 				_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
-													ssx_raw.data_ptr(), 256, self._skinny_work().data_ptr(), self._stream()))
+													ssx_raw.data_ptr(), 256, nc, self._skinny_work().data_ptr(), self._stream()))
 			xt = torch.zeros((nx, k32), dtype=torch.float64, device=self.device)
 			rw_work = torch.empty((32 * ((k32 + 1023) // 1024), ), dtype=torch.float64, device=self.device)
 			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
@@ -228,7 +228,7 @@ class Engine:
 			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
 			ssraw = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), NRM_F64 if y.dtype == torch.float64 else NRM_F32, ny, n, y.stride(0),
-												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, self._skinny_work().data_ptr(), self._stream()))
+												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, nc + nx, self._skinny_work().data_ptr(), self._stream()))
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
