@@ -1,7 +1,7 @@
 // binnet: binarise a co-expression P-value matrix at a per-row Benjamini-Hochberg q-value cutoff
 // (reference binnet.py:134-173, bh at :77-131) -- the consumer of the coex p-matrix, kept on the device so
-// that a 30k x 30k p-matrix never has to cross PCIe.  HBM-bound: the matrix is read from HBM once (a row
-// stays in L2 for the handful of counting passes), one byte per entry is written.
+// that a 30k x 30k p-matrix never has to cross PCIe.  HBM-bound: the matrix is read from HBM once (a row is held
+// in registers -- or stays in L2 for very wide rows -- for the handful of counting passes), one byte per entry is written.
 //
 // No sort.  For row i with m = ng-1 off-diagonal entries the reference computes, for each distinct value v with
 // rank c_v = #{p <= v}:  q_v = v / (c_v / m)  (arithmetic in the matrix dtype), takes the running minimum from
@@ -10,13 +10,6 @@
 // largest k for which ANY element of rank > k fails the test even with a relative slack d >> rounding error,
 // so only the few distinct values just below that bound need the reference's exact floating-point test.
 #include "nrm_common.h"
-
-template <typename T>
-struct BnRow {
-	const T* p;
-	int64_t ng;
-	int64_t self;  // diagonal index to skip
-};
 
 __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
 #pragma unroll
@@ -35,29 +28,60 @@ __device__ __forceinline__ double bn_block_max(double v, double* sm) {
 	return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
+// Row access policies for the counting passes: GlobalRow re-reads the row (L2-resident) on every pass; RegRow<ITEMS> loads it
+// once into registers (ITEMS values per lane, 256 lanes) so that the ~15 passes of a row are register-only.
 template <typename T>
-__device__ __forceinline__ int64_t bn_count_le(const BnRow<T>& r, double x, double* sm) {
+struct GlobalRow {
+	const T* p;
+	int64_t ng, self;
+	__device__ __forceinline__ GlobalRow(const T* row, int64_t ng_, int64_t self_) : p(row), ng(ng_), self(self_) {}
+	template <typename F>
+	__device__ __forceinline__ void each(F f) const {
+		for (int64_t j = threadIdx.x; j < ng; j += 256)
+			if (j != self) f((double)p[j]);
+	}
+};
+template <typename T, int ITEMS>
+struct RegRow {
+	T v[ITEMS];  // entries outside the row or on the diagonal hold 2 (> any p-value: never counted, never a maximum <= x)
+	__device__ __forceinline__ RegRow(const T* row, int64_t ng, int64_t self) {
+#pragma unroll
+		for (int q = 0; q < ITEMS; q++) {
+			const int64_t j = (int64_t)q * 256 + threadIdx.x;
+			v[q] = (j < ng && j != self) ? row[j] : (T)2;
+		}
+	}
+	template <typename F>
+	__device__ __forceinline__ void each(F f) const {
+#pragma unroll
+		for (int q = 0; q < ITEMS; q++)
+			if (v[q] <= (T)1.5) f((double)v[q]);
+	}
+};
+
+template <typename Row>
+__device__ __forceinline__ int64_t bn_count_le(const Row& r, double x, double* sm) {
 	double c = 0;
-	for (int64_t j = threadIdx.x; j < r.ng; j += 256)
-		if (j != r.self && (double)r.p[j] <= x) c += 1.0;
+	r.each([&](double pj) {
+		if (pj <= x) c += 1.0;
+	});
 	return (int64_t)bn_block_sum(c, sm);
 }
-template <typename T>
-__device__ __forceinline__ double bn_max_le(const BnRow<T>& r, double x, double* sm) {
+template <typename Row>
+__device__ __forceinline__ double bn_max_le(const Row& r, double x, double* sm) {
 	double v = -1.0;
-	for (int64_t j = threadIdx.x; j < r.ng; j += 256) {
-		const double pj = (double)r.p[j];
-		if (j != r.self && pj <= x) v = fmax(v, pj);
-	}
+	r.each([&](double pj) {
+		if (pj <= x) v = fmax(v, pj);
+	});
 	return bn_block_max(v, sm);
 }
 
-template <typename T>
+template <typename T, typename Row>
 __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, int64_t ng, int64_t ldp, double qcut, unsigned char* __restrict__ out,
 													 int64_t ldo, unsigned long long* __restrict__ total, int32_t* __restrict__ flags) {
 	__shared__ double sm[4];
 	const int64_t i = blockIdx.x;
-	BnRow<T> r{p + i * ldp, ng, i};
+	const T* prow = p + i * ldp;
 	const double m = (double)(ng - 1);
 	const T qc = (T)qcut;  // the reference compares in the matrix dtype (numpy weak-scalar promotion)
 	const double slack = sizeof(T) == 4 ? 1e-5 : 1e-12;
@@ -65,11 +89,12 @@ __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, in
 	{
 		double bad = 0;
 		for (int64_t j = threadIdx.x; j < ng; j += 256) {
-			const double v = (double)r.p[j];
+			const double v = (double)prow[j];
 			if (!(v >= 0.0 && v <= 1.0)) bad += 1.0;
 		}
 		if (bn_block_sum(bad, sm) > 0 && threadIdx.x == 0) atomicAdd(&flags[0], 1);
 	}
+	const Row r(prow, ng, i);
 	double x = 2.0;       // every entry is a candidate
 	double tau = -1.0;    // tau*: nothing selected yet
 	for (int guard = 0; guard < 1000000; guard++) {
@@ -102,12 +127,26 @@ __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, in
 	double cnt = 0;
 	unsigned char* o = out + i * ldo;
 	for (int64_t j = threadIdx.x; j < ng; j += 256) {
-		const unsigned char b = (j != i && (double)r.p[j] <= tau) ? 1 : 0;
+		const unsigned char b = (j != i && (double)prow[j] <= tau) ? 1 : 0;
 		o[j] = b;
 		cnt += b;
 	}
 	cnt = bn_block_sum(cnt, sm);
 	if (threadIdx.x == 0 && cnt > 0) atomicAdd(total, (unsigned long long)cnt);
+}
+
+template <typename T>
+static void bn_launch(const T* p, int64_t ng, int64_t ldp, double qcut, unsigned char* out, int64_t ldo, unsigned long long* total, int32_t* flags,
+					  hipStream_t st) {
+	dim3 grid((unsigned)ng);
+	if (ng <= 8 * 256)
+		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 8>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
+	else if (ng <= 32 * 256)
+		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 32>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
+	else if (ng <= 96 * 256 && sizeof(T) == 4)
+		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 96>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
+	else
+		hipLaunchKernelGGL((k_binnet_rows<T, GlobalRow<T>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
 }
 
 extern "C" int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp, double qcut, unsigned char* d_out, int64_t ldo,
@@ -119,8 +158,8 @@ extern "C" int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp,
 	hipStream_t st = (hipStream_t)stream;
 	NRM_HIP(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
 	if (p_dtype == NRM_F64)
-		hipLaunchKernelGGL(k_binnet_rows<double>, dim3((unsigned)ng), dim3(256), 0, st, (const double*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags);
+		bn_launch<double>((const double*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags, st);
 	else
-		hipLaunchKernelGGL(k_binnet_rows<float>, dim3((unsigned)ng), dim3(256), 0, st, (const float*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags);
+		bn_launch<float>((const float*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags, st);
 	return nrm_check_launch("k_binnet_rows");
 }

@@ -520,6 +520,19 @@ def test_binnet_golden_and_oracle(golden, norm):
 	pt = np.triu(pt, 1) + np.triu(pt, 1).T
 	for q in (0.003, 0.05, 0.25, 0.9):
 		assert np.array_equal(norm.binnet(pt, q), oracle.binnet(pt, q)), q
+	# wide rows: > 8192 genes uses the 96-value register path (fp32) / the L2 re-read path (fp64)
+	ngw = 8300
+	pw = rng.random((ngw, ngw))**3
+	pw = np.triu(pw, 1) + np.triu(pw, 1).T
+	rows = rng.choice(ngw, 40, replace=False)
+	for dtype in (np.float32, np.float64):
+		got = norm.binnet(pw.astype(dtype), 0.07)
+		pwd = pw.astype(dtype)
+		for i in rows:
+			off = np.arange(ngw) != i
+			exp = np.zeros(ngw, dtype=bool)
+			exp[off] = oracle.bh(pwd[i, off]) <= (np.float32(0.07) if dtype == np.float32 else 0.07)
+			assert np.array_equal(got[i], exp), (dtype, i)
 	with pytest.raises(RuntimeError):
 		norm.binnet(np.ones((20, 20)), 0.01)  # nothing survives: "Empty binary network."
 	with pytest.raises(ValueError):
