@@ -607,3 +607,25 @@ def test_large_cell_counts_vs_oracle(norm):
 	p, gam, a, vg, vt = norm.de(dg, dt, dc)
 	po, go, ao, vgo, vto = oracle.de(dg, dt, dc)
 	assert p_close(p, po) and close(gam, go, floor=1e-12) and close(vg, vgo, 1e-10) and close(vt, vto, 1e-10)
+
+
+def test_schedule_regimes_many_tiles(norm, monkeypatch):
+	"""K2's schedule phases at other tile counts: two full waves + remainder (1326 symmetric tiles), a rectangular grid
+	with 626 tiles, and a single-tile problem; few cells keep the oracle cheap."""
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(515)
+	n = 160
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	dt = rng.normal(size=(6500, n)) + 0.6 * rng.normal(size=(6500, 1)) * rng.normal(size=(1, n))
+	p, d, v = norm.coex(dt, dc)
+	po, do, vo = oracle.coex(dt, dc)
+	assert p_close(p, po) and close(d, do, floor=1e-12) and close(v, vo, 1e-12)
+	assert (np.diag(p) == 0).all() and (p == p.T).all() and (d == d.T).all()
+	monkeypatch.setenv('NRM_DE_PATH', 'general')
+	dg = (rng.random((130, n)) < 0.3).astype(float)
+	dy = rng.normal(size=(40000, n))
+	p, g, a, vx, vy = association_tests(dg, dy, dc, return_dot=False)
+	po, go, ao, vxo, vyo = oracle.association_tests(dg, dy, dc, return_dot=False)
+	assert p_close(p, po) and close(g, go, floor=1e-12) and close(vy, vyo, 1e-12)
+	p, g, a, vx, vy = association_tests(dg[:3], dy[:7], dc, return_dot=False)
+	assert p_close(p, po[:3, :7]) and close(g, go[:3, :7], floor=1e-12)
