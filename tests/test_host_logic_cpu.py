@@ -1,0 +1,79 @@
+"""CPU tests of the host-side mirror (no GPU): de's row filtering / re-inflation, coex's return selection and the
+CLI runners' file IO, with the device call (association_tests) replaced by the oracle.  The arithmetic itself is
+tested on the GPU; here the Python around it is held to the golden vectors."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import relerr
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch):
+	import normalisr_amd.association as assoc
+	import normalisr_amd.coex as coex_mod
+	import normalisr_amd.de as de_mod
+
+	def fake(dx, dy, dc, **ka):
+		ka.pop('nth', None)
+		bs = ka.pop('bs', None)
+		if bs is not None:
+			ka.setdefault('bsx', bs)
+			ka.setdefault('bsy', bs)
+		return oracle.association_tests(np.asarray(dx, dtype=np.float64), None if dy is None else np.asarray(dy), np.asarray(dc), **ka)
+	monkeypatch.setattr(de_mod, 'association_tests', fake)
+	monkeypatch.setattr(coex_mod, 'association_tests', fake)
+	monkeypatch.setattr(assoc, 'association_tests', fake)
+	return fake
+
+
+def test_de_filter_and_reinflate(golden, oracle_backend):
+	from normalisr_amd.de import de, _varying_rows
+	g = golden('G1_c1')
+	p, gam, a, vg, vt = de(g['dg'], g['dt'], g['dc'], lowmem=False)
+	assert relerr(p, g['de_lm0_p']) < 1e-9 and relerr(gam, g['de_lm0_gamma'], 1e-14) < 1e-9 and relerr(a, g['de_lm0_alpha'], 1e-12) < 1e-9
+	assert (p[2] == 1).all() and (gam[2] == 0).all() and (a[2] == 0).all() and vg[2] == 0 and (vt[2] == 0).all()  # de.py:107-122
+	assert vt.shape == (4, 500) and (vt[0] == vt[1]).all()  # per-gene variance broadcast over the tested rows (Q5)
+	x = np.array([[0., 0, 0], [1, 0, 1], [np.nan, np.nan, np.nan], [2, 2, 2.]])
+	assert _varying_rows(x).tolist() == [False, True, False, False]  # np.unique treats NaNs as one value (de.py:93)
+	assert _varying_rows(np.array([[1, 1, 2], [3, 3, 3]])).tolist() == [True, False]
+	with pytest.raises(AssertionError):
+		de(np.ones((2, 300)), g['dt'], g['dc'])  # nothing left to test: assert len(ans0) > 0 (association.py:998)
+
+
+def test_coex_returns(golden, oracle_backend):
+	from normalisr_amd.coex import coex
+	g = golden('G1_c1')
+	ns = int(g['coex_n'])
+	p, d, v = coex(g['dt'][:ns], g['dc'], nth=4)
+	assert relerr(p, g['coex_p'], 1e-300) < 1e-9 and relerr(d, g['coex_dot'], 1e-14) < 1e-9 and relerr(v, g['coex_var']) < 1e-12
+	p2 = coex(g['dt'][:ns], g['dc'], bs=50)[0]  # `bs` accepted
+	assert relerr(p2, g['coex_p'], 1e-300) < 1e-9
+
+
+def test_cli_runners_text_io(golden, oracle_backend, tmp_path):
+	"""`normalisr de|coex` on the G6 TSV inputs: the written text equals the reference CLI's up to '%.8G' precision."""
+	from normalisr_amd.__main__ import main
+	g = golden('G6_cli')
+	files = {k: bytes(g[k]) for k in g.files}
+	(tmp_path / 'g.tsv').write_bytes(files['g_tsv'])
+	(tmp_path / 'e.tsv.gz').write_bytes(gzip.compress(files['e_tsv_gz']))
+	(tmp_path / 'c.tsv').write_bytes(files['c_tsv'])
+	old = os.getcwd()
+	os.chdir(str(tmp_path))
+	try:
+		assert main(['de', 'g.tsv', 'e.tsv.gz', 'c.tsv', 'pv.tsv', 'lfc.tsv', '--vard_out', 'vard.tsv', '--vart_out', 'vart.tsv', '-n', '1']) == 0
+		assert main(['-v', 'coex', 'e.tsv.gz', 'c.tsv', 'cpv.tsv.gz', '--var_out', 'cvar.tsv', '--dot_out', 'cdot.tsv', '-d', '1']) == 0
+	finally:
+		os.chdir(old)
+	load = lambda raw: np.loadtxt(raw.decode().splitlines(), delimiter='\t', ndmin=2)
+	for mine, ref in (('pv.tsv', 'pv_tsv'), ('lfc.tsv', 'lfc_tsv'), ('vard.tsv', 'vard_tsv'), ('vart.tsv', 'vart_tsv'),
+					  ('cpv.tsv.gz', 'cpv_tsv_gz'), ('cvar.tsv', 'cvar_tsv'), ('cdot.tsv', 'cdot_tsv')):
+		got = np.loadtxt(str(tmp_path / mine), delimiter='\t', ndmin=2)
+		exp = load(files[ref])
+		assert got.shape == exp.shape and relerr(got, exp, 1e-12) < 2e-7, mine
+	# identical text for the files that hold exactly representable numbers
+	assert (tmp_path / 'vard.tsv').read_bytes().split() == files['vard_tsv'].split()
