@@ -301,3 +301,27 @@ class DePlan:
 
 	def streaming(self):
 		return self.eng.de_streaming_ok(self.dx, self.dy, self.dc64)
+
+
+def coex(dt_local, dc, group=None, dimreduce=0):
+	"""Sharded norm.coex for one-process-per-GPU programs: every rank passes ITS block of gene rows (same row count on
+	every rank; numpy or a torch tensor on its GPU) and the replicated covariates.  Rank 0 gets (p, dot, var) as numpy
+	arrays with the reference's contract (symmetric, zero diagonals; coex.py:4-48); other ranks get None.
+
+	    # torchrun --nproc-per-node 8 script.py
+	    dist.init_process_group('nccl'); torch.cuda.set_device(local_rank)
+	    res = normalisr_amd.distributed.coex(dt[rank * R:(rank + 1) * R], dc)
+	"""
+	import torch
+	import torch.distributed as dist
+	world = dist.get_world_size(group) if dist.is_initialized() else 1
+	rank = dist.get_rank(group) if dist.is_initialized() else 0
+	dev = torch.device('cuda', torch.cuda.current_device())
+	if isinstance(dt_local, np.ndarray):
+		a = dt_local if dt_local.dtype in (np.float32, np.float64) else dt_local.astype(np.float64)
+		dt_local = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+	plan = CoexPlan(dt_local, dc, rank=rank, world=world, group=group if group is not None else (dist.group.WORLD if world > 1 else None),
+					dimreduce=dimreduce)
+	plan.step()
+	plan.be.eng.check_flags(plan.flags)
+	return plan.assemble(lambda t: t.detach().cpu().numpy())

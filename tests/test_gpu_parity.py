@@ -371,10 +371,14 @@ def _sharded_worker(rank, world, port, q):
 	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(np.float32)
 	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(np.float32)
 	R = ng // world
-	plan = CoexPlan(torch.from_numpy(dt[rank * R:(rank + 1) * R]).cuda(), torch.from_numpy(dc).cuda(), rank=rank, world=world,
-					group=dist.group.WORLD)
-	plan.step()
-	res = plan.assemble(lambda t: t.detach().cpu().numpy())
+	if world == 2:
+		plan = CoexPlan(torch.from_numpy(dt[rank * R:(rank + 1) * R]).cuda(), torch.from_numpy(dc).cuda(), rank=rank, world=world,
+						group=dist.group.WORLD)
+		plan.step()
+		res = plan.assemble(lambda t: t.detach().cpu().numpy())
+	else:  # the public wrapper, numpy rows in
+		from normalisr_amd.distributed import coex as coex_sharded
+		res = coex_sharded(dt[rank * R:(rank + 1) * R], dc)
 	if rank == 0:
 		q.put(res)
 	dist.barrier()
