@@ -633,3 +633,39 @@ def test_schedule_regimes_many_tiles(norm, monkeypatch):
 	assert p_close(p, po) and close(g, go, floor=1e-12) and close(vy, vyo, 1e-12)
 	p, g, a, vx, vy = association_tests(dg[:3], dy[:7], dc, return_dot=False)
 	assert p_close(p, po[:3, :7]) and close(g, go[:3, :7], floor=1e-12)
+
+
+def test_beyond_2g_elements(eng):
+	"""Maximum sizes: expression matrices with more than 2^31 elements, resident in HBM (generated on the device), through
+	coex (K1+K2+K3), the streaming de path and the general de path; sampled blocks are checked against the oracle run
+	on the same rows copied to the host.  Guards the 64-bit index arithmetic of every kernel on the path."""
+	import torch
+	from normalisr_amd.association import inv_rank
+	ng, n, nc = 22016, 100000, 4
+	assert ng * n > 2**31
+	gen = torch.Generator(device='cuda').manual_seed(77)
+	dt = torch.randn((ng, n), dtype=torch.float32, device='cuda', generator=gen)
+	lat = torch.randn((1, n), dtype=torch.float32, device='cuda', generator=gen)
+	dt += 0.2 * torch.randn((ng, 1), dtype=torch.float32, device='cuda', generator=gen) * lat
+	rng = np.random.default_rng(78)
+	dc = np.vstack([rng.standard_normal((nc - 1, n)), np.ones((1, n))])
+	dci, rank = inv_rank(dc @ dc.T)
+	blocks = [slice(0, 40), slice(11000, 11040), slice(ng - 40, ng)]
+	rows = np.concatenate([np.arange(ng)[b] for b in blocks])
+	sub = dt[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64)
+	# coex
+	res = eng.association_single0(dt, None, dc, dci, rank, 0, True, False, np.float32, device_out=True)
+	po, do, vo = oracle.coex(sub, dc)
+	idx = torch.from_numpy(rows).cuda()
+	p = res['p'][idx][:, idx].cpu().numpy()
+	d = res['stat'][idx][:, idx].cpu().numpy()
+	assert close(p, po, 2e-6, 1e-38) and close(d, do, 1e-6, 1e-7) and close(res['vary'][rows], vo, 1e-6)
+	assert bool((torch.diagonal(res['p']) == 0).all()) and bool((res['p'][-200:, :200] == res['p'][:200, -200:].T).all())
+	del res
+	# de: streaming (2 design rows) and general (40 design rows) over all 2.2e9 expression values
+	for nx in (2, 40):
+		dg = (rng.random((nx, n)) < 0.3).astype(np.float64)
+		r = eng.association_single0(dg, dt, dc, dci, rank, 0, False, False, np.float32)
+		po, go, ao, vxo, vyo = oracle.association_tests(dg, sub, dc, return_dot=False)
+		assert close(r['p'][:, rows], po, 2e-6, 1e-38) and close(r['stat'][:, rows], go, 1e-6, 1e-7)
+		assert close(r['vary'][rows], vyo, 1e-6)
