@@ -45,6 +45,13 @@ const char* nrm_last_error(void);
 /* hipGetDeviceCount / hipSetDevice wrappers so that a pure-C host needs no HIP headers. */
 int nrm_device_count(int* count);
 int nrm_set_device(int device);
+/* Result buffers on the host (the caller's numpy arrays, filled where the reference's gather loop fills them,
+ * association.py:1005-1034): nrm_host_pin faults the pages of [ptr, ptr+bytes) in with `threads` host threads
+ * (0 = choose; contents are preserved) and page-locks the range so device->host copies run at the PCIe rate;
+ * nrm_copy_to_host queues such a copy on `stream`; nrm_host_unpin releases the lock (after the stream is synchronised). */
+int nrm_host_pin(void* ptr, int64_t bytes, int threads);
+int nrm_host_unpin(void* ptr);
+int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, void* stream);
 
 /*
  * K1 -- residualise rows against covariates and take their sums of squares.
@@ -78,6 +85,12 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
 int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad,
 				 int64_t lda, int64_t ldb, double* d_dot, int64_t ldd, int symmetric,
 				 int64_t m_rows, int64_t n_rows, void* d_work, void* stream);
+/* The same for the output rows [row0, row1) only (cut at multiples of 8 * NRM_ROW_TILE, or at m_pad): lets the caller
+ * pipeline K2 -> K3 -> copy-out band by band, as the reference hands finished tiles to the gather loop
+ * (association.py:997-1034).  Consecutive bands on one stream may share d_work. */
+int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad,
+					  int64_t lda, int64_t ldb, double* d_dot, int64_t ldd, int symmetric,
+					  int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream);
 /* Size of the device scratch nrm_gram_f64 needs in d_work (partial tiles of the stream-K tail; summed in a fixed
  * order, so results are bitwise reproducible).  Independent of the problem size. */
 int64_t nrm_gram_workspace_bytes(void);
@@ -115,6 +128,12 @@ int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d_ssx, const
 					int64_t nx, int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind,
 					void* d_p, void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo,
 					int32_t* d_flags, void* stream);
+/* The same for the x rows [row0, row1) (multiples of 64, or nx).  Symmetric problems: the band reads only dot rows
+ * < row1 and, once the bands [0, row1) have run in order, output rows [0, row1) are complete (mirrored halves included). */
+int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy,
+						 int64_t nx, int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind,
+						 void* d_p, void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo,
+						 int32_t* d_flags, int64_t row0, int64_t row1, void* stream);
 
 /*
  * alpha[i,j,c] = by[j,c] - gamma[i,j] * bx[i,c]  (association.py:238-243), fp64 in, out_dtype out.

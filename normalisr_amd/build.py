@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
 	if not force and not is_stale():
 		return LIB
 	# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (with AGPR accumulators v_mfma_f64_16x16x4_f64 runs at half rate on MI355X)
-	cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-o', LIB] + SOURCES
+	cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-pthread', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-o', LIB] + SOURCES
 	if verbose:
 		print(' '.join(cmd))
 	r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

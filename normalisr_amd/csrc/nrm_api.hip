@@ -4,6 +4,9 @@
 #include <cstdarg>
 #include <cstring>
 #include <vector>
+#include <algorithm>
+#include <thread>
+#include <vector>
 #include "nrm_common.h"
 
 static thread_local char g_err[512] = "";
@@ -26,6 +29,49 @@ extern "C" int nrm_device_count(int* count) {
 
 extern "C" int nrm_set_device(int device) {
 	NRM_HIP(hipSetDevice(device));
+	return NRM_OK;
+}
+
+extern "C" int nrm_host_pin(void* ptr, int64_t bytes, int threads) {
+	NRM_REQUIRE(ptr != nullptr && bytes > 0, "nrm_host_pin: empty range");
+	const int64_t page = 4096;
+	if (threads <= 0) {
+		threads = (int)std::min<int64_t>(16, std::max<int64_t>(1, bytes / (8 << 20)));
+		threads = (int)std::min<int64_t>(threads, std::max(1u, std::thread::hardware_concurrency()));
+	}
+	// first touch from several threads: page faults of a fresh mapping are the cost of page-locking it (a single thread
+	// faults ~13 GB/s, hipHostRegister of an untouched range ~22 GB/s, 16 threads > 100 GB/s)
+	auto touch = [=](int64_t lo, int64_t hi) {
+		volatile char* q = (volatile char*)ptr;
+		for (int64_t o = lo; o < hi; o += page) q[o] = q[o];
+		if (hi > lo) q[hi - 1] = q[hi - 1];
+	};
+	if (threads == 1) {
+		touch(0, bytes);
+	} else {
+		const int64_t chunk = ((bytes + threads - 1) / threads + page - 1) / page * page;
+		std::vector<std::thread> pool;
+		for (int t = 0; t < threads; t++) {
+			const int64_t lo = t * chunk, hi = std::min<int64_t>(bytes, lo + chunk);
+			if (hi > lo) pool.emplace_back(touch, lo, hi);
+		}
+		for (auto& th : pool) th.join();
+	}
+	NRM_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+	return NRM_OK;
+}
+
+extern "C" int nrm_host_unpin(void* ptr) {
+	NRM_REQUIRE(ptr != nullptr, "nrm_host_unpin: null pointer");
+	NRM_HIP(hipHostUnregister(ptr));
+	return NRM_OK;
+}
+
+extern "C" int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, void* stream) {
+	NRM_REQUIRE(bytes >= 0, "nrm_copy_to_host: negative size");
+	if (bytes == 0) return NRM_OK;
+	NRM_REQUIRE(h_dst && d_src, "nrm_copy_to_host: null pointer");
+	NRM_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
 	return NRM_OK;
 }
 

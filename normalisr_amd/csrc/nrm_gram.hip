@@ -23,6 +23,7 @@
 // not cover the whole K range are written to workspace slabs and summed per tile in a fixed order by a small
 // fix-up kernel (deterministic: no atomics).
 // Symmetric (coex) launches only enumerate tiles on or above the block diagonal (association.py:893-894).
+#include <algorithm>
 #include "nrm_common.h"
 
 #define GM 128
@@ -189,6 +190,7 @@ struct GramSched {
 	int tiles_sk;   // tiles of the tail, cut into unit ranges
 	int units_per_wg;
 	int nwg;        // persistent workgroups (multiple of 8)
+	int tile0;      // first tile of this launch in the gram_tile_coords order (band launches)
 	double* work;   // slabs of partial pieces: [tiles_al*parts] then [2 per workgroup]
 };
 
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 			break;
 		}
 		int ti, tj;
-		gram_tile_coords(t, symmetric, s.ntm, s.ntn, ti, tj);
+		gram_tile_coords(s.tile0 + t, symmetric, s.ntm, s.ntn, ti, tj);
 		// which of this wave's 4x4 sub-blocks are wanted: rows/columns inside the matrix and, on diagonal tiles of a
 		// symmetric problem, not strictly below the diagonal (K3 only reads dot[min(i,j)][max(i,j)])
 		unsigned need = 0;
@@ -259,13 +261,13 @@ __global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int6
 	int first, count;       // slab range (aligned tiles) or workgroup range (stream-K tiles)
 	const double* base;
 	if (b < s.tiles_al) {
-		gram_tile_coords(s.tiles_dp + b, symmetric, s.ntm, s.ntn, ti, tj);
+		gram_tile_coords(s.tile0 + s.tiles_dp + b, symmetric, s.ntm, s.ntn, ti, tj);
 		base = s.work + (int64_t)b * s.parts * (GM * GN);
 		first = 0;
 		count = s.parts;
 	} else {
 		const int ts = b - s.tiles_al;
-		gram_tile_coords(s.tiles_dp + s.tiles_al + ts, symmetric, s.ntm, s.ntn, ti, tj);
+		gram_tile_coords(s.tile0 + s.tiles_dp + s.tiles_al + ts, symmetric, s.ntm, s.ntn, ti, tj);
 		const int64_t u0 = (int64_t)ts * s.nkt, u1 = u0 + s.nkt;
 		first = (int)(u0 / s.units_per_wg);
 		int last = (int)((u1 - 1) / s.units_per_wg);
@@ -306,15 +308,41 @@ extern "C" int64_t nrm_gram_workspace_bytes(void) {
 	return (int64_t)3 * (2 * g_num_cu) * GM * GN * (int64_t)sizeof(double);
 }
 
+// Tiles that precede super-block row `bi` in the gram_tile_coords order.
+static int64_t gram_tiles_before(int64_t bi, int symmetric, int64_t ntm, int64_t ntn) {
+	const int64_t nbn = (ntn + GSB - 1) / GSB;
+	int64_t t = 0;
+	for (int64_t b = 0; b < bi; b++) {
+		const int64_t h = std::min<int64_t>(GSB, ntm - b * GSB);
+		for (int64_t bj = symmetric ? b : 0; bj < nbn; bj++) {
+			const int64_t w = std::min<int64_t>(GSB, ntn - bj * GSB);
+			t += (symmetric && b == bj) ? h * (h + 1) / 2 : h * w;
+		}
+	}
+	return t;
+}
+
+extern "C" int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,
+								 int64_t ldb, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0,
+								 int64_t row1, void* d_work, void* stream);
+
 extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,
 							int64_t ldb, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, void* d_work,
 							void* stream) {
+	return nrm_gram_f64_band(d_a, d_b, m_pad, n_pad, k_pad, lda, ldb, d_dot, ldd, symmetric, m_rows, n_rows, 0, m_pad, d_work, stream);
+}
+
+extern "C" int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,
+								 int64_t ldb, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0,
+								 int64_t row1, void* d_work, void* stream) {
 	NRM_REQUIRE(m_pad >= 0 && n_pad >= 0 && k_pad > 0, "nrm_gram_f64: bad sizes");
 	NRM_REQUIRE(m_pad % GM == 0 && n_pad % GN == 0 && k_pad % GK == 0, "nrm_gram_f64: sizes must be padded to %d/%d/%d", GM, GN, GK);
 	NRM_REQUIRE(lda >= k_pad && ldb >= k_pad && ldd >= n_pad, "nrm_gram_f64: pitch too small");
 	NRM_REQUIRE(lda % 2 == 0 && ldb % 2 == 0 && ldd % 2 == 0, "nrm_gram_f64: pitches must be even (16-byte rows)");
 	NRM_REQUIRE(!symmetric || m_pad == n_pad, "nrm_gram_f64: symmetric needs square output");
-	if (m_pad == 0 || n_pad == 0) return NRM_OK;
+	NRM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= m_pad && row0 % (GSB * GM) == 0 && (row1 % (GSB * GM) == 0 || row1 == m_pad),
+				"nrm_gram_f64_band: rows [row0, row1) must be cut at multiples of %d", GSB * GM);
+	if (m_pad == 0 || n_pad == 0 || row0 == row1) return NRM_OK;
 	NRM_REQUIRE(d_a && d_b && d_dot, "nrm_gram_f64: null pointer");
 	NRM_REQUIRE(((uintptr_t)d_a % 16 == 0) && ((uintptr_t)d_b % 16 == 0), "nrm_gram_f64: operands must be 16-byte aligned");
 	if (g_num_cu == 0) {
@@ -324,9 +352,12 @@ extern "C" int nrm_gram_f64(const double* d_a, const double* d_b, int64_t m_pad,
 		if (g_num_cu <= 0) g_num_cu = 256;
 	}
 	const int64_t ntm = m_pad / GM, ntn = n_pad / GN;
-	const int64_t tiles = symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn;
+	NRM_REQUIRE((symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn) < (1LL << 30), "nrm_gram_f64: problem too large for one launch");
+	const int64_t tile0 = gram_tiles_before(row0 / (GSB * GM), symmetric, ntm, ntn);
+	const int64_t tiles = gram_tiles_before((row1 + GSB * GM - 1) / (GSB * GM), symmetric, ntm, ntn) - tile0;
 	NRM_REQUIRE(tiles < (1LL << 30) && k_pad / GK < (1LL << 30), "nrm_gram_f64: problem too large for one launch");
 	GramSched s;
+	s.tile0 = (int)tile0;
 	s.m_rows = (int)((m_rows > 0 && m_rows < m_pad) ? m_rows : m_pad);
 	s.n_rows = (int)((n_rows > 0 && n_rows < n_pad) ? n_rows : n_pad);
 	s.ntm = (int)ntm;

@@ -102,10 +102,10 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 													  int64_t nx, int64_t ny, double ncells, double dof, int symmetric,
 													  int stat_kind, PvalPlan pl, void* __restrict__ p_out,
 													  void* __restrict__ stat_out, void* __restrict__ r_out,
-													  void* __restrict__ t_out, int64_t ldo, int32_t* __restrict__ flags) {
+													  void* __restrict__ t_out, int64_t ldo, int32_t* __restrict__ flags, int bi0) {
 	__shared__ double tile[SW_T][SW_T + 1];
 	__shared__ double sx[SW_T], sy[SW_T];
-	const int bi = blockIdx.y, bj = blockIdx.x;
+	const int bi = blockIdx.y + bi0, bj = blockIdx.x;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
 	// source tile: for coex always from the upper triangle (association.py:1050-1057)
 	const bool mirror = symmetric && bi > bj;
@@ -174,10 +174,10 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 template <typename OutT>
 __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ss,
 														  int64_t ng, int nb, double ncells, PvalPlan pl, OutT* __restrict__ p_out,
-														  OutT* __restrict__ stat_out, int64_t ldo, int32_t* __restrict__ flags) {
+														  OutT* __restrict__ stat_out, int64_t ldo, int32_t* __restrict__ flags, int bi0) {
 	__shared__ double tile[SW_T][SW_T + 1];
 	__shared__ double sx[SW_T], sy[SW_T];
-	int b = blockIdx.x, bi = 0, len = nb;
+	int b = blockIdx.x, bi = bi0, len = nb - bi0;
 	while (b >= len) {
 		b -= len;
 		bi++;
@@ -342,38 +342,50 @@ extern "C" int nrm_pvalues_from_r2(const double* d_r2, int64_t count, double dof
 	return nrm_check_launch("k_pvalues_from_r2");
 }
 
+extern "C" int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t nx,
+									int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind, void* d_p,
+									void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo, int32_t* d_flags,
+									int64_t row0, int64_t row1, void* stream) {
+	NRM_REQUIRE(nx >= 0 && ny >= 0 && n_cells > 0, "nrm_assoc_sweep: bad sizes");
+	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_assoc_sweep: bad out_dtype");
+	NRM_REQUIRE(!symmetric || nx == ny, "nrm_assoc_sweep: symmetric needs nx == ny");
+	NRM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= nx && row0 % SW_T == 0 && (row1 % SW_T == 0 || row1 == nx),
+				"nrm_assoc_sweep_band: rows [row0, row1) must be cut at multiples of %d", SW_T);
+	nrm_pvalue_plan plan;
+	int rc = nrm_pvalue_plan_init(&plan, dof);
+	if (rc) return rc;
+	if (nx == 0 || ny == 0 || row0 == row1) return NRM_OK;
+	NRM_REQUIRE(d_dot && d_ssx && d_ssy && d_p && d_stat, "nrm_assoc_sweep: null pointer");
+	NRM_REQUIRE(ldo >= ny && ldd >= ny, "nrm_assoc_sweep: pitch smaller than row length");
+	const int64_t b0 = row0 / SW_T, b1 = (row1 + SW_T - 1) / SW_T;
+	if (symmetric && !d_r && !d_t && stat_kind == 0) {
+		// upper-triangle blocks of block rows [b0, b1); their mirrored writes land in rows >= row0, columns [row0, row1)
+		const int64_t nb = (nx + SW_T - 1) / SW_T;
+		dim3 g((unsigned)((b1 - b0) * nb - (b1 * (b1 - 1) - b0 * (b0 - 1)) / 2));
+		if (out_dtype == NRM_F64)
+			hipLaunchKernelGGL(k_assoc_sweep_sym<double>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
+							   (double)n_cells, to_dev(plan), (double*)d_p, (double*)d_stat, ldo, d_flags, (int)b0);
+		else
+			hipLaunchKernelGGL(k_assoc_sweep_sym<float>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
+							   (double)n_cells, to_dev(plan), (float*)d_p, (float*)d_stat, ldo, d_flags, (int)b0);
+		return nrm_check_launch("k_assoc_sweep_sym");
+	}
+	dim3 grid((unsigned)((ny + SW_T - 1) / SW_T), (unsigned)(b1 - b0));
+	if (out_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_assoc_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
+						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags, (int)b0);
+	else
+		hipLaunchKernelGGL(k_assoc_sweep<float>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
+						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags, (int)b0);
+	return nrm_check_launch("k_assoc_sweep");
+}
+
 extern "C" int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t nx,
 							   int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind, void* d_p,
 							   void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo, int32_t* d_flags,
 							   void* stream) {
-	NRM_REQUIRE(nx >= 0 && ny >= 0 && n_cells > 0, "nrm_assoc_sweep: bad sizes");
-	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_assoc_sweep: bad out_dtype");
-	NRM_REQUIRE(!symmetric || nx == ny, "nrm_assoc_sweep: symmetric needs nx == ny");
-	nrm_pvalue_plan plan;
-	int rc = nrm_pvalue_plan_init(&plan, dof);
-	if (rc) return rc;
-	if (nx == 0 || ny == 0) return NRM_OK;
-	NRM_REQUIRE(d_dot && d_ssx && d_ssy && d_p && d_stat, "nrm_assoc_sweep: null pointer");
-	NRM_REQUIRE(ldo >= ny && ldd >= ny, "nrm_assoc_sweep: pitch smaller than row length");
-	if (symmetric && !d_r && !d_t && stat_kind == 0) {
-		const int64_t nb = (nx + SW_T - 1) / SW_T;
-		dim3 g((unsigned)(nb * (nb + 1) / 2));
-		if (out_dtype == NRM_F64)
-			hipLaunchKernelGGL(k_assoc_sweep_sym<double>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
-							   (double)n_cells, to_dev(plan), (double*)d_p, (double*)d_stat, ldo, d_flags);
-		else
-			hipLaunchKernelGGL(k_assoc_sweep_sym<float>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
-							   (double)n_cells, to_dev(plan), (float*)d_p, (float*)d_stat, ldo, d_flags);
-		return nrm_check_launch("k_assoc_sweep_sym");
-	}
-	dim3 grid((unsigned)((ny + SW_T - 1) / SW_T), (unsigned)((nx + SW_T - 1) / SW_T));
-	if (out_dtype == NRM_F64)
-		hipLaunchKernelGGL(k_assoc_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
-						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags);
-	else
-		hipLaunchKernelGGL(k_assoc_sweep<float>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
-						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags);
-	return nrm_check_launch("k_assoc_sweep");
+	return nrm_assoc_sweep_band(d_dot, ldd, d_ssx, d_ssy, nx, ny, n_cells, dof, symmetric, stat_kind, d_p, d_stat, d_r, d_t, out_dtype,
+								ldo, d_flags, 0, nx, stream);
 }
 
 extern "C" int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d_bx, const double* d_by,

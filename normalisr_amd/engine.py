@@ -54,6 +54,7 @@ class Engine:
 		self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
 		self._gram_work = None
 		self._skinny_ws = None
+		self._copy = None
 
 	def _stream(self):
 		return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -64,16 +65,31 @@ class Engine:
 			t = t.to(dtype)
 		return t.to(self.device, non_blocking=False)
 
+	_NP = {'torch.float32': np.float32, 'torch.float64': np.float64, 'torch.bool': np.bool_, 'torch.int32': np.int32,
+		   'torch.uint8': np.uint8, 'torch.int64': np.int64}
+
+	def host_pin(self, a):
+		_lib.check(self.lib.nrm_host_pin(a.ctypes.data, a.nbytes, 0))
+
+	def host_unpin(self, a):
+		_lib.check(self.lib.nrm_host_unpin(a.ctypes.data))
+
 	def download(self, t):
-		"""Device tensor -> numpy.  Large results go through page-locked host memory (the returned array is backed by
-		it): a pageable D2H copy runs at a fraction of the PCIe rate."""
-		if t.numel() * t.element_size() < (1 << 20):
+		"""Device tensor -> a fresh numpy array.  Large results are copied into the array while it is page-locked (a
+		pageable D2H copy runs at a tenth of the PCIe rate); the lock is dropped before returning."""
+		if t.numel() * t.element_size() < (1 << 20) or str(t.dtype) not in self._NP:
 			return t.cpu().numpy()
 		torch = self.torch
-		host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-		host.copy_(t, non_blocking=True)
-		torch.cuda.current_stream(self.device).synchronize()
-		return host.numpy()
+		t = t.contiguous()
+		out = np.empty(tuple(t.shape), dtype=self._NP[str(t.dtype)])
+		self.host_pin(out)
+		try:
+			with torch.cuda.device(self.device):
+				_lib.check(self.lib.nrm_copy_to_host(out.ctypes.data, t.data_ptr(), out.nbytes, self._stream()))
+				torch.cuda.current_stream(self.device).synchronize()
+		finally:
+			self.host_unpin(out)
+		return out
 
 	def covariates(self, dc, dci):
 		"""fp64 covariates and pseudo-inverse on the device (replicated; tiny)."""
@@ -103,17 +119,95 @@ class Engine:
 				out.data_ptr(), kp, rp, ss.data_ptr(), 0 if coef is None else coef.data_ptr(), self._stream()))
 		return Residualized(rows, n, out, ss, coef)
 
-	def gram(self, a, b, symmetric):
-		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T on the fp64 matrix cores."""
+	def gram(self, a, b, symmetric, dot=None, rows=None):
+		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T on the fp64 matrix cores.  rows=(row0, row1): only that band of dot."""
 		torch = self.torch
 		with torch.cuda.device(self.device):
-			dot = torch.empty((a.rows_pad, b.rows_pad), dtype=torch.float64, device=self.device)
+			if dot is None:
+				dot = torch.empty((a.rows_pad, b.rows_pad), dtype=torch.float64, device=self.device)
 			if self._gram_work is None:
 				self._gram_work = torch.empty((int(self.lib.nrm_gram_workspace_bytes()) // 8, ), dtype=torch.float64, device=self.device)
-			_lib.check(self.lib.nrm_gram_f64(a.data.data_ptr(), b.data.data_ptr(), a.rows_pad, b.rows_pad, a.k_pad,
-											 a.data.stride(0), b.data.stride(0), dot.data_ptr(), dot.stride(0),
-											 1 if symmetric else 0, int(a.rows), int(b.rows), self._gram_work.data_ptr(), self._stream()))
+			row0, row1 = (0, a.rows_pad) if rows is None else rows
+			_lib.check(self.lib.nrm_gram_f64_band(a.data.data_ptr(), b.data.data_ptr(), a.rows_pad, b.rows_pad, a.k_pad,
+												  a.data.stride(0), b.data.stride(0), dot.data_ptr(), dot.stride(0),
+												  1 if symmetric else 0, int(a.rows), int(b.rows), int(row0), int(row1),
+												  self._gram_work.data_ptr(), self._stream()))
 		return dot
+
+	BAND = 8 * ROW_TILE  # rows per band of the pipelined path (one row of K2's 8x8 super-blocks)
+
+	def banded_ok(self, nx, ny, out_dtype):
+		"""Pipeline K2 -> K3 -> copy-out by row bands when there is more than one band and the results are large enough
+		for the PCIe leg to matter (NRM_PIPELINE=0 switches it off)."""
+		import os
+		if os.environ.get('NRM_PIPELINE', '1') == '0':
+			return False
+		return nx > self.BAND and 2 * nx * ny * np.dtype(out_dtype).itemsize >= (16 << 20)
+
+	def start_host_results(self, nx, ny, out_dtype):
+		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps the upload and K1)."""
+		import threading
+		odt = np.dtype(out_dtype)
+		res = dict(p=np.empty((nx, ny), dtype=odt), stat=np.empty((nx, ny), dtype=odt), pinned=[], error=[])
+
+		def lock_pages():
+			try:
+				for k in ('p', 'stat'):
+					self.host_pin(res[k])
+					res['pinned'].append(res[k])
+			except Exception as e:  # re-raised by the consumer
+				res['error'].append(e)
+		res['thread'] = threading.Thread(target=lock_pages)
+		res['thread'].start()
+		return res
+
+	def finish_host_results(self, host):
+		host['thread'].join()
+		self.torch.cuda.synchronize(self.device)
+		for a in host['pinned']:
+			self.host_unpin(a)
+		host['pinned'] = []
+
+	def association_banded(self, rx, ry, samexy, nx, ny, n, dof, stat_kind, out_dtype, host):
+		"""K2 + K3 band by band on the compute stream while finished bands of p and stat travel to the page-locked result
+		arrays on a copy stream.  Same kernels as the one-launch path; K2's split of the cells between workgroups depends
+		on the tiles of a launch, so dot may differ from it in the last bits (each path is bitwise reproducible)."""
+		torch = self.torch
+		tdt = torch.float64 if np.dtype(out_dtype) == np.float64 else torch.float32
+		cuts = list(range(0, nx, self.BAND)) + [nx]
+		with torch.cuda.device(self.device):
+			main = torch.cuda.current_stream(self.device)
+			if self._copy is None:
+				self._copy = torch.cuda.Stream(device=self.device)
+			odt = np.dtype(out_dtype)
+			hp, hs, th = host['p'], host['stat'], host['thread']
+			try:
+				dot = torch.empty((rx.rows_pad, ry.rows_pad), dtype=torch.float64, device=self.device)
+				p = torch.empty((nx, ny), dtype=tdt, device=self.device)
+				stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
+				flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+				done = []
+				for a, b in zip(cuts[:-1], cuts[1:]):
+					self.gram(rx, ry, samexy, dot=dot, rows=(a, rx.rows_pad if b == nx else b))
+					_lib.check(self.lib.nrm_assoc_sweep_band(dot.data_ptr(), dot.stride(0), rx.ss.data_ptr(), ry.ss.data_ptr(), nx, ny, int(n),
+															 float(dof), 1 if samexy else 0, int(stat_kind), p.data_ptr(), stat.data_ptr(), 0, 0,
+															 _code(out_dtype), max(ny, 1), flags.data_ptr(), a, b, self._stream()))
+					ev = torch.cuda.Event()
+					ev.record(main)
+					done.append(ev)
+				th.join()
+				if host['error']:
+					raise host['error'][0]
+				row = ny * odt.itemsize
+				for (a, b), ev in zip(zip(cuts[:-1], cuts[1:]), done):
+					self._copy.wait_event(ev)
+					for h, d in ((hp, p), (hs, stat)):
+						_lib.check(self.lib.nrm_copy_to_host(h.ctypes.data + a * row, d.data_ptr() + a * row, (b - a) * row, self._copy.cuda_stream))
+				self._copy.synchronize()
+			finally:
+				self.finish_host_results(host)
+			self.check_flags(flags)
+		return hp, hs
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None):
 		"""K3: p, stat (covariance or gamma) and optionally Pearson r and t for every pair."""
@@ -266,11 +360,23 @@ class Engine:
 		ny = nx if samexy else dy.shape[0]
 		nc = dc.shape[0]
 		dof = n - 1 - rank - dimreduce
-		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
-		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
-		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
-		dot = self.gram(rx, ry, samexy)
 		stat_kind = 0 if (samexy or return_dot) else 1
+		host = None
+		if not (device_out or want_rt or want_alpha) and self.banded_ok(nx, ny, out_dtype):
+			host = self.start_host_results(nx, ny, out_dtype)
+		try:
+			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
+			rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
+			ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
+		except BaseException:
+			if host is not None:
+				self.finish_host_results(host)
+			raise
+		if host is not None:
+			p, stat = self.association_banded(rx, ry, samexy, nx, ny, n, dof, stat_kind, out_dtype, host)
+			return dict(p=p, stat=stat, alpha=None, varx=None if samexy else self.variances(rx.ss, nx, n, out_dtype),
+						vary=self.variances(ry.ss, ny, n, out_dtype), dof=dof)
+		dot = self.gram(rx, ry, samexy)
 		p, stat, r, t, flags = self.sweep(dot, rx.ss, ry.ss, nx, ny, n, dof, samexy, stat_kind, out_dtype, want_rt)
 		alpha = None
 		if want_alpha:

@@ -669,3 +669,33 @@ def test_beyond_2g_elements(eng):
 		po, go, ao, vxo, vyo = oracle.association_tests(dg, sub, dc, return_dot=False)
 		assert close(r['p'][:, rows], po, 2e-6, 1e-38) and close(r['stat'][:, rows], go, 1e-6, 1e-7)
 		assert close(r['vary'][rows], vyo, 1e-6)
+
+
+def test_banded_pipeline_matches_one_launch(norm, eng, monkeypatch):
+	"""Large results leave the device band by band (K2 -> K3 -> copy-out overlapped, engine.association_banded).  Same
+	answers as the one-launch path (dot to fp64 round-off: the split of the cells between workgroups differs), exact
+	symmetry / zero diagonal, bitwise reproducible, and the reference's assertion still fires (association.py:252)."""
+	rng = np.random.default_rng(808)
+	ng, n = 2600, 900
+	dt = rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dg = (rng.random((1500, n)) < 0.2).astype(float)
+	assert eng.banded_ok(ng, ng, np.float64) and eng.banded_ok(1500, ng, np.float64)
+	monkeypatch.setenv('NRM_PIPELINE', '0')
+	c0, d0 = norm.coex(dt, dc), norm.de(dg, dt, dc)
+	monkeypatch.setenv('NRM_PIPELINE', '1')
+	c1, d1 = norm.coex(dt, dc), norm.de(dg, dt, dc)
+	c2 = norm.coex(dt, dc)
+	assert all(np.array_equal(x, y) for x, y in zip(c1, c2))
+	assert p_close(c1[0], c0[0], 1e-9) and close(c1[1], c0[1], 1e-9, 1e-6) and np.array_equal(c1[2], c0[2])
+	assert (np.diag(c1[0]) == 0).all() and (c1[0] == c1[0].T).all() and (c1[1] == c1[1].T).all()
+	assert p_close(d1[0], d0[0], 1e-9) and close(d1[1], d0[1], 1e-9, 1e-6) and d1[2] is None
+	assert np.array_equal(d1[3], d0[3]) and np.array_equal(d1[4], d0[4])
+	po, do, vo = oracle.coex(dt, dc)
+	assert p_close(c1[0], po) and close(c1[1], do, floor=1e-12)
+	bad = dt.copy()
+	bad[1234, 5] = np.inf
+	with pytest.raises(AssertionError):
+		norm.coex(bad, dc)
+	c3 = norm.coex(dt, dc)  # the page locks of the failed call were released
+	assert np.array_equal(c3[0], c1[0])
