@@ -100,6 +100,37 @@ inline size_t esize(int dtype) { return dtype == NRM_F64 ? 8 : 4; }
 		if (rc_) return rc_; \
 	} while (0)
 
+namespace {
+// Page-lock of a caller-owned result array for the duration of one call; a range that cannot be locked (already
+// registered by the caller, locked-memory limit) is simply copied to at the pageable rate.
+struct HostPin {
+	void* p = nullptr;
+	void try_pin(void* q, int64_t bytes) {
+		if (q && bytes >= (1 << 20) && nrm_host_pin(q, bytes, 0) == NRM_OK) p = q;
+	}
+	~HostPin() {
+		if (p) {
+			(void)hipDeviceSynchronize();
+			(void)hipHostUnregister(p);
+		}
+	}
+};
+struct CopyStream {
+	hipStream_t s = nullptr;
+	std::vector<hipEvent_t> events;
+	~CopyStream() {
+		for (hipEvent_t e : events) (void)hipEventDestroy(e);
+		if (s) (void)hipStreamDestroy(s);
+	}
+};
+struct Joiner {
+	std::thread& t;
+	~Joiner() {
+		if (t.joinable()) t.join();
+	}
+};
+}  // namespace
+
 extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
 										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
 										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
@@ -121,6 +152,16 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	const int64_t kp = round_up(n, NRM_K_TILE), mp = round_up(nx, NRM_ROW_TILE), np_ = round_up(ny, NRM_ROW_TILE);
 
 	DevBuf dx, dy, dc, dci, rx, ry, ssx, ssy, bx, by, dot, flags, op, ostat, oalpha, orr, ot;
+	// the caller's result arrays are page-locked in place by a helper thread while the inputs are uploaded
+	const size_t ob = (size_t)nx * ny * esize(out_dtype);
+	HostPin pin_p, pin_s, pin_r, pin_t;
+	std::thread pinner([&] {
+		pin_p.try_pin(h_p, (int64_t)ob);
+		pin_s.try_pin(h_stat, (int64_t)ob);
+		pin_r.try_pin(h_r, (int64_t)ob);
+		pin_t.try_pin(h_t, (int64_t)ob);
+	});
+	Joiner joiner{pinner};
 	// covariates as fp64
 	std::vector<double> c64;
 	if (nc > 0) {
@@ -161,34 +202,53 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	NRM_TRY(dot.alloc((size_t)mp * np_ * 8));
 	DevBuf gwork;
 	NRM_TRY(gwork.alloc((size_t)nrm_gram_workspace_bytes()));
-	NRM_TRY(nrm_gram_f64(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, gwork.p, st));
 	NRM_TRY(flags.alloc(8));
 	NRM_HIP(hipMemsetAsync(flags.p, 0, 8, st));
-	const size_t ob = (size_t)nx * ny * esize(out_dtype);
 	NRM_TRY(op.alloc(ob));
 	NRM_TRY(ostat.alloc(ob));
 	if (h_r) NRM_TRY(orr.alloc(ob));
 	if (h_t) NRM_TRY(ot.alloc(ob));
 	// coex always converts to covariance (association.py:1037-1039); de keeps gamma unless return_dot
 	const int stat_kind = (samexy || return_dot) ? 0 : 1;
-	NRM_TRY(nrm_assoc_sweep(dot.as<double>(), np_, sx, sy, nx, ny, n, dof, samexy ? 1 : 0, stat_kind, op.p, ostat.p,
-							h_r ? orr.p : nullptr, h_t ? ot.p : nullptr, out_dtype, ny, flags.as<int32_t>(), st));
+	// K2 -> K3 per band of output rows; finished bands are copied out on a second stream while later bands compute
+	// (the reference's gather loop, association.py:997-1034, consumes finished tiles the same way)
+	const int64_t band = 8 * NRM_ROW_TILE;
+	CopyStream cs;
+	NRM_HIP(hipStreamCreateWithFlags(&cs.s, hipStreamNonBlocking));
+	for (int64_t a = 0; a < nx; a += band) {
+		const int64_t b = std::min(nx, a + band);
+		NRM_TRY(nrm_gram_f64_band(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, a, b == nx ? mp : b, gwork.p, st));
+		NRM_TRY(nrm_assoc_sweep_band(dot.as<double>(), np_, sx, sy, nx, ny, n, dof, samexy ? 1 : 0, stat_kind, op.p, ostat.p,
+									 h_r ? orr.p : nullptr, h_t ? ot.p : nullptr, out_dtype, ny, flags.as<int32_t>(), a, b, st));
+		hipEvent_t ev;
+		NRM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		cs.events.push_back(ev);
+		NRM_HIP(hipEventRecord(ev, st));
+	}
+	pinner.join();
+	const size_t row = (size_t)ny * esize(out_dtype);
+	for (int64_t a = 0, i = 0; a < nx; a += band, i++) {
+		const int64_t b = std::min(nx, a + band);
+		NRM_HIP(hipStreamWaitEvent(cs.s, cs.events[(size_t)i], 0));
+		const size_t off = (size_t)a * row, len = (size_t)(b - a) * row;
+		NRM_HIP(hipMemcpyAsync((char*)h_p + off, (const char*)op.p + off, len, hipMemcpyDeviceToHost, cs.s));
+		NRM_HIP(hipMemcpyAsync((char*)h_stat + off, (const char*)ostat.p + off, len, hipMemcpyDeviceToHost, cs.s));
+		if (h_r) NRM_HIP(hipMemcpyAsync((char*)h_r + off, (const char*)orr.p + off, len, hipMemcpyDeviceToHost, cs.s));
+		if (h_t) NRM_HIP(hipMemcpyAsync((char*)h_t + off, (const char*)ot.p + off, len, hipMemcpyDeviceToHost, cs.s));
+	}
 	if (want_alpha) {
 		NRM_REQUIRE(!samexy && stat_kind == 1, "alpha is only defined for dy != None with return_dot=False");
 		NRM_TRY(oalpha.alloc(ob * nc));
 		NRM_TRY(nrm_alpha(ostat.p, out_dtype, ny, bx.as<double>(), by.as<double>(), nx, ny, nc, oalpha.p, out_dtype, st));
 	}
 	NRM_HIP(hipStreamSynchronize(st));
+	NRM_HIP(hipStreamSynchronize(cs.s));
 	int32_t hf[2];
 	NRM_HIP(hipMemcpy(hf, flags.p, 8, hipMemcpyDeviceToHost));
 	if (hf[0] || hf[1]) {
 		nrm_set_error("association results failed the reference's assertions (association.py:248,252): %d tiles non-finite, %d tiles with R^2 > 1+1e-8", hf[0], hf[1]);
 		return NRM_E_NUMERIC;
 	}
-	NRM_HIP(hipMemcpy(h_p, op.p, ob, hipMemcpyDeviceToHost));
-	NRM_HIP(hipMemcpy(h_stat, ostat.p, ob, hipMemcpyDeviceToHost));
-	if (h_r) NRM_HIP(hipMemcpy(h_r, orr.p, ob, hipMemcpyDeviceToHost));
-	if (h_t) NRM_HIP(hipMemcpy(h_t, ot.p, ob, hipMemcpyDeviceToHost));
 	if (want_alpha) NRM_HIP(hipMemcpy(h_alpha, oalpha.p, ob * nc, hipMemcpyDeviceToHost));
 	// variances = ss / n with the 0 -> 1 rule (association.py:230-233), cast to the output dtype
 	std::vector<double> hs((size_t)std::max(mp, np_));

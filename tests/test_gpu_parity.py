@@ -252,6 +252,15 @@ def test_host_entry_numpy_in_out(eng):
 												  vp(p32), vp(d32), None, None, vp(v32), None, None, 0))
 	po, do, vo = oracle.coex(dt32.astype(np.float64), dc)
 	assert close(p32, po, 1e-6, 1e-38) and close(d32, do, 1e-6, 1e-7) and (np.diag(p32) == 0).all()
+	# several bands of output rows, page-locked result arrays (coex 2500 genes, fp32 in/out) against the Python engine path
+	rng = np.random.default_rng(31)
+	big = rng.standard_normal((2500, n), dtype=np.float32) + 0.4 * rng.standard_normal((2500, 1), dtype=np.float32) * rng.standard_normal((1, n), dtype=np.float32)
+	pb, db, vb = np.empty((2500, 2500), np.float32), np.empty((2500, 2500), np.float32), np.empty(2500, np.float32)
+	_lib.check(eng.lib.nrm_association_tests_host(vp(big), 0, 2500, None, 0, 0, vp(dc), 1, nc, n, vp(dci), rank, 0, 1,
+												  vp(pb), vp(db), None, None, vp(vb), None, None, 0))
+	res = eng.association_single0(big, None, dc, dci, rank, 0, True, False, np.float32)
+	assert np.array_equal(pb, res['p']) and np.array_equal(db, res['stat']) and np.array_equal(vb, res['vary'])
+	assert (pb == pb.T).all() and (np.diag(pb) == 0).all()
 	# error mapping: too few cells -> ValueError like association.py:213-216
 	with pytest.raises(ValueError):
 		_lib.check(eng.lib.nrm_association_tests_host(vp(dg), 1, nx, vp(dt), 1, ny, vp(dc), 1, nc, 4, vp(dci), rank, 0, 0,
