@@ -13,6 +13,8 @@ there is no all-reduce.  xGMI is point-to-point: an all-gather in which every GP
 de (dy given): gene rows of Y are sharded, the (few) design rows X are residualised redundantly on every
 rank -- no collective at all (see DePlan).
 """
+import os
+
 import numpy as np
 
 from ._lib import ROW_TILE, K_TILE
@@ -125,12 +127,16 @@ class CoexPlan:
 		self.flags = None
 		self._pending = []
 		self._ev = dict(residualize=[], exchange=[], gram=[], sweep=[])
+		self._timed_steps = 0
 		# what travels over xGMI: the fp64 residual blocks, or -- when the input is narrower than fp64 -- the raw input
 		# blocks (half the bytes for fp32; partner blocks are then residualised again locally, K1 is HBM-cheap)
 		self.exchange_raw = world > 1 and backend is None and 'float32' in str(dt_local.dtype)
 		if world > 1:
 			if self.exchange_raw:
-				self.all_x = self.be.torch.empty((world * self.rows, self.n), dtype=dt_local.dtype, device=dt_local.device)
+				# blocks 0..world-1 as gathered, then copies of the first blocks so that the partners rank+1..rank+K of any
+				# rank are one contiguous run of rows (one K1, one K2 and one K3 launch for all of them)
+				self.n_partners = (world - 1) // 2
+				self.all_x = self.be.torch.empty(((world + self.n_partners) * self.rows, self.n), dtype=dt_local.dtype, device=dt_local.device)
 				self._blocks = {}
 			else:
 				self.all_data = self.be.empty((world * self.rows_pad, self.k_pad))
@@ -154,8 +160,8 @@ class CoexPlan:
 		if self.exchange_raw:
 			self._blocks = {}
 			if nccl:
-				return [dist.all_gather_into_tensor(self.all_x, self.x, group=self.group, async_op=True)]
-			dist.all_gather(list(self.all_x.view(self.world, self.rows, self.n).unbind(0)), self.x.contiguous(), group=self.group)
+				return [dist.all_gather_into_tensor(self.all_x[:self.world * self.rows], self.x, group=self.group, async_op=True)]
+			dist.all_gather(list(self.all_x[:self.world * self.rows].view(self.world, self.rows, self.n).unbind(0)), self.x.contiguous(), group=self.group)
 			return []
 		if nccl:
 			return [dist.all_gather_into_tensor(self.all_data, data, group=self.group, async_op=True),
@@ -173,13 +179,45 @@ class CoexPlan:
 			return self._blocks[b]
 		return (self.all_data[b * self.rows_pad:(b + 1) * self.rows_pad], self.all_ss[b * self.rows_pad:(b + 1) * self.rows_pad])
 
+	def _pair(self, outs, timed, bi, bj, lo, hi, sym):
+		a, ssa = self.block(bi)
+		b, ssb = self.block(bj)
+		a, ssa = a[lo:hi], ssa[lo:hi]
+		nx = max(0, min(hi, self.rows) - lo)
+		ny = self.rows
+		if nx == 0:
+			return
+		dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym, nx, ny))
+		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
+		outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
+
+	def _partners_merged(self, outs, timed):
+		"""All full block pairs (rank, rank+k), k = 1..K, as ONE rectangular problem: the partners' raw rows are a contiguous
+		run of the gathered buffer, residualised by one K1 launch, contracted against the own block by one K2 launch
+		(K x more tiles per launch: the persistent schedule stays in its whole-tile regime) and swept by one K3 launch."""
+		R, W, K = self.rows, self.world, self.n_partners
+		wrap = self.rank + K - (W - 1)
+		if wrap > 0:
+			self.all_x[W * R:(W + wrap) * R].copy_(self.all_x[:wrap * R])
+		xs = self.all_x[(self.rank + 1) * R:(self.rank + 1 + K) * R]
+		pd, pss = self._timed('residualize', timed, lambda: self.be.residualize(xs, self.cov, _round_up(K * R, ROW_TILE)))
+		dot = self._timed('gram', timed, lambda: self.be.gram(self._data, pd, False, R, K * R))
+		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, self._ss, pss, R, K * R, self.n, self.dof, False, self.out_dtype, self.flags))
+		for j in range(K):
+			outs.append(dict(bi=self.rank, bj=(self.rank + 1 + j) % W, row_lo=0, nx=R, ny=R, symmetric=False,
+							 p=p[:, j * R:(j + 1) * R], stat=stat[:, j * R:(j + 1) * R]))
+
 	def step(self, timed=False):
+		if timed:
+			self._timed_steps += 1
 		data, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
 		self._data, self._ss = data, ss
 		self._pending = []
 		if self.world > 1:
 			self._pending = self._exchange(data, ss)
 		outs = []
+		merged = self.exchange_raw and self.n_partners >= 1 and os.environ.get('NRM_MERGE_PARTNERS', '1') != '0'
+		merged_done = False
 		for bi, bj, lo, hi, sym in self.sched:
 			if self._pending and not (bi == self.rank and bj == self.rank):
 				def wait():
@@ -187,16 +225,12 @@ class CoexPlan:
 						w.wait()
 				self._timed('exchange', timed, wait)  # time the part of the exchange that compute did not hide
 				self._pending = []
-			a, ssa = self.block(bi)
-			b, ssb = self.block(bj)
-			a, ssa = a[lo:hi], ssa[lo:hi]
-			nx = max(0, min(hi, self.rows) - lo)
-			ny = self.rows
-			if nx == 0:
+			if merged and not sym and bi == self.rank and lo == 0 and hi == self.rows_pad and (bj - bi) % self.world <= self.n_partners:
+				if not merged_done:
+					self._partners_merged(outs, timed)
+					merged_done = True
 				continue
-			dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym, nx, ny))
-			p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
-			outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
+			self._pair(outs, timed, bi, bj, lo, hi, sym)
 		for w in self._pending:
 			w.wait()
 		self._pending = []
@@ -217,7 +251,7 @@ class CoexPlan:
 		if not ev:
 			return 0.0
 		self.be.sync()
-		per_step = max(1, len(self._ev['residualize']))
+		per_step = max(1, self._timed_steps)
 		return sum(a.elapsed_time(b) for a, b in ev) / per_step
 
 	def gram_ms(self):

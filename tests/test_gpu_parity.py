@@ -394,7 +394,7 @@ def _sharded_worker(rank, world, port, q):
 	dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 5, 8])
 def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
 	"""The N>1 path with the real HIP backend: `world` processes share this box's single GPU and exchange
 	residual blocks over gloo (RCCL needs one GPU per rank); result must equal the single-process oracle."""
