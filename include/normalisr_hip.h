@@ -108,6 +108,9 @@ typedef struct nrm_pvalue_plan {
 	double coef[NRM_PCOEF];  /* fast path: p = exp(-alpha u)(erfcx(sqrt(alpha u)) + sqrt(alpha u) sum_j coef[j] u^j) */
 } nrm_pvalue_plan;
 int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof);
+/* The same for `count` dofs (single=1: one dof per grouping, association.py:374): record j = the 24 doubles of the plan
+ * for dof[j], written at out + j * pitch (pitch in doubles, >= 24). */
+int nrm_pvalue_plan_init_many(const double* dof, int64_t count, double* out, int64_t pitch);
 
 /* Elementwise p-values from R^2 (device arrays); kernel-level entry for the table tests. */
 int nrm_pvalues_from_r2(const double* d_r2, int64_t count, double dof, double* d_p, void* stream);

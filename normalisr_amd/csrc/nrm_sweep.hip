@@ -69,6 +69,18 @@ extern "C" int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof) {
 	return NRM_OK;
 }
 
+extern "C" int nrm_pvalue_plan_init_many(const double* dof, int64_t count, double* out, int64_t pitch) {
+	NRM_REQUIRE(count >= 0 && pitch >= (int64_t)(sizeof(nrm_pvalue_plan) / sizeof(double)), "nrm_pvalue_plan_init_many: bad sizes");
+	NRM_REQUIRE(count == 0 || (dof && out), "nrm_pvalue_plan_init_many: null pointer");
+	for (int64_t j = 0; j < count; j++) {
+		nrm_pvalue_plan plan;
+		int rc = nrm_pvalue_plan_init(&plan, dof[j]);
+		if (rc) return rc;
+		memcpy(out + j * pitch, &plan, sizeof(plan));
+	}
+	return NRM_OK;
+}
+
 static PvalPlan to_dev(const nrm_pvalue_plan& p) {
 	PvalPlan d;
 	d.a = p.a;

@@ -5,12 +5,29 @@ from .association import association_tests
 
 
 def _varying_rows(dg):
-	"""Rows with more than one distinct value (de.py:93 uses len(np.unique(x)) > 1; NaNs compare equal there)."""
-	first = dg[:, :1]
-	diff = dg != first
-	if dg.dtype.kind == 'f':
-		diff &= ~(np.isnan(dg) & np.isnan(first))
-	return diff.any(axis=1)
+	"""Rows with more than one distinct value (de.py:93 uses len(np.unique(x)) > 1; NaNs compare equal there).
+	Column blocks of growing width, only over the rows still undecided: a row is settled by its first value that differs
+	from its first entry, so a 0/1 incidence matrix costs far less than one pass."""
+	rows, n = dg.shape
+	varying = np.zeros(rows, dtype=bool)
+	if n < 2:
+		return varying
+	isf = dg.dtype.kind == 'f'
+	todo = np.arange(rows)
+	c0, width = 1, 256
+	while todo.size and c0 < n:
+		c1 = min(n, c0 + width)
+		whole = todo.size == rows
+		blk = dg[:, c0:c1] if whole else dg[todo, c0:c1]
+		first = dg[:, :1] if whole else dg[todo, :1]
+		diff = blk != first
+		if isf:
+			diff &= ~(np.isnan(blk) & np.isnan(first))
+		hit = diff.any(axis=1)
+		varying[todo[hit]] = True
+		todo = todo[~hit]
+		c0, width = c1, width * 4
+	return varying
 
 
 def de(dg, dt, dc, bs=0, **ka):
@@ -30,7 +47,14 @@ def de(dg, dt, dc, bs=0, **ka):
 	gid = _varying_rows(dg0)
 	nt, nc, ng0 = dt.shape[0], dc.shape[0], dg0.shape[0]
 	odt = dt.dtype if dt.dtype in (np.float32, np.float64) else np.dtype(np.float64)
-	p, gam, alpha, varg, vart = association_tests(dg0[gid], dt, dc, bsx=bs, bsy=bs, return_dot=False, **ka)
+	allrows = bool(gid.all())
+	p, gam, alpha, varg, vart = association_tests(dg0 if allrows else dg0[gid], dt, dc, bsx=bs, bsy=bs, return_dot=False, **ka)
+	if allrows and p.dtype == odt:  # nothing to re-inflate (de.py:107-122 is the identity then)
+		P, G, A, VG = p, gam, alpha, varg
+		VT = vart if np.ndim(vart) == 2 else np.broadcast_to(vart, (ng0, nt)).copy()  # single=0: (n_gene,) for every row
+		assert np.isfinite(P).all() and np.isfinite(G).all() and np.isfinite(VG).all() and np.isfinite(VT).all()
+		assert (P >= 0).all() and (P <= 1).all() and (VG >= 0).all() and (VT >= 0).all()
+		return (P, G, A, VG, VT)
 	P = np.ones((ng0, nt), dtype=odt)
 	P[gid] = p
 	G = np.zeros((ng0, nt), dtype=odt)

@@ -37,6 +37,17 @@ def as_input(a):
 	return np.ascontiguousarray(a)
 
 
+def host_blas(limit=8):
+	"""Context for the small host LAPACK calls of the path (inverses / eigenvalues of matrices of a few hundred to a
+	thousand rows): on a many-core host an unbounded BLAS thread pool makes them 5-10x slower, so cap it."""
+	try:
+		from threadpoolctl import threadpool_limits
+		return threadpool_limits(limits=limit)
+	except ImportError:
+		import contextlib
+		return contextlib.nullcontext()
+
+
 class Residualized:
 	"""Residualised rows resident in HBM, plus their sums of squares and OLS coefficients."""
 
@@ -143,6 +154,53 @@ class Engine:
 		if os.environ.get('NRM_PIPELINE', '1') == '0':
 			return False
 		return nx > self.BAND and 2 * nx * ny * np.dtype(out_dtype).itemsize >= (16 << 20)
+
+	CHUNK_BYTES = 256 << 20
+
+	def chunked_ok(self, dy):
+		"""de whose expression matrix still sits on the host and is large: upload it in row chunks on a second stream
+		so that K1/K2/K3 of chunk c run while chunk c+1 crosses PCIe (NRM_PIPELINE=0 switches it off)."""
+		import os
+		return (isinstance(dy, np.ndarray) and dy.nbytes >= 2 * self.CHUNK_BYTES and os.environ.get('NRM_PIPELINE', '1') != '0')
+
+	def association_de_chunked(self, dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov=None):
+		"""General de path with the expression rows streamed from the host: every chunk of genes is an independent
+		problem against the same residualised design rows (association.py:890-909: the reference's tiles are independent
+		in the same way), so the H2D leg -- the longest leg of a one-shot call -- hides the kernels."""
+		torch = self.torch
+		dy = as_input(dy)
+		nx, n = dx.shape
+		ny = dy.shape[0]
+		tdt = torch.float64 if np.dtype(out_dtype) == np.float64 else torch.float32
+		rows = max(ROW_TILE, (self.CHUNK_BYTES // (n * dy.itemsize)) // ROW_TILE * ROW_TILE)
+		with torch.cuda.device(self.device):
+			main = torch.cuda.current_stream(self.device)
+			if self._copy is None:
+				self._copy = torch.cuda.Stream(device=self.device)
+			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
+			rx = self.residualize(dx, d_c, d_dci, rank)
+			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
+			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
+			ssy = torch.empty((ny, ), dtype=torch.float64, device=self.device)
+			flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+			esz = p.element_size()
+			for a in range(0, ny, rows):
+				b = min(ny, a + rows)
+				with torch.cuda.stream(self._copy):
+					yc = torch.from_numpy(dy[a:b]).to(self.device)  # host blocks here; the GPU is busy with the previous chunk
+				arrived = torch.cuda.Event()
+				arrived.record(self._copy)
+				main.wait_event(arrived)
+				yc.record_stream(main)
+				ry = self.residualize(yc, d_c, d_dci, rank)
+				dot = self.gram(rx, ry, False)
+				_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), rx.ss.data_ptr(), ry.ss.data_ptr(), nx, b - a, int(n),
+													float(dof), 0, int(stat_kind), p.data_ptr() + a * esz, stat.data_ptr() + a * esz, 0, 0,
+													_code(out_dtype), ny, flags.data_ptr(), self._stream()))
+				ssy[a:b] = ry.ss[:b - a]
+			self.check_flags(flags)
+			return dict(p=self.download(p), stat=self.download(stat), alpha=None, varx=self.variances(rx.ss, nx, n, out_dtype),
+						vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
 
 	def start_host_results(self, nx, ny, out_dtype):
 		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps the upload and K1)."""
@@ -361,6 +419,8 @@ class Engine:
 		nc = dc.shape[0]
 		dof = n - 1 - rank - dimreduce
 		stat_kind = 0 if (samexy or return_dot) else 1
+		if not (samexy or device_out or want_rt or want_alpha) and self.chunked_ok(dy):
+			return self.association_de_chunked(dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov)
 		host = None
 		if not (device_out or want_rt or want_alpha) and self.banded_ok(nx, ny, out_dtype):
 			host = self.start_host_results(nx, ny, out_dtype)

@@ -12,14 +12,13 @@ loop collapses into two Gram contractions on the fp64 matrix cores (K2),
 a tiny host step per grouping (inv_rank of C_S C_S^T: the rank is an integer and stays on the host) and one
 sweep kernel (csrc/nrm_single1.hip).  Groupings are processed in chunks to bound the size of W.
 """
-import ctypes
 import logging
 
 import numpy as np
 
 from . import _lib
 from . import engine as _engine
-from ._lib import ROW_TILE, PvaluePlan
+from ._lib import ROW_TILE
 from .association import inv_rank
 
 
@@ -50,12 +49,6 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		logging.warning('No covariate dc input.')
 	if nc > 31:
 		raise NotImplementedError('single=1 on the device supports at most 31 covariates.')
-	assert dx.max() == 1  # association.py:914
-	x64 = dx.astype(np.float64)
-	sel = x64 == x64.sum(axis=0)  # association.py:915-916
-	selx = np.where(sel, x64, np.nan)
-	assert ((np.nanmax(selx, axis=1) - np.nanmin(selx, axis=1)) > 0).all()  # >1 distinct value among the selected cells (:917-918)
-	ns = sel.sum(axis=1)
 	c64 = np.asarray(dc, dtype=np.float64)
 	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 	eng = _engine.get_engine()
@@ -63,6 +56,16 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	tdt = torch.float64 if out_dtype == np.float64 else torch.float32
 	nw = nc + 1
 	with torch.cuda.device(eng.device):
+		# cell selection on the device (association.py:914-918): the design matrix travels once, in its own dtype
+		d_dx = eng.upload(_engine.as_input(dx))
+		assert float(d_dx.max()) == 1  # association.py:914
+		sel = d_dx == torch.sum(d_dx, dim=0, dtype=torch.float64)  # association.py:915-916
+		big = torch.finfo(d_dx.dtype).max
+		lo = torch.where(sel, d_dx, big).amin(dim=1)
+		hi = torch.where(sel, d_dx, -big).amax(dim=1)
+		assert bool((hi > lo).all())  # >1 distinct value among the selected cells (:917-918)
+		del lo, hi
+		ns = sel.sum(dim=1).cpu().numpy().astype(np.float64)
 		ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
 		y2 = Residualized_sq(ry, eng)
 		d_c = eng.upload(c64) if nc else None
@@ -77,8 +80,8 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		for i0 in range(0, nx, chunk):
 			i1 = min(nx, i0 + chunk)
 			m = i1 - i0
-			d_sel = eng.upload(sel[i0:i1].astype(np.float64))  # (m, n)
-			d_x = eng.upload(x64[i0:i1])
+			d_sel = sel[i0:i1].to(torch.float64)  # (m, n)
+			d_x = d_dx[i0:i1].to(torch.float64)
 			wrows = _round_up(m * nw, ROW_TILE)
 			w = torch.zeros((wrows, kp), dtype=torch.float64, device=eng.device)
 			wv = w[:m * nw].view(m, nw, kp)
@@ -93,36 +96,27 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			g = eng.gram(ry, W, False)   # (ny_pad, wrows): y . (1_S C), y . (1_S x)
 			g2 = eng.gram(y2, S, False)  # (ny_pad, srows): |y_S|^2
 			# grouping-side statistics: M_i = C_S C_S^T, xC_i = C_S x_S, xx_i = |x_S|^2 (tiny; W against [C; x] rows)
+			xx = (wv[:, nc, :n] * d_x).sum(dim=1).cpu().numpy()
+			info = np.zeros((m, pitch))
+			rk = np.zeros(m, dtype=np.int64)
 			if nc:
 				mc = torch.einsum('icn,dn->icd', wv[:, :nc, :n], d_c).cpu().numpy()       # (m, nc, nc)
 				xc = torch.einsum('in,dn->id', wv[:, nc, :n], d_c).cpu().numpy()          # (m, nc)
-			xx = (wv[:, nc, :n] * d_x).sum(dim=1).cpu().numpy()
-			info = np.zeros((m, pitch))
-			for j in range(m):
-				i = i0 + j
-				r = 0
-				ccx = np.zeros(nc)
-				mi = np.zeros((nc, nc))
-				if nc:
-					mi, r = inv_rank(mc[j])  # association.py:350-351
-					if r > 0:
-						ccx = mi @ xc[j]
-					else:
-						mi = np.zeros((nc, nc))
-				vxx = (xx[j] - (xc[j] @ ccx if nc else 0.0)) / ns[i]
-				if vxx == 0:
-					vxx = 1  # association.py:362-364
-				varx[i] = vxx
-				dof = ns[i] - 1 - r - dimreduce
-				if dof <= 0:
-					raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
-				plan = PvaluePlan()
-				_lib.check(eng.lib.nrm_pvalue_plan_init(ctypes.byref(plan), float(dof)))
-				info[j, 0], info[j, 1] = ns[i], vxx
-				info[j, 2:6] = plan.a, plan.alpha, plan.ln_front, plan.umax
-				info[j, 6:26] = plan.coef[:]
-				info[j, 26:26 + nc] = ccx
-				info[j, 26 + nc:] = np.asarray(mi, dtype=np.float64).ravel()
+				mi, rk = inv_rank(mc)  # association.py:350-351, all groupings of the chunk
+				mi[rk == 0] = 0
+				ccx = np.einsum('icd,id->ic', mi, xc)
+				info[:, 26:26 + nc] = ccx
+				info[:, 26 + nc:] = mi.reshape(m, nc * nc)
+				xx = xx - np.einsum('ic,ic->i', xc, ccx)
+			vxx = xx / ns[i0:i1]
+			vxx[vxx == 0] = 1  # association.py:362-364
+			varx[i0:i1] = vxx
+			dof = ns[i0:i1] - 1 - rk - dimreduce
+			if (dof <= 0).any():
+				raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+			info[:, 0], info[:, 1] = ns[i0:i1], vxx
+			dof = np.ascontiguousarray(dof, dtype=np.float64)
+			_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, m, info.ctypes.data + 16, pitch))
 			d_info = eng.upload(info)
 			code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
 			_lib.check(eng.lib.nrm_single1_sweep(g.data_ptr(), g.stride(0), g2.data_ptr(), g2.stride(0), d_info.data_ptr(), pitch, nc, m, ny,

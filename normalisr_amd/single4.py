@@ -82,6 +82,19 @@ def _per_grouping_host(prod, prodyT, yy, nx, nc, n, dimreduce, tol, lowmem, eng,
 	return p, gam, alpha, vx, vy
 
 
+def _spd_inverse(m):
+	"""Inverse of a symmetric positive definite matrix (its conditioning was checked by the caller): Cholesky, an order
+	of magnitude cheaper than the eigendecomposition for the ~1000 x 1000 matrices of a CRISPR screen."""
+	from scipy.linalg import cho_factor, cho_solve, LinAlgError
+	try:
+		c = cho_factor(m, lower=True, check_finite=False)
+		inv = cho_solve(c, np.eye(m.shape[0]), check_finite=False)
+		return 0.5 * (inv + inv.T)
+	except LinAlgError:
+		w, v = np.linalg.eigh(m)
+		return (v / w) @ v.T
+
+
 def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, tol=1E-8,
 							  method='auto', mpc=0, qr=0, **ka):
 	"""Device path of association_tests(..., single=4) for dy is not None; returns (p, gamma|dot, alpha|None, varx, vary)
@@ -113,32 +126,39 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	m = nx + nc
 	eng = _engine.get_engine()
 	torch = eng.torch
-	a_host = np.concatenate([np.asarray(dx, dtype=np.float64), np.asarray(dc, dtype=np.float64)], axis=0)  # association.py:935
-	ra = eng.residualize(a_host, None, None, 0)  # rank 0: fp64 padded copy of A
+	# A = [X; C] (association.py:935) is stacked on the device: X travels in its own dtype and is widened there
+	from .engine import Residualized
+	mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
+	with torch.cuda.device(eng.device):
+		a_dev = torch.zeros((mp, kp), dtype=torch.float64, device=eng.device)
+		a_dev[:nx, :n] = eng.upload(_engine.as_input(dx))
+		if nc:
+			a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
+	ra = Residualized(m, n, a_dev, None, None)
 	ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y and sum y^2 (association.py:968)
 	prod_d = eng.gram(ra, ra, True)  # A A^T, tiles on/above the diagonal (association.py:936-950)
 	prod = prod_d[:m, :m].cpu().numpy()
 	prod = np.triu(prod) + np.triu(prod, 1).T
 	prodyT_d = eng.gram(ry, ra, False)  # Y A^T  (association.py:952-967, transposed)
-	ev = np.linalg.eigvalsh(prod)
+	with _engine.host_blas():
+		ev = np.linalg.eigvalsh(prod)
 	full_rank = ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)
 	if not full_rank:
 		logging.info('single=4: A A^T is rank deficient; following the per-grouping algorithm on the host.')
-		p, gam, alpha, vx, vy = _per_grouping_host(prod, prodyT_d[:ny, :m].cpu().numpy(), ry.ss[:ny].cpu().numpy(), nx, nc, n,
-												   dimreduce, tol, lowmem, eng, out_dtype)
+		with _engine.host_blas():
+			p, gam, alpha, vx, vy = _per_grouping_host(prod, prodyT_d[:ny, :m].cpu().numpy(), ry.ss[:ny].cpu().numpy(), nx, nc, n,
+													   dimreduce, tol, lowmem, eng, out_dtype)
 		stat = (gam.T * vx).T if return_dot else gam
 		cast = lambda v: None if v is None else v.astype(out_dtype, copy=False)
 		return (cast(p), cast(stat), cast(alpha), cast(vx), cast(vy))
 	if n <= m + dimreduce:
 		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
 	dof = n - m - dimreduce
-	w, v = np.linalg.eigh(prod)
-	ninv = (v / w) @ v.T  # N = M^-1 (symmetric)
+	with _engine.host_blas():
+		ninv = _spd_inverse(prod)  # N = M^-1 (symmetric)
 	dxx = 1.0 / (n * np.diag(ninv)[:nx])
-	mp = ra.rows_pad
 	n_pad = np.zeros((mp, mp))
 	n_pad[:m, :m] = ninv
-	from .engine import Residualized
 	with torch.cuda.device(eng.device):
 		d_n = eng.upload(n_pad)
 		pt = Residualized(ny, mp, prodyT_d, None, None)  # (ny_pad, m_pad): K dimension = rows of A, zero padded
@@ -161,4 +181,4 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			alpha = np.broadcast_to(b_cov[None, :, :], (nx, ny, nc)).copy()
 		vx = dxx.copy()
 		vx[vx == 0] = 1
-		return (p.cpu().numpy(), stat.cpu().numpy(), alpha, vx.astype(out_dtype), vary.cpu().numpy())
+		return (eng.download(p), eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary))

@@ -708,3 +708,31 @@ def test_banded_pipeline_matches_one_launch(norm, eng, monkeypatch):
 		norm.coex(bad, dc)
 	c3 = norm.coex(dt, dc)  # the page locks of the failed call were released
 	assert np.array_equal(c3[0], c1[0])
+
+
+def test_chunked_upload_de_matches_one_shot(norm, eng, monkeypatch):
+	"""de with a large host-resident expression matrix streams it to the device in row chunks on a second stream
+	(engine.association_de_chunked); here the chunk size is forced down so that a small problem takes that path with a
+	ragged last chunk.  Same answers as the one-shot path and as the oracle; bitwise reproducible."""
+	rng = np.random.default_rng(909)
+	nx, ny, n = 40, 1900, 600
+	dt = (rng.normal(size=(ny, n)) * rng.uniform(0.5, 2, (ny, 1)) - 5).astype(np.float32)
+	dc = np.vstack([rng.normal(size=(3, n)), np.ones((1, n))]).astype(np.float32)
+	dg = (rng.random((nx, n)) < 0.25).astype(np.float32)
+	dt[:30] += 0.4 * dg[0]
+	monkeypatch.setenv('NRM_DE_PATH', 'general')
+	monkeypatch.setenv('NRM_PIPELINE', '0')
+	one = norm.de(dg, dt, dc)
+	monkeypatch.setenv('NRM_PIPELINE', '1')
+	monkeypatch.setattr(eng, 'CHUNK_BYTES', 512 * n * 4, raising=False)
+	assert eng.chunked_ok(dt)
+	a = norm.de(dg, dt, dc)
+	b = norm.de(dg, dt, dc)
+	assert all(np.array_equal(x, y) for x, y in zip(a, b) if x is not None)
+	assert close(a[0], one[0], 1e-6, 1e-38) and close(a[1], one[1], 1e-6, 1e-7) and np.array_equal(a[3], one[3]) and np.array_equal(a[4], one[4])
+	po, go, ao, vgo, vto = oracle.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
+	assert close(a[0], po, 1e-6, 1e-38) and close(a[1], go, 1e-6, 1e-7) and close(a[4], vto, 1e-6) and a[2] is None
+	bad = dt.copy()
+	bad[1500, 3] = np.nan
+	with pytest.raises(AssertionError):
+		norm.de(dg, bad, dc)
