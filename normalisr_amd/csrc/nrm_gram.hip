@@ -8,13 +8,17 @@
 //   workgroup tile 128 x 128, 256 threads = 4 waves as 2(M) x 2(N); each wave owns 64 x 64 = 4 x 4 MFMA
 //   tiles (64 fp64 accumulators per lane, kept in VGPRs: with AGPR accumulators this instruction issues
 //   at half rate on MI355X, tools/mfma_peak.hip).  K is consumed in slabs of GK = 16 cells staged through
-//   a double-buffered LDS image [row][k] with a 17-element (odd) pitch so that the 16 rows of an operand
-//   read land on distinct bank pairs (measured: the 18-element pitch cost 40 % of the LDS cycles in conflicts).
+//   a double-buffered LDS image [row][16 cells], rows unpadded (128 B = one line), whose 16-byte chunks are
+//   XOR-swizzled with (row >> 1) & 7 so that the 16 rows of an operand read fall on distinct banks.
 //   MFMA operand maps (f64 16x16x4): lane l supplies A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15];
 //   it receives D[row = (l >> 4) + 4 q][col = l & 15] in accumulator element q.
-//   Global -> register -> LDS staging: the next slab's loads are issued before the MFMA block of the
-//   current slab and stored to the other LDS buffer after it (one barrier per slab); two workgroups per
-//   CU (74 KB LDS each) cover each other's barrier bubbles.
+//   Staging is global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write; each wave
+//   instruction fills 8 rows x 128 B linearly, the swizzle is applied to the source chunk a lane fetches): the next
+//   slab's loads are issued before the MFMA block of the current slab into the other buffer, one barrier per slab
+//   (it also drains vmcnt); two workgroups per CU (64 KB LDS each) cover each other's barrier bubbles.
+//   Measured on C2 (tools/k2_time.py, experiments with parts of the loop compiled out): MFMA + LDS reads alone
+//   72.5 TF executed (= the instruction's ceiling on this chip); register-staged loads cost 5 %, the ds_writes 3 %,
+//   the barrier 7 % -> 63.9 TF; direct-to-LDS staging removes the first two: 68.3 TF executed.
 //
 // Scheduling (persistent, "data-parallel + stream-K"): the launch is 2 workgroups per CU.  Whole waves of
 // tiles are processed tile-per-workgroup with all workgroups in K-lockstep (operand slabs shared through
@@ -29,7 +33,6 @@
 #define GM 128
 #define GN 128
 #define GK 16
-#define GP 17  // LDS row pitch in doubles (136 B, odd): the 16 rows of an operand read fall on 16 distinct bank pairs
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -77,35 +80,39 @@ __device__ __forceinline__ void gram_tile_coords(int t, int symmetric, int ntm, 
 __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const double* __restrict__ B, int64_t lda, int64_t ldb,
 										   double* __restrict__ C, int64_t ldc, int ti, int tj, int kt0, int kt1, double* __restrict__ slab,
 										   const unsigned need /* bit i*4+j: this wave's 16x16 sub-block (i,j) is wanted */,
-										   double* lds /* [2][2][GM*GP] */) {
+										   double* lds /* [2][2][GM*GK] */) {
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int wm = wid >> 1, wn = wid & 1;
 	const int l15 = lane & 15, lg = lane >> 4;
-	// staging map: 8 consecutive lanes cover one 128-byte row slab; 4 passes of 32 rows
-	const int srow = tid >> 3, scol = (tid & 7) * 2;
-	const double* ga = A + ((int64_t)ti * GM + srow) * lda + scol + (int64_t)kt0 * GK;
-	const double* gb = B + ((int64_t)tj * GN + srow) * ldb + scol + (int64_t)kt0 * GK;
-	const int soff = srow * GP + scol;
 	const int nk = kt1 - kt0;
-	double* ldsA0 = lds;
-	double* ldsB0 = lds + GM * GP;
-	double* ldsA1 = lds + 2 * GM * GP;
-	double* ldsB1 = lds + 3 * GM * GP;
-
-	d2_t ra[4], rb[4];
+	// Staging: global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write).  One wave instruction
+	// writes 1 KB of LDS linearly = 8 rows x 128 B of a slab (16 cells of a row = one 128-byte line, 8 chunks of 16 B);
+	// rows are unpadded, so the 16-byte chunks of row r are stored XOR-swizzled with (r >> 1) & 7 -- applied to the SOURCE
+	// chunk each lane fetches and again to the chunk index of every operand read (same involution on both sides) -- which
+	// spreads the 16 rows of an MFMA operand read over all banks.  Wave w stages rows [32 w, 32 w + 32) of A and of B.
+	typedef const __attribute__((address_space(1))) void* gptr_t;
+	typedef __attribute__((address_space(3))) void* lptr_t;
+	const int jr = lane >> 3, jc = lane & 7;  // row within the instruction's 8 rows, physical chunk
+	const double* ga[4];
+	const double* gb[4];
 #pragma unroll
-	for (int j = 0; j < 4; j++) {
-		ra[j] = *reinterpret_cast<const d2_t*>(ga + (int64_t)j * 32 * lda);
-		rb[j] = *reinterpret_cast<const d2_t*>(gb + (int64_t)j * 32 * ldb);
+	for (int q = 0; q < 4; q++) {
+		const int r = wid * 32 + q * 8 + jr;
+		const int c = jc ^ ((r >> 1) & 7);
+		ga[q] = A + ((int64_t)ti * GM + r) * lda + (int64_t)kt0 * GK + c * 2;
+		gb[q] = B + ((int64_t)tj * GN + r) * ldb + (int64_t)kt0 * GK + c * 2;
 	}
-#pragma unroll
-	for (int j = 0; j < 4; j++) {  // 8-byte stores: with the odd pitch rows are only 8-byte aligned
-		ldsA0[soff + j * 32 * GP] = ra[j][0];
-		ldsA0[soff + j * 32 * GP + 1] = ra[j][1];
-		ldsB0[soff + j * 32 * GP] = rb[j][0];
-		ldsB0[soff + j * 32 * GP + 1] = rb[j][1];
+	double* const ldsA0 = lds;
+	double* const ldsB0 = lds + GM * GK;
+	double* const ldsA1 = lds + 2 * GM * GK;
+	double* const ldsB1 = lds + 3 * GM * GK;
+	const int wrow = wid * 32 * GK;  // this wave's staging rows (doubles)
+#define GRAM_STAGE(dstA, dstB, koff)                                                                                              \
+	_Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                               \
+		__builtin_amdgcn_global_load_lds((gptr_t)(ga[q] + (koff)), (lptr_t)((dstA) + wrow + q * 8 * GK), 16, 0, 0);              \
+		__builtin_amdgcn_global_load_lds((gptr_t)(gb[q] + (koff)), (lptr_t)((dstB) + wrow + q * 8 * GK), 16, 0, 0);              \
 	}
-	__syncthreads();
+	GRAM_STAGE(ldsA0, ldsB0, 0)
 
 	d4_t acc[4][4];
 #pragma unroll
@@ -113,18 +120,23 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 #pragma unroll
 		for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-	const int aoff = (wm * 64 + l15) * GP + lg;
-	const int boff = (wn * 64 + l15) * GP + lg;
+	// operand reads: row = 16 i + l15 (+ wave offset), cell = 4 kk + lg -> chunk 2 kk + (lg >> 1), swizzled with l15 >> 1
+	const int t = (lg >> 1) ^ (l15 >> 1);
+	int koffs[GK / 4];
+#pragma unroll
+	for (int kk = 0; kk < GK / 4; kk++) koffs[kk] = (((kk * 2) ^ t) << 1) + (lg & 1);
+	const int aoff = (wm * 64 + l15) * GK;
+	const int boff = (wn * 64 + l15) * GK;
+	__syncthreads();
 
 	for (int kt = 0; kt < nk; kt++) {
 		const int cur = kt & 1;
-		const bool more = kt + 1 < nk;
-		if (more) {
+		if (kt + 1 < nk) {
 			const int64_t ko = (int64_t)(kt + 1) * GK;
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				ra[j] = *reinterpret_cast<const d2_t*>(ga + (int64_t)j * 32 * lda + ko);
-				rb[j] = *reinterpret_cast<const d2_t*>(gb + (int64_t)j * 32 * ldb + ko);
+			if (cur) {
+				GRAM_STAGE(ldsA0, ldsB0, ko)
+			} else {
+				GRAM_STAGE(ldsA1, ldsB1, ko)
 			}
 		}
 		const double* la = (cur ? ldsA1 : ldsA0) + aoff;
@@ -136,8 +148,8 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 			double fa[4], fb[4];
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				fa[i] = la[i * 16 * GP + kk * 4];
-				fb[i] = lb[i * 16 * GP + kk * 4];
+				fa[i] = la[i * 16 * GK + koffs[kk]];
+				fb[i] = lb[i * 16 * GK + koffs[kk]];
 			}
 #pragma unroll
 			for (int i = 0; i < 4; i++)
@@ -145,19 +157,9 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 				for (int j = 0; j < 4; j++)
 					acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
 		}
-		if (more) {
-			double* wa = cur ? ldsA0 : ldsA1;
-			double* wb = cur ? ldsB0 : ldsB1;
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				wa[soff + j * 32 * GP] = ra[j][0];
-				wa[soff + j * 32 * GP + 1] = ra[j][1];
-				wb[soff + j * 32 * GP] = rb[j][0];
-				wb[soff + j * 32 * GP + 1] = rb[j][1];
-			}
-		}
-		__syncthreads();
+		__syncthreads();  // drains the slab in flight (vmcnt) and fences the buffer just read
 	}
+#undef GRAM_STAGE
 
 	// epilogue: lane l holds D[row = lg + 4 q][col = l15] of each 16x16 tile.  A piece that covers the whole K range goes
 	// straight to C; a partial piece goes to its own 128x128 slab of the workspace and k_gram_fixup adds the slabs of a
@@ -196,7 +198,7 @@ struct GramSched {
 
 __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ A, const double* __restrict__ B, int64_t lda,
 													  int64_t ldb, double* __restrict__ C, int64_t ldc, int symmetric, GramSched s) {
-	__shared__ __attribute__((aligned(16))) double lds[2 * 2 * GM * GP];
+	__shared__ __attribute__((aligned(16))) double lds[2 * 2 * GM * GK];
 	// workgroups that share an XCD (same blockIdx % 8) take consecutive tiles so that operand panels are shared in its L2
 	const int per_xcd = s.nwg >> 3;
 	const int p = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
