@@ -152,15 +152,11 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	const int64_t kp = round_up(n, NRM_K_TILE), mp = round_up(nx, NRM_ROW_TILE), np_ = round_up(ny, NRM_ROW_TILE);
 
 	DevBuf dx, dy, dc, dci, rx, ry, ssx, ssy, bx, by, dot, flags, op, ostat, oalpha, orr, ot;
-	// the caller's result arrays are page-locked in place by a helper thread while the inputs are uploaded
+	// the caller's result arrays are page-locked in place by a helper thread while K1/K2 run (started after the uploads:
+	// a hipHostRegister racing a pageable H2D copy was measured to stall that copy by ~20 ms)
 	const size_t ob = (size_t)nx * ny * esize(out_dtype);
 	HostPin pin_p, pin_s, pin_r, pin_t;
-	std::thread pinner([&] {
-		pin_p.try_pin(h_p, (int64_t)ob);
-		pin_s.try_pin(h_stat, (int64_t)ob);
-		pin_r.try_pin(h_r, (int64_t)ob);
-		pin_t.try_pin(h_t, (int64_t)ob);
-	});
+	std::thread pinner;
 	Joiner joiner{pinner};
 	// covariates as fp64
 	std::vector<double> c64;
@@ -199,6 +195,12 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	const double* B = samexy ? A : ry.as<double>();
 	const double* sx = ssx.as<double>();
 	const double* sy = samexy ? sx : ssy.as<double>();
+	pinner = std::thread([&] {
+		pin_p.try_pin(h_p, (int64_t)ob);
+		pin_s.try_pin(h_stat, (int64_t)ob);
+		pin_r.try_pin(h_r, (int64_t)ob);
+		pin_t.try_pin(h_t, (int64_t)ob);
+	});
 	NRM_TRY(dot.alloc((size_t)mp * np_ * 8));
 	DevBuf gwork;
 	NRM_TRY(gwork.alloc((size_t)nrm_gram_workspace_bytes()));
@@ -225,7 +227,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 		cs.events.push_back(ev);
 		NRM_HIP(hipEventRecord(ev, st));
 	}
-	pinner.join();
+	if (pinner.joinable()) pinner.join();
 	const size_t row = (size_t)ny * esize(out_dtype);
 	for (int64_t a = 0, i = 0; a < nx; a += band, i++) {
 		const int64_t b = std::min(nx, a + band);

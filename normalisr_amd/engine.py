@@ -203,7 +203,7 @@ class Engine:
 						vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
 
 	def start_host_results(self, nx, ny, out_dtype):
-		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps the upload and K1)."""
+		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps K1 and the first band of K2)."""
 		import threading
 		odt = np.dtype(out_dtype)
 		res = dict(p=np.empty((nx, ny), dtype=odt), stat=np.empty((nx, ny), dtype=odt), pinned=[], error=[])
@@ -421,17 +421,15 @@ class Engine:
 		stat_kind = 0 if (samexy or return_dot) else 1
 		if not (samexy or device_out or want_rt or want_alpha) and self.chunked_ok(dy):
 			return self.association_de_chunked(dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov)
+		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
+		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
+		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
 		host = None
 		if not (device_out or want_rt or want_alpha) and self.banded_ok(nx, ny, out_dtype):
+			# the result arrays are page-locked by a helper thread while K1/K2 run.  Started only now, after the uploads: a
+			# hipHostRegister racing a pageable H2D copy (right after the previous call's hipHostUnregister) was measured
+			# to stall that copy by ~20 ms -- twice the whole C2 call
 			host = self.start_host_results(nx, ny, out_dtype)
-		try:
-			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
-			rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
-			ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
-		except BaseException:
-			if host is not None:
-				self.finish_host_results(host)
-			raise
 		if host is not None:
 			p, stat = self.association_banded(rx, ry, samexy, nx, ny, n, dof, stat_kind, out_dtype, host)
 			return dict(p=p, stat=stat, alpha=None, varx=None if samexy else self.variances(rx.ss, nx, n, out_dtype),
