@@ -9,7 +9,7 @@
 //   tiles (64 fp64 accumulators per lane, kept in VGPRs: with AGPR accumulators this instruction issues
 //   at half rate on MI355X, tools/mfma_peak.hip).  K is consumed in slabs of GK = 16 cells staged through
 //   a double-buffered LDS image [row][16 cells], rows unpadded (128 B = one line), whose 16-byte chunks are
-//   XOR-swizzled with (row >> 1) & 7 so that the 16 rows of an operand read fall on distinct banks.
+//   XOR-swizzled with row & 7 so that the 8 rows served per clock of a 16-byte operand read cover all banks.
 //   MFMA operand maps (f64 16x16x4): lane l supplies A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15];
 //   it receives D[row = (l >> 4) + 4 q][col = l & 15] in accumulator element q.
 //   Staging is global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write; each wave
@@ -87,7 +87,7 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 	const int nk = kt1 - kt0;
 	// Staging: global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write).  One wave instruction
 	// writes 1 KB of LDS linearly = 8 rows x 128 B of a slab (16 cells of a row = one 128-byte line, 8 chunks of 16 B);
-	// rows are unpadded, so the 16-byte chunks of row r are stored XOR-swizzled with (r >> 1) & 7 -- applied to the SOURCE
+	// rows are unpadded, so the 16-byte chunks of row r are stored XOR-swizzled with r & 7 -- applied to the SOURCE
 	// chunk each lane fetches and again to the chunk index of every operand read (same involution on both sides) -- which
 	// spreads the 16 rows of an MFMA operand read over all banks.  Wave w stages rows [32 w, 32 w + 32) of A and of B.
 	typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
 		const int r = wid * 32 + q * 8 + jr;
-		const int c = jc ^ ((r >> 1) & 7);
+		const int c = jc ^ (r & 7);
 		ga[q] = A + ((int64_t)ti * GM + r) * lda + (int64_t)kt0 * GK + c * 2;
 		gb[q] = B + ((int64_t)tj * GN + r) * ldb + (int64_t)kt0 * GK + c * 2;
 	}
@@ -120,11 +120,11 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 #pragma unroll
 		for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-	// operand reads: row = 16 i + l15 (+ wave offset), cell = 4 kk + lg -> chunk 2 kk + (lg >> 1), swizzled with l15 >> 1
-	const int t = (lg >> 1) ^ (l15 >> 1);
-	int koffs[GK / 4];
-#pragma unroll
-	for (int kk = 0; kk < GK / 4; kk++) koffs[kk] = (((kk * 2) ^ t) << 1) + (lg & 1);
+	// operand reads: 16 bytes (two cells) per lane and read.  Lane group lg reads chunks lg and 4 + lg of its row; the
+	// first cells of the four lane groups feed one MFMA, the second cells the next -- a permutation of the 16 cells of
+	// the slab that is the same for A and B, so the contraction is unchanged.  Eight consecutive lanes (rows r..r+7, one
+	// chunk each, swizzled with r & 7) cover all 32 banks: conflict-free ds_read_b128.
+	const int c0 = (lg ^ (l15 & 7)) * 2, c1 = ((4 + lg) ^ (l15 & 7)) * 2;
 	const int aoff = (wm * 64 + l15) * GK;
 	const int boff = (wn * 64 + l15) * GK;
 	__syncthreads();
@@ -144,20 +144,26 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 		// (predicating individual MFMAs on `need` was measured: the 16 scalar branches per k-step cost 3 % on full tiles,
 		//  more than the 5 % of padded / mirrored sub-blocks they save on 80 of 820 tiles -- so the loop stays branch-free)
 #pragma unroll
-		for (int kk = 0; kk < GK / 4; kk++) {
-			double fa[4], fb[4];
+		for (int h = 0; h < 2; h++) {
+			d2_t fa[4], fb[4];
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				fa[i] = la[i * 16 * GK + koffs[kk]];
-				fb[i] = lb[i * 16 * GK + koffs[kk]];
+				fa[i] = *reinterpret_cast<const d2_t*>(la + i * 16 * GK + (h ? c1 : c0));
+				fb[i] = *reinterpret_cast<const d2_t*>(lb + i * 16 * GK + (h ? c1 : c0));
 			}
 #pragma unroll
-			for (int i = 0; i < 4; i++)
+			for (int e = 0; e < 2; e++)
 #pragma unroll
-				for (int j = 0; j < 4; j++)
-					acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+				for (int i = 0; i < 4; i++)
+#pragma unroll
+					for (int j = 0; j < 4; j++)
+						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
 		}
+#if defined(GRAM_EXP) && (GRAM_EXP & 4)
+		__builtin_amdgcn_s_waitcnt(0);
+#else
 		__syncthreads();  // drains the slab in flight (vmcnt) and fences the buffer just read
+#endif
 	}
 #undef GRAM_STAGE
 
