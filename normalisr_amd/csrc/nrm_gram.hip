@@ -159,11 +159,7 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 					for (int j = 0; j < 4; j++)
 						acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
 		}
-#if defined(GRAM_EXP) && (GRAM_EXP & 4)
-		__builtin_amdgcn_s_waitcnt(0);
-#else
 		__syncthreads();  // drains the slab in flight (vmcnt) and fences the buffer just read
-#endif
 	}
 #undef GRAM_STAGE
 

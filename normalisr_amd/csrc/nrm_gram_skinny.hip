@@ -15,9 +15,11 @@
 // cells lane (r = l & 15, g = l >> 4) loads the 4 consecutive cells 4g..4g+3 of row r (one 16-byte load for
 // fp32), and MFMA step s = 0..3 consumes cell 4g+s; a dot product does not care about the order of its
 // terms as long as the Z operand uses the same permutation (it does: lane (z, g) reads cells 4g..4g+3 of Z
-// row z from LDS).  Slabs are prefetched 4 (fp32) / 2 (fp64) deep in registers to cover HBM latency; one wave per SIMD
-// with the whole 512-entry register file (accumulators forced into VGPRs: -amdgpu-mfma-vgpr-form, AGPR accumulators
-// halve the fp64 MFMA rate).  Z (tiny, shared
+// row z from LDS).  Slabs are prefetched 4 (fp32) / 2 (fp64) deep in registers to cover HBM latency (accumulators
+// forced into VGPRs: -amdgpu-mfma-vgpr-form, AGPR accumulators halve the fp64 MFMA rate; 240-256 VGPRs, so two
+// workgroups share a CU).  Measured by compiling parts out (tools/k2s_time.py, C3 shape, 21 Z rows): everything but
+// MFMA + LDS reads removed 1.77 ms (72.5 TF, the instruction ceiling for 32 padded Z rows); the expression-row loads
+// cost 0.6 ms, re-staging Z 0.5 ms, the chunk barrier 0.15 ms -> 2.73 ms.  Z (tiny, shared
 // by every wave) is staged through LDS in chunks of 128 cells, double buffered, one barrier per chunk.
 // Persistent DP + stream-K schedule as in K2 so that 79 row tiles still fill 256 CUs; partial pieces go to
 // workspace slabs and are summed in a fixed order (k_skinny_fixup): bitwise reproducible, no atomics.
