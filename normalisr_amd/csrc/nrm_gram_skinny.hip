@@ -61,12 +61,18 @@ struct Slab<double> {
 	__device__ __forceinline__ double get(int s) const { return s == 0 ? a[0] : s == 1 ? a[1] : s == 2 ? b[0] : b[1]; }
 };
 
-// NT = number of 16-row Z tiles actually used (1 when nx + nc <= 16: half the MFMA work)
-template <typename T, int NT>
+// NT = number of 16-row Z tiles contracted with v_mfma_f64_16x16x4 (1 when nx + nc <= 16: half the MFMA work);
+// NQ = number of further 4-row Z groups contracted with v_mfma_f64_4x4x4 (four independent 4x4x4 blocks per
+// instruction, 16 instead of 64 cycles): 17-24 Z rows cost 64 + NQ * 16 cycles per step instead of 128.  Its A operand
+// map is the 16x16x4 one (lane 16 k + r holds row r, cell k; block = r >> 2), so the expression registers feed both;
+// its B operand lane 16 k + 4 b + j holds Z[4 g + j][k] for every block b (an LDS broadcast); it returns
+// D[row 4 b + i][z 4 g + j] in lane 16 i + 4 b + j (tools/mfma444_probe.hip).
+template <typename T, int NT, int NQ>
 __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A, int64_t rows, int64_t n16, int64_t lda,
 														 const double* __restrict__ Z, int64_t ldz, double* __restrict__ G,
 														 double* __restrict__ ss, SkinnySched s) {
-	__shared__ __attribute__((aligned(16))) double lds[2][NT * 16 * SKP];
+	constexpr int ZR = NT * 16 + NQ * 4;  // Z rows held in LDS
+	__shared__ __attribute__((aligned(16))) double lds[2][ZR * SKP];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int l15 = lane & 15, lg = lane >> 4;
 	const int per_xcd = s.nwg >> 3;
@@ -110,6 +116,11 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 		for (int i = 0; i < 4; i++)
 #pragma unroll
 			for (int j = 0; j < NT; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+		double accq[4][NQ ? NQ : 1];
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+#pragma unroll
+			for (int g = 0; g < (NQ ? NQ : 1); g++) accq[i][g] = 0.0;
 		double sq[4] = {0.0, 0.0, 0.0, 0.0};
 		const int64_t kbeg = (int64_t)c0 * SKC;
 		constexpr int DEPTH = sizeof(T) == 4 ? 4 : 2;  // slabs (16 cells) in flight per wave: 16 KB per wave, 64 KB per CU
@@ -129,7 +140,7 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 		const double* zsrc = Z + (int64_t)(tid >> 3) * ldz + (tid & 7) * 16;
 		const int zdst = (tid >> 3) * SKP + (tid & 7) * 16;
 		auto stage_z = [&](int buf, int64_t k0) {
-			if ((tid >> 3) < NT * 16) {  // NT = 1: only the first 16 Z rows exist in LDS
+			if ((tid >> 3) < ZR) {  // only the Z rows in use exist in LDS
 				const double* src = zsrc + k0;
 				double* dst = &lds[buf][zdst];
 #pragma unroll
@@ -143,6 +154,7 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 			const int buf = (c - c0) & 1;
 			if (c + 1 < c1) stage_z(buf ^ 1, (int64_t)(c + 1) * SKC);
 			const double* zl = &lds[buf][l15 * SKP + 4 * lg];
+			const double* zql = &lds[buf][(NT * 16 + (l15 & 3)) * SKP + 4 * lg];
 			const int64_t kc = (int64_t)c * SKC;
 #pragma unroll 1
 			for (int h = 0; h < SKC / 16 / DEPTH; h++) {
@@ -172,6 +184,16 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 						zf[j][2] = z23[0];
 						zf[j][3] = z23[1];
 					}
+					double zq[NQ ? NQ : 1][4];
+#pragma unroll
+					for (int g = 0; g < NQ; g++) {
+						const d2_t z01 = *reinterpret_cast<const d2_t*>(zql + g * 4 * SKP + sl * 16);
+						const d2_t z23 = *reinterpret_cast<const d2_t*>(zql + g * 4 * SKP + sl * 16 + 2);
+						zq[g][0] = z01[0];
+						zq[g][1] = z01[1];
+						zq[g][2] = z23[0];
+						zq[g][3] = z23[1];
+					}
 #pragma unroll
 					for (int st = 0; st < 4; st++)
 #pragma unroll
@@ -180,6 +202,8 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 							sq[i] = fma(a, a, sq[i]);
 #pragma unroll
 							for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zf[j][st], acc[i][j], 0, 0, 0);
+#pragma unroll
+							for (int g = 0; g < NQ; g++) accq[i][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, zq[g][st], accq[i][g], 0, 0, 0);
 						}
 				}
 			}
@@ -194,11 +218,18 @@ __global__ void __launch_bounds__(256, 1) k_gram_skinny(const T* __restrict__ A,
 			for (int j = 0; j < NT; j++)
 #pragma unroll
 				for (int q = 0; q < 4; q++) gbase[(int64_t)(i * 16 + lg + 4 * q) * SKN + j * 16 + l15] = acc[i][j][q];
-		if (NT < 2) {
+		if (NT < 2) {  // columns not covered by a 16-row tile: the 4-row groups, zeros beyond them
+			const int yrow = 4 * ((lane >> 2) & 3) + lg, zc = lane & 3;
 #pragma unroll
 			for (int i = 0; i < 4; i++)
 #pragma unroll
-				for (int q = 0; q < 4; q++) gbase[(int64_t)(i * 16 + lg + 4 * q) * SKN + 16 + l15] = 0.0;
+				for (int g = 0; g < 4; g++) {
+					double v = 0.0;
+#pragma unroll
+					for (int gg = 0; gg < NQ; gg++)
+						if (gg == g) v = accq[i][gg];
+					gbase[(int64_t)(i * 16 + yrow) * SKN + 16 + 4 * g + zc] = v;
+				}
 		}
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
@@ -274,19 +305,24 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 	s.tiles_sk = (int)sk;
 	s.tiles_dp = (int)(tiles - sk);
 	s.units_per_wg = (int)((sk * s.nkt + s.nwg - 1) / s.nwg);
-	// nz <= 16 used Z rows: one MFMA column tile instead of two (half the matrix-core work: the pass becomes HBM-bound)
-	const bool one = nz > 0 && nz <= 16;
+	// nz <= 16 used Z rows: one MFMA column tile instead of two (half the matrix-core work: the pass becomes HBM-bound);
+	// 17..24: one column tile plus one or two 4-row groups on the 4x4x4 instruction (80 / 96 cycles per step instead of 128)
+	const int variant = (nz > 0 && nz <= 16) ? 0 : (nz > 16 && nz <= 20) ? 1 : (nz > 20 && nz <= 24) ? 2 : 3;
+#define SK_LAUNCH(TT, NT_, NQ_)                                                                                                        \
+	hipLaunchKernelGGL((k_gram_skinny<TT, NT_, NQ_>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const TT*)d_a, rows, n16, lda, d_z, ldz, \
+					   d_g, d_ss, s)
 	if (a_dtype == NRM_F64) {
-		if (one)
-			hipLaunchKernelGGL((k_gram_skinny<double, 1>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
-		else
-			hipLaunchKernelGGL((k_gram_skinny<double, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const double*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+		if (variant == 0) SK_LAUNCH(double, 1, 0);
+		else if (variant == 1) SK_LAUNCH(double, 1, 1);
+		else if (variant == 2) SK_LAUNCH(double, 1, 2);
+		else SK_LAUNCH(double, 2, 0);
 	} else {
-		if (one)
-			hipLaunchKernelGGL((k_gram_skinny<float, 1>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
-		else
-			hipLaunchKernelGGL((k_gram_skinny<float, 2>), dim3((unsigned)s.nwg), dim3(256), 0, st, (const float*)d_a, rows, n16, lda, d_z, ldz, d_g, d_ss, s);
+		if (variant == 0) SK_LAUNCH(float, 1, 0);
+		else if (variant == 1) SK_LAUNCH(float, 1, 1);
+		else if (variant == 2) SK_LAUNCH(float, 1, 2);
+		else SK_LAUNCH(float, 2, 0);
 	}
+#undef SK_LAUNCH
 	if (s.tiles_sk > 0) hipLaunchKernelGGL(k_skinny_fixup, dim3((unsigned)s.tiles_sk, (SK_SLAB + 255) / 256), dim3(256), 0, st, d_g, d_ss, s);
 	return nrm_check_launch("k_gram_skinny");
 }

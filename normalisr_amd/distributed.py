@@ -210,10 +210,12 @@ class CoexPlan:
 	def step(self, timed=False):
 		if timed:
 			self._timed_steps += 1
+		self._pending = []
+		if self.world > 1 and self.exchange_raw:
+			self._pending = self._exchange(None, None)  # raw rows travel: nothing to wait for, start before K1
 		data, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
 		self._data, self._ss = data, ss
-		self._pending = []
-		if self.world > 1:
+		if self.world > 1 and not self.exchange_raw:
 			self._pending = self._exchange(data, ss)
 		outs = []
 		merged = self.exchange_raw and self.n_partners >= 1 and os.environ.get('NRM_MERGE_PARTNERS', '1') != '0'
