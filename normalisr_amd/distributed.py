@@ -299,7 +299,8 @@ class CoexPlan:
 class DePlan:
 	"""Sharded de (dy given): rank r owns a block of gene rows of Y; the design rows X and the covariates are
 	replicated and residualised redundantly, so there is NO collective on the data path (outputs are disjoint
-	column blocks of the (n_x, n_y) result).  step() leaves this rank's (p, gamma, varx, vary) in self.result."""
+	column blocks of the (n_x, n_y) result).  step() runs one resident pass (outputs stay in HBM, self.result);
+	results() returns this rank's (p, gamma, varx, vary) as numpy arrays."""
 
 	def __init__(self, dx, dy_local, dc, rank=0, world=1, dimreduce=0, return_dot=False, device=None):
 		from .association import _prepare_covariates
@@ -324,12 +325,21 @@ class DePlan:
 		if timed:
 			e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 			e0.record()
+		# resident step: p / gamma / sums of squares stay in HBM; results() brings them to the host and checks the flags
 		self.result = self.eng.association_single0(self.dx, self.dy, self.dc64, self.dci, self.dcr, self.dimreduce,
-												   return_dot=self.return_dot, want_alpha=False, out_dtype=self.out_dtype, cov=self.cov)
+												   return_dot=self.return_dot, want_alpha=False, out_dtype=self.out_dtype, cov=self.cov,
+												   resident=True)
 		if timed:
 			e1.record()
 			self._ev.append((e0, e1))
 		return self.result
+
+	def results(self):
+		"""(p, gamma, varx, vary) of the last step as numpy arrays, after the reference's assertions (association.py:248,252)."""
+		r = self.result
+		self.eng.check_flags(r['flags'])
+		return (self.eng.download(r['p']), self.eng.download(r['stat']), self.eng.variances(r['ssx'], self.nx, self.n, self.out_dtype),
+				self.eng.variances(r['ssy'], self.ny, self.n, self.out_dtype))
 
 	def step_ms(self):
 		self.eng.torch.cuda.synchronize()

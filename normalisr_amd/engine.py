@@ -343,7 +343,8 @@ class Engine:
 			raise ValueError('NRM_DE_PATH=streaming needs nx + nc <= 32')
 		return ok
 
-	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None):
+	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
+								 resident=False):
 		"""de with nx + nc <= 32: stream the raw expression rows once (HBM-bound), see csrc/nrm_gram_skinny.hip."""
 		torch = self.torch
 		nx, n = dx.shape
@@ -399,6 +400,8 @@ class Engine:
 					alpha = self.alpha(stat, rx.coef, by, nc).cpu().numpy()
 				else:
 					alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
+			if resident:  # resident pipeline: nothing leaves the device, the caller checks `flags` when it reads the results
+				return dict(p=p, stat=stat, alpha=alpha, ssx=rx.ss, ssy=ssy, flags=flags, dof=dof)
 			self.check_flags(flags)
 			res = dict(p=self.download(p), stat=self.download(stat), alpha=alpha, varx=self.variances(rx.ss, nx, n, out_dtype),
 					   vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
@@ -408,24 +411,25 @@ class Engine:
 		return res
 
 	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
-							device_out=False):
+							device_out=False, resident=False):
 		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric).
 		cov: optional (d_c, d_dci) already on the device (repeated calls with the same covariates)."""
 		samexy = dy is None
 		if self.de_streaming_ok(dx, dy, dc):
-			return self.association_de_streaming(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov)
+			return self.association_de_streaming(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov,
+												 resident=resident and not (want_alpha or want_rt))
 		nx, n = dx.shape
 		ny = nx if samexy else dy.shape[0]
 		nc = dc.shape[0]
 		dof = n - 1 - rank - dimreduce
 		stat_kind = 0 if (samexy or return_dot) else 1
-		if not (samexy or device_out or want_rt or want_alpha) and self.chunked_ok(dy):
+		if not (samexy or device_out or resident or want_rt or want_alpha) and self.chunked_ok(dy):
 			return self.association_de_chunked(dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov)
 		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
 		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
 		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
 		host = None
-		if not (device_out or want_rt or want_alpha) and self.banded_ok(nx, ny, out_dtype):
+		if not (device_out or resident or want_rt or want_alpha) and self.banded_ok(nx, ny, out_dtype):
 			# the result arrays are page-locked by a helper thread while K1/K2 run.  Started only now, after the uploads: a
 			# hipHostRegister racing a pageable H2D copy (right after the previous call's hipHostUnregister) was measured
 			# to stall that copy by ~20 ms -- twice the whole C2 call
@@ -442,6 +446,8 @@ class Engine:
 				alpha = self.download(self.alpha(stat, rx.coef, ry.coef, nc))
 			else:
 				alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
+		if resident and not (want_alpha or want_rt):  # resident pipeline (see association_de_streaming)
+			return dict(p=p, stat=stat, alpha=alpha, ssx=None if samexy else rx.ss, ssy=ry.ss, flags=flags, dof=dof)
 		self.check_flags(flags)
 		keep = (lambda t: t) if device_out else self.download  # device_out: p / stat stay in HBM (torch tensors) for a device pipeline
 		res = dict(p=keep(p), stat=keep(stat), alpha=alpha,

@@ -736,3 +736,32 @@ def test_chunked_upload_de_matches_one_shot(norm, eng, monkeypatch):
 	bad[1500, 3] = np.nan
 	with pytest.raises(AssertionError):
 		norm.de(dg, bad, dc)
+
+
+def test_de_plan_shards_equal_whole(norm, de_path):
+	"""DePlan (the sharded de of bench.py --workload de_c3 / de_c4): every rank owns a block of genes and there is no
+	collective, so the ranks' results side by side must equal the single-call result -- both de paths, resident steps."""
+	import torch
+	from normalisr_amd.distributed import DePlan
+	rng = np.random.default_rng(616)
+	nx, ny, n, nc = (2, 900, 1500, 6) if de_path == 'streaming' else (40, 900, 700, 6)
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))]).astype(np.float32)
+	dg = (rng.random((nx, n)) < 0.3).astype(np.float32)
+	dt = (rng.normal(size=(ny, n)) - 4).astype(np.float32)
+	dt[:25] += 0.3 * dg[0]
+	whole = norm.de(dg, dt, dc)
+	world = 3
+	R = ny // world
+	parts = []
+	for rank in range(world):
+		plan = DePlan(torch.from_numpy(dg).cuda(), torch.from_numpy(dt[rank * R:(rank + 1) * R]).cuda(), dc, rank=rank, world=world)
+		assert plan.streaming() == (de_path == 'streaming')
+		plan.step()
+		plan.step(timed=True)
+		assert plan.step_ms() > 0
+		parts.append(plan.results())
+	p = np.concatenate([q[0] for q in parts], axis=1)
+	g = np.concatenate([q[1] for q in parts], axis=1)
+	vt = np.concatenate([q[3] for q in parts])
+	assert close(p, whole[0], 1e-6, 1e-38) and close(g, whole[1], 1e-6, 1e-7) and close(vt, whole[4][0], 1e-6)
+	assert all(close(q[2], whole[3], 1e-6) for q in parts)
