@@ -226,6 +226,9 @@ int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int
  *   return_dot: 1 -> covariance, 0 -> gamma (association.py:769).
  * Runs on the current device (nrm_set_device) and synchronises before returning.
  */
+/* Frees the device scratch nrm_association_tests_host keeps between calls (it is reused best-fit; calls are
+ * serialised per process). */
+int nrm_release_cache(void);
 int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
 							   const void* h_dy, int y_dtype, int64_t ny,
 							   const void* h_dc, int c_dtype, int64_t nc, int64_t n_cells,

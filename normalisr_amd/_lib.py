@@ -22,6 +22,7 @@ _SIGNATURES = {
 	'nrm_last_error': ([], ctypes.c_char_p),
 	'nrm_device_count': ([ctypes.POINTER(_i32)], _i32),
 	'nrm_set_device': ([_i32], _i32),
+	'nrm_release_cache': ([], _i32),
 	'nrm_host_pin': ([_vp, _i64, _i32], _i32),
 	'nrm_host_unpin': ([_vp], _i32),
 	'nrm_copy_to_host': ([_vp, _vp, _i64, _vp], _i32),

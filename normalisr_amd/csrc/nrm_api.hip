@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "nrm_common.h"
@@ -76,13 +77,75 @@ extern "C" int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, v
 }
 
 namespace {
+// Device scratch of the host entry, kept between calls (hipMalloc / hipFree of GB-sized buffers cost milliseconds
+// each): blocks return to a per-process pool and are reused best-fit; nrm_release_cache() frees them.
+struct DevPool {
+	struct Block {
+		void* p;
+		size_t cap;
+		bool used;
+	};
+	std::mutex mu;
+	std::vector<Block> blocks;
+	void* take(size_t bytes) {
+		std::lock_guard<std::mutex> g(mu);
+		int best = -1;
+		for (size_t i = 0; i < blocks.size(); i++)
+			if (!blocks[i].used && blocks[i].cap >= bytes && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
+		if (best >= 0 && blocks[(size_t)best].cap <= 2 * bytes + (1 << 20)) {
+			blocks[(size_t)best].used = true;
+			return blocks[(size_t)best].p;
+		}
+		void* p = nullptr;
+		if (hipMalloc(&p, bytes) != hipSuccess) {  // out of memory: drop the idle blocks and retry once
+			(void)hipGetLastError();
+			for (size_t i = 0; i < blocks.size();) {
+				if (!blocks[i].used) {
+					(void)hipFree(blocks[i].p);
+					blocks.erase(blocks.begin() + (long)i);
+				} else {
+					i++;
+				}
+			}
+			if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+		}
+		blocks.push_back({p, bytes, true});
+		return p;
+	}
+	void give(void* p) {
+		std::lock_guard<std::mutex> g(mu);
+		for (auto& b : blocks)
+			if (b.p == p) b.used = false;
+	}
+	void release() {
+		std::lock_guard<std::mutex> g(mu);
+		for (size_t i = 0; i < blocks.size();) {
+			if (!blocks[i].used) {
+				(void)hipFree(blocks[i].p);
+				blocks.erase(blocks.begin() + (long)i);
+			} else {
+				i++;
+			}
+		}
+	}
+};
+DevPool g_pool;
+std::mutex g_host_entry;  // one whole-problem call at a time per process (the pool and the default stream are shared)
+
 struct DevBuf {
 	void* p = nullptr;
 	~DevBuf() {
-		if (p) (void)hipFree(p);
+		if (p) {
+			(void)hipDeviceSynchronize();
+			g_pool.give(p);
+		}
 	}
 	int alloc(size_t bytes) {
-		NRM_HIP(hipMalloc(&p, bytes ? bytes : 16));
+		p = g_pool.take(bytes ? bytes : 16);
+		if (!p) {
+			nrm_set_error("hipMalloc of %zu bytes failed", bytes);
+			return NRM_E_DEVICE;
+		}
 		return NRM_OK;
 	}
 	template <typename T>
@@ -131,10 +194,16 @@ struct Joiner {
 };
 }  // namespace
 
+extern "C" int nrm_release_cache(void) {
+	g_pool.release();
+	return NRM_OK;
+}
+
 extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
 										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
 										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
 										  void* h_vary, void* h_r, void* h_t, int out_dtype) {
+	std::lock_guard<std::mutex> serial(g_host_entry);
 	const bool samexy = (h_dy == nullptr);
 	if (samexy) {
 		ny = nx;
