@@ -371,3 +371,44 @@ def coex(dt_local, dc, group=None, dimreduce=0):
 	plan.step()
 	plan.be.eng.check_flags(plan.flags)
 	return plan.assemble(lambda t: t.detach().cpu().numpy())
+
+
+def de(dg, dt_local, dc, group=None, dimreduce=0):
+	"""Sharded norm.de (single=0) for one-process-per-GPU programs: every rank passes the full grouping matrix dg, ITS
+	block of gene rows of dt (numpy or a torch tensor on its GPU) and the replicated covariates.  No collective on the data
+	path; rank 0 gathers the column blocks and returns (p, gamma, None, varg, vart) with the reference's contract
+	(de.py:4-132, constant groupings re-inflated), other ranks get None."""
+	import torch
+	import torch.distributed as dist
+	from .de import _varying_rows
+	world = dist.get_world_size(group) if dist.is_initialized() else 1
+	rank = dist.get_rank(group) if dist.is_initialized() else 0
+	dev = torch.device('cuda', torch.cuda.current_device())
+	dg = np.asarray(dg)
+	gid = _varying_rows(dg)  # de.py:93
+	if isinstance(dt_local, np.ndarray):
+		a = dt_local if dt_local.dtype in (np.float32, np.float64) else dt_local.astype(np.float64)
+		dt_local = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+	x = dg[gid]
+	x = x if x.dtype in (np.float32, np.float64) else x.astype(np.float64)
+	plan = DePlan(torch.from_numpy(np.ascontiguousarray(x)).to(dev), dt_local, dc, rank=rank, world=world, dimreduce=dimreduce)
+	plan.step()
+	mine = plan.results()
+	if world > 1:
+		gathered = [None] * world if rank == 0 else None
+		dist.gather_object(mine, gathered, dst=0, group=group)
+		if rank != 0:
+			return None
+	else:
+		gathered = [mine]
+	odt = plan.out_dtype
+	p = np.concatenate([g[0] for g in gathered], axis=1)
+	gam = np.concatenate([g[1] for g in gathered], axis=1)
+	vt = np.concatenate([g[3] for g in gathered])
+	ng0, nt = dg.shape[0], p.shape[1]
+	P = np.ones((ng0, nt), dtype=odt)
+	G = np.zeros((ng0, nt), dtype=odt)
+	VG = np.zeros((ng0, ), dtype=odt)
+	VT = np.zeros((ng0, nt), dtype=odt)
+	P[gid], G[gid], VG[gid], VT[gid] = p, gam, gathered[0][2], vt  # de.py:107-122
+	return (P, G, None, VG, VT)

@@ -385,9 +385,15 @@ def _sharded_worker(rank, world, port, q):
 						group=dist.group.WORLD)
 		plan.step()
 		res = plan.assemble(lambda t: t.detach().cpu().numpy())
-	else:  # the public wrapper, numpy rows in
-		from normalisr_amd.distributed import coex as coex_sharded
+	else:  # the public wrappers, numpy rows in
+		from normalisr_amd.distributed import coex as coex_sharded, de as de_sharded
 		res = coex_sharded(dt[rank * R:(rank + 1) * R], dc)
+		if world == 3:
+			dg = (np.random.default_rng(78).random((5, n)) < 0.3).astype(np.float32)
+			dg[2] = 1  # constant grouping: not tested, re-inflated (de.py:107-122)
+			rde = de_sharded(dg, dt[rank * R:(rank + 1) * R], dc)
+			if rank == 0:
+				res = res + (rde, )
 	if rank == 0:
 		q.put(res)
 	dist.barrier()
@@ -409,7 +415,8 @@ def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
 	procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
 	for p in procs:
 		p.start()
-	P, D, V = q.get(timeout=300)
+	got = q.get(timeout=300)
+	P, D, V = got[:3]
 	for p in procs:
 		p.join(timeout=120)
 		assert p.exitcode == 0
@@ -421,6 +428,13 @@ def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
 	assert P.dtype == np.float32
 	assert close(P, po, 1e-6, 1e-38) and close(D, do, 1e-6, 1e-7) and close(V, vo, 1e-6)
 	assert (np.diag(P) == 0).all() and (P == P.T).all() and (D == D.T).all()
+	if len(got) > 3:  # sharded de through the public wrapper against the single-process oracle
+		dg = (np.random.default_rng(78).random((5, n)) < 0.3).astype(np.float32)
+		dg[2] = 1
+		pd, gd, ad, vgd, vtd = got[3]
+		po, go, ao, vgo, vto = oracle.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
+		assert ad is None and close(pd, po, 1e-6, 1e-38) and close(gd, go, 1e-6, 1e-7) and close(vgd, vgo, 1e-6, 1e-12) and close(vtd, vto, 1e-6, 1e-12)
+		assert (pd[2] == 1).all() and (gd[2] == 0).all() and vgd[2] == 0
 
 
 def test_randomised_shapes_vs_oracle(norm):
