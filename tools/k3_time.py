@@ -1,0 +1,31 @@
+"""Time nrm_assoc_sweep alone (symmetric, C2 shape, fp32 outputs) from a given build.  Usage: k3_time.py [lib.so]"""
+import sys
+import torch
+sys.path.insert(0, '.')
+from normalisr_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1] != '-':
+	_lib.LIB_PATH = sys.argv[1]
+lib = _lib.load()
+ng, n = 5000, 10000
+mp = 5120
+g = torch.Generator(device='cuda').manual_seed(3)
+x = torch.randn((ng, n), dtype=torch.float64, device='cuda', generator=g)
+dot = torch.zeros((mp, mp), dtype=torch.float64, device='cuda')
+dot[:ng, :ng] = x @ x.T
+ss = torch.zeros(mp, dtype=torch.float64, device='cuda')
+ss[:ng] = (x * x).sum(1)
+p = torch.empty((ng, ng), dtype=torch.float32, device='cuda')
+st = torch.empty((ng, ng), dtype=torch.float32, device='cuda')
+flags = torch.zeros(2, dtype=torch.int32, device='cuda')
+s = torch.cuda.current_stream().cuda_stream
+def run():
+	_lib.check(lib.nrm_assoc_sweep(dot.data_ptr(), mp, ss.data_ptr(), ss.data_ptr(), ng, ng, n, float(n - 4), 1, 0, p.data_ptr(), st.data_ptr(), 0, 0, 0, ng, flags.data_ptr(), s))
+for _ in range(3):
+	run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+	run()
+e1.record()
+torch.cuda.synchronize()
+print('%s: %.4f ms' % (sys.argv[1] if len(sys.argv) > 1 else 'default', e0.elapsed_time(e1) / 20))
