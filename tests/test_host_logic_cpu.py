@@ -77,3 +77,46 @@ def test_cli_runners_text_io(golden, oracle_backend, tmp_path):
 		assert got.shape == exp.shape and relerr(got, exp, 1e-12) < 2e-7, mine
 	# identical text for the files that hold exactly representable numbers
 	assert (tmp_path / 'vard.tsv').read_bytes().split() == files['vard_tsv'].split()
+
+
+def test_varying_rows_matches_unique_rule():
+	"""de.py:93 keeps groupings with more than one distinct value (np.unique collapses NaNs); the early-exit scan must
+	agree on every dtype, on rows that differ only in their last cell, on all-NaN rows and on single-column input."""
+	from normalisr_amd.de import _varying_rows
+	rng = np.random.default_rng(0)
+
+	def rule(dg):
+		return np.array([len(np.unique(x)) > 1 for x in dg], dtype=bool)
+	for dt in (np.float32, np.float64, np.int64, np.uint8, bool):
+		for n in (1, 2, 5, 257, 258, 1300, 5000):
+			a = (rng.random((40, n)) < 0.002).astype(dt)
+			a[3] = a[3, 0]
+			a[4] = 0
+			a[4, n - 1] = 1  # differs in the last cell only
+			if np.dtype(dt).kind == 'f':
+				a[5] = np.nan
+				a[6] = 1
+				a[6, n - 1] = np.nan
+				a[7, 0] = np.nan
+			assert np.array_equal(_varying_rows(a), rule(a)), (dt, n)
+	assert _varying_rows(np.zeros((0, 10))).shape == (0, )
+
+
+def test_spd_inverse_and_partner_runs():
+	"""single=4's Cholesky inverse against the eigendecomposition it replaced; and the contiguous-run bookkeeping of the
+	merged partner launch (distributed.CoexPlan): partners rank+1..rank+K of every rank are K consecutive blocks of the
+	gathered buffer once the first blocks are appended behind the last."""
+	from normalisr_amd.single4 import _spd_inverse
+	rng = np.random.default_rng(1)
+	a = rng.normal(size=(60, 400))
+	m = a @ a.T
+	w, v = np.linalg.eigh(m)
+	assert relerr(_spd_inverse(m), (v / w) @ v.T) < 1e-9
+	for world in range(2, 10):
+		K = (world - 1) // 2
+		for rank in range(world):
+			buf = list(range(world)) + [None] * K
+			wrap = rank + K - (world - 1)
+			for i in range(max(0, wrap)):
+				buf[world + i] = buf[i]
+			assert buf[rank + 1:rank + 1 + K] == [(rank + 1 + j) % world for j in range(K)]
