@@ -263,6 +263,7 @@ __global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int6
 	const int b = blockIdx.x;
 	int ti, tj;
 	int first, count;       // slab range (aligned tiles) or workgroup range (stream-K tiles)
+	int sk_first_local = 0;
 	const double* base;
 	if (b < s.tiles_al) {
 		gram_tile_coords(s.tile0 + s.tiles_dp + b, symmetric, s.ntm, s.ntn, ti, tj);
@@ -279,6 +280,7 @@ __global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int6
 		count = last - first + 1;
 		if (count == 1 && (int64_t)first * s.units_per_wg <= u0 && (int64_t)(first + 1) * s.units_per_wg >= u1) return;  // stored whole
 		base = s.work + (int64_t)s.tiles_al * s.parts * (GM * GN);
+		sk_first_local = ((int64_t)first * s.units_per_wg / s.nkt) == ts ? 0 : 1;
 	}
 	// blockIdx.y selects 16 of the tile's 128 rows: 8 workgroups per tile keep enough loads in flight
 	double* ct = C + (int64_t)ti * GM * ldc + (int64_t)tj * GN;
@@ -288,13 +290,12 @@ __global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int6
 		if (b < s.tiles_al) {
 			for (int q = 0; q < count; q++) acc += *reinterpret_cast<const d2_t*>(base + (int64_t)q * (GM * GN) + e);
 		} else {
-			const int ts = b - s.tiles_al;
-			for (int q = 0; q < count; q++) {
-				const int p = first + q;
-				// this workgroup's first stream-K piece lies in tile floor(p U / nkt); a second piece (if any) in the next tile
-				const int local = ((int64_t)p * s.units_per_wg / s.nkt) == ts ? 0 : 1;
-				acc += *reinterpret_cast<const d2_t*>(base + ((int64_t)2 * p + local) * (GM * GN) + e);
-			}
+			// a workgroup's first stream-K piece lies in tile floor(p U / nkt), a second piece (if any) in the next tile:
+			// only the first contributor of this tile can be on its second piece
+			const double* src = base + ((int64_t)2 * first + sk_first_local) * (GM * GN) + e;
+			acc = *reinterpret_cast<const d2_t*>(src);
+			src += (int64_t)(2 - sk_first_local) * (GM * GN);
+			for (int q = 1; q < count; q++, src += 2 * (GM * GN)) acc += *reinterpret_cast<const d2_t*>(src);
 		}
 		*reinterpret_cast<d2_t*>(ct + (int64_t)(e / GN) * ldc + (e % GN)) = acc;
 	}

@@ -251,17 +251,18 @@ __global__ void __launch_bounds__(256) k_skinny_fixup(double* __restrict__ G, do
 	if (last > s.nwg - 1) last = s.nwg - 1;
 	if (first == last && (int64_t)first * s.units_per_wg <= u0 && (int64_t)(first + 1) * s.units_per_wg >= u1) return;  // written whole
 	const int64_t t = s.tiles_dp + ts;
-	const int e = blockIdx.y * 256 + threadIdx.x;
+	const int e = (blockIdx.y * 256 + threadIdx.x) * 2;  // two consecutive elements per thread (16-byte loads)
 	if (e >= SK_SLAB) return;
-	double acc = 0.0;
-	for (int p = first; p <= last; p++) {
-		const int local = ((int64_t)p * s.units_per_wg / s.nkt) == ts ? 0 : 1;
-		acc += s.work[((int64_t)2 * p + local) * SK_SLAB + e];
-	}
+	// only the first contributing workgroup can have started in the previous tile (then this tile holds its second piece)
+	const int first_local = ((int64_t)first * s.units_per_wg / s.nkt) == ts ? 0 : 1;
+	const double* src = s.work + ((int64_t)2 * first + first_local) * SK_SLAB + e;
+	d2_t acc = *reinterpret_cast<const d2_t*>(src);
+	src += (int64_t)(2 - first_local) * SK_SLAB;  // first piece of workgroup first + 1
+	for (int p = first + 1; p <= last; p++, src += 2 * SK_SLAB) acc += *reinterpret_cast<const d2_t*>(src);
 	if (e < SKM * SKN)
-		G[t * SKM * SKN + e] = acc;
+		*reinterpret_cast<d2_t*>(G + t * SKM * SKN + e) = acc;
 	else
-		ss[t * SKM + (e - SKM * SKN)] = acc;
+		*reinterpret_cast<d2_t*>(ss + t * SKM + (e - SKM * SKN)) = acc;
 }
 
 static int g_num_cu_s = 0;
@@ -323,6 +324,6 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 		else SK_LAUNCH(float, 2, 0);
 	}
 #undef SK_LAUNCH
-	if (s.tiles_sk > 0) hipLaunchKernelGGL(k_skinny_fixup, dim3((unsigned)s.tiles_sk, (SK_SLAB + 255) / 256), dim3(256), 0, st, d_g, d_ss, s);
+	if (s.tiles_sk > 0) hipLaunchKernelGGL(k_skinny_fixup, dim3((unsigned)s.tiles_sk, (SK_SLAB / 2 + 255) / 256), dim3(256), 0, st, d_g, d_ss, s);
 	return nrm_check_launch("k_gram_skinny");
 }
