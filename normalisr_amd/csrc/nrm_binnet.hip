@@ -28,27 +28,83 @@ __device__ __forceinline__ double bn_block_max(double v, double* sm) {
 	return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
+// largest value of the matrix dtype that is <= x: (double)v <= x  <=>  v <= bn_floor_to<T>(x) for every v of that dtype
+template <typename T>
+__device__ __forceinline__ T bn_floor_to(double x);
+template <>
+__device__ __forceinline__ double bn_floor_to<double>(double x) {
+	return x;
+}
+template <>
+__device__ __forceinline__ float bn_floor_to<float>(double x) {
+	if (x >= 3.0e38) return 3.0e38f;
+	if (x <= -3.0e38) return -3.0e38f;
+	float f = (float)x;
+	if ((double)f > x) f = nextafterf(f, -INFINITY);
+	return f;
+}
+
 // Row access policies for the counting passes: GlobalRow re-reads the row (L2-resident) on every pass; RegRow<ITEMS> loads it
 // once into registers (ITEMS values per lane, 256 lanes) so that the ~15 passes of a row are register-only.
 template <typename T>
 struct GlobalRow {
 	const T* p;
 	int64_t ng, self;
-	__device__ __forceinline__ GlobalRow(const T* row, int64_t ng_, int64_t self_) : p(row), ng(ng_), self(self_) {}
+	double bad;  // entries outside [0,1] or not finite seen by this lane (binnet.py:151-152)
+	__device__ __forceinline__ GlobalRow(const T* row, int64_t ng_, int64_t self_) : p(row), ng(ng_), self(self_), bad(0) {
+		for (int64_t j = threadIdx.x; j < ng; j += 256) {
+			const double v = (double)p[j];
+			if (!(v >= 0.0 && v <= 1.0)) bad += 1.0;
+		}
+	}
 	template <typename F>
 	__device__ __forceinline__ void each(F f) const {
 		for (int64_t j = threadIdx.x; j < ng; j += 256)
 			if (j != self) f((double)p[j]);
 	}
+	__device__ __forceinline__ int64_t count_le(double x, double* sm) const {
+		double c = 0;
+		each([&](double pj) {
+			if (pj <= x) c += 1.0;
+		});
+		return (int64_t)bn_block_sum(c, sm);
+	}
+	__device__ __forceinline__ double max_le(double x, double* sm) const {
+		double m = -1.0;
+		each([&](double pj) {
+			if (pj <= x) m = fmax(m, pj);
+		});
+		return bn_block_max(m, sm);
+	}
+	__device__ __forceinline__ double emit(unsigned char* o, double tau) const {
+		double cnt = 0;
+		for (int64_t j = threadIdx.x; j < ng; j += 256) {
+			const unsigned char b = (j != self && (double)p[j] <= tau) ? 1 : 0;
+			o[j] = b;
+			cnt += b;
+		}
+		return cnt;
+	}
 };
 template <typename T, int ITEMS>
 struct RegRow {
 	T v[ITEMS];  // entries outside the row or on the diagonal hold 2 (> any p-value: never counted, never a maximum <= x)
-	__device__ __forceinline__ RegRow(const T* row, int64_t ng, int64_t self) {
+	int64_t ng;
+	double bad;
+	int phase = 0;
+	// the row is read from memory exactly once, with all ITEMS loads of a lane in flight together (a run-time loop of
+	// dependent scalar loads made the first version latency-bound: 0.44 TB/s)
+	__device__ __forceinline__ RegRow(const T* row, int64_t ng_, int64_t self) : ng(ng_), bad(0) {
 #pragma unroll
 		for (int q = 0; q < ITEMS; q++) {
 			const int64_t j = (int64_t)q * 256 + threadIdx.x;
-			v[q] = (j < ng && j != self) ? row[j] : (T)2;
+			v[q] = j < ng ? row[j] : (T)0;
+		}
+#pragma unroll
+		for (int q = 0; q < ITEMS; q++) {
+			const int64_t j = (int64_t)q * 256 + threadIdx.x;
+			if (!(v[q] >= (T)0 && v[q] <= (T)1)) bad += 1.0;
+			if (j >= ng || j == self) v[q] = (T)2;
 		}
 	}
 	template <typename F>
@@ -57,52 +113,70 @@ struct RegRow {
 		for (int q = 0; q < ITEMS; q++)
 			if (v[q] <= (T)1.5) f((double)v[q]);
 	}
+	// counting in the matrix dtype with wave ballots: one compare per item and no fp64 arithmetic in the ~15 passes of a row
+	__device__ __forceinline__ int64_t count_le(double x, double* sm) {
+		const T xf = bn_floor_to<T>(fmin(x, 1.5));
+		int c = 0;
+#pragma unroll
+		for (int q = 0; q < ITEMS; q++) c += __popcll(__ballot(v[q] <= xf));
+		// one barrier per pass: the four per-wave results alternate between two LDS slots (a slot is rewritten only after
+		// the barrier of the pass in between, by which every wave has read it)
+		double* slot = sm + 4 + 4 * (phase & 1);
+		phase++;
+		if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = (double)c;
+		__syncthreads();
+		return (int64_t)(slot[0] + slot[1] + slot[2] + slot[3]);
+	}
+	__device__ __forceinline__ double max_le(double x, double* sm) {
+		const T xf = bn_floor_to<T>(fmin(x, 1.5));
+		T m = (T)-1;
+#pragma unroll
+		for (int q = 0; q < ITEMS; q++) m = (v[q] <= xf && v[q] > m) ? v[q] : m;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const T w = __shfl_down(m, o, 64);
+			m = w > m ? w : m;
+		}
+		double* slot = sm + 4 + 4 * (phase & 1);
+		phase++;
+		if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = (double)m;
+		__syncthreads();
+		return fmax(fmax(slot[0], slot[1]), fmax(slot[2], slot[3]));
+	}
+	__device__ __forceinline__ double emit(unsigned char* o, double tau) const {
+		double cnt = 0;
+		const T tf = bn_floor_to<T>(fmin(tau, 1.5));
+#pragma unroll
+		for (int q = 0; q < ITEMS; q++) {
+			const int64_t j = (int64_t)q * 256 + threadIdx.x;
+			const unsigned char b = (v[q] <= tf) ? 1 : 0;  // diagonal and padding hold 2: never selected
+			if (j < ng) o[j] = b;
+			cnt += b;
+		}
+		return cnt;
+	}
 };
-
-template <typename Row>
-__device__ __forceinline__ int64_t bn_count_le(const Row& r, double x, double* sm) {
-	double c = 0;
-	r.each([&](double pj) {
-		if (pj <= x) c += 1.0;
-	});
-	return (int64_t)bn_block_sum(c, sm);
-}
-template <typename Row>
-__device__ __forceinline__ double bn_max_le(const Row& r, double x, double* sm) {
-	double v = -1.0;
-	r.each([&](double pj) {
-		if (pj <= x) v = fmax(v, pj);
-	});
-	return bn_block_max(v, sm);
-}
 
 template <typename T, typename Row>
 __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, int64_t ng, int64_t ldp, double qcut, unsigned char* __restrict__ out,
 													 int64_t ldo, unsigned long long* __restrict__ total, int32_t* __restrict__ flags) {
-	__shared__ double sm[4];
+	__shared__ double sm[12];  // [0,4): block reductions with two barriers; [4,12): the alternating slots of the counting passes
 	const int64_t i = blockIdx.x;
 	const T* prow = p + i * ldp;
 	const double m = (double)(ng - 1);
 	const T qc = (T)qcut;  // the reference compares in the matrix dtype (numpy weak-scalar promotion)
 	const double slack = sizeof(T) == 4 ? 1e-5 : 1e-12;
+	Row r(prow, ng, i);
 	// validity (binnet.py:151-152): finite and inside [0,1]
-	{
-		double bad = 0;
-		for (int64_t j = threadIdx.x; j < ng; j += 256) {
-			const double v = (double)prow[j];
-			if (!(v >= 0.0 && v <= 1.0)) bad += 1.0;
-		}
-		if (bn_block_sum(bad, sm) > 0 && threadIdx.x == 0) atomicAdd(&flags[0], 1);
-	}
-	const Row r(prow, ng, i);
+	if (bn_block_sum(r.bad, sm) > 0 && threadIdx.x == 0) atomicAdd(&flags[0], 1);
 	double x = 2.0;       // every entry is a candidate
 	double tau = -1.0;    // tau*: nothing selected yet
 	for (int guard = 0; guard < 1000000; guard++) {
 		// skip everything that fails the test even with slack: largest fixed point of k <- #{p <= min(x, qcut (1+slack) k/m)}
-		int64_t k = bn_count_le(r, x, sm);
+		int64_t k = r.count_le(x, sm);
 		while (k > 0) {
 			const double bound = fmin(x, qcut * (1.0 + slack) * (double)k / m);
-			const int64_t c = bn_count_le(r, bound, sm);
+			const int64_t c = r.count_le(bound, sm);
 			if (c == k) {
 				x = bound;
 				break;
@@ -110,9 +184,9 @@ __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, in
 			k = c;
 		}
 		if (k == 0) break;
-		const double v = bn_max_le(r, x, sm);
+		const double v = r.max_le(x, sm);
 		if (v < 0.0) break;
-		const int64_t c = bn_count_le(r, v, sm);
+		const int64_t c = r.count_le(v, sm);
 		// the reference's arithmetic, in the matrix dtype: w = c/m, q = v/w, clipped to [0,1]  (binnet.py:121-125)
 		const T w = (T)c / (T)(ng - 1);
 		T q = (T)v / w;
@@ -124,13 +198,7 @@ __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, in
 		}
 		x = nextafter(v, -1.0);  // v fails: continue strictly below it
 	}
-	double cnt = 0;
-	unsigned char* o = out + i * ldo;
-	for (int64_t j = threadIdx.x; j < ng; j += 256) {
-		const unsigned char b = (j != i && (double)prow[j] <= tau) ? 1 : 0;
-		o[j] = b;
-		cnt += b;
-	}
+	double cnt = r.emit(out + i * ldo, tau);
 	cnt = bn_block_sum(cnt, sm);
 	if (threadIdx.x == 0 && cnt > 0) atomicAdd(total, (unsigned long long)cnt);
 }
