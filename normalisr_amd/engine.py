@@ -93,7 +93,10 @@ class Engine:
 		torch = self.torch
 		t = t.contiguous()
 		out = np.empty(tuple(t.shape), dtype=self._NP[str(t.dtype)])
-		self.host_pin(out)
+		try:
+			self.host_pin(out)
+		except RuntimeError:  # e.g. a locked-memory limit: plain pageable copy
+			return t.cpu().numpy()
 		try:
 			with torch.cuda.device(self.device):
 				_lib.check(self.lib.nrm_copy_to_host(out.ctypes.data, t.data_ptr(), out.nbytes, self._stream()))
@@ -254,8 +257,9 @@ class Engine:
 					ev.record(main)
 					done.append(ev)
 				th.join()
-				if host['error']:
-					raise host['error'][0]
+				if host['error']:  # e.g. a locked-memory limit: the copies below still work, at the pageable rate
+					import logging
+					logging.warning('normalisr_amd: result arrays could not be page-locked (%s); copying out unpinned.', host['error'][0])
 				row = ny * odt.itemsize
 				for (a, b), ev in zip(zip(cuts[:-1], cuts[1:]), done):
 					self._copy.wait_event(ev)
