@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- association tests/sec on the BASELINE.json workload.
+"""bench.py -- association tests/sec on the BASELINE.json workloads.
 
-N=1 workload = BASELINE.json configs[1]: norm.coex gene x gene on 5k genes x 10k cells, fp32 input,
-3 covariates (2 random + intercept), seeded synthetic data.  A step is one full
-pass of the hot path over the matrix resident in HBM: residualise (K1) -> fp64-MFMA Gram (K2) ->
-per-pair sweep R^2 -> p, covariance (K3); outputs stay in HBM.  tests = ng(ng-1)/2 unique pairs.
-For N>1 (one process per GPU, RCCL) the gene count grows as sqrt(N) so the pairs per GPU stay fixed
-(weak scaling); gene-row blocks are residualised locally and exchanged by all-gather.
+Headline (`value`): BASELINE.json configs[1] -- norm.coex gene x gene on 5k genes x 10k cells, fp32 input,
+3 covariates (2 random + intercept), seeded synthetic data.  A step is one full pass of
+the hot path over the matrix resident in HBM: residualise (K1) -> fp64-MFMA Gram (K2) -> per-pair sweep
+R^2 -> p, covariance (K3); outputs stay in HBM.  tests = ng(ng-1)/2 unique pairs.  For N>1 (one process per
+GPU, RCCL) the gene count grows as sqrt(N) so the pairs per GPU stay fixed (weak scaling); gene-row blocks are
+residualised locally and exchanged by all-gather.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gram_f64), timed live with HIP
-events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the reference's algorithm,
-test infrastructure) on a bounded sample on this box's host cores.
+The same JSON line carries, under `extra_workloads`, the other BASELINE configs measured the same way (each
+with its own ms_per_step and roofline): de_c3 = configs[2] (1 x 20k genes x 100k cells, 20 covariates:
+HBM-bound streaming kernel), de_c4 = configs[3] (1k gRNAs x 15k genes x 50k cells, gene rows sharded over the
+ranks, no collective), coex_c5 = the per-rank shape of configs[4] (3750 gene rows per rank x 500k cells,
+fp64; at N=8 that is the full 30k x 30k problem, residual blocks exchanged by all-gather).  `--workload X`
+makes X the headline instead; `--no-extras` skips them.
+
+Launch: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when it is
+not already running under one; under `python -m torch.distributed.run ... bench.py --gpus N` it uses the
+ranks it was given.  Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gram_f64),
+timed live with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the
+reference's algorithm, test infrastructure) on a bounded sample on this box's host cores (N=1 only).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -24,21 +34,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_pmc_c2.json')  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+PMC_FILES = [os.path.join(ROOT, 'profiles', f) for f in ('r02_pmc_c2.json', 'r01_pmc_c2.json')]  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
 F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (= 1/2 of the 157.3 TF fp32 matrix peak of MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+C5_ROWS_PER_RANK = 3750  # configs[4]: 30 000 genes over 8 GPUs
+C5_CELLS = 500000
 
 
-def synth_c2(ng, n, seed, device, torch, row0=0):
-	"""N(0,1) + 0.3 * loading * shared latent factor; dc = [2 x N(0,1); ones]; fp32."""
+def synth_c2(ng, n, seed, device, torch, row0=0, dtype=None, loading=0.3):
+	"""N(0,1) + loading * gene loading * shared latent factor; dc = [2 x N(0,1); ones]."""
+	dtype = torch.float32 if dtype is None else dtype
 	g = torch.Generator(device=device)
 	g.manual_seed(seed)
-	lat = torch.randn((1, n), generator=g, device=device, dtype=torch.float32)
-	dc = torch.cat([torch.randn((2, n), generator=g, device=device, dtype=torch.float32),
-					torch.ones((1, n), device=device, dtype=torch.float32)])
+	lat = torch.randn((1, n), generator=g, device=device, dtype=dtype)
+	dc = torch.cat([torch.randn((2, n), generator=g, device=device, dtype=dtype),
+					torch.ones((1, n), device=device, dtype=dtype)])
 	g2 = torch.Generator(device=device)
 	g2.manual_seed(seed * 1000003 + row0)
-	load = torch.randn((ng, 1), generator=g2, device=device, dtype=torch.float32)
-	dt = torch.randn((ng, n), generator=g2, device=device, dtype=torch.float32) + 0.3 * load * lat
+	load = torch.randn((ng, 1), generator=g2, device=device, dtype=dtype)
+	dt = torch.randn((ng, n), generator=g2, device=device, dtype=dtype)
+	dt.addcmul_(load, lat, value=loading)  # in place: no second matrix-sized temporary (C5 rows are 15 GB per rank)
 	return dt, dc
 
 
@@ -77,11 +92,123 @@ def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0):
 	return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-def bench_de(args, torch, nd, world, rank, device):
-	"""Extra measurements on the de shapes of BASELINE configs[2] (1 x 20k x 100k, 20 covariates: HBM-bound streaming
-	path) and configs[3] (1k gRNAs x 15k genes x 50k cells: MFMA-bound general path); gene rows sharded over ranks."""
-	if args.workload == 'de_c3':
-		nx, ny, n, nc, seed = 1, 20000, 100000, args.covariates, 3
+def self_launch(args):
+	"""`python bench.py --gpus N` outside a launcher: start N ranks with torch.distributed.run BEFORE this process
+	touches the GPU (device_count does not initialise it) and hand their output through."""
+	import socket
+	import subprocess
+	import torch
+	have = torch.cuda.device_count()
+	env = dict(os.environ)
+	env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+	if have < args.gpus and env.get('NRM_SHARE_GPU') != '1':
+		raise SystemExit('bench.py --gpus {}: only {} GPU(s) visible (NRM_SHARE_GPU=1 NRM_DIST_BACKEND=gloo runs the ranks on one GPU for a functional check)'.format(args.gpus, have))
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+		   '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+	return subprocess.run(cmd, env=env).returncode
+
+
+class Ranks:
+	"""The process group of this run (or a single process)."""
+
+	def __init__(self, args):
+		import torch
+		self.torch = torch
+		self.world = int(os.environ.get('WORLD_SIZE', '1'))
+		self.rank = int(os.environ.get('RANK', '0'))
+		local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+		self.backend = os.environ.get('NRM_DIST_BACKEND', 'nccl')  # 'gloo' + NRM_SHARE_GPU=1: functional test of the N>1 path on a 1-GPU box
+		if os.environ.get('NRM_SHARE_GPU') == '1':
+			local_rank = 0
+		torch.cuda.set_device(local_rank)
+		self.device = torch.device('cuda', local_rank)
+		self.group = None
+		self.ranks_seen = 1
+		if self.world > 1:
+			import torch.distributed as dist
+			if self.backend == 'nccl':
+				dist.init_process_group('nccl', device_id=self.device)
+			else:
+				dist.init_process_group(self.backend)
+			self.group = dist.group.WORLD
+			one = torch.ones(1, device=self.device if self.backend == 'nccl' else 'cpu', dtype=torch.float64)
+			dist.all_reduce(one)  # how many ranks the collective library really connected
+			self.ranks_seen = int(one.item())
+
+	def barrier(self):
+		if self.world > 1:
+			self.torch.distributed.barrier()
+		self.torch.cuda.synchronize()
+
+	def max_over_ranks(self, v):
+		if self.world == 1:
+			return v
+		t = self.torch.tensor([v], device=self.device if self.backend == 'nccl' else 'cpu', dtype=self.torch.float64)
+		self.torch.distributed.all_reduce(t, op=self.torch.distributed.ReduceOp.MAX)
+		return float(t.item())
+
+	def close(self):
+		if self.world > 1:
+			self.torch.distributed.destroy_process_group()
+
+
+def timed_steps(rk, plan, steps, warmup, events_inside):
+	"""W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+	for _ in range(warmup):
+		plan.step()
+	rk.barrier()
+	t0 = time.perf_counter()
+	for _ in range(steps):
+		plan.step(timed=events_inside)
+	rk.barrier()
+	return rk.max_over_ranks(time.perf_counter() - t0)
+
+
+def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading=0.3):
+	"""Sharded coex: every rank owns `rows_local` gene rows (generated on its GPU), see normalisr_amd.distributed.CoexPlan."""
+	torch = rk.torch
+	world, rank = rk.world, rk.rank
+	ng = rows_local * world
+	dt_local, dc = synth_c2(rows_local, n, seed, rk.device, torch, row0=rank * rows_local, dtype=dtype, loading=loading)
+	plan = nd.CoexPlan(dt_local, dc, rank=rank, world=world, group=rk.group)
+	# N = 1: the kernels are bracketed by HIP events inside the timed region (one stream, the events cost nothing).
+	# N > 1: the exchange runs on RCCL's stream; timing events recorded on the launch stream were measured to slow
+	# cross-stream work of the same process on ROCm 7.2 (see the end_to_end_pcie note), so the timed region runs without
+	# them and the per-kernel breakdown comes from three extra steps after it (`kernels_ms_from`).
+	events_inside = world == 1
+	elapsed = timed_steps(rk, plan, steps, warmup, events_inside)
+	if not events_inside:
+		for _ in range(3):
+			plan.step(timed=True)
+		rk.barrier()
+	tests = ng * (ng - 1) // 2
+	gram_ms = plan.gram_ms()  # average duration of the dominant kernel launch(es) per step on this rank
+	flops = 2.0 * n * plan.local_pair_count()  # algorithmic: 2 n_cell flop per test (SURVEY 8d), tests this rank's launches cover
+	achieved = flops / (gram_ms * 1e-3) / 1e12
+	esz = 4 if dtype == torch.float32 else 8
+	out = dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
+			   scaling='weak', dtype='f64',
+			   config=dict(workload=label.format(genes=ng, cells=n), genes=ng, cells=n, covariates=3, tests_per_step=tests,
+						   parallelism='gene-row blocks x{}'.format(world), exchange=None if world == 1 else (
+							   'all-gather of raw fp32 blocks' if plan.exchange_raw else 'all-gather of fp64 residual blocks'),
+						   exchange_bytes_per_rank=None if world == 1 else int((world - 1) * rows_local * n * (esz if plan.exchange_raw else 8))),
+			   roofline=dict(bound='mfma', kernel='k_gram_f64', achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+							 frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=None, algorithmic_bytes=8.0 * plan.rows_pad * plan.k_pad, kernel_ms=gram_ms),
+			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region')
+	return out, plan
+
+
+def bench_de(rk, nd, steps, warmup, which, covariates=20):
+	"""de shapes of BASELINE configs[2] (1 x 20k x 100k, 20 covariates: HBM-bound streaming path) and configs[3]
+	(1k gRNAs x 15k genes x 50k cells: MFMA-bound general path); gene rows of Y sharded over the ranks, no collective."""
+	torch = rk.torch
+	world, rank, device = rk.world, rk.rank, rk.device
+	if which == 'de_c3':
+		nx, ny, n, nc, seed = 1, 20000, 100000, covariates, 3
 	else:
 		nx, ny, n, nc, seed = 1000, 15000, 50000, 5, 4
 	ny_local = ny // world
@@ -95,38 +222,21 @@ def bench_de(args, torch, nd, world, rank, device):
 	dy = torch.randn((ny_local, n), generator=g2, device=device, dtype=torch.float32)
 	dy[:16] += 0.2 * dx[0]
 	plan = nd.DePlan(dx, dy, dc, rank=rank, world=world)
-
-	def barrier():
-		if world > 1:
-			torch.distributed.barrier()
-		torch.cuda.synchronize()
-	for _ in range(args.warmup):
-		plan.step()
-	barrier()
-	t0 = time.perf_counter()
-	for _ in range(args.steps):
-		plan.step(timed=True)
-	barrier()
-	elapsed = time.perf_counter() - t0
-	if world > 1:
-		tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-		torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-		elapsed = float(tmax.item())
+	elapsed = timed_steps(rk, plan, steps, warmup, True)
 	tests = nx * ny_local * world
-	if rank == 0:
-		ms = plan.step_ms()
-		if plan.streaming():
-			byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
-			roof = dict(bound='hbm', kernel='k_gram_skinny + sweep (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=8000.0, unit='GB/s',
-						frac=byts / (ms * 1e-3) / 8e12, traffic=None, step_ms=ms)
-		else:
-			fl = 2.0 * n * nx * ny_local
-			roof = dict(bound='mfma', kernel='k_gram_f64 (whole step)', achieved=fl / (ms * 1e-3) / 1e12, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-						frac=fl / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, traffic=None, step_ms=ms)
-		print(json.dumps(dict(metric='association tests/sec (de)', value=tests * args.steps / elapsed, unit='tests/s', n_gpus=world, steps=args.steps,
-							  warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='strong', vs_baseline=None,
-							  dtype='f64', data='synthetic', config=dict(workload='norm.de {} x {} genes x {} cells, fp32 input, {} covariates'.format(nx, ny, n, nc),
-							  parallelism='gene rows of Y x{}'.format(world)), roofline=roof, cpu_baseline=None)))
+	ms = plan.step_ms()
+	if plan.streaming():
+		byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
+		roof = dict(bound='hbm', kernel='k_gram_skinny + sweep (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms)
+	else:
+		fl = 2.0 * n * nx * ny_local
+		roof = dict(bound='mfma', kernel='k_gram_f64 (whole step: K1 + K2 + K3)', achieved=fl / (ms * 1e-3) / 1e12, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+					frac=fl / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, traffic=None, kernel_ms=ms)
+	return dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
+				scaling='strong', dtype='f64',
+				config=dict(workload='norm.de {} x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[{}])'.format(
+					nx, ny, n, nc, 2 if which == 'de_c3' else 3), parallelism='gene rows of Y x{}, no collective'.format(world)), roofline=roof)
 
 
 def main():
@@ -138,8 +248,11 @@ def main():
 	ap.add_argument('--cells', type=int, default=10000)
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
 	ap.add_argument('--cpu-worker', nargs=5, default=None, help=argparse.SUPPRESS)
-	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4'],
-					help='coex_c2 = BASELINE configs[1] (the headline line); de_c3 / de_c4 = configs[2] / configs[3] shapes (extra measurements)')
+	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5'],
+					help='headline workload: coex_c2 = BASELINE configs[1] (default); de_c3 / de_c4 / coex_c5 = configs[2] / [3] / [4] shapes')
+	ap.add_argument('--no-extras', action='store_true', help='skip the extra_workloads entries (the other BASELINE configs)')
+	ap.add_argument('--extras-steps', type=int, default=5)
+	ap.add_argument('--extras-timeout', type=float, default=240.0, help='seconds after which a stuck extra workload is abandoned and the headline line printed')
 	ap.add_argument('--covariates', type=int, default=20, help='covariates of the de_c3 workload (<= 15 selects the half-width streaming kernel)')
 	ap.add_argument('--seed', type=int, default=2)
 	ap.add_argument('--e2e', type=int, default=2, help='repetitions of the numpy-in/numpy-out end-to-end timing (0 = skip)')
@@ -147,53 +260,33 @@ def main():
 	if args.cpu_worker:
 		w = args.cpu_worker
 		cpu_baseline_worker(int(w[0]), int(w[1]), int(w[2]), int(w[3]), float(w[4]))
-		return
+		return 0
 
+	if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+		return self_launch(args)
 	world = int(os.environ.get('WORLD_SIZE', '1'))
-	rank = int(os.environ.get('RANK', '0'))
-	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	if args.gpus != world:
+		raise SystemExit('bench.py --gpus {} inside a launcher with WORLD_SIZE={}'.format(args.gpus, world))
 	cpu = None
-	if world == 1 and args.cpu_seconds > 0:
+	if world == 1 and args.cpu_seconds > 0 and args.workload == 'coex_c2':
 		# CPU baseline first, in a child process, before this process touches the GPU
 		cpu = cpu_baseline(int(round(args.genes)), args.cells, 3, args.seed, args.cpu_seconds)
 
 	import torch
 	from normalisr_amd import distributed as nd
-	if args.gpus != world:
-		if world == 1 and args.gpus > 1:
-			raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {}'.format(args.gpus, args.gpus))
-	backend = os.environ.get('NRM_DIST_BACKEND', 'nccl')  # 'gloo' + NRM_SHARE_GPU=1: functional test of the N>1 path on a 1-GPU box
-	if os.environ.get('NRM_SHARE_GPU') == '1':
-		local_rank = 0
-	torch.cuda.set_device(local_rank)
-	device = torch.device('cuda', local_rank)
-	group = None
-	if world > 1:
-		import torch.distributed as dist
-		if backend == 'nccl':
-			dist.init_process_group('nccl', device_id=device)
-		else:
-			dist.init_process_group(backend)
-		group = dist.group.WORLD
-
-	if args.workload != 'coex_c2':
-		bench_de(args, torch, nd, world, rank, device)
-		if world > 1:
-			torch.distributed.destroy_process_group()
-		return
-
+	rk = Ranks(args)
+	rank = rk.rank
 	n = args.cells
-	# weak scaling: pairs per GPU fixed -> genes ~ sqrt(N); rounded so every rank owns the same number of rows
-	ng = int(round(args.genes * np.sqrt(world) / world)) * world
-	rows_local = ng // world
-	dt_local, dc = synth_c2(rows_local, n, args.seed, device, torch, row0=rank * rows_local)
+
 	e2e = None
-	if world == 1 and args.e2e > 0:
+	if world == 1 and args.e2e > 0 and args.workload == 'coex_c2':
 		# numpy in -> numpy out through the drop-in API (H2D + kernels + D2H over PCIe); reported beside `value`, never as it
 		import normalisr_amd.normalisr as norm
 		# (measured before any timing event exists in this process: after hipEvents with timing have been recorded,
 		#  cross-stream copies of the same process run several times slower on ROCm 7.2 -- a bench artefact, not an API cost)
+		dt_local, dc = synth_c2(args.genes, n, args.seed, rk.device, torch)
 		h_dt, h_dc = dt_local.cpu().numpy(), dc.cpu().numpy()
+		del dt_local, dc
 		norm.coex(h_dt[:256], h_dc)
 		ts = []
 		for _ in range(args.e2e):
@@ -201,69 +294,81 @@ def main():
 			t1 = time.perf_counter()
 			res = norm.coex(h_dt, h_dc)
 			ts.append(time.perf_counter() - t1)
-		e2e = dict(seconds=min(ts), all_seconds=[round(t, 5) for t in ts], tests_per_s=rows_local * (rows_local - 1) // 2 / min(ts), note='norm.coex(numpy fp32) -> numpy, pageable host memory, PCIe inclusive')
+		e2e = dict(seconds=min(ts), all_seconds=[round(t, 5) for t in ts], tests_per_s=args.genes * (args.genes - 1) // 2 / min(ts),
+				   note='norm.coex(numpy fp32) -> numpy, pageable host memory, PCIe inclusive')
 		res = h_dt = None
 
-	plan = nd.CoexPlan(dt_local, dc, rank=rank, world=world, group=group)
+	def run(which, steps, warmup):
+		if which == 'coex_c2':
+			# weak scaling: pairs per GPU fixed -> genes ~ sqrt(N); rounded so every rank owns the same number of rows
+			rows_local = int(round(args.genes * np.sqrt(world) / world))
+			out, plan = bench_coex(rk, nd, steps, warmup, rows_local, n, args.seed, torch.float32,
+								   'norm.coex gene x gene, {genes} genes x {cells} cells, fp32 input, 3 covariates (BASELINE configs[1]' + ('' if world == 1 else ', genes scaled by sqrt(N)') + ')')
+			out['metric'] = 'association tests/sec (gene x gene coex)'
+			if world == 1 and rows_local == 5000 and n == 10000:
+				# HBM-side bytes per k_gram_f64 launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+				for f in PMC_FILES:
+					try:
+						with open(f) as fh:
+							out['roofline']['traffic'] = json.load(fh)['k_gram_f64']['hbm_bytes_per_launch']
+						out['roofline']['traffic_unit'] = 'bytes/launch'
+						out['roofline']['traffic_source'] = '{} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(os.path.relpath(f, ROOT))
+						break
+					except (OSError, KeyError, ValueError):
+						continue
+			return out
+		if which == 'coex_c5':
+			out, plan = bench_coex(rk, nd, steps, warmup, C5_ROWS_PER_RANK, C5_CELLS, 5, torch.float64,
+								   'norm.coex gene x gene, {genes} genes x {cells} cells, fp64 input, 3 covariates (BASELINE configs[4] at 3750 gene rows per rank' +
+								   ('; N=8 is the full 30k x 30k problem)' if world != 8 else ': the full problem)'), loading=0.05)
+			out['metric'] = 'association tests/sec (gene x gene coex)'
+			out['scaling'] = 'rows per rank fixed (block pairs per rank grow as (N+1)/2)'
+			return out
+		out = bench_de(rk, nd, steps, warmup, which, args.covariates)
+		out['metric'] = 'association tests/sec (de)'
+		return out
 
-	def barrier():
-		if world > 1:
-			torch.distributed.barrier()
-		torch.cuda.synchronize()
+	head = run(args.workload, args.steps, args.warmup)
+	head = dict(dict(metric=head.pop('metric'), value=head.pop('value'), unit=head.pop('unit'), n_gpus=world, steps=head.pop('steps'),
+					 warmup=head.pop('warmup'), ms_per_step=head.pop('ms_per_step'), higher_is_better=True, scaling=head.pop('scaling'),
+					 vs_baseline=None, dtype=head.pop('dtype'), data='synthetic'), **head)
+	head['ranks_seen_by_collective'] = rk.ranks_seen
+	head['dist_backend'] = None if world == 1 else ('rccl (torch nccl backend)' if rk.backend == 'nccl' else rk.backend)
+	head['cpu_baseline'] = cpu
+	head['end_to_end_pcie'] = e2e
 
-	for _ in range(args.warmup):
-		plan.step()
-	barrier()
-	# N = 1: the kernels are bracketed by HIP events inside the timed region (one stream, the events cost nothing).
-	# N > 1: the exchange runs on RCCL's stream; timing events recorded on the launch stream were measured to slow
-	# cross-stream work of the same process on ROCm 7.2 (see the end_to_end_pcie note), so the timed region runs without
-	# them and the per-kernel breakdown comes from three extra steps after it.
-	events_inside = world == 1
-	t0 = time.perf_counter()
-	for _ in range(args.steps):
-		plan.step(timed=events_inside)
-	barrier()
-	elapsed = time.perf_counter() - t0
-	if not events_inside:
-		for _ in range(3):
-			plan.step(timed=True)
-		barrier()
-	if world > 1:
-		tmax = torch.tensor([elapsed], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
-		torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-		elapsed = float(tmax.item())
-	tests = ng * (ng - 1) // 2
-	value = tests * args.steps / elapsed
-	gram_ms = plan.gram_ms()  # average duration of the dominant kernel launch(es) per step on this rank
-	local_pairs = plan.local_pair_count()
-	traffic, traffic_src = None, None
-	if world == 1 and ng == 5000 and n == 10000 and os.path.exists(PMC_FILE):
-		# HBM-side bytes per k_gram_f64 launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-		try:
-			with open(PMC_FILE) as f:
-				traffic = json.load(f)['k_gram_f64']['hbm_bytes_per_launch']
-			traffic_src = 'profiles/r01_pmc_c2.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'
-		except (KeyError, ValueError):
-			traffic = None
-	if rank == 0:
-		flops = 2.0 * n * local_pairs  # algorithmic: 2 n_cell flop per test, tests this rank's launches cover
-		achieved = flops / (gram_ms * 1e-3) / 1e12
-		out = dict(metric='association tests/sec (gene x gene coex)', value=value, unit='tests/s', n_gpus=world,
-				   steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True,
-				   scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
-				   config=dict(workload='norm.coex gene x gene, {} genes x {} cells, fp32 input, 3 covariates (BASELINE configs[1]{})'.format(
-					   ng, n, '' if world == 1 else ', genes scaled by sqrt(N)'), genes=ng, cells=n, covariates=3,
-					   tests_per_step=tests, parallelism='gene-row blocks x{}'.format(world)),
-				   roofline=dict(bound='mfma', kernel='k_gram_f64', achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-								 frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit='bytes/launch', traffic_source=traffic_src,
-								 algorithmic_bytes=8.0 * plan.rows_pad * plan.k_pad, kernel_ms=gram_ms),
-				   kernels_ms=plan.kernel_breakdown())
-		out['cpu_baseline'] = cpu
-		out['end_to_end_pcie'] = e2e
-		print(json.dumps(out))
-	if world > 1:
-		torch.distributed.destroy_process_group()
+	printed = threading.Event()
+
+	def emit():
+		if rank == 0 and not printed.is_set():
+			printed.set()
+			print(json.dumps(head), flush=True)
+
+	extras = {}
+	head['extra_workloads'] = extras
+	if not args.no_extras:
+		# the other BASELINE configs, measured like the headline; a stuck collective must not lose the headline line
+		def give_up():
+			extras['_abandoned'] = 'extra workloads exceeded --extras-timeout {} s'.format(args.extras_timeout)
+			emit()
+			os._exit(0)
+		dog = threading.Timer(args.extras_timeout, give_up)
+		dog.daemon = True
+		dog.start()
+		names = [w for w in ('de_c3', 'de_c4', 'coex_c5') if w != args.workload]
+		for w in names:
+			try:
+				torch.cuda.empty_cache()
+				r = run(w, args.extras_steps, 2)
+				r['n_gpus'] = world
+				extras[w] = r
+			except Exception as e:  # reported, never fatal for the headline
+				extras[w] = dict(error='{}: {}'.format(type(e).__name__, e))
+		dog.cancel()
+	emit()
+	rk.close()
+	return 0
 
 
 if __name__ == '__main__':
-	main()
+	sys.exit(main())

@@ -139,10 +139,15 @@ int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const double* d_ssx, 
 						 int32_t* d_flags, int64_t row0, int64_t row1, void* stream);
 
 /*
- * alpha[i,j,c] = by[j,c] - gamma[i,j] * bx[i,c]  (association.py:238-243), fp64 in, out_dtype out.
+ * alpha[i,j,c] = by[j,c] - gamma[i,j] * bx[i,c]  (association.py:238-243), fp64 coefficients in, out_dtype out.
+ * The reference computes alpha from gamma whatever return_dot says (return_dot only rescales the returned
+ * statistic afterwards, association.py:1044-1048), so d_stat may hold either form of K3's output:
+ *   stat_kind 1: d_stat = gamma;  stat_kind 0: d_stat = covariance x~.y~/n, turned back into gamma with
+ *   d_ssx (nx, sums of squares from nrm_residualize; 0 -> n_cells as in K3) and n_cells.
  */
-int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d_bx, const double* d_by,
-			  int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype, void* stream);
+int nrm_alpha(const void* d_stat, int stat_dtype, int64_t ldg, int stat_kind, const double* d_ssx, int64_t n_cells,
+			  const double* d_bx, const double* d_by, int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype,
+			  void* stream);
 
 /*
  * K2s + sweep -- streaming path for de with few design rows (nx + nc <= 32): HBM-bound, every expression
@@ -202,6 +207,12 @@ int nrm_single1_sweep(const double* d_g, int64_t ldg, const double* d_g2, int64_
  */
 int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp, double qcut, unsigned char* d_out, int64_t ldo,
 			   unsigned long long* d_total, int32_t* d_flags, void* stream);
+/* The same for a block of gene rows [row0, row0 + rows) of the (ng, ng) matrix: d_p (rows, ldp) and d_out (rows, ldo) hold only
+ * that block (row i of the block is gene row0 + i; its diagonal entry is column row0 + i).  Rows are independent in the reference
+ * (binnet.py:159 maps bh over the rows), so a GPU that owns a row block of a sharded coex binarises it without the other blocks;
+ * *d_total counts this block's selected entries (the caller sums the blocks before the "Empty binary network" test). */
+int nrm_binnet_rows(const void* d_p, int p_dtype, int64_t rows, int64_t ng, int64_t ldp, int64_t row0, double qcut,
+					unsigned char* d_out, int64_t ldo, unsigned long long* d_total, int32_t* d_flags, void* stream);
 
 /*
  * normvar (reference norm.py:131-289): per-gene weighted covariate removal, e_gk = w_k^wt_g.

@@ -242,6 +242,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 		if (h_dci) NRM_HIP(hipMemcpy(dci.p, h_dci, (size_t)nc * nc * 8, hipMemcpyHostToDevice));
 	}
 	const bool want_alpha = h_alpha != nullptr && nc > 0;
+	NRM_REQUIRE(!(want_alpha && samexy), "alpha is not provided for dy == NULL (meaningless in the reference, association.py:1066-1068)");
 	NRM_TRY(dx.alloc((size_t)nx * n * esize(x_dtype)));
 	NRM_HIP(hipMemcpy(dx.p, h_dx, (size_t)nx * n * esize(x_dtype), hipMemcpyHostToDevice));
 	NRM_TRY(rx.alloc((size_t)mp * kp * 8));
@@ -308,9 +309,10 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 		if (h_t) NRM_HIP(hipMemcpyAsync((char*)h_t + off, (const char*)ot.p + off, len, hipMemcpyDeviceToHost, cs.s));
 	}
 	if (want_alpha) {
-		NRM_REQUIRE(!samexy && stat_kind == 1, "alpha is only defined for dy != None with return_dot=False");
+		// alpha comes from gamma whatever return_dot says (association.py:238-243 vs :1044-1048)
 		NRM_TRY(oalpha.alloc(ob * nc));
-		NRM_TRY(nrm_alpha(ostat.p, out_dtype, ny, bx.as<double>(), by.as<double>(), nx, ny, nc, oalpha.p, out_dtype, st));
+		NRM_TRY(nrm_alpha(ostat.p, out_dtype, ny, stat_kind, ssx.as<double>(), n, bx.as<double>(), by.as<double>(), nx, ny, nc, oalpha.p,
+						  out_dtype, st));
 	}
 	NRM_HIP(hipStreamSynchronize(st));
 	NRM_HIP(hipStreamSynchronize(cs.s));

@@ -159,14 +159,14 @@ struct RegRow {
 
 template <typename T, typename Row>
 __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, int64_t ng, int64_t ldp, double qcut, unsigned char* __restrict__ out,
-													 int64_t ldo, unsigned long long* __restrict__ total, int32_t* __restrict__ flags) {
+													 int64_t ldo, unsigned long long* __restrict__ total, int32_t* __restrict__ flags, int64_t row0) {
 	__shared__ double sm[12];  // [0,4): block reductions with two barriers; [4,12): the alternating slots of the counting passes
 	const int64_t i = blockIdx.x;
 	const T* prow = p + i * ldp;
 	const double m = (double)(ng - 1);
 	const T qc = (T)qcut;  // the reference compares in the matrix dtype (numpy weak-scalar promotion)
 	const double slack = sizeof(T) == 4 ? 1e-5 : 1e-12;
-	Row r(prow, ng, i);
+	Row r(prow, ng, row0 + i);  // row i of this block is gene row0 + i: its diagonal entry sits in that column
 	// validity (binnet.py:151-152): finite and inside [0,1]
 	if (bn_block_sum(r.bad, sm) > 0 && threadIdx.x == 0) atomicAdd(&flags[0], 1);
 	double x = 2.0;       // every entry is a candidate
@@ -204,30 +204,37 @@ __global__ void __launch_bounds__(256) k_binnet_rows(const T* __restrict__ p, in
 }
 
 template <typename T>
-static void bn_launch(const T* p, int64_t ng, int64_t ldp, double qcut, unsigned char* out, int64_t ldo, unsigned long long* total, int32_t* flags,
-					  hipStream_t st) {
-	dim3 grid((unsigned)ng);
+static void bn_launch(const T* p, int64_t rows, int64_t ng, int64_t ldp, double qcut, unsigned char* out, int64_t ldo, unsigned long long* total,
+					  int32_t* flags, int64_t row0, hipStream_t st) {
+	dim3 grid((unsigned)rows);
 	if (ng <= 8 * 256)
-		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 8>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
+		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 8>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags, row0);
 	else if (ng <= 32 * 256)
-		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 32>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
+		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 32>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags, row0);
 	else if (ng <= 96 * 256 && sizeof(T) == 4)
-		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 96>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
+		hipLaunchKernelGGL((k_binnet_rows<T, RegRow<T, 96>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags, row0);
 	else
-		hipLaunchKernelGGL((k_binnet_rows<T, GlobalRow<T>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags);
+		hipLaunchKernelGGL((k_binnet_rows<T, GlobalRow<T>>), grid, dim3(256), 0, st, p, ng, ldp, qcut, out, ldo, total, flags, row0);
 }
 
-extern "C" int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp, double qcut, unsigned char* d_out, int64_t ldo,
-						  unsigned long long* d_total, int32_t* d_flags, void* stream) {
+extern "C" int nrm_binnet_rows(const void* d_p, int p_dtype, int64_t rows, int64_t ng, int64_t ldp, int64_t row0, double qcut,
+							   unsigned char* d_out, int64_t ldo, unsigned long long* d_total, int32_t* d_flags, void* stream) {
 	NRM_REQUIRE(p_dtype == NRM_F32 || p_dtype == NRM_F64, "nrm_binnet: bad dtype");
 	NRM_REQUIRE(ng > 1 && ldp >= ng && ldo >= ng, "Wrong shape of net or namet.");
+	NRM_REQUIRE(rows >= 0 && row0 >= 0 && row0 + rows <= ng, "nrm_binnet_rows: rows [row0, row0 + rows) outside the matrix");
 	NRM_REQUIRE(qcut > 0 && qcut < 1, "Q-value cutoff must be between 0 and 1.");
 	NRM_REQUIRE(d_p && d_out && d_total && d_flags, "nrm_binnet: null pointer");
 	hipStream_t st = (hipStream_t)stream;
 	NRM_HIP(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
+	if (rows == 0) return NRM_OK;
 	if (p_dtype == NRM_F64)
-		bn_launch<double>((const double*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags, st);
+		bn_launch<double>((const double*)d_p, rows, ng, ldp, qcut, d_out, ldo, d_total, d_flags, row0, st);
 	else
-		bn_launch<float>((const float*)d_p, ng, ldp, qcut, d_out, ldo, d_total, d_flags, st);
+		bn_launch<float>((const float*)d_p, rows, ng, ldp, qcut, d_out, ldo, d_total, d_flags, row0, st);
 	return nrm_check_launch("k_binnet_rows");
+}
+
+extern "C" int nrm_binnet(const void* d_p, int p_dtype, int64_t ng, int64_t ldp, double qcut, unsigned char* d_out, int64_t ldo,
+						  unsigned long long* d_total, int32_t* d_flags, void* stream) {
+	return nrm_binnet_rows(d_p, p_dtype, ng, ng, ldp, 0, qcut, d_out, ldo, d_total, d_flags, stream);
 }

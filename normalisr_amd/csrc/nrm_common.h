@@ -11,6 +11,7 @@ void nrm_set_error(const char* fmt, ...);
 	do {                                                                                   \
 		hipError_t e_ = (call);                                                            \
 		if (e_ != hipSuccess) {                                                            \
+			(void)hipGetLastError(); /* the error is reported here: do not leave it for the next launch check */ \
 			nrm_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
 						  __LINE__);                                                       \
 			return NRM_E_DEVICE;                                                           \

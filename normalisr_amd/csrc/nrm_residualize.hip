@@ -13,7 +13,7 @@
 
 #define RES_R 4
 #define RES_CB 8
-#define RES_NC_MAX 256
+#define RES_NC_MAX 2048  // OLS tables a = x C^T and b = a dci live in dynamic LDS: 2 * RES_R * nc doubles (128 KiB at 2048)
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -28,8 +28,9 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 													  double* __restrict__ out, int64_t ldo, double* __restrict__ ss,
 													  double* __restrict__ coef) {
 	__shared__ double s_part[4][RES_R * RES_CB];
-	__shared__ double s_a[RES_R][RES_NC_MAX];  // x_i C^T
-	__shared__ double s_b[RES_R][RES_NC_MAX];  // (x_i C^T) dci
+	extern __shared__ double s_dyn[];
+	double* const ta = s_dyn;                    // [RES_R][nc]  x_i C^T
+	double* const tb = s_dyn + (size_t)RES_R * nc;  // [RES_R][nc]  (x_i C^T) dci
 	__shared__ double s_ss[4][RES_R];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int64_t row0 = (int64_t)blockIdx.x * RES_R;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 			__syncthreads();
 			if (tid < RES_R * RES_CB) {
 				int r = tid / RES_CB, q = tid % RES_CB;
-				if (c0 + q < nc) s_a[r][c0 + q] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+				if (c0 + q < nc) ta[r * nc + c0 + q] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
 			}
 			__syncthreads();
 		}
@@ -78,8 +79,8 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 		for (int i = tid; i < RES_R * nc; i += 256) {
 			int r = i / nc, q = i % nc;
 			double v = 0.0;
-			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], s_a[r][e], v);
-			s_b[r][q] = v;
+			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], ta[r * nc + e], v);
+			tb[r * nc + q] = v;
 			if (coef && live[r]) coef[(row0 + r) * nc + q] = v;
 		}
 		__syncthreads();
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 			for (int q = 0; q < nc; q++) {
 				double cv = c[(int64_t)q * ldc + k];
 #pragma unroll
-				for (int r = 0; r < RES_R; r++) v[r] = fma(-s_b[r][q], cv, v[r]);
+				for (int r = 0; r < RES_R; r++) v[r] = fma(-tb[r * nc + q], cv, v[r]);
 			}
 		}
 #pragma unroll
@@ -148,8 +149,9 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 														 const double* __restrict__ dci, int active, double* __restrict__ out,
 														 int64_t ldo, double* __restrict__ ss, double* __restrict__ coef) {
 	__shared__ double s_part[4][RES_R * CB];
-	__shared__ double s_a[RES_R][RES_NC_MAX];
-	__shared__ double s_b[RES_R][RES_NC_MAX];
+	extern __shared__ double s_dyn[];
+	double* const ta = s_dyn;                    // [RES_R][nc]  x_i C^T
+	double* const tb = s_dyn + (size_t)RES_R * nc;  // [RES_R][nc]  (x_i C^T) dci
 	__shared__ double s_ss[4][RES_R];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int64_t row0 = (int64_t)blockIdx.x * RES_R;
@@ -204,15 +206,15 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			__syncthreads();
 			if (tid < RES_R * CB) {
 				int r = tid / CB, q = tid % CB;
-				if (c0 + q < nc) s_a[r][c0 + q] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+				if (c0 + q < nc) ta[r * nc + c0 + q] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
 			}
 			__syncthreads();
 		}
 		for (int i = tid; i < RES_R * nc; i += 256) {
 			int r = i / nc, q = i % nc;
 			double v = 0.0;
-			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], s_a[r][e], v);
-			s_b[r][q] = v;
+			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], ta[r * nc + e], v);
+			tb[r * nc + q] = v;
 			if (coef && live[r]) coef[(row0 + r) * nc + q] = v;
 		}
 		__syncthreads();
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 #pragma unroll
 					for (int r = 0; r < RES_R; r++)
 #pragma unroll
-						for (int i = 0; i < 4; i++) v[r][i] = fma(-s_b[r][q], cv[i], v[r][i]);
+						for (int i = 0; i < 4; i++) v[r][i] = fma(-tb[r * nc + q], cv[i], v[r][i]);
 				}
 			}
 		} else {
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 					for (int q = 0; q < nc; q++) {
 						double cv = c[(int64_t)q * ldc + kk];
 #pragma unroll
-						for (int r = 0; r < RES_R; r++) v[r][i] = fma(-s_b[r][q], cv, v[r][i]);
+						for (int r = 0; r < RES_R; r++) v[r][i] = fma(-tb[r * nc + q], cv, v[r][i]);
 					}
 				}
 			}
@@ -274,12 +276,18 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 							   const double* dci, int active, double* out, int64_t ldo, int64_t rows_pad, double* ss, double* coef,
 							   hipStream_t st) {
 	dim3 grid((unsigned)(rows_pad / RES_R));
+	const size_t lds = (size_t)2 * RES_R * (nc > 0 ? nc : 1) * sizeof(double);
+	auto go = [&](auto kern) {
+		if (lds > 48 * 1024)  // beyond the default dynamic-LDS window (more than 768 covariates)
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+	};
 	if (!vec)
-		hipLaunchKernelGGL(k_residualize<T>, grid, dim3(256), 0, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+		go(k_residualize<T>);
 	else if (nc <= 4)
-		hipLaunchKernelGGL((k_residualize_v4<T, 4>), grid, dim3(256), 0, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+		go(k_residualize_v4<T, 4>);
 	else
-		hipLaunchKernelGGL((k_residualize_v4<T, 8>), grid, dim3(256), 0, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+		go(k_residualize_v4<T, 8>);
 }
 
 extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c,

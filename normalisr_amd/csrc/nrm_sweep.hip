@@ -327,16 +327,21 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 }
 
 template <typename GT, typename OutT>
-__global__ void __launch_bounds__(256) k_alpha(const GT* __restrict__ gamma, int64_t ldg, const double* __restrict__ bx,
-												const double* __restrict__ by, int64_t nx, int64_t ny, int64_t nc,
-												OutT* __restrict__ alpha) {
+__global__ void __launch_bounds__(256) k_alpha(const GT* __restrict__ stat, int64_t ldg, const double* __restrict__ ssx, double ncells,
+												const double* __restrict__ bx, const double* __restrict__ by, int64_t nx, int64_t ny,
+												int64_t nc, OutT* __restrict__ alpha) {
 	int64_t total = nx * ny * nc;
 	int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (; i < total; i += stride) {
 		int64_t c = i % nc, ij = i / nc;
 		int64_t j = ij % ny, x = ij / ny;
-		alpha[i] = (OutT)(by[j * nc + c] - (double)gamma[x * ldg + j] * bx[x * nc + c]);  // association.py:238-243
+		double g = (double)stat[x * ldg + j];
+		if (ssx) {  // stat holds the covariance x~.y~/n (return_dot, association.py:1044-1048): gamma = cov * n / |x~|^2
+			double vx = ssx[x];
+			g *= ncells / (vx == 0.0 ? ncells : vx);
+		}
+		alpha[i] = (OutT)(by[j * nc + c] - g * bx[x * nc + c]);  // association.py:238-243
 	}
 }
 
@@ -400,19 +405,23 @@ extern "C" int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d
 								ldo, d_flags, 0, nx, stream);
 }
 
-extern "C" int nrm_alpha(const void* d_gamma, int gamma_dtype, int64_t ldg, const double* d_bx, const double* d_by,
-						 int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype, void* stream) {
-	NRM_REQUIRE(gamma_dtype == out_dtype, "nrm_alpha: gamma and alpha dtypes must match");
+extern "C" int nrm_alpha(const void* d_stat, int stat_dtype, int64_t ldg, int stat_kind, const double* d_ssx, int64_t n_cells,
+						 const double* d_bx, const double* d_by, int64_t nx, int64_t ny, int64_t nc, void* d_alpha, int out_dtype,
+						 void* stream) {
+	NRM_REQUIRE(stat_dtype == out_dtype, "nrm_alpha: stat and alpha dtypes must match");
+	NRM_REQUIRE(stat_kind == 1 || (stat_kind == 0 && d_ssx && n_cells > 0), "nrm_alpha: stat_kind 0 (covariance) needs d_ssx and n_cells");
 	if (nx * ny * nc == 0) return NRM_OK;
+	NRM_REQUIRE(d_stat && d_bx && d_by && d_alpha, "nrm_alpha: null pointer");
+	const double* ssx = stat_kind == 0 ? d_ssx : nullptr;
 	int64_t total = nx * ny * nc;
 	int grid = (int)((total + 255) / 256);
 	if (grid > 8192) grid = 8192;
 	if (out_dtype == NRM_F64)
-		hipLaunchKernelGGL((k_alpha<double, double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double*)d_gamma,
-						   ldg, d_bx, d_by, nx, ny, nc, (double*)d_alpha);
+		hipLaunchKernelGGL((k_alpha<double, double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double*)d_stat,
+						   ldg, ssx, (double)n_cells, d_bx, d_by, nx, ny, nc, (double*)d_alpha);
 	else
-		hipLaunchKernelGGL((k_alpha<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)d_gamma, ldg,
-						   d_bx, d_by, nx, ny, nc, (float*)d_alpha);
+		hipLaunchKernelGGL((k_alpha<float, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)d_stat, ldg,
+						   ssx, (double)n_cells, d_bx, d_by, nx, ny, nc, (float*)d_alpha);
 	return nrm_check_launch("k_alpha");
 }
 

@@ -60,6 +60,70 @@ def schedule_covers_all_pairs(world, rows_pad):
 	return True
 
 
+def _coll_tensor(values, group, device, dtype=None):
+	"""Small tensor for a collective: on the GPU for RCCL, on the host for gloo."""
+	import torch
+	import torch.distributed as dist
+	dev = device if dist.get_backend(group) == 'nccl' else 'cpu'
+	return torch.tensor(values, dtype=torch.int64 if dtype is None else dtype, device=dev)
+
+
+def _all_gather_ints(values, group, device):
+	"""(world, len(values)) int64 numpy array with every rank's values."""
+	import torch
+	import torch.distributed as dist
+	mine = _coll_tensor(list(values), group, device)
+	out = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+	dist.all_gather(out, mine, group=group)
+	return np.stack([t.cpu().numpy() for t in out])
+
+
+class SharedArrays:
+	"""Result arrays visible to every rank of the node, so that each rank copies ITS finished rows straight into the
+	caller-visible output (the reference's gather loop fills one array from every tile, association.py:1005-1034) and
+	nothing is pickled through rank 0.  The arrays are .npy files mapped by every rank (numpy.lib.format.open_memmap)
+	in a directory created by rank 0 -- on tmpfs (/dev/shm) by default, i.e. shared memory; with keep=True in a
+	directory of the caller's choice, i.e. the per-run result files.  Only the directory name travels between ranks."""
+
+	def __init__(self, specs, rank, world, group, base=None, keep=False):
+		import tempfile
+		self.rank, self.world, self.group, self.keep = rank, world, group, keep
+		path = [None]
+		if rank == 0:
+			if keep:
+				os.makedirs(base, exist_ok=True)
+				path[0] = base
+			else:
+				base = base or ('/dev/shm' if os.path.isdir('/dev/shm') else None)
+				path[0] = tempfile.mkdtemp(prefix='nrm_shared_', dir=base)
+			for name, (shape, dtype) in specs.items():
+				m = np.lib.format.open_memmap(os.path.join(path[0], name + '.npy'), mode='w+', dtype=np.dtype(dtype), shape=tuple(shape))
+				del m
+		if world > 1:
+			import torch.distributed as dist
+			dist.broadcast_object_list(path, src=0, group=group)  # a directory name, not data
+		self.dir = path[0]
+		self.arrays = {name: np.lib.format.open_memmap(os.path.join(self.dir, name + '.npy'), mode='r+') for name in specs}
+
+	def __getitem__(self, name):
+		return self.arrays[name]
+
+	def finish(self):
+		"""All ranks have written: rank 0 keeps its mappings (returned to the caller) and removes the files unless keep."""
+		for a in self.arrays.values():
+			a.flush()
+		if self.world > 1:
+			import torch.distributed as dist
+			dist.barrier(group=self.group)
+		if self.rank != 0:
+			self.arrays = {}
+			return None
+		if not self.keep:
+			import shutil
+			shutil.rmtree(self.dir, ignore_errors=True)  # the mappings stay valid until the arrays are released
+		return self.arrays
+
+
 class HipBackend:
 	"""Block operations on the local GPU through the C ABI (normalisr_amd.engine)."""
 
@@ -131,6 +195,13 @@ class CoexPlan:
 		# what travels over xGMI: the fp64 residual blocks, or -- when the input is narrower than fp64 -- the raw input
 		# blocks (half the bytes for fp32; partner blocks are then residualised again locally, K1 is HBM-cheap)
 		self.exchange_raw = world > 1 and backend is None and 'float32' in str(dt_local.dtype)
+		if world > 1 and backend is None:
+			# every rank must own the same number of rows of the same dtype: a mismatch would hang the all-gather or
+			# mis-slice the gathered rows, and ranks with different dtypes would issue different collectives
+			code = {'torch.float32': 0, 'torch.float64': 1}.get(str(dt_local.dtype), 2)
+			shapes = _all_gather_ints([self.rows, self.n, code], group, dt_local.device)
+			if not (shapes == shapes[0]).all():
+				raise ValueError('Sharded coex needs the same (rows, cells, dtype) on every rank; got {}'.format(shapes.tolist()))
 		if world > 1:
 			if self.exchange_raw:
 				# blocks 0..world-1 as gathered, then copies of the first blocks so that the partners rank+1..rank+K of any
@@ -262,38 +333,142 @@ class CoexPlan:
 	def kernel_breakdown(self):
 		return {k: round(self._avg_ms(k), 4) for k in self._ev}
 
-	# ---- assembly (validation / numpy out) -------------------------------------------------------
-	def assemble(self, to_numpy):
-		"""Gather every rank's output blocks on rank 0 and build the full symmetric (p, dot) matrices with
-		zero diagonals.  to_numpy converts a backend array to numpy.  Returns (p, dot, var) on rank 0, None elsewhere."""
-		mine = [dict(bi=o['bi'], bj=o['bj'], row_lo=o['row_lo'], symmetric=o['symmetric'], p=to_numpy(o['p']), stat=to_numpy(o['stat']))
-				for o in self.outputs]
-		var = to_numpy(self._ss)[:self.rows] / float(self.n)
-		var[var == 0] = 1
+	# ---- complete row blocks on the owner, without rank 0 in the middle ---------------------------------------
+	def _mirror_messages(self):
+		"""Every off-diagonal schedule entry (rank s computed rows [lo, hi) of block bi against block bj) as seen from this
+		rank: the owner of block bi needs those rows as they are, the owner of block bj needs them transposed.
+		Returns (local, sends, recvs): lists of (entry, transposed) / (peer, entry, transposed) in one global order."""
+		local, sends, recvs = [], [], []
+		for s_rank in range(self.world):
+			for bi, bj, lo, hi, sym in block_pair_schedule(s_rank, self.world, self.rows_pad):
+				if sym:
+					continue
+				hi_v = min(hi, self.rows)
+				if hi_v <= lo:
+					continue
+				e = (bi, bj, lo, hi_v)
+				for owner, transposed in ((bi, False), (bj, True)):
+					if s_rank == self.rank and owner == self.rank:
+						local.append((e, transposed))
+					elif s_rank == self.rank:
+						sends.append((owner, e, transposed))
+					elif owner == self.rank:
+						recvs.append((s_rank, e, transposed))
+		return local, sends, recvs
+
+	def complete_rows(self):
+		"""After step(): the complete rows of this rank's gene block, (rows, world * rows) for p and for the covariance, on
+		this rank's device.  The blocks this rank did not compute itself arrive from the ranks that did (mirrored blocks
+		transposed by the sender) in ONE point-to-point exchange -- every block travels to exactly the one rank that needs
+		it, nothing passes through rank 0 and nothing is pickled.  (association.py:1049-1057 mirrors the upper triangle in
+		the same way, on one host.)"""
+		torch = self.be.torch
+		R, W = self.rows, self.world
+		as_t = lambda v: v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))
+		outs = {(o['bi'], o['bj'], o['row_lo']): (as_t(o['p']), as_t(o['stat'])) for o in self.outputs}
+		own = outs[(self.rank, self.rank, 0)]
+		P = torch.empty((R, W * R), dtype=own[0].dtype, device=own[0].device)
+		S = torch.empty((R, W * R), dtype=own[1].dtype, device=own[1].device)
+		P[:, self.rank * R:(self.rank + 1) * R] = own[0]
+		S[:, self.rank * R:(self.rank + 1) * R] = own[1]
+
+		def place(e, transposed, p, st):
+			bi, bj, lo, hi = e
+			if transposed:  # rows of block bj (all of them), columns lo..hi of block bi
+				P[:, bi * R + lo:bi * R + hi] = p
+				S[:, bi * R + lo:bi * R + hi] = st
+			else:
+				P[lo:hi, bj * R:(bj + 1) * R] = p
+				S[lo:hi, bj * R:(bj + 1) * R] = st
+		local, sends, recvs = self._mirror_messages()
+		for e, transposed in local:
+			p, st = outs[(e[0], e[1], e[2])]
+			place(e, transposed, p.t() if transposed else p, st.t() if transposed else st)
+		if W > 1:
+			import torch.distributed as dist
+			on_host = dist.get_backend(self.group) != 'nccl'  # gloo moves host tensors only (functional tests); RCCL sends from HBM
+			ops, inbox, keep = [], [], []
+			for peer, e, transposed in sends:
+				p, st = outs[(e[0], e[1], e[2])]
+				msg = torch.stack([p.t() if transposed else p, st.t() if transposed else st]).contiguous()
+				msg = msg.cpu() if on_host else msg
+				keep.append(msg)
+				ops.append(dist.P2POp(dist.isend, msg, peer, group=self.group))
+			for peer, e, transposed in recvs:
+				shape = (2, R, e[3] - e[2]) if transposed else (2, e[3] - e[2], R)
+				buf = torch.empty(shape, dtype=P.dtype, device='cpu' if on_host else P.device)
+				inbox.append((e, transposed, buf))
+				ops.append(dist.P2POp(dist.irecv, buf, peer, group=self.group))
+			if ops:
+				for w in dist.batch_isend_irecv(ops):
+					w.wait()
+			for e, transposed, buf in inbox:
+				buf = buf.to(P.device)
+				place(e, transposed, buf[0], buf[1])
+		return P, S
+
+	def _flags_ok_everywhere(self):
+		"""The reference's assertions (association.py:248,252) as ONE decision of all ranks: a rank that raised alone
+		would leave the others waiting in the next collective."""
+		if self.flags is None:
+			return
+		f = self.flags
 		if self.world > 1:
 			import torch.distributed as dist
-			gathered = [None] * self.world if self.rank == 0 else None
-			dist.gather_object((mine, var), gathered, dst=0, group=self.group)
-			if self.rank != 0:
-				return None
+			f = f.clone() if dist.get_backend(self.group) == 'nccl' else f.cpu()
+			dist.all_reduce(f, group=self.group)
+		self.be.eng.check_flags(f)
+
+	def binnet_rows(self, p_rows, qcut):
+		"""binnet (binnet.py:134-173) of this rank's complete row block, in HBM: per-row BH q-values need nothing but the
+		row.  Returns the (rows, n_gene) uint8 block; the "Empty binary network" test is made on the sum over ranks."""
+		from . import _lib
+		eng = self.be.eng
+		torch = eng.torch
+		R, ng = p_rows.shape
+		with torch.cuda.device(eng.device):
+			out = torch.empty((R, ng), dtype=torch.uint8, device=eng.device)
+			total = torch.zeros(1, dtype=torch.int64, device=eng.device)
+			flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
+			_lib.check(eng.lib.nrm_binnet_rows(p_rows.data_ptr(), _lib.NRM_F64 if p_rows.dtype == torch.float64 else _lib.NRM_F32, R, ng,
+											   p_rows.stride(0), self.rank * R, float(qcut), out.data_ptr(), out.stride(0), total.data_ptr(),
+											   flags.data_ptr(), eng._stream()))
+			stats = torch.stack([total[0], flags[0].to(torch.int64)])
+			if self.world > 1:
+				import torch.distributed as dist
+				stats = stats if dist.get_backend(self.group) == 'nccl' else stats.cpu()
+				dist.all_reduce(stats, group=self.group)
+			bad, tot = int(stats[1].item()), int(stats[0].item())
+		if bad:
+			raise AssertionError('P-values must be finite and within [0,1] (binnet.py:151-152).')
+		if tot == 0:
+			raise RuntimeError('Empty binary network.')
+		return out
+
+	def _to_host_rows(self, t, dst):
+		"""This rank's row block -> its rows of a result array shared by the ranks."""
+		if hasattr(self.be, 'eng') and t.is_cuda:
+			self.be.eng.download_into(t, dst)
 		else:
-			gathered = [(mine, var)]
-		ng = self.world * self.rows
-		P = np.zeros((ng, ng), dtype=self.out_dtype)
-		D = np.zeros((ng, ng), dtype=self.out_dtype)
-		V = np.concatenate([g[1] for g in gathered]).astype(self.out_dtype)
-		R = self.rows
-		for blocks, _ in gathered:
-			for o in blocks:
-				r0 = o['bi'] * R + o['row_lo']
-				c0 = o['bj'] * R
-				nx, ny = o['p'].shape
-				P[r0:r0 + nx, c0:c0 + ny] = o['p']
-				D[r0:r0 + nx, c0:c0 + ny] = o['stat']
-				if not o['symmetric']:
-					P[c0:c0 + ny, r0:r0 + nx] = o['p'].T
-					D[c0:c0 + ny, r0:r0 + nx] = o['stat'].T
-		return P, D, V
+			dst[...] = t.numpy() if hasattr(t, 'numpy') else np.asarray(t)
+
+	def assemble(self, to_numpy=None, out_dir=None):
+		"""(p, dot, var) of the whole problem on rank 0 (None elsewhere) with the reference's contract (symmetric, zero
+		diagonals, coex.py:4-48): every rank completes its row block on its device and copies it into ITS rows of result
+		arrays shared by the ranks (SharedArrays).  out_dir: keep the arrays as p.npy / dot.npy / var.npy there."""
+		P, S = self.complete_rows()
+		R, ng = self.rows, self.world * self.rows
+		sh = SharedArrays(dict(p=((ng, ng), self.out_dtype), dot=((ng, ng), self.out_dtype), var=((ng, ), self.out_dtype)),
+						  self.rank, self.world, self.group, base=out_dir, keep=out_dir is not None)
+		a, b = self.rank * R, (self.rank + 1) * R
+		self._to_host_rows(P, sh['p'][a:b])
+		self._to_host_rows(S, sh['dot'][a:b])
+		ss = self._ss[:R]
+		var = (ss.cpu().numpy() if hasattr(ss, 'cpu') else np.asarray(ss)) / float(self.n)
+		var[var == 0] = 1
+		sh['var'][a:b] = var
+		res = sh.finish()
+		return None if res is None else (res['p'], res['dot'], res['var'])
 
 
 class DePlan:
@@ -349,66 +524,98 @@ class DePlan:
 		return self.eng.de_streaming_ok(self.dx, self.dy, self.dc64)
 
 
-def coex(dt_local, dc, group=None, dimreduce=0):
+def _local_rows(dt_local, dev):
+	import torch
+	if isinstance(dt_local, np.ndarray):
+		a = dt_local if dt_local.dtype in (np.float32, np.float64) else dt_local.astype(np.float64)
+		dt_local = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+	return dt_local
+
+
+def _world(group):
+	import torch.distributed as dist
+	if not dist.is_initialized():
+		return 0, 1, None
+	return dist.get_rank(group), dist.get_world_size(group), (group if group is not None else dist.group.WORLD)
+
+
+def coex(dt_local, dc, group=None, dimreduce=0, out_dir=None):
 	"""Sharded norm.coex for one-process-per-GPU programs: every rank passes ITS block of gene rows (same row count on
 	every rank; numpy or a torch tensor on its GPU) and the replicated covariates.  Rank 0 gets (p, dot, var) as numpy
-	arrays with the reference's contract (symmetric, zero diagonals; coex.py:4-48); other ranks get None.
+	arrays with the reference's contract (symmetric, zero diagonals; coex.py:4-48); other ranks get None.  Every rank
+	copies its own rows into arrays shared by the ranks (see CoexPlan.assemble); out_dir keeps them as .npy files.
 
 	    # torchrun --nproc-per-node 8 script.py
 	    dist.init_process_group('nccl'); torch.cuda.set_device(local_rank)
 	    res = normalisr_amd.distributed.coex(dt[rank * R:(rank + 1) * R], dc)
 	"""
 	import torch
-	import torch.distributed as dist
-	world = dist.get_world_size(group) if dist.is_initialized() else 1
-	rank = dist.get_rank(group) if dist.is_initialized() else 0
+	rank, world, group = _world(group)
 	dev = torch.device('cuda', torch.cuda.current_device())
-	if isinstance(dt_local, np.ndarray):
-		a = dt_local if dt_local.dtype in (np.float32, np.float64) else dt_local.astype(np.float64)
-		dt_local = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-	plan = CoexPlan(dt_local, dc, rank=rank, world=world, group=group if group is not None else (dist.group.WORLD if world > 1 else None),
-					dimreduce=dimreduce)
+	plan = CoexPlan(_local_rows(dt_local, dev), dc, rank=rank, world=world, group=group, dimreduce=dimreduce)
 	plan.step()
-	plan.be.eng.check_flags(plan.flags)
-	return plan.assemble(lambda t: t.detach().cpu().numpy())
+	plan._flags_ok_everywhere()
+	return plan.assemble(out_dir=out_dir)
 
 
-def de(dg, dt_local, dc, group=None, dimreduce=0):
-	"""Sharded norm.de (single=0) for one-process-per-GPU programs: every rank passes the full grouping matrix dg, ITS
-	block of gene rows of dt (numpy or a torch tensor on its GPU) and the replicated covariates.  No collective on the data
-	path; rank 0 gathers the column blocks and returns (p, gamma, None, varg, vart) with the reference's contract
-	(de.py:4-132, constant groupings re-inflated), other ranks get None."""
+def coex_binnet(dt_local, dc, qcut, group=None, dimreduce=0, out_dir=None):
+	"""coex -> binnet as one sharded device pipeline (examples/GSE123139/code/cmd_coex.sh:40-42 chains the two through a
+	P-value file): every rank completes its rows of the P-value matrix in HBM and binarises them there (per-row BH,
+	binnet.py:134-173), so the n_gene^2 P-values never cross PCIe -- only one byte per pair does.  Rank 0 gets the boolean
+	(n_gene, n_gene) network (net.npy in out_dir if given), other ranks None."""
 	import torch
-	import torch.distributed as dist
+	rank, world, group = _world(group)
+	dev = torch.device('cuda', torch.cuda.current_device())
+	plan = CoexPlan(_local_rows(dt_local, dev), dc, rank=rank, world=world, group=group, dimreduce=dimreduce)
+	plan.step()
+	plan._flags_ok_everywhere()
+	P, _ = plan.complete_rows()
+	net = plan.binnet_rows(P, qcut)
+	R, ng = plan.rows, world * plan.rows
+	sh = SharedArrays(dict(net=((ng, ng), np.bool_)), rank, world, group, base=out_dir, keep=out_dir is not None)
+	plan._to_host_rows(net, sh['net'][rank * R:(rank + 1) * R].view(np.uint8))  # the kernel writes exact 0/1 bytes
+	res = sh.finish()
+	return None if res is None else res['net']
+
+
+def de(dg, dt_local, dc, group=None, dimreduce=0, out_dir=None):
+	"""Sharded norm.de (single=0) for one-process-per-GPU programs: every rank passes the full grouping matrix dg, ITS
+	block of gene rows of dt (numpy or a torch tensor on its GPU; the blocks may differ in size) and the replicated
+	covariates.  No collective on the data path; every rank writes its gene columns into result arrays shared by the ranks
+	and rank 0 returns (p, gamma, None, varg, vart) with the reference's contract (de.py:4-132, constant groupings
+	re-inflated), other ranks get None."""
+	import torch
 	from .de import _varying_rows
-	world = dist.get_world_size(group) if dist.is_initialized() else 1
-	rank = dist.get_rank(group) if dist.is_initialized() else 0
+	rank, world, group = _world(group)
 	dev = torch.device('cuda', torch.cuda.current_device())
 	dg = np.asarray(dg)
 	gid = _varying_rows(dg)  # de.py:93
-	if isinstance(dt_local, np.ndarray):
-		a = dt_local if dt_local.dtype in (np.float32, np.float64) else dt_local.astype(np.float64)
-		dt_local = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+	dt_local = _local_rows(dt_local, dev)
 	x = dg[gid]
 	x = x if x.dtype in (np.float32, np.float64) else x.astype(np.float64)
 	plan = DePlan(torch.from_numpy(np.ascontiguousarray(x)).to(dev), dt_local, dc, rank=rank, world=world, dimreduce=dimreduce)
 	plan.step()
-	mine = plan.results()
+	flags = plan.result['flags']
+	counts = np.array([[plan.ny]])
 	if world > 1:
-		gathered = [None] * world if rank == 0 else None
-		dist.gather_object(mine, gathered, dst=0, group=group)
-		if rank != 0:
-			return None
-	else:
-		gathered = [mine]
+		import torch.distributed as dist
+		f = flags.clone() if dist.get_backend(group) == 'nccl' else flags.cpu()
+		dist.all_reduce(f, group=group)  # one decision for all ranks (see CoexPlan._flags_ok_everywhere)
+		plan.result['flags'] = f
+		counts = _all_gather_ints([plan.ny], group, dev)
+	p, gam, vg, vt = plan.results()
+	starts = np.concatenate([[0], np.cumsum(counts[:, 0])])
+	ng0, nt = dg.shape[0], int(starts[-1])
 	odt = plan.out_dtype
-	p = np.concatenate([g[0] for g in gathered], axis=1)
-	gam = np.concatenate([g[1] for g in gathered], axis=1)
-	vt = np.concatenate([g[3] for g in gathered])
-	ng0, nt = dg.shape[0], p.shape[1]
-	P = np.ones((ng0, nt), dtype=odt)
-	G = np.zeros((ng0, nt), dtype=odt)
-	VG = np.zeros((ng0, ), dtype=odt)
-	VT = np.zeros((ng0, nt), dtype=odt)
-	P[gid], G[gid], VG[gid], VT[gid] = p, gam, gathered[0][2], vt  # de.py:107-122
-	return (P, G, None, VG, VT)
+	sh = SharedArrays(dict(p=((ng0, nt), odt), gamma=((ng0, nt), odt), varg=((ng0, ), odt), vart=((ng0, nt), odt)), rank, world, group,
+					  base=out_dir, keep=out_dir is not None)
+	a, b = int(starts[rank]), int(starts[rank + 1])
+	# de.py:107-122: tested groupings get their results, constant ones p = 1, gamma = 0, variances 0
+	P, G, VT = sh['p'], sh['gamma'], sh['vart']
+	P[:, a:b], G[:, a:b], VT[:, a:b] = 1, 0, 0
+	P[gid, a:b], G[gid, a:b], VT[gid, a:b] = p, gam, vt
+	if rank == 0:
+		sh['varg'][...] = 0
+		sh['varg'][gid] = vg
+	res = sh.finish()
+	return None if res is None else (res['p'], res['gamma'], None, res['varg'], res['vart'])

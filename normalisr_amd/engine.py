@@ -105,6 +105,30 @@ class Engine:
 			self.host_unpin(out)
 		return out
 
+	def download_into(self, t, out):
+		"""Device tensor -> an existing C-contiguous numpy array (e.g. this rank's rows of a result matrix shared between the
+		ranks of a node): page-locked in place for the copy when possible, plain pageable copy otherwise."""
+		assert out.flags['C_CONTIGUOUS'] and out.nbytes == t.numel() * t.element_size(), 'download_into: shape/dtype mismatch'
+		if out.nbytes == 0:
+			return out
+		torch = self.torch
+		t = t.contiguous()
+		pinned = False
+		if out.nbytes >= (1 << 20):
+			try:
+				self.host_pin(out)
+				pinned = True
+			except RuntimeError:  # locked-memory limit, or a mapping that cannot be registered
+				pinned = False
+		try:
+			with torch.cuda.device(self.device):
+				_lib.check(self.lib.nrm_copy_to_host(out.ctypes.data, t.data_ptr(), out.nbytes, self._stream()))
+				torch.cuda.current_stream(self.device).synchronize()
+		finally:
+			if pinned:
+				self.host_unpin(out)
+		return out
+
 	def covariates(self, dc, dci):
 		"""fp64 covariates and pseudo-inverse on the device (replicated; tiny)."""
 		torch = self.torch
@@ -289,14 +313,16 @@ class Engine:
 												flags.data_ptr(), self._stream()))
 		return p, stat, r, t, flags
 
-	def alpha(self, gamma, bx, by, nc):
+	def alpha(self, stat, stat_kind, ssx, n_cells, bx, by, nc):
+		"""alpha = by - gamma bx (association.py:238-243) from K3's statistic: gamma (stat_kind 1) or the covariance
+		(stat_kind 0, return_dot) -- the reference derives alpha from gamma either way (:1044-1048 only rescales)."""
 		torch = self.torch
-		nx, ny = gamma.shape
+		nx, ny = stat.shape
 		with torch.cuda.device(self.device):
-			out = torch.empty((nx, ny, nc), dtype=gamma.dtype, device=self.device)
-			code = NRM_F64 if gamma.dtype == torch.float64 else NRM_F32
-			_lib.check(self.lib.nrm_alpha(gamma.data_ptr(), code, gamma.stride(0), bx.data_ptr(), by.data_ptr(), nx, ny, nc,
-										  out.data_ptr(), code, self._stream()))
+			out = torch.empty((nx, ny, nc), dtype=stat.dtype, device=self.device)
+			code = NRM_F64 if stat.dtype == torch.float64 else NRM_F32
+			_lib.check(self.lib.nrm_alpha(stat.data_ptr(), code, stat.stride(0), int(stat_kind), ssx.data_ptr(), int(n_cells),
+										  bx.data_ptr(), by.data_ptr(), nx, ny, nc, out.data_ptr(), code, self._stream()))
 		return out
 
 	@staticmethod
@@ -400,8 +426,8 @@ class Engine:
 												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), self._stream()))
 			alpha = None
 			if want_alpha:
-				if nc > 0 and stat_kind == 1:
-					alpha = self.alpha(stat, rx.coef, by, nc).cpu().numpy()
+				if nc > 0:
+					alpha = self.alpha(stat, stat_kind, rx.ss, n, rx.coef, by, nc).cpu().numpy()
 				else:
 					alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
 			if resident:  # resident pipeline: nothing leaves the device, the caller checks `flags` when it reads the results
@@ -446,8 +472,8 @@ class Engine:
 		p, stat, r, t, flags = self.sweep(dot, rx.ss, ry.ss, nx, ny, n, dof, samexy, stat_kind, out_dtype, want_rt)
 		alpha = None
 		if want_alpha:
-			if nc > 0 and not samexy and stat_kind == 1:
-				alpha = self.download(self.alpha(stat, rx.coef, ry.coef, nc))
+			if nc > 0 and not samexy:
+				alpha = self.download(self.alpha(stat, stat_kind, rx.ss, n, rx.coef, ry.coef, nc))
 			else:
 				alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
 		if resident and not (want_alpha or want_rt):  # resident pipeline (see association_de_streaming)

@@ -139,7 +139,12 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	prod_d = eng.gram(ra, ra, True)  # A A^T, tiles on/above the diagonal (association.py:936-950)
 	prod = prod_d[:m, :m].cpu().numpy()
 	prod = np.triu(prod) + np.triu(prod, 1).T
-	prodyT_d = eng.gram(ry, ra, False)  # Y A^T  (association.py:952-967, transposed)
+	# Y A^T (association.py:952-967, transposed).  It is the K-operand of the next contraction (K = m_pad columns), and K2
+	# leaves 16-column sub-blocks that are pure padding unwritten: start from zeros so that no stale NaN/Inf bit pattern
+	# of the allocator can reach 0 * NaN there
+	with torch.cuda.device(eng.device):
+		prodyT_d = torch.zeros((ry.rows_pad, mp), dtype=torch.float64, device=eng.device)
+	eng.gram(ry, ra, False, dot=prodyT_d)
 	with _engine.host_blas():
 		ev = np.linalg.eigvalsh(prod)
 	full_rank = ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)

@@ -365,7 +365,7 @@ def test_cli_round_trip_golden(golden, tmp_path):
 	assert main([]) == 1
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, dtype='float32'):
 	import os
 	import sys
 	import torch
@@ -377,33 +377,43 @@ def _sharded_worker(rank, world, port, q):
 	torch.cuda.set_device(0)
 	rng = np.random.default_rng(77)
 	ng, n = 150 * world, 700
-	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(np.float32)
-	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(np.float32)
+	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(dtype)
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(dtype)
 	R = ng // world
 	if world == 2:
 		plan = CoexPlan(torch.from_numpy(dt[rank * R:(rank + 1) * R]).cuda(), torch.from_numpy(dc).cuda(), rank=rank, world=world,
 						group=dist.group.WORLD)
+		assert plan.exchange_raw == (dtype == 'float32')  # fp64 rows: the fp64 residual blocks travel, per-pair launches
 		plan.step()
-		res = plan.assemble(lambda t: t.detach().cpu().numpy())
+		res = plan.assemble()
 	else:  # the public wrappers, numpy rows in
-		from normalisr_amd.distributed import coex as coex_sharded, de as de_sharded
+		from normalisr_amd.distributed import coex as coex_sharded, de as de_sharded, coex_binnet
 		res = coex_sharded(dt[rank * R:(rank + 1) * R], dc)
 		if world == 3:
-			dg = (np.random.default_rng(78).random((5, n)) < 0.3).astype(np.float32)
+			dg = (np.random.default_rng(78).random((5, n)) < 0.3).astype(dtype)
 			dg[2] = 1  # constant grouping: not tested, re-inflated (de.py:107-122)
-			rde = de_sharded(dg, dt[rank * R:(rank + 1) * R], dc)
+			# ragged gene blocks: no collective on the de data path, so the ranks need not own equal shares
+			cuts = [0, 100, 290, ng]
+			rde = de_sharded(dg, dt[cuts[rank]:cuts[rank + 1]], dc)
 			if rank == 0:
 				res = res + (rde, )
+		if world == 4:  # coex -> binnet with the P-values staying in HBM on every rank
+			net = coex_binnet(dt[rank * R:(rank + 1) * R], dc, 0.3)
+			if rank == 0:
+				res = res + (net, )
 	if rank == 0:
-		q.put(res)
+		q.put(tuple(None if a is None else (tuple(None if b is None else np.array(b) for b in a) if isinstance(a, tuple) else np.array(a)) for a in res))
 	dist.barrier()
 	dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3, 5, 8])
-def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
+@pytest.mark.parametrize('world,dtype', [(2, 'float32'), (3, 'float32'), (5, 'float32'), (8, 'float32'), (2, 'float64'), (4, 'float64'),
+										 (8, 'float64'), (4, 'float32')])
+def test_sharded_coex_hip_backend_two_ranks_one_gpu(world, dtype):
 	"""The N>1 path with the real HIP backend: `world` processes share this box's single GPU and exchange
-	residual blocks over gloo (RCCL needs one GPU per rank); result must equal the single-process oracle."""
+	blocks over gloo (RCCL needs one GPU per rank); result must equal the single-process oracle.  fp32 rows travel raw
+	(partners residualised again, one merged launch), fp64 rows travel as fp64 residual blocks with per-pair launches
+	and the half-split pair of an even world -- the BASELINE configs[4] code path."""
 	import socket
 	import torch.multiprocessing as mp
 	s = socket.socket()
@@ -412,7 +422,7 @@ def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
 	s.close()
 	ctx = mp.get_context('spawn')
 	q = ctx.Queue()
-	procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+	procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, dtype)) for r in range(world)]
 	for p in procs:
 		p.start()
 	got = q.get(timeout=300)
@@ -422,14 +432,19 @@ def test_sharded_coex_hip_backend_two_ranks_one_gpu(world):
 		assert p.exitcode == 0
 	rng = np.random.default_rng(77)
 	ng, n = 150 * world, 700
-	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(np.float32)
-	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(np.float32)
+	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(dtype)
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(dtype)
 	po, do, vo = oracle.coex(dt.astype(np.float64), dc.astype(np.float64))
-	assert P.dtype == np.float32
-	assert close(P, po, 1e-6, 1e-38) and close(D, do, 1e-6, 1e-7) and close(V, vo, 1e-6)
+	assert P.dtype == np.dtype(dtype)
+	if dtype == 'float32':
+		assert close(P, po, 1e-6, 1e-38) and close(D, do, 1e-6, 1e-7) and close(V, vo, 1e-6)
+	else:
+		assert p_close(P, po) and close(D, do, floor=1e-12) and close(V, vo, 1e-12)
 	assert (np.diag(P) == 0).all() and (P == P.T).all() and (D == D.T).all()
-	if len(got) > 3:  # sharded de through the public wrapper against the single-process oracle
-		dg = (np.random.default_rng(78).random((5, n)) < 0.3).astype(np.float32)
+	if world == 4:  # sharded coex -> binnet: bit-exact booleans (the network is not symmetric: BH runs per row)
+		assert got[3].dtype == np.bool_ and np.array_equal(got[3], oracle.binnet(P, 0.3))
+	if world == 3:  # sharded de through the public wrapper against the single-process oracle
+		dg = (np.random.default_rng(78).random((5, n)) < 0.3).astype(dtype)
 		dg[2] = 1
 		pd, gd, ad, vgd, vtd = got[3]
 		po, go, ao, vgo, vto = oracle.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
@@ -758,7 +773,8 @@ def test_de_plan_shards_equal_whole(norm, de_path):
 	import torch
 	from normalisr_amd.distributed import DePlan
 	rng = np.random.default_rng(616)
-	nx, ny, n, nc = (2, 900, 1500, 6) if de_path == 'streaming' else (40, 900, 700, 6)
+	streaming = de_path == 'auto'  # 'auto' picks the streaming kernel (K2s) for nx + nc <= 32; 'general' forces K1 -> K2 -> K3
+	nx, ny, n, nc = (2, 900, 1500, 6)
 	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))]).astype(np.float32)
 	dg = (rng.random((nx, n)) < 0.3).astype(np.float32)
 	dt = (rng.normal(size=(ny, n)) - 4).astype(np.float32)
@@ -769,7 +785,7 @@ def test_de_plan_shards_equal_whole(norm, de_path):
 	parts = []
 	for rank in range(world):
 		plan = DePlan(torch.from_numpy(dg).cuda(), torch.from_numpy(dt[rank * R:(rank + 1) * R]).cuda(), dc, rank=rank, world=world)
-		assert plan.streaming() == (de_path == 'streaming')
+		assert plan.streaming() == streaming
 		plan.step()
 		plan.step(timed=True)
 		assert plan.step_ms() > 0
@@ -779,3 +795,5 @@ def test_de_plan_shards_equal_whole(norm, de_path):
 	vt = np.concatenate([q[3] for q in parts])
 	assert close(p, whole[0], 1e-6, 1e-38) and close(g, whole[1], 1e-6, 1e-7) and close(vt, whole[4][0], 1e-6)
 	assert all(close(q[2], whole[3], 1e-6) for q in parts)
+	po, go, ao, vgo, vto = oracle.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
+	assert close(p, po, 1e-6, 1e-38) and close(g, go, 1e-6, 1e-7) and close(vt, vto[0], 1e-6)

@@ -1,0 +1,284 @@
+"""GPU parity tests added in round 2: the BASELINE configs at their full cell counts (configs[2] exactly, configs[3]
+exactly and sharded, the per-rank shape of configs[4] in fp64 at 500 000 cells), alpha with return_dot, allocator
+poisoning of single=4, the unpinned-copy fallback, the self-launching bench, and the row-block binnet.  Same parity
+bar as test_gpu_parity.py: integers/zeros/shapes bit-exact, r, t and p within 1e-6 relative (floors stated)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, relerr
+from test_gpu_parity import close, p_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def norm():
+	import normalisr_amd.normalisr as norm
+	return norm
+
+
+@pytest.fixture(scope='module')
+def eng():
+	from normalisr_amd.engine import get_engine
+	return get_engine()
+
+
+@pytest.mark.parametrize('path', ['auto', 'general'])
+def test_alpha_with_return_dot(path, monkeypatch):
+	"""association_tests(lowmem=False, return_dot=True): the reference computes alpha from gamma inside association_test_1
+	(association.py:238-243) whatever return_dot says; return_dot only rescales the statistic afterwards (:1044-1048)."""
+	from normalisr_amd.association import association_tests
+	monkeypatch.setenv('NRM_DE_PATH', path)
+	rng = np.random.default_rng(909)
+	n, nc = 900, 3
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+	dx = (rng.random((4, n)) < 0.4).astype(np.float64)
+	dy = rng.normal(size=(150, n)) + 0.7 * dc[0] + 0.3 * dx[1]
+	for return_dot in (True, False):
+		p, st, al, vx, vy = association_tests(dx, dy, dc, lowmem=False, return_dot=return_dot)
+		po, so, ao, vxo, vyo = oracle.association_tests(dx, dy, dc, lowmem=False, return_dot=return_dot)
+		assert al.shape == (4, 150, nc) and np.abs(ao).max() > 0.1
+		assert p_close(p, po) and close(st, so, floor=1e-12) and close(al, ao, floor=1e-9)
+	# fp32 in: the conversion of the rounded covariance back to gamma stays within the tolerance
+	p, st, al, vx, vy = association_tests(dx.astype(np.float32), dy.astype(np.float32), dc.astype(np.float32), lowmem=False, return_dot=True)
+	po, so, ao, vxo, vyo = oracle.association_tests(dx, dy.astype(np.float32).astype(np.float64), dc.astype(np.float32).astype(np.float64), lowmem=False, return_dot=True)
+	assert al.dtype == np.float32 and close(al, ao, 1e-5, 1e-4)
+
+
+def test_host_entry_alpha_with_return_dot(eng):
+	"""The C host entry (no torch) returns alpha for return_dot=1 instead of failing after the whole computation."""
+	import ctypes
+	from normalisr_amd import _lib
+	from normalisr_amd.association import inv_rank
+	rng = np.random.default_rng(910)
+	n, nc, nx, ny = 500, 2, 3, 40
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	dx = (rng.random((nx, n)) < 0.4).astype(np.float64)
+	dy = rng.normal(size=(ny, n)) + 0.5 * dc[0]
+	dci, rank = inv_rank(dc @ dc.T)
+	p, st, al = np.empty((nx, ny)), np.empty((nx, ny)), np.empty((nx, ny, nc))
+	vx, vy = np.empty(nx), np.empty(ny)
+	ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+	rc = eng.lib.nrm_association_tests_host(ptr(dx), _lib.NRM_F64, nx, ptr(dy), _lib.NRM_F64, ny, ptr(dc), _lib.NRM_F64, nc, n, ptr(dci), rank, 0, 1,
+											ptr(p), ptr(st), ptr(al), ptr(vx), ptr(vy), None, None, _lib.NRM_F64)
+	assert rc == 0, eng.lib.nrm_last_error()
+	po, so, ao, vxo, vyo = oracle.association_tests(dx, dy, dc, lowmem=False, return_dot=True)
+	assert p_close(p, po) and close(st, so, floor=1e-12) and close(al, ao, floor=1e-9)
+
+
+def test_single4_after_poisoned_allocator(norm):
+	"""single=4 with m = nx + nc not a multiple of 128 right after the caching allocator held NaNs: the Y A^T buffer is the
+	K-operand of the next contraction, so its padding columns must be zeros, not whatever the allocator hands back."""
+	import torch
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(911)
+	n, nx, ny, nc = 1200, 21, 300, 2
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	dx = (rng.random((nx, n)) < 0.1).astype(np.float64)
+	dy = rng.normal(size=(ny, n)) + 0.4 * dx[3]
+	ref = oracle.association_tests(dx, dy, dc, single=4, return_dot=False)
+	for _ in range(3):
+		junk = [torch.full((384, 128 * k), float('nan'), dtype=torch.float64, device='cuda') for k in (1, 2, 3)]
+		del junk
+		got = association_tests(dx, dy, dc, single=4, return_dot=False)
+		assert p_close(got[0], ref[0]) and close(got[1], ref[1], floor=1e-12) and close(got[4], ref[4], 1e-9)
+
+
+def test_pin_failure_falls_back_and_leaves_no_sticky_error(eng):
+	"""Engine.download / download_into fall back to a pageable copy when the result array cannot be page-locked (here: it is
+	registered already), and the failed hipHostRegister must not surface as the next launch's error."""
+	import torch
+	t = torch.arange(1 << 19, dtype=torch.float64, device='cuda')  # 4 MB: above the pinning threshold
+	out = np.empty(1 << 19)
+	eng.host_pin(out)
+	try:
+		with pytest.raises(RuntimeError):
+			eng.host_pin(out)  # double registration fails ...
+		d_r2 = torch.full((1000, ), 0.01, dtype=torch.float64, device='cuda')
+		d_p = torch.empty_like(d_r2)
+		from normalisr_amd import _lib
+		_lib.check(eng.lib.nrm_pvalues_from_r2(d_r2.data_ptr(), 1000, 50.0, d_p.data_ptr(), eng._stream()))  # ... and the next launch check is clean
+		torch.cuda.synchronize()
+		assert np.array_equal(eng.download_into(t, out), np.arange(1 << 19, dtype=np.float64))  # copy into the already locked range
+	finally:
+		eng.host_unpin(out)
+	assert np.array_equal(eng.download(t), np.arange(1 << 19, dtype=np.float64))
+
+
+def test_covariate_caps_raise_value_error(norm):
+	"""Shapes beyond the kernels' tables fail loudly with ValueError (never silently wrong)."""
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(912)
+	n = 2000
+	dy = rng.normal(size=(50, n))
+	dx = (rng.random((3, n)) < 0.3).astype(np.float64)
+	dc = rng.normal(size=(300, n))
+	p, g, a, vx, vy = association_tests(dx, dy, dc, return_dot=False)  # 300 covariates: beyond one LDS table of K1
+	po, go, ao, vxo, vyo = oracle.association_tests(dx, dy, dc, return_dot=False)
+	assert p_close(p, po) and close(g, go, floor=1e-12) and close(vy, vyo, 1e-9)
+
+
+def test_binnet_row_blocks_equal_whole(eng):
+	"""nrm_binnet_rows on row blocks (what a rank of a sharded coex runs on its rows) == nrm_binnet on the whole matrix ==
+	the oracle, bit for bit, for fp32 and fp64 matrices."""
+	import torch
+	from normalisr_amd import _lib
+	rng = np.random.default_rng(913)
+	ng = 700
+	p = rng.random((ng, ng))**3
+	p = np.triu(p, 1) + np.triu(p, 1).T
+	p[5, 7:60] = p[5, 6]  # ties
+	for dt in (np.float64, np.float32):
+		pm = p.astype(dt)
+		ref = oracle.binnet(pm, 0.2)
+		d_p = torch.from_numpy(pm).cuda()
+		out = torch.zeros((ng, ng), dtype=torch.uint8, device='cuda')
+		tot = 0
+		for a, b in ((0, 128), (128, 333), (333, ng)):
+			total = torch.zeros(1, dtype=torch.int64, device='cuda')
+			flags = torch.zeros(2, dtype=torch.int32, device='cuda')
+			blk = d_p[a:b].contiguous()
+			_lib.check(eng.lib.nrm_binnet_rows(blk.data_ptr(), _lib.NRM_F64 if dt == np.float64 else _lib.NRM_F32, b - a, ng, ng, a, 0.2,
+											   out[a:b].data_ptr(), ng, total.data_ptr(), flags.data_ptr(), eng._stream()))
+			tot += int(total.item())
+			assert int(flags[0].item()) == 0
+		assert np.array_equal(out.cpu().numpy().astype(bool), ref) and tot == int(ref.sum())
+
+
+def test_config2_exact_shape_sampled(eng):
+	"""BASELINE configs[2] at its exact shape: norm.de, 1 grouping x 20 000 genes x 100 000 cells, 20 covariates, fp32,
+	the expression matrix generated in HBM (8 GB); through DePlan (what bench.py --workload de_c3 times, streaming kernel)
+	and through the general path; sampled genes against the oracle on the same rows."""
+	import torch
+	from normalisr_amd.distributed import DePlan
+	ny, n, nc = 20000, 100000, 20
+	gen = torch.Generator(device='cuda').manual_seed(31)
+	dc = torch.cat([torch.randn((nc - 1, n), generator=gen, device='cuda'), torch.ones((1, n), device='cuda')])
+	dx = (torch.rand((1, n), generator=gen, device='cuda') < 0.5).float()
+	dy = torch.randn((ny, n), generator=gen, device='cuda') * 1.5 + 3.0
+	eff = torch.linspace(0.0, 0.05, 64, device='cuda')
+	dy[:64] += eff[:, None] * dx[0]
+	rows = np.concatenate([np.arange(64), np.arange(9990, 10010), np.arange(ny - 20, ny)])
+	sub = dy[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64)
+	po, go, ao, vgo, vto = oracle.de(dx.cpu().numpy().astype(np.float64), sub, dc.cpu().numpy().astype(np.float64))
+	assert po.min() < 1e-30 and po.max() > 0.3
+	plan = DePlan(dx, dy, dc)
+	assert plan.streaming()
+	plan.step()
+	p, g, vg, vt = plan.results()
+	assert p.shape == (1, ny) and p.dtype == np.float32
+	assert close(p[:, rows], po, 1e-6, 1e-38) and close(g[:, rows], go, 1e-6, 1e-7) and close(vt[rows], vto[0], 1e-6) and close(vg, vgo, 1e-6)
+	os.environ['NRM_DE_PATH'] = 'general'
+	try:
+		plan = DePlan(dx, dy, dc)
+		assert not plan.streaming()
+		plan.step()
+		p2, g2, vg2, vt2 = plan.results()
+	finally:
+		del os.environ['NRM_DE_PATH']
+	assert close(p2[:, rows], po, 1e-6, 1e-38) and close(g2[:, rows], go, 1e-6, 1e-7) and close(vt2[rows], vto[0], 1e-6)
+	# the two paths agree on ALL 20 000 genes (fp32 outputs: to the last bit or two)
+	assert close(p2, p, 1e-5, 1e-38) and close(g2, g, 1e-5, 1e-7)
+
+
+def test_config3_exact_shape_sharded(eng):
+	"""BASELINE configs[3] at its exact shape: 1 000 gRNAs x 15 000 genes x 50 000 cells fp32, gene rows sharded over 2 and 8
+	DePlan ranks (run one after the other on this GPU: there is no collective on the de data path); sampled genes vs oracle,
+	and the 8-way shards equal the 2-way shards."""
+	import torch
+	from normalisr_amd.distributed import DePlan
+	nx, ny, n, nc = 1000, 15000, 50000, 5
+	gen = torch.Generator(device='cuda').manual_seed(41)
+	dc = torch.cat([torch.randn((nc - 1, n), generator=gen, device='cuda'), torch.ones((1, n), device='cuda')])
+	dx = (torch.rand((nx, n), generator=gen, device='cuda') < 0.01).float()
+	dy = torch.randn((ny, n), generator=gen, device='cuda')
+	dy[:15] += 0.5 * dx[:15]
+	rows = np.concatenate([np.arange(24), np.arange(7490, 7510), np.arange(ny - 20, ny)])
+	sub = dy[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64)
+	po, go, ao, vxo, vyo = oracle.association_tests(dx.cpu().numpy().astype(np.float64), sub, dc.cpu().numpy().astype(np.float64), return_dot=False)
+	assert po.min() < 1e-20
+	res = {}
+	for world in (2, 8):
+		R = ny // world
+		parts = []
+		for rank in range(world):
+			plan = DePlan(dx, dy[rank * R:(rank + 1) * R], dc, rank=rank, world=world)
+			assert not plan.streaming()
+			plan.step()
+			parts.append(plan.results())
+		res[world] = (np.concatenate([q[0] for q in parts], axis=1), np.concatenate([q[1] for q in parts], axis=1),
+					  np.concatenate([q[3] for q in parts]))
+		p, g, vt = res[world]
+		assert p.shape == (nx, ny)
+		assert close(p[:, rows], po, 1e-6, 1e-38) and close(g[:, rows], go, 1e-6, 1e-7) and close(vt[rows], vyo, 1e-6)
+		assert close(parts[0][2], vxo, 1e-6)
+	assert close(res[8][0], res[2][0], 1e-5, 1e-38) and close(res[8][1], res[2][1], 1e-5, 1e-7)
+
+
+def test_config4_rank_shape_fp64_500k_cells(eng):
+	"""BASELINE configs[4], the shape one of 8 ranks works on: 3 840 gene rows (two blocks of 1 920) x 500 000 cells in fp64,
+	generated in HBM (15 GB), coex through the engine with Pearson r and t; sampled rows against the oracle at 1e-6 on
+	p, r and t (dof = 499 996: p spans 1 ... 1e-200 for |r| up to 0.05), exact zero diagonal and symmetry."""
+	import torch
+	from normalisr_amd.association import inv_rank
+	ng, n, nc = 3840, 500000, 3
+	gen = torch.Generator(device='cuda').manual_seed(51)
+	lat = torch.randn((1, n), generator=gen, device='cuda', dtype=torch.float64)
+	load = torch.randn((ng, 1), generator=gen, device='cuda', dtype=torch.float64)
+	dt = torch.randn((ng, n), generator=gen, device='cuda', dtype=torch.float64)
+	dt.addcmul_(load, lat, value=0.06)
+	rng = np.random.default_rng(52)
+	dc = np.vstack([rng.standard_normal((nc - 1, n)), np.ones((1, n))])
+	dci, rank = inv_rank(dc @ dc.T)
+	rows = np.concatenate([np.arange(16), np.arange(1912, 1928), np.arange(ng - 16, ng)])
+	idx = torch.from_numpy(rows).cuda()
+	sub = dt[idx].cpu().numpy()
+	res = eng.association_single0(dt, None, dc, dci, rank, 0, True, False, np.float64, want_rt=True)
+	po, do, vo = oracle.coex(sub, dc)
+	dof = n - 1 - rank
+	ro, to = oracle.pearson_r_t(do, vo, vo, dof)
+	sel = np.ix_(rows, rows)
+	off = ~np.eye(len(rows), dtype=bool)
+	assert po[off].min() < 1e-100 and po[off].max() > 0.5
+	assert p_close(res['p'][sel], po) and close(res['stat'][sel], do, floor=1e-13) and close(res['vary'][rows], vo, 1e-10)
+	assert close(res['r'][sel][off], ro[off], floor=1e-12) and close(res['t'][sel][off], to[off], floor=1e-6)
+	assert (np.diag(res['p']) == 0).all() and (res['p'] == res['p'].T).all() and (res['stat'] == res['stat'].T).all()
+
+
+def _run_bench(extra_args, env_extra, timeout=900):
+	env = dict(os.environ)
+	env.update(env_extra)
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+					   timeout=timeout)
+	assert r.returncode == 0, r.stderr[-3000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+	assert len(lines) == 1, r.stdout[-2000:]
+	return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+	"""`python bench.py --gpus 2` as a plain invocation starts its own ranks (here both on this GPU over gloo: functional
+	check of the launcher and the N>1 path; RCCL needs one GPU per rank) and prints exactly one JSON line."""
+	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--genes', '1200', '--cells', '2000', '--no-extras'],
+					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
+	assert out['n_gpus'] == 2 and out['ranks_seen_by_collective'] == 2 and out['value'] > 0
+	assert out['roofline']['bound'] == 'mfma' and out['roofline']['kernel_ms'] > 0 and 'exchange' in out['kernels_ms']
+	assert out['config']['exchange'] == 'all-gather of raw fp32 blocks'
+
+
+def test_bench_default_line_carries_the_other_configs():
+	"""The default N=1 line: configs[1] as `value` plus de_c3 / de_c4 / coex_c5 under extra_workloads, each with its roofline."""
+	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
+	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'] == 'f64'
+	ex = out['extra_workloads']
+	assert set(ex) == {'de_c3', 'de_c4', 'coex_c5'}, ex
+	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'mfma' and ex['coex_c5']['roofline']['bound'] == 'mfma'
+	for k, v in ex.items():
+		assert 'error' not in v, (k, v)
+		assert v['value'] > 0 and v['ms_per_step'] > 0 and 0 < v['roofline']['frac'] < 1.2
