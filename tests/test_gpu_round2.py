@@ -90,38 +90,44 @@ def test_single4_after_poisoned_allocator(norm):
 		assert p_close(got[0], ref[0]) and close(got[1], ref[1], floor=1e-12) and close(got[4], ref[4], 1e-9)
 
 
-def test_pin_failure_falls_back_and_leaves_no_sticky_error(eng):
-	"""Engine.download / download_into fall back to a pageable copy when the result array cannot be page-locked (here: it is
-	registered already), and the failed hipHostRegister must not surface as the next launch's error."""
+def test_pin_failure_falls_back_and_leaves_no_sticky_error(eng, monkeypatch):
+	"""A failed HIP call reported through the C ABI (here: unpinning a range that was never page-locked) must not surface
+	again as the next launch's error; and Engine.download / download_into fall back to a pageable copy when the result
+	array cannot be page-locked (hipHostRegister is made to fail: on this ROCm even a double registration succeeds)."""
 	import torch
+	from normalisr_amd import _lib
 	t = torch.arange(1 << 19, dtype=torch.float64, device='cuda')  # 4 MB: above the pinning threshold
 	out = np.empty(1 << 19)
-	eng.host_pin(out)
-	try:
-		with pytest.raises(RuntimeError):
-			eng.host_pin(out)  # double registration fails ...
-		d_r2 = torch.full((1000, ), 0.01, dtype=torch.float64, device='cuda')
-		d_p = torch.empty_like(d_r2)
-		from normalisr_amd import _lib
-		_lib.check(eng.lib.nrm_pvalues_from_r2(d_r2.data_ptr(), 1000, 50.0, d_p.data_ptr(), eng._stream()))  # ... and the next launch check is clean
-		torch.cuda.synchronize()
-		assert np.array_equal(eng.download_into(t, out), np.arange(1 << 19, dtype=np.float64))  # copy into the already locked range
-	finally:
-		eng.host_unpin(out)
+	with pytest.raises(RuntimeError):
+		eng.host_unpin(out)  # hipHostUnregister of an unregistered range fails ...
+	d_r2 = torch.full((1000, ), 0.01, dtype=torch.float64, device='cuda')
+	d_p = torch.empty_like(d_r2)
+	_lib.check(eng.lib.nrm_pvalues_from_r2(d_r2.data_ptr(), 1000, 50.0, d_p.data_ptr(), eng._stream()))  # ... and the next launch check is clean
+	torch.cuda.synchronize()
+	assert np.array_equal(eng.download_into(t, out), np.arange(1 << 19, dtype=np.float64))  # page-locked copy
+
+	def no_pin(a):
+		raise RuntimeError('hipHostRegister failed: out of memory (simulated locked-memory limit)')
+	monkeypatch.setattr(eng, 'host_pin', no_pin)
+	out[:] = 0
+	assert np.array_equal(eng.download_into(t, out), np.arange(1 << 19, dtype=np.float64))  # pageable fallback
 	assert np.array_equal(eng.download(t), np.arange(1 << 19, dtype=np.float64))
 
 
-def test_covariate_caps_raise_value_error(norm):
-	"""Shapes beyond the kernels' tables fail loudly with ValueError (never silently wrong)."""
+def test_many_covariates_beyond_one_lds_table(norm):
+	"""300 covariates (the first K1 held its OLS tables in a fixed 256-entry LDS array): dynamic LDS tables, same parity bar."""
 	from normalisr_amd.association import association_tests
 	rng = np.random.default_rng(912)
 	n = 2000
 	dy = rng.normal(size=(50, n))
 	dx = (rng.random((3, n)) < 0.3).astype(np.float64)
-	dc = rng.normal(size=(300, n))
-	p, g, a, vx, vy = association_tests(dx, dy, dc, return_dot=False)  # 300 covariates: beyond one LDS table of K1
-	po, go, ao, vxo, vyo = oracle.association_tests(dx, dy, dc, return_dot=False)
-	assert p_close(p, po) and close(g, go, floor=1e-12) and close(vy, vyo, 1e-9)
+	for nc in (300, 1000):  # 1000: tables beyond the default 48 KB dynamic-LDS window
+		dc = rng.normal(size=(nc, n))
+		p, g, a, vx, vy = association_tests(dx, dy, dc, return_dot=False)
+		po, go, ao, vxo, vyo = oracle.association_tests(dx, dy, dc, return_dot=False)
+		assert p_close(p, po) and close(g, go, floor=1e-12) and close(vy, vyo, 1e-9)
+	with pytest.raises(ValueError):
+		association_tests(dx, dy[:, :1500], rng.normal(size=(1400, 1500)), return_dot=False)  # n <= rank + 1 (association.py:213-216)
 
 
 def test_binnet_row_blocks_equal_whole(eng):
