@@ -52,6 +52,10 @@ int nrm_set_device(int device);
 int nrm_host_pin(void* ptr, int64_t bytes, int threads);
 int nrm_host_unpin(void* ptr);
 int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, void* stream);
+/* Device-side assembly of the padded operand buffers (zero padding, stacking [C; X~] for the streaming path, gathering sums of
+ * squares of row chunks): asynchronous on `stream`; pitches and row_bytes in BYTES. */
+int nrm_fill_zero(void* d_dst, int64_t bytes, void* stream);
+int nrm_copy_rows(void* d_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows, void* stream);
 
 /*
  * K1 -- residualise rows against covariates and take their sums of squares.

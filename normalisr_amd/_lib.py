@@ -26,6 +26,8 @@ _SIGNATURES = {
 	'nrm_host_pin': ([_vp, _i64, _i32], _i32),
 	'nrm_host_unpin': ([_vp], _i32),
 	'nrm_copy_to_host': ([_vp, _vp, _i64, _vp], _i32),
+	'nrm_fill_zero': ([_vp, _i64, _vp], _i32),
+	'nrm_copy_rows': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
 	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_f64_band': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),

@@ -76,6 +76,24 @@ extern "C" int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, v
 	return NRM_OK;
 }
 
+extern "C" int nrm_fill_zero(void* d_dst, int64_t bytes, void* stream) {
+	NRM_REQUIRE(bytes >= 0, "nrm_fill_zero: negative size");
+	if (bytes == 0) return NRM_OK;
+	NRM_REQUIRE(d_dst != nullptr, "nrm_fill_zero: null pointer");
+	NRM_HIP(hipMemsetAsync(d_dst, 0, (size_t)bytes, (hipStream_t)stream));
+	return NRM_OK;
+}
+
+extern "C" int nrm_copy_rows(void* d_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows,
+							 void* stream) {
+	NRM_REQUIRE(row_bytes >= 0 && rows >= 0 && dst_pitch >= row_bytes && src_pitch >= row_bytes, "nrm_copy_rows: pitches smaller than the row");
+	if (row_bytes == 0 || rows == 0) return NRM_OK;
+	NRM_REQUIRE(d_dst && d_src, "nrm_copy_rows: null pointer");
+	NRM_HIP(hipMemcpy2DAsync(d_dst, (size_t)dst_pitch, d_src, (size_t)src_pitch, (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToDevice,
+							 (hipStream_t)stream));
+	return NRM_OK;
+}
+
 namespace {
 // Device scratch of the host entry, kept between calls (hipMalloc / hipFree of GB-sized buffers cost milliseconds
 // each): blocks return to a per-process pool and are reused best-fit; nrm_release_cache() frees them.

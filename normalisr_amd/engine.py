@@ -105,6 +105,19 @@ class Engine:
 			self.host_unpin(out)
 		return out
 
+	def zeros(self, shape, dtype):
+		"""Zero-filled device buffer (allocation by torch, the fill through the C ABI on the launch stream)."""
+		t = self.torch.empty(shape, dtype=dtype, device=self.device)
+		_lib.check(self.lib.nrm_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._stream()))
+		return t
+
+	def copy_rows(self, dst, src):
+		"""dst[:rows, :cols] = src for 2-D device tensors of one dtype with unit column stride (strided rows allowed)."""
+		rows, cols = src.shape
+		assert dst.dtype == src.dtype and dst.stride(1) == 1 and src.stride(1) == 1 and dst.shape[0] >= rows and dst.shape[1] >= cols
+		es = src.element_size()
+		_lib.check(self.lib.nrm_copy_rows(dst.data_ptr(), dst.stride(0) * es, src.data_ptr(), src.stride(0) * es, cols * es, rows, self._stream()))
+
 	def download_into(self, t, out):
 		"""Device tensor -> an existing C-contiguous numpy array (e.g. this rank's rows of a result matrix shared between the
 		ranks of a node): page-locked in place for the copy when possible, plain pageable copy otherwise."""
@@ -149,7 +162,7 @@ class Engine:
 			kp = _round_up(n, K_TILE)
 			out = torch.empty((rp, kp), dtype=torch.float64, device=self.device)
 			ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
-			coef = torch.zeros((rows, nc), dtype=torch.float64, device=self.device) if want_coef else None
+			coef = self.zeros((rows, nc), torch.float64) if want_coef else None
 			_lib.check(self.lib.nrm_residualize(
 				x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 				0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
@@ -209,7 +222,7 @@ class Engine:
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			ssy = torch.empty((ny, ), dtype=torch.float64, device=self.device)
-			flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+			flags = self.zeros((2, ), torch.int32)
 			esz = p.element_size()
 			for a in range(0, ny, rows):
 				b = min(ny, a + rows)
@@ -224,7 +237,7 @@ class Engine:
 				_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), rx.ss.data_ptr(), ry.ss.data_ptr(), nx, b - a, int(n),
 													float(dof), 0, int(stat_kind), p.data_ptr() + a * esz, stat.data_ptr() + a * esz, 0, 0,
 													_code(out_dtype), ny, flags.data_ptr(), self._stream()))
-				ssy[a:b] = ry.ss[:b - a]
+				_lib.check(self.lib.nrm_copy_rows(ssy.data_ptr() + a * 8, 8 * (b - a), ry.ss.data_ptr(), 8 * (b - a), 8 * (b - a), 1, self._stream()))
 			self.check_flags(flags)
 			return dict(p=self.download(p), stat=self.download(stat), alpha=None, varx=self.variances(rx.ss, nx, n, out_dtype),
 						vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
@@ -270,7 +283,7 @@ class Engine:
 				dot = torch.empty((rx.rows_pad, ry.rows_pad), dtype=torch.float64, device=self.device)
 				p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 				stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
-				flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+				flags = self.zeros((2, ), torch.int32)
 				done = []
 				for a, b in zip(cuts[:-1], cuts[1:]):
 					self.gram(rx, ry, samexy, dot=dot, rows=(a, rx.rows_pad if b == nx else b))
@@ -305,7 +318,7 @@ class Engine:
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
 			t = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
 			if flags is None:
-				flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+				flags = self.zeros((2, ), torch.int32)
 			_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), ssx.data_ptr(), ssy.data_ptr(), nx, ny,
 												int(n_cells), float(dof), 1 if symmetric else 0, int(stat_kind),
 												p.data_ptr(), stat.data_ptr(), 0 if r is None else r.data_ptr(),
@@ -353,13 +366,13 @@ class Engine:
 			t = torch.from_numpy(np.ascontiguousarray(a))
 			if n16 == n:
 				return t.to(self.device)
-			buf = torch.zeros((rows, n16), dtype=t.dtype, device=self.device)
-			buf[:, :n] = t.to(self.device)
+			buf = self.zeros((rows, n16), t.dtype)
+			self.copy_rows(buf, t.to(self.device))
 			return buf[:, :n]
 		if n16 == n and a.stride(1) == 1 and a.stride(0) % 4 == 0:
 			return a
-		buf = torch.zeros((rows, n16), dtype=a.dtype, device=self.device)
-		buf[:, :n] = a
+		buf = self.zeros((rows, n16), a.dtype)
+		self.copy_rows(buf, a if a.stride(1) == 1 else a.contiguous())
 		return buf[:, :n]
 
 	def de_streaming_ok(self, dx, dy, dc):
@@ -385,9 +398,9 @@ class Engine:
 			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
 			# design rows: a = x C^T through the streaming Gram (all CUs), then x~ = x - (a dci) C spread along the cells
 			k32 = _round_up(n, 128)
-			z = torch.zeros((32, k32), dtype=torch.float64, device=self.device)
+			z = self.zeros((32, k32), torch.float64)  # Z = [C; X~; 0]: stacked on the device through the C ABI
 			if nc:
-				z[:nc, :n] = d_c
+				self.copy_rows(z, d_c)
 			xd = self._rows_padded16(as_input(dx) if isinstance(dx, np.ndarray) else dx)
 			xcode = NRM_F64 if xd.dtype == torch.float64 else NRM_F32
 			gx = torch.empty((256, 32), dtype=torch.float64, device=self.device)
@@ -396,16 +409,15 @@ class Engine:
 			if active:
 				_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
 													ssx_raw.data_ptr(), 256, nc, self._skinny_work().data_ptr(), self._stream()))
-			xt = torch.zeros((nx, k32), dtype=torch.float64, device=self.device)
+			xt = z[nc:nc + nx]  # the residualised design rows are written straight into their rows of Z (zero padded up to k32)
 			rw_work = torch.empty((32 * ((k32 + 1023) // 1024), ), dtype=torch.float64, device=self.device)
 			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
-			coefx = torch.zeros((nx, nc), dtype=torch.float64, device=self.device) if want_alpha else None
+			coefx = self.zeros((nx, nc), torch.float64) if want_alpha else None
 			_lib.check(self.lib.nrm_residualize_wide(xd.data_ptr(), xcode, nx, n, xd.stride(0), 0 if d_c is None else d_c.data_ptr(), nc,
 													 0 if d_c is None else d_c.stride(0), gx.data_ptr(), 0 if d_dci is None else d_dci.data_ptr(),
 													 int(rank), xt.data_ptr(), k32, ssx.data_ptr(), 0 if coefx is None else coefx.data_ptr(),
 													 rw_work.data_ptr(), self._stream()))
 			rx = Residualized(nx, n, xt, ssx, coefx)
-			z[nc:nc + nx] = xt
 			y = self._rows_padded16(dy)
 			ny_pad = _round_up(ny, 256)
 			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
@@ -417,8 +429,8 @@ class Engine:
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
 			t = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
 			ssy = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
-			by = torch.zeros((ny, nc), dtype=torch.float64, device=self.device) if (want_alpha and nc) else None
-			flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+			by = self.zeros((ny, nc), torch.float64) if (want_alpha and nc) else None
+			flags = self.zeros((2, ), torch.int32)
 			stat_kind = 0 if return_dot else 1
 			_lib.check(self.lib.nrm_de_small_sweep(g.data_ptr(), ssraw.data_ptr(), 0 if d_dci is None else d_dci.data_ptr(), nc, int(rank),
 												   rx.ss.data_ptr(), nx, ny, n, float(dof), stat_kind, p.data_ptr(), stat.data_ptr(),

@@ -168,7 +168,7 @@ def test_config2_exact_shape_sampled(eng):
 	dc = torch.cat([torch.randn((nc - 1, n), generator=gen, device='cuda'), torch.ones((1, n), device='cuda')])
 	dx = (torch.rand((1, n), generator=gen, device='cuda') < 0.5).float()
 	dy = torch.randn((ny, n), generator=gen, device='cuda') * 1.5 + 3.0
-	eff = torch.linspace(0.0, 0.05, 64, device='cuda')
+	eff = torch.linspace(0.0, 0.3, 64, device='cuda')
 	dy[:64] += eff[:, None] * dx[0]
 	rows = np.concatenate([np.arange(64), np.arange(9990, 10010), np.arange(ny - 20, ny)])
 	sub = dy[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64)
@@ -251,7 +251,7 @@ def test_config4_rank_shape_fp64_500k_cells(eng):
 	ro, to = oracle.pearson_r_t(do, vo, vo, dof)
 	sel = np.ix_(rows, rows)
 	off = ~np.eye(len(rows), dtype=bool)
-	assert po[off].min() < 1e-100 and po[off].max() > 0.5
+	assert po[off].min() < 1e-40 and po[off].max() > 0.5
 	assert p_close(res['p'][sel], po) and close(res['stat'][sel], do, floor=1e-13) and close(res['vary'][rows], vo, 1e-10)
 	assert close(res['r'][sel][off], ro[off], floor=1e-12) and close(res['t'][sel][off], to[off], floor=1e-6)
 	assert (np.diag(res['p']) == 0).all() and (res['p'] == res['p'].T).all() and (res['stat'] == res['stat'].T).all()
