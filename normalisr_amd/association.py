@@ -14,13 +14,39 @@ import numpy as np
 from . import engine as _engine
 
 
+def _randomized_inverse(mat, tol, mpc, qr, ka):
+	"""Truncated pseudo-inverse through scikit-learn's randomized SVD with random_state=0 -- the third-party routine the
+	reference calls for method='sklearn' (association.py:81-98: start from min(mpc, n) components, or n; without a cap grow
+	the number of components until the smallest one kept falls under tol * largest; count those above the threshold)."""
+	try:
+		from sklearn.utils.extmath import randomized_svd
+	except ImportError as e:  # same dependency as the reference for this option
+		raise RuntimeError("inv_rank(method='sklearn') / mpc > 0 on matrices larger than mpc needs scikit-learn: {}".format(e))
+	n = mat.shape[-1]
+	k = min(mpc, n) if mpc > 0 else n
+	opts = dict(ka, random_state=0)
+	if qr >= 1:
+		opts['power_iteration_normalizer'] = 'QR'
+	if qr > 1:
+		opts['n_iter'] = qr
+	while True:
+		_, s, vh = randomized_svd(mat, k, **opts)
+		if k == n or s[-1] <= tol * s[0] or mpc > 0:
+			break
+		k += min(k, n - k)
+	r = int(k - np.searchsorted(s[::-1], tol * s[0]))
+	if mpc > 0:
+		r = min(r, mpc)
+	return np.matmul(vh[:r].T / s[:r], vh[:r]).T, r
+
+
 def inv_rank(m, tol=1E-8, method='auto', logger=None, mpc=0, qr=0, **ka):
 	"""Pseudo-inverse and rank of symmetric matrices by truncated SVD (reference association.py:4-134).
 
-	Singular values below tol*largest count as zero; the integer rank is the number kept.  Runs on the
-	host in fp64: the matrices are (n_cov, n_cov) and the rank must be bit-exact.  `method`, `mpc`, `qr`
-	are accepted for signature compatibility; only the exact LAPACK route is implemented
-	(`mpc` still caps the rank as association.py:78-79 does).
+	Singular values below tol*largest count as zero; the integer rank is the number kept (capped by mpc > 0).  Runs on
+	the host in fp64: the matrices are (n_cov, n_cov) and the rank must be bit-exact.  method 'scipy' = exact LAPACK SVD;
+	'sklearn' = scikit-learn's randomized SVD (random_state=0, qr as in the reference); 'auto' picks the exact route
+	unless mpc > 0 and the matrix is larger than mpc (association.py:52-63).
 	"""
 	if logger is None:
 		logger = logging
@@ -33,17 +59,24 @@ def inv_rank(m, tol=1E-8, method='auto', logger=None, mpc=0, qr=0, **ka):
 		raise ValueError('qr must be non-negative integer.')
 	if method not in ('auto', 'scipy', 'sklearn'):
 		raise ValueError('Unknown method {}'.format(method))
-	if m.ndim > 2 and mpc > 0:
-		raise NotImplementedError('No current method supports >2 dimensions with mpc>0.')
-	if method == 'sklearn' or (method == 'auto' and mpc > 0 and m.shape[-1] > mpc):
-		logger.debug('randomized SVD not implemented here; using exact SVD with rank cap mpc.')
 	n = m.shape[-1]
+	if method == 'auto':
+		if m.ndim > 2 and mpc > 0:
+			raise NotImplementedError('No current method supports >2 dimensions with mpc>0.')
+		method = 'scipy' if (n <= mpc or mpc == 0) else 'sklearn'
+	if m.ndim > 2 and method == 'sklearn':
+		raise NotImplementedError('Not supporting >2 dimensions for method=sklearn.')
+	if m.ndim > 2 and mpc > 0:
+		raise NotImplementedError('Not supporting >2 dimensions for mpc>0.')
 	if not np.isfinite(m).all():
 		raise ValueError('array must not contain infs or NaNs')  # scipy.linalg.svd(check_finite=True) in the reference
 	flat = m.reshape((-1, n, n)).astype(np.float64, copy=False)
 	inv = np.empty_like(flat)
 	ranks = np.empty(flat.shape[0], dtype=int)
 	for i, mat in enumerate(flat):
+		if method == 'sklearn':
+			inv[i], ranks[i] = _randomized_inverse(mat, tol, mpc, qr, ka)
+			continue
 		_, s, vh = np.linalg.svd(mat)
 		r = int(n - np.searchsorted(s[::-1], tol * s[0]))
 		if mpc > 0:

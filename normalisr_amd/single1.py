@@ -47,8 +47,7 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		raise ValueError('Unmatching dx/dy/dc dimensions.')
 	if nc == 0:
 		logging.warning('No covariate dc input.')
-	if nc > 31:
-		raise NotImplementedError('single=1 on the device supports at most 31 covariates.')
+	chunk = max(1, min(chunk, 8192 // (nc + 1)))  # bounds the masked-row operand W (chunk * (nc + 1) rows) for many covariates
 	c64 = np.asarray(dc, dtype=np.float64)
 	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 	eng = _engine.get_engine()

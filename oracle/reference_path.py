@@ -60,20 +60,43 @@ def beta_cdf_half(x, a):
 	return ensure_built().nrm_oracle_beta_cdf_half(float(x), float(a))
 
 
-def inv_rank(m, tol=1E-8):
+def inv_rank(m, tol=1E-8, method='auto', mpc=0, qr=0):
 	"""Truncated-SVD pseudo-inverse and integer rank of a symmetric PSD matrix.
 
 	association.py:67-80 (2-D, method='scipy'): singular values below tol*largest are dropped;
-	rank = number kept; inverse = (Vh[:r].T / s[:r]) @ Vh[:r], transposed.
+	rank = number kept (at most mpc when mpc > 0, :78-79); inverse = (Vh[:r].T / s[:r]) @ Vh[:r], transposed.
+	method='sklearn', or 'auto' with mpc > 0 on a matrix larger than mpc (:52-63): the reference calls scikit-learn's
+	randomized_svd (third-party, absent from /root/reference; the version used for the fixtures is in tests/golden/meta.json)
+	with random_state=0, starting from min(mpc, n) components (n without a cap) and -- only without a cap -- doubling them
+	until the smallest kept singular value falls below the threshold (:81-98).
 	"""
 	m = np.asarray(m, dtype=np.float64)
 	if m.ndim != 2 or m.shape[0] != m.shape[1]:
 		raise ValueError('Wrong shape for m.')
 	if tol <= 0:
 		raise ValueError('tol must be positive.')
-	u, s, vh = np.linalg.svd(m)
 	n = m.shape[0]
-	r = int(n - np.searchsorted(s[::-1], tol * s[0]))
+	if method == 'auto':
+		method = 'scipy' if (n <= mpc or mpc == 0) else 'sklearn'
+	if method == 'scipy':
+		u, s, vh = np.linalg.svd(m)
+		r = int(n - np.searchsorted(s[::-1], tol * s[0]))
+	else:
+		from sklearn.utils.extmath import randomized_svd
+		k = min(mpc, n) if mpc > 0 else n
+		opt = dict(random_state=0)
+		if qr >= 1:
+			opt['power_iteration_normalizer'] = 'QR'
+		if qr > 1:
+			opt['n_iter'] = qr
+		while True:
+			u, s, vh = randomized_svd(m, k, **opt)
+			if k == n or s[-1] <= tol * s[0] or mpc > 0:
+				break
+			k += min(k, n - k)
+		r = int(k - np.searchsorted(s[::-1], tol * s[0]))
+	if mpc > 0:
+		r = min(r, mpc)
 	mi = np.matmul(vh[:r].T / s[:r], vh[:r]).T
 	return mi, r
 
@@ -140,48 +163,58 @@ def _pool_map(nth, tasks):
 		return pool.map(lambda t: t[0](*t[1], **t[2]), tasks)
 
 
-def _test4_block(vx, vy, prod, prody, prodyy, na, dimreduce=0, lowmem=False, tol=1E-8):
-	"""association.py:421-576 for dy is not None (the de path): per tested x, every other row of
-	[dx;dc] is a covariate; pseudo-inverse of their Gram matrix; Schur-style partial products."""
+def _test4_block(vx, vy, prod, prody, prodyy, na, dimreduce=0, lowmem=False, **ka):
+	"""association.py:421-576: per tested x, every other row of [dx;dc] is a covariate; pseudo-inverse of their Gram matrix
+	(ka: inv_rank options tol/method/mpc/qr, :527-528); Schur-style partial products.  prody None = dx tested against itself
+	(:489-498): pairs x < y only, neither of the two a covariate (:506-510,:524-525).  dimreduce: int or one value per y (:558)."""
 	nx, ny, nc, n, lenx = na
+	samexy = prody is None
+	if samexy:
+		prody = prod[:, vy:vy + ny]
+		prodyy = prod[np.arange(ny) + vy, np.arange(ny) + vy]
 	p = np.zeros((lenx, ny))
 	vxo = np.zeros((lenx, ))
 	vyo = np.zeros((lenx, ny))
 	gam = np.zeros((lenx, ny))
 	alpha = None if lowmem else np.zeros((lenx, ny, nc))
 	rank = np.zeros((lenx, ny), dtype=int)
-	for i in range(lenx):
-		t0 = [k for k in range(nx + nc) if k != vx + i]  # :523
+	if samexy:
+		todo = [(i, [j]) for i in range(lenx) for j in range(ny) if i + vx < j + vy]
+	else:
+		todo = [(i, np.arange(ny)) for i in range(lenx)]
+	for i, ys in todo:
+		t0 = [k for k in range(nx + nc) if k != vx + i and not (samexy and k == vy + ys[0])]  # :523-525
 		if len(t0) > 0:
-			t1i, r = inv_rank(prod[np.ix_(t0, t0)], tol=tol)  # :527-528
+			t1i, r = inv_rank(prod[np.ix_(t0, t0)], **ka)  # :527-528
 		else:
 			r = 0
-		rank[i] = r
+		rank[i, ys] = r
 		if r == 0:
 			dxx = prod[vx + i, vx + i] / n
-			dyy = prodyy / n
-			dxy = prody[vx + i] / n
+			dyy = prodyy[ys] / n
+			dxy = prody[vx + i, ys] / n
 		else:
 			ccx = np.matmul(prod[[vx + i], t0], t1i)
 			dxx = (prod[vx + i, vx + i] - float(np.matmul(ccx, prod[t0, [vx + i]]))) / n  # :539-540
-			ccy = np.matmul(prody[t0].T, t1i)
-			dyy = (prodyy - (ccy.T * prody[t0]).sum(axis=0)) / n  # :542
-			dxy = (prody[vx + i] - np.matmul(ccy, prod[t0, [vx + i]]).ravel()) / n  # :543-544
+			ccy = np.matmul(prody[t0][:, ys].T, t1i)
+			dyy = (prodyy[ys] - (ccy.T * prody[t0][:, ys]).sum(axis=0)) / n  # :542
+			dxy = (prody[vx + i, ys] - np.matmul(ccy, prod[t0, [vx + i]]).ravel()) / n  # :543-544
 		if dxx == 0:
 			dxx = 1
 		vxo[i] = dxx
-		vyo[i] = dyy
-		gam[i] = dxy / dxx
+		vyo[i, ys] = dyy
+		gam[i, ys] = dxy / dxx
 		if (not lowmem) and r > 0:
-			alpha[i] = (ccy[:, -nc:] - gam[i][:, None] * ccx[-nc:]) if nc > 0 else 0
-		p[i] = (dxy**2) / (dxx * dyy)
+			alpha[i, ys] = (ccy[:, -nc:] - gam[i, ys][:, None] * ccx[-nc:]) if nc > 0 else 0
+		p[i, ys] = (dxy**2) / (dxx * dyy)
 	assert (p >= 0).all() and (p <= 1 + 1E-8).all()
-	dof = n - 1 - rank - dimreduce
+	dof = n - 1 - rank - dimreduce  # :558 (an array dimreduce broadcasts over the y axis)
 	if (dof <= 0).any():
 		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
-	for i in range(lenx):
-		p[i] = pvalues(p[i], dof[i, 0])
-	return [vx, vy, p, gam, alpha, vxo, vyo]
+	for d in np.unique(dof):
+		sel = dof == d
+		p[sel] = pvalues(p[sel], d)
+	return [vx, vy, p, gam, alpha, None if samexy else vxo, vyo]
 
 
 def _test2_block(vx, vy, dx, dy, dc, sselectx, dimreduce=0, lowmem=False):
@@ -263,14 +296,18 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 			assert len(np.unique(dx[i, sel[i]])) > 1  # :917-918
 		tasks = [(_test2_block, (x[0], y[0], dx[x[0]:x[1]], dy[y[0]:y[1]], dc, sel[x[0]:x[1]]), ka0) for x, y in tiles]
 	else:
-		if samexy:
-			raise NotImplementedError('oracle: single=4 with dy=None not restated')
 		t1 = np.concatenate([dx, dc], axis=0).astype(np.float64)  # :935
 		prod = np.matmul(t1, t1.T)
-		prody = np.matmul(t1, dy.T.astype(np.float64))
-		prodyy = (dy.astype(np.float64)**2).sum(axis=1)
-		tasks = [(_test4_block, (x[0], y[0], prod, prody[:, y[0]:y[1]], prodyy[y[0]:y[1]], [nx, y[1] - y[0], nc, ns, x[1] - x[0]]), ka0)
-				 for x, y in tiles]
+		dr = ka0.pop('dimreduce', 0)
+		drs = (lambda y: dr[y[0]:y[1]]) if np.ndim(dr) else (lambda y: dr)
+		if samexy:  # :974-980: the Gram matrix alone; association_test_4 takes its y products from it
+			tasks = [(_test4_block, (x[0], y[0], prod, None, None, [nx, y[1] - y[0], nc, ns, x[1] - x[0]]), dict(ka0, dimreduce=drs(y)))
+					 for x, y in tiles]
+		else:
+			prody = np.matmul(t1, dy.T.astype(np.float64))
+			prodyy = (dy.astype(np.float64)**2).sum(axis=1)
+			tasks = [(_test4_block, (x[0], y[0], prod, prody[:, y[0]:y[1]], prodyy[y[0]:y[1]], [nx, y[1] - y[0], nc, ns, x[1] - x[0]]),
+					  dict(ka0, dimreduce=drs(y))) for x, y in tiles]
 	res = _pool_map(nth, tasks)
 	assert len(res) > 0
 	p = np.ones((nx, ny), dtype=dy.dtype)  # :1005
@@ -291,13 +328,17 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		else:
 			vary[i:i + r[6].shape[0], j:j + r[6].shape[1]] = r[6]
 	if samexy:
-		dot = (dot.T * vary).T  # :1039  coefficient -> covariance x~_i.x~_j/n
+		dot = (dot.T * vary).T if single == 0 else dot * vary  # :1039-1042  coefficient -> covariance x~_i.x~_j/n
 		p = np.triu(p, 1)
 		p = p + p.T  # :1050-1051  diagonals exactly 0
+		if single == 4:  # :1052-1055
+			vary = np.triu(vary, 1)
+			vary = vary + vary.T
+			vary[np.arange(ny), np.arange(ny)] = 1
 		dot = np.triu(dot, 1)
 		dot = dot + dot.T
 		if not return_dot:
-			dot = (dot.T / vary).T
+			dot = (dot.T / vary).T if single == 0 else dot / vary  # :1059-1064
 	elif return_dot:
 		dot = (dot.T * varx).T  # :1048
 	assert np.isfinite(p).all() and np.isfinite(dot).all() and np.isfinite(vary).all()

@@ -299,6 +299,40 @@ def g9():
 	save('G9_normvar', **out)
 
 
+def g10():
+	"""single=4 variants (association.py:421-576,926-980): dy=None (every pair given all other rows), one dimreduce value per
+	gene, a pseudo-inverse truncated to mpc principal components (scikit-learn randomized SVD, random_state=0); single=1 with
+	more covariates than the first device kernel accepted."""
+	import sklearn
+	rng = np.random.default_rng(10)
+	nx, ny, n = 12, 40, 400
+	dg = (rng.random((nx, n)) < 0.15).astype(np.float64)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dt = rng.normal(size=(ny, n)) + (rng.normal(size=(ny, 3)) @ dg[:3]) * 0.5
+	out = dict(dg=dg, dc=dc, dt=dt)
+	for rd in (True, False):
+		p, d, a, vx, vy = association_tests(dt[:14], None, dc, single=4, return_dot=rd)
+		assert a is None and vx is None
+		out.update({'sx_p_rd%d' % rd: p, 'sx_dot_rd%d' % rd: d, 'sx_vy_rd%d' % rd: vy})
+	dr = rng.integers(0, 3, ny)
+	p, g, a, vg, vt = norm.de(dg, dt, dc, single=4, dimreduce=dr)
+	out.update(dr=dr, dr_p=p, dr_gamma=g, dr_varg=vg, dr_vart=vt)
+	p, g, a, vg, vt = norm.de(dg, dt, dc, single=4, mpc=5, lowmem=False)
+	out.update(mpc_p=p, mpc_gamma=g, mpc_alpha=a, mpc_varg=vg, mpc_vart=vt)
+	dcd = np.vstack([dc, dc[0] - 2 * dc[1]])  # rank-deficient covariates: the reference's per-grouping pseudo-inverses
+	p, g, a, vg, vt = norm.de(dg, dt, dcd, single=4, dimreduce=dr)
+	out.update(rdd_dc=dcd, rdd_p=p, rdd_gamma=g, rdd_varg=vg, rdd_vart=vt)
+	dg1 = np.zeros((5, n))
+	lab = rng.integers(0, 8, n)
+	for i in range(5):
+		dg1[i, lab == i] = 1
+	dcm = np.vstack([rng.normal(size=(39, n)), np.ones((1, n))])
+	p, g, a, vg, vt = norm.de(dg1, dt[:16], dcm, single=1, lowmem=False)
+	out.update(s1c_dg=dg1, s1c_dc=dcm, s1c_p=p, s1c_gamma=g, s1c_alpha=a, s1c_varg=vg, s1c_vart=vt)
+	save('G10_single4', **out)
+	return sklearn.__version__
+
+
 def main():
 	g1()
 	g2()
@@ -309,7 +343,8 @@ def main():
 	g7()
 	g8()
 	g9()
-	meta = dict(reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
+	skl = g10()
+	meta = dict(sklearn=skl, reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:
 		json.dump(meta, f, indent=1)

@@ -288,3 +288,44 @@ def test_bench_default_line_carries_the_other_configs():
 	for k, v in ex.items():
 		assert 'error' not in v, (k, v)
 		assert v['value'] > 0 and v['ms_per_step'] > 0 and 0 < v['roofline']['frac'] < 1.2
+
+
+def test_single4_variants_golden_and_oracle(golden, norm):
+	"""single=4 to the reference's contract (association.py:421-576,926-980): dy=None (closed form from the inverse Gram
+	matrix), one dimreduce per gene, mpc-truncated pseudo-inverses and rank-deficient covariates (the reference's
+	per-grouping algorithm on device-computed Gram matrices) -- golden G10 and a larger seeded case against the oracle."""
+	from normalisr_amd.association import association_tests
+	g = golden('G10_single4')
+	dg, dc, dt = g['dg'], g['dc'], g['dt']
+	for rd in (1, 0):
+		p, d, a, vx, vy = association_tests(dt[:14], None, dc, single=4, return_dot=bool(rd))
+		assert a is None and vx is None and p.shape == (14, 14)
+		assert p_close(p, g['sx_p_rd%d' % rd]) and close(d, g['sx_dot_rd%d' % rd], floor=1e-12) and close(vy, g['sx_vy_rd%d' % rd], 1e-9)
+		assert (np.diag(p) == 0).all() and (p == p.T).all() and (d == d.T).all() and (np.diag(vy) == 1).all()
+	p, gam, a, vg, vt = norm.de(dg, dt, dc, single=4, dimreduce=g['dr'])
+	assert p_close(p, g['dr_p']) and close(gam, g['dr_gamma'], floor=1e-12) and close(vg, g['dr_varg'], 1e-9) and close(vt, g['dr_vart'], 1e-9)
+	p, gam, a, vg, vt = norm.de(dg, dt, dc, single=4, mpc=5, lowmem=False)
+	assert p_close(p, g['mpc_p']) and close(gam, g['mpc_gamma'], floor=1e-12) and close(a, g['mpc_alpha'], floor=1e-9)
+	assert close(vg, g['mpc_varg'], 1e-9) and close(vt, g['mpc_vart'], 1e-9)
+	p, gam, a, vg, vt = norm.de(dg, dt, g['rdd_dc'], single=4, dimreduce=g['dr'])
+	assert p_close(p, g['rdd_p']) and close(gam, g['rdd_gamma'], floor=1e-12) and close(vt, g['rdd_vart'], 1e-9)
+	# larger dy=None case: 150 genes given each other and 3 covariates, per-gene dimreduce on the closed form
+	rng = np.random.default_rng(1010)
+	n, ng = 900, 150
+	dx = rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))
+	dc2 = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	p, d, a, vx, vy = association_tests(dx, None, dc2, single=4)
+	po, do, ao, vxo, vyo = oracle.association_tests(dx[:40], None, dc2, single=4)
+	p40, d40, a40, vx40, vy40 = association_tests(dx[:40], None, dc2, single=4)
+	assert p_close(p40, po) and close(d40, do, floor=1e-12) and close(vy40, vyo, 1e-9)
+	assert p.shape == (ng, ng) and (p == p.T).all() and np.isfinite(d).all() and p.max() <= 1 and p[0, 1] != p40[0, 1]
+	with pytest.raises(NotImplementedError):
+		association_tests(dx[:10], None, dc2, single=4, lowmem=False)
+
+
+def test_single1_many_covariates(golden, norm):
+	"""single=1 with 40 covariates (golden G10 s1c_*): the device sweep loops over the covariates, nothing caps them."""
+	g = golden('G10_single4')
+	p, gam, a, vg, vt = norm.de(g['s1c_dg'], g['dt'][:16], g['s1c_dc'], single=1, lowmem=False)
+	assert p_close(p, g['s1c_p']) and close(gam, g['s1c_gamma'], floor=1e-12) and close(a, g['s1c_alpha'], floor=1e-9)
+	assert close(vg, g['s1c_varg'], 1e-9) and close(vt, g['s1c_vart'], 1e-9)

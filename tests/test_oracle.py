@@ -152,3 +152,24 @@ def test_normvar(golden):
 	assert relerr(r[0], g['b_dtn'], 1e-12) < 1e-9 and np.array_equal(r[1], g['b_dcn']) and np.array_equal(r[2], g['b_dex'])
 	r = oracle.normvar(dt, dc, w, wt, cat=0)
 	assert relerr(r[0], g['c_dtn'], 1e-12) < 1e-9 and np.array_equal(r[1], g['c_dcn'])
+
+
+def test_single4_variants_golden(golden):
+	"""G10: single=4 with dy=None (pairs given all other rows), one dimreduce per gene, a pseudo-inverse truncated to mpc
+	components (scikit-learn randomized SVD, as the reference), rank-deficient covariates; single=1 with 40 covariates."""
+	g = golden('G10_single4')
+	dg, dc, dt = g['dg'], g['dc'], g['dt']
+	for rd in (1, 0):
+		p, d, a, vx, vy = oracle.association_tests(dt[:14], None, dc, single=4, return_dot=bool(rd))
+		assert a is None and vx is None
+		assert relerr(p, g['sx_p_rd%d' % rd], 1e-300) < 1e-8 and relerr(d, g['sx_dot_rd%d' % rd], 1e-12) < 1e-8
+		assert relerr(vy, g['sx_vy_rd%d' % rd]) < 1e-10 and (np.diag(p) == 0).all() and (p == p.T).all()
+	p, gam, a, vg, vt = oracle.de(dg, dt, dc, single=4, dimreduce=g['dr'])
+	assert relerr(p, g['dr_p']) < 1e-8 and relerr(gam, g['dr_gamma'], 1e-12) < 1e-8 and relerr(vt, g['dr_vart']) < 1e-10
+	p, gam, a, vg, vt = oracle.de(dg, dt, dc, single=4, mpc=5, lowmem=False)
+	assert relerr(p, g['mpc_p']) < 1e-8 and relerr(gam, g['mpc_gamma'], 1e-12) < 1e-8 and relerr(a, g['mpc_alpha'], 1e-10) < 1e-8
+	assert relerr(vg, g['mpc_varg']) < 1e-10 and relerr(vt, g['mpc_vart']) < 1e-10
+	p, gam, a, vg, vt = oracle.de(dg, dt, g['rdd_dc'], single=4, dimreduce=g['dr'])
+	assert relerr(p, g['rdd_p']) < 1e-8 and relerr(gam, g['rdd_gamma'], 1e-12) < 1e-8 and relerr(vt, g['rdd_vart']) < 1e-10
+	p, gam, a, vg, vt = oracle.de(g['s1c_dg'], dt[:16], g['s1c_dc'], single=1, lowmem=False)
+	assert relerr(p, g['s1c_p']) < 1e-8 and relerr(gam, g['s1c_gamma'], 1e-12) < 1e-8 and relerr(a, g['s1c_alpha'], 1e-10) < 1e-8
