@@ -36,6 +36,30 @@ if ROOT not in sys.path:
 
 PMC_FILES = [os.path.join(ROOT, 'profiles', f) for f in ('r02_pmc_c2.json', 'r01_pmc_c2.json')]  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
 F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (= 1/2 of the 157.3 TF fp32 matrix peak of MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TFLOPS = 157.3  # the roofline BASELINE.json's north_star names
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, matrix cores): 2 x 2.5 PF
+
+
+def gram_roofline(n_cells, flops, gram_ms, rows_pad, k_pad):
+	"""Roofline entry of the dominant kernel (K2).  `achieved` is ALGORITHMIC work (2 n_cell flop per test) over the
+	kernel's measured duration.  The integer engine (>= 2048 cells) spends nslices (nslices + 1) / 2 int8 multiply-adds per
+	fp64-equivalent one, so its peak is the dense int8 MFMA peak divided by that count; the fp64 kernel is priced against the
+	fp64 MFMA peak.  Both are also shown against the fp32 MFMA peak the north star names."""
+	from normalisr_amd.engine import Engine
+	ns = Engine.gram_slices(n_cells)
+	achieved = flops / (gram_ms * 1e-3) / 1e12
+	if ns:
+		pairs = ns * (ns + 1) // 2
+		peak = I8_MFMA_PEAK_TOPS / pairs
+		kern, note = 'k_gram_i8', ('exact fixed-point contraction: {}-bit operands in {} int8 digit planes, {} digit products per multiply-add on '
+								   'v_mfma_i32_32x32x32_i8, int32 accumulation, fp64 combine; peak = {:.0f} TOP/s dense int8 MFMA / {}').format(
+									   8 * ns - 2, ns, pairs, I8_MFMA_PEAK_TOPS, pairs)
+		abytes = float(2 * ns) * rows_pad * k_pad  # both operand panels, one byte per digit
+	else:
+		peak, kern, note, abytes = F64_MFMA_PEAK_TFLOPS, 'k_gram_f64', 'fp64 matrix cores (v_mfma_f64_16x16x4_f64)', 16.0 * rows_pad * k_pad
+	return dict(bound='mfma', kernel=kern, achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=None,
+				algorithmic_bytes=abytes, kernel_ms=gram_ms, arithmetic=note, int8_tops_executed=(achieved * (ns * (ns + 1) // 2) if ns else None),
+				frac_of_fp64_mfma_peak=achieved / F64_MFMA_PEAK_TFLOPS, frac_of_fp32_mfma_peak=achieved / F32_MFMA_PEAK_TFLOPS)
 HBM_PEAK_GBS = 8000.0
 C5_ROWS_PER_RANK = 3750  # configs[4]: 30 000 genes over 8 GPUs
 C5_CELLS = 500000
@@ -90,6 +114,13 @@ def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0):
 	r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(ng), str(n_cells), str(nc), str(seed), str(min_seconds)],
 					   env=env, stdout=subprocess.PIPE, text=True, timeout=600)
 	return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def ARITH(n_cells):
+	"""`dtype` of the JSON line: the arithmetic the dominant kernel computes in."""
+	from normalisr_amd.engine import Engine
+	ns = Engine.gram_slices(n_cells)
+	return 'i8 digits x i8 -> i32 exact, {}-bit fixed point, f64 combine (f64 residuals, sums of squares and P-values)'.format(8 * ns - 2) if ns else 'f64'
 
 
 def self_launch(args):
@@ -188,16 +219,14 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 	tests = ng * (ng - 1) // 2
 	gram_ms = plan.gram_ms()  # average duration of the dominant kernel launch(es) per step on this rank
 	flops = 2.0 * n * plan.local_pair_count()  # algorithmic: 2 n_cell flop per test, tests this rank's launches cover
-	achieved = flops / (gram_ms * 1e-3) / 1e12
 	esz = 4 if dtype == torch.float32 else 8
 	out = dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
-			   scaling='weak', dtype='f64',
+			   scaling='weak', dtype=ARITH(n),
 			   config=dict(workload=label.format(genes=ng, cells=n), genes=ng, cells=n, covariates=3, tests_per_step=tests,
 						   parallelism='gene-row blocks x{}'.format(world), exchange=None if world == 1 else (
 							   'all-gather of raw fp32 blocks' if plan.exchange_raw else 'all-gather of fp64 residual blocks'),
 						   exchange_bytes_per_rank=None if world == 1 else int((world - 1) * rows_local * n * (esz if plan.exchange_raw else 8))),
-			   roofline=dict(bound='mfma', kernel='k_gram_f64', achieved=achieved, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-							 frac=achieved / F64_MFMA_PEAK_TFLOPS, traffic=None, algorithmic_bytes=8.0 * plan.rows_pad * plan.k_pad, kernel_ms=gram_ms),
+			   roofline=gram_roofline(n, flops, gram_ms, plan.rows_pad, plan.k_pad),
 			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region')
 	return out, plan
 
@@ -230,11 +259,11 @@ def bench_de(rk, nd, steps, warmup, which, covariates=20):
 		roof = dict(bound='hbm', kernel='k_gram_skinny + sweep (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
 					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms)
 	else:
-		fl = 2.0 * n * nx * ny_local
-		roof = dict(bound='mfma', kernel='k_gram_f64 (whole step: K1 + K2 + K3)', achieved=fl / (ms * 1e-3) / 1e12, peak=F64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-					frac=fl / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, traffic=None, kernel_ms=ms)
+		roof = gram_roofline(n, 2.0 * n * nx * ny_local, ms, 0, 0)
+		roof['kernel'] += ' (whole step: K1 + quantise + K2 + K3)'
+		roof['algorithmic_bytes'] = None
 	return dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
-				scaling='strong', dtype='f64',
+				scaling='strong', dtype='f64' if plan.streaming() else ARITH(n),
 				config=dict(workload='norm.de {} x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[{}])'.format(
 					nx, ny, n, nc, 2 if which == 'de_c3' else 3), parallelism='gene rows of Y x{}, no collective'.format(world)), roofline=roof)
 
@@ -310,7 +339,7 @@ def main():
 				for f in PMC_FILES:
 					try:
 						with open(f) as fh:
-							out['roofline']['traffic'] = json.load(fh)['k_gram_f64']['hbm_bytes_per_launch']
+							out['roofline']['traffic'] = json.load(fh)[out['roofline']['kernel']]['hbm_bytes_per_launch']
 						out['roofline']['traffic_unit'] = 'bytes/launch'
 						out['roofline']['traffic_source'] = '{} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(os.path.relpath(f, ROOT))
 						break

@@ -74,6 +74,15 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
 					double* d_out, int64_t ldo, int64_t rows_pad,
 					double* d_ss, double* d_coef, void* stream);
 
+/* K1 with fixed-point output for the integer Gram engine (see nrm_quantize_rows below): the residuals are rounded and cut into
+ * digit planes inside K1 (a second sweep over the rows, which are in L2 by then), so the fp64 residuals need not travel through
+ * HBM at all: d_out may be NULL.  Needs 16-byte aligned rows and rows_pad % NRM_ROW_TILE == 0; d_q holds
+ * nrm_quant_bytes(rows_pad, round_up(n, 16), nslices) bytes, d_exp rows_pad int32. */
+int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
+					  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
+					  double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
+					  int nslices, void* d_q, int32_t* d_exp, void* stream);
+
 /*
  * K2 -- Gram contraction dot[i,j] = sum_k A[i,k] B[j,k] on the fp64 matrix cores
  * (v_mfma_f64_16x16x4_f64, 128x128 workgroup tiles staged through LDS).
@@ -98,6 +107,22 @@ int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m_pad, int64
 /* Size of the device scratch nrm_gram_f64 needs in d_work (partial tiles of the stream-K tail; summed in a fixed
  * order, so results are bitwise reproducible).  Independent of the problem size. */
 int64_t nrm_gram_workspace_bytes(void);
+
+/*
+ * K2, integer engine -- the same contraction computed EXACTLY on the int8 matrix cores from fixed-point operands
+ * (csrc/nrm_gram_i8.hip): every row is scaled by a power of two, rounded once to 8 * nslices - 2 bits (nslices = 6: 46 bits,
+ * 1.4e-14 of the row's largest entry; 5: 38 bits) and cut into nslices balanced base-256 digits; the digit products are
+ * accumulated in int32 without rounding and combined in fp64.  About 2.5x (6 slices) / 3.4x (5) the rate of the fp64 kernel.
+ *   nrm_quantize_rows: d_x (rows_pad, ldx) fp64 rows as written by nrm_residualize (rows_pad % NRM_ROW_TILE == 0, k_pad % 16 == 0,
+ *       zero padded) -> d_q (nrm_quant_bytes() bytes: digit planes in the kernel's tiled layout) and d_exp (rows_pad) int32 with
+ *       x = q * 2^exp.
+ *   nrm_gram_i8_band: as nrm_gram_f64_band with quantised operands (d_qb == d_qa, d_eb == d_ea for symmetric problems).
+ */
+int64_t nrm_quant_bytes(int64_t rows_pad, int64_t k_pad, int nslices);
+int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_t ldx, int nslices, void* d_q, int32_t* d_exp, void* stream);
+int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, const void* d_qb, const int32_t* d_eb, int64_t m_pad, int64_t n_pad,
+					 int64_t k_pad, int nslices, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0,
+					 int64_t row1, void* d_work, void* stream);
 
 /*
  * P-value plan: host-side constants of p = I_{1-R^2}(dof/2, 1/2) for one dof

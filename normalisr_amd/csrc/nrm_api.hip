@@ -2,6 +2,7 @@
 // (numpy buffers in, numpy buffers out) that stands where association_tests() does
 // (association.py:761-771,1093) for single=0.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <algorithm>
@@ -261,23 +262,49 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	}
 	const bool want_alpha = h_alpha != nullptr && nc > 0;
 	NRM_REQUIRE(!(want_alpha && samexy), "alpha is not provided for dy == NULL (meaningless in the reference, association.py:1066-1068)");
+	// K2 engine as in the Python host (NRM_GRAM): exact fixed-point contraction on the int8 matrix cores (6 slices = 46 bits; i8x5: 5
+	// slices = 38 bits), or the fp64 matrix-core kernel (f64).  With the integer engine K1 writes the digit planes itself and the
+	// fp64 residuals are never stored.
+	int nslices = 6;
+	if (n < 2048) nslices = 0;  // small problems stay on the fp64 kernel (the integer engine's error in r grows as 1/sqrt(n))
+	else if (const char* g = getenv("NRM_GRAM")) {
+		if (!strcmp(g, "f64")) nslices = 0;
+		else if (!strcmp(g, "i8x5")) nslices = 5;
+		else NRM_REQUIRE(!strcmp(g, "i8"), "NRM_GRAM must be i8, i8x5 or f64");
+	}
+	if (nslices && (n % 4 != 0)) nslices = 0;  // K1's fused quantiser needs 16-byte aligned rows of the (unpadded) host matrices
+	DevBuf qx, qy, ex, ey;
 	NRM_TRY(dx.alloc((size_t)nx * n * esize(x_dtype)));
 	NRM_HIP(hipMemcpy(dx.p, h_dx, (size_t)nx * n * esize(x_dtype), hipMemcpyHostToDevice));
-	NRM_TRY(rx.alloc((size_t)mp * kp * 8));
 	NRM_TRY(ssx.alloc((size_t)mp * 8));
 	if (want_alpha) NRM_TRY(bx.alloc((size_t)nx * nc * 8));
 	if (want_alpha) NRM_HIP(hipMemsetAsync(bx.p, 0, (size_t)nx * nc * 8, st));
-	NRM_TRY(nrm_residualize(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, rx.as<double>(), kp, mp,
-							ssx.as<double>(), want_alpha ? bx.as<double>() : nullptr, st));
+	if (nslices) {
+		NRM_TRY(qx.alloc((size_t)nrm_quant_bytes(mp, kp, nslices)));
+		NRM_TRY(ex.alloc((size_t)mp * 4));
+		NRM_TRY(nrm_residualize_q(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, mp, ssx.as<double>(),
+								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), st));
+	} else {
+		NRM_TRY(rx.alloc((size_t)mp * kp * 8));
+		NRM_TRY(nrm_residualize(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, rx.as<double>(), kp, mp,
+								ssx.as<double>(), want_alpha ? bx.as<double>() : nullptr, st));
+	}
 	if (!samexy) {
 		NRM_TRY(dy.alloc((size_t)ny * n * esize(y_dtype)));
 		NRM_HIP(hipMemcpy(dy.p, h_dy, (size_t)ny * n * esize(y_dtype), hipMemcpyHostToDevice));
-		NRM_TRY(ry.alloc((size_t)np_ * kp * 8));
 		NRM_TRY(ssy.alloc((size_t)np_ * 8));
 		if (want_alpha) NRM_TRY(by.alloc((size_t)ny * nc * 8));
 		if (want_alpha) NRM_HIP(hipMemsetAsync(by.p, 0, (size_t)ny * nc * 8, st));
-		NRM_TRY(nrm_residualize(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, ry.as<double>(), kp, np_,
-								ssy.as<double>(), want_alpha ? by.as<double>() : nullptr, st));
+		if (nslices) {
+			NRM_TRY(qy.alloc((size_t)nrm_quant_bytes(np_, kp, nslices)));
+			NRM_TRY(ey.alloc((size_t)np_ * 4));
+			NRM_TRY(nrm_residualize_q(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, np_, ssy.as<double>(),
+									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), st));
+		} else {
+			NRM_TRY(ry.alloc((size_t)np_ * kp * 8));
+			NRM_TRY(nrm_residualize(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, ry.as<double>(), kp, np_,
+									ssy.as<double>(), want_alpha ? by.as<double>() : nullptr, st));
+		}
 	}
 	const double* A = rx.as<double>();
 	const double* B = samexy ? A : ry.as<double>();
@@ -307,7 +334,11 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	NRM_HIP(hipStreamCreateWithFlags(&cs.s, hipStreamNonBlocking));
 	for (int64_t a = 0; a < nx; a += band) {
 		const int64_t b = std::min(nx, a + band);
-		NRM_TRY(nrm_gram_f64_band(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, a, b == nx ? mp : b, gwork.p, st));
+		if (nslices)
+			NRM_TRY(nrm_gram_i8_band(qx.p, ex.as<int32_t>(), samexy ? qx.p : qy.p, samexy ? ex.as<int32_t>() : ey.as<int32_t>(), mp, np_, kp, nslices,
+									 dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, a, b == nx ? mp : b, gwork.p, st));
+		else
+			NRM_TRY(nrm_gram_f64_band(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, a, b == nx ? mp : b, gwork.p, st));
 		NRM_TRY(nrm_assoc_sweep_band(dot.as<double>(), np_, sx, sy, nx, ny, n, dof, samexy ? 1 : 0, stat_kind, op.p, ostat.p,
 									 h_r ? orr.p : nullptr, h_t ? ot.p : nullptr, out_dtype, ny, flags.as<int32_t>(), a, b, st));
 		hipEvent_t ev;

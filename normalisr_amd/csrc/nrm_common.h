@@ -26,6 +26,12 @@ void nrm_set_error(const char* fmt, ...);
 		}                           \
 	} while (0)
 
+#define NRM_TRY_RC(call)     \
+	do {                     \
+		int rc_ = (call);    \
+		if (rc_) return rc_; \
+	} while (0)
+
 static inline int nrm_check_launch(const char* what) {
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {

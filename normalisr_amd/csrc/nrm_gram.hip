@@ -27,54 +27,9 @@
 // not cover the whole K range are written to workspace slabs and summed per tile in a fixed order by a small
 // fix-up kernel (deterministic: no atomics).
 // Symmetric (coex) launches only enumerate tiles on or above the block diagonal (association.py:893-894).
-#include <algorithm>
-#include "nrm_common.h"
+#include "nrm_gram_sched.h"
 
-#define GM 128
-#define GN 128
 #define GK 16
-
-typedef double d2_t __attribute__((ext_vector_type(2)));
-
-// Tile order: the tile grid is cut into 8x8 super-blocks that are visited one after another (row-major
-// inside a super-block).  64 consecutive tiles -- what the 64 co-resident workgroups of one XCD process at
-// the same time -- therefore touch 8 A panels and 8 B panels instead of 1 + 64, and those slabs are shared
-// through the XCD's L2 while the workgroups advance through K in lockstep.  Symmetric launches keep only
-// super-blocks and tiles on or above the diagonal (association.py:893-894).
-#define GSB 8
-__device__ __forceinline__ void gram_tile_coords(int t, int symmetric, int ntm, int ntn, int& ti, int& tj) {
-	const int nbm = (ntm + GSB - 1) / GSB, nbn = (ntn + GSB - 1) / GSB;
-	for (int bi = 0; bi < nbm; bi++) {
-		const int h = min(GSB, ntm - bi * GSB);
-		for (int bj = symmetric ? bi : 0; bj < nbn; bj++) {
-			const int w = min(GSB, ntn - bj * GSB);
-			const bool diag = symmetric && bi == bj;
-			const int cnt = diag ? h * (h + 1) / 2 : h * w;
-			if (t < cnt) {
-				int li, lj;
-				if (!diag) {
-					li = t / w;
-					lj = t - li * w;
-				} else {
-					li = 0;
-					int len = h;
-					while (t >= len) {
-						t -= len;
-						li++;
-						len--;
-					}
-					lj = li + t;
-				}
-				ti = bi * GSB + li;
-				tj = bj * GSB + lj;
-				return;
-			}
-			t -= cnt;
-		}
-	}
-	ti = 0;
-	tj = 0;
-}
 
 // One tile piece: k-tiles [kt0, kt1) of tile (ti, tj).  slab != null -> partial piece, stored to its workspace slab.
 __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const double* __restrict__ B, int64_t lda, int64_t ldb,
@@ -184,60 +139,10 @@ __device__ __forceinline__ void gram_piece(const double* __restrict__ A, const d
 				if (slab || (need & (1u << (i * 4 + j)))) cbase[(int64_t)(i * 16 + lg + 4 * q) * pitch + j * 16 + l15] = acc[i][j][q];
 }
 
-struct GramSched {
-	int m_rows, n_rows;  // valid (unpadded) rows of A and B
-	int ntm, ntn;   // tile grid (M, N)
-	int nkt;        // k-tiles (slabs of GK cells)
-	int tiles_dp;   // tiles processed whole, one per workgroup per wave
-	int tiles_al;   // tiles cut into `parts` equal K ranges, one range per workgroup (K-aligned: slabs still shared in L2)
-	int parts;
-	int tiles_sk;   // tiles of the tail, cut into unit ranges
-	int units_per_wg;
-	int nwg;        // persistent workgroups (multiple of 8)
-	int tile0;      // first tile of this launch in the gram_tile_coords order (band launches)
-	double* work;   // slabs of partial pieces: [tiles_al*parts] then [2 per workgroup]
-};
-
 __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ A, const double* __restrict__ B, int64_t lda,
 													  int64_t ldb, double* __restrict__ C, int64_t ldc, int symmetric, GramSched s) {
 	__shared__ __attribute__((aligned(16))) double lds[2 * 2 * GM * GK];
-	// workgroups that share an XCD (same blockIdx % 8) take consecutive tiles so that operand panels are shared in its L2
-	const int per_xcd = s.nwg >> 3;
-	const int p = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-	int t_dp = p;
-	bool al_todo = p < s.tiles_al * s.parts;
-	int64_t u = (int64_t)p * s.units_per_wg;
-	const int64_t total = (int64_t)s.tiles_sk * s.nkt;
-	int64_t uend = u + s.units_per_wg;
-	if (uend > total) uend = total;
-	int sk_piece = 0;
-	for (;;) {  // one call site for gram_piece: whole tiles first, then this workgroup's share of the tail
-		int t, k0, k1;
-		double* slab = nullptr;
-		if (t_dp < s.tiles_dp) {
-			t = t_dp;
-			k0 = 0;
-			k1 = s.nkt;
-			t_dp += s.nwg;
-		} else if (al_todo) {
-			al_todo = false;
-			const int ta = p / s.parts, part = p - ta * s.parts;
-			t = s.tiles_dp + ta;
-			k0 = (int)((int64_t)s.nkt * part / s.parts);
-			k1 = (int)((int64_t)s.nkt * (part + 1) / s.parts);
-			slab = s.work + (int64_t)p * (GM * GN);
-		} else if (u < uend) {
-			const int ts = (int)(u / s.nkt);
-			k0 = (int)(u - (int64_t)ts * s.nkt);
-			int64_t k1l = k0 + (uend - u);
-			k1 = k1l > s.nkt ? s.nkt : (int)k1l;
-			t = s.tiles_dp + s.tiles_al + ts;
-			u += k1 - k0;
-			if (!(k0 == 0 && k1 == s.nkt)) slab = s.work + ((int64_t)s.tiles_al * s.parts + 2 * p + sk_piece) * (GM * GN);
-			sk_piece++;
-		} else {
-			break;
-		}
+	gram_for_each_piece(s, [&](int t, int k0, int k1, double* slab) {
 		int ti, tj;
 		gram_tile_coords(s.tile0 + t, symmetric, s.ntm, s.ntn, ti, tj);
 		// which of this wave's 4x4 sub-blocks are wanted: rows/columns inside the matrix and, on diagonal tiles of a
@@ -255,50 +160,7 @@ __global__ void __launch_bounds__(256, 2) k_gram_f64(const double* __restrict__ 
 			need = __builtin_amdgcn_readfirstlane(need);
 		}
 		gram_piece(A, B, lda, ldb, C, ldc, ti, tj, k0, k1, slab, need, lds);
-	}
-}
-
-// Adds the slabs of every split tile in a fixed order and writes the tile of C.  One workgroup per split tile.
-__global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int64_t ldc, int symmetric, GramSched s) {
-	const int b = blockIdx.x;
-	int ti, tj;
-	int first, count;       // slab range (aligned tiles) or workgroup range (stream-K tiles)
-	int sk_first_local = 0;
-	const double* base;
-	if (b < s.tiles_al) {
-		gram_tile_coords(s.tile0 + s.tiles_dp + b, symmetric, s.ntm, s.ntn, ti, tj);
-		base = s.work + (int64_t)b * s.parts * (GM * GN);
-		first = 0;
-		count = s.parts;
-	} else {
-		const int ts = b - s.tiles_al;
-		gram_tile_coords(s.tile0 + s.tiles_dp + s.tiles_al + ts, symmetric, s.ntm, s.ntn, ti, tj);
-		const int64_t u0 = (int64_t)ts * s.nkt, u1 = u0 + s.nkt;
-		first = (int)(u0 / s.units_per_wg);
-		int last = (int)((u1 - 1) / s.units_per_wg);
-		if (last > s.nwg - 1) last = s.nwg - 1;
-		count = last - first + 1;
-		if (count == 1 && (int64_t)first * s.units_per_wg <= u0 && (int64_t)(first + 1) * s.units_per_wg >= u1) return;  // stored whole
-		base = s.work + (int64_t)s.tiles_al * s.parts * (GM * GN);
-		sk_first_local = ((int64_t)first * s.units_per_wg / s.nkt) == ts ? 0 : 1;
-	}
-	// blockIdx.y selects 16 of the tile's 128 rows: 8 workgroups per tile keep enough loads in flight
-	double* ct = C + (int64_t)ti * GM * ldc + (int64_t)tj * GN;
-	const int e0 = blockIdx.y * (16 * GN);
-	for (int e = e0 + threadIdx.x * 2; e < e0 + 16 * GN; e += 512) {
-		d2_t acc = (d2_t){0.0, 0.0};
-		if (b < s.tiles_al) {
-			for (int q = 0; q < count; q++) acc += *reinterpret_cast<const d2_t*>(base + (int64_t)q * (GM * GN) + e);
-		} else {
-			// a workgroup's first stream-K piece lies in tile floor(p U / nkt), a second piece (if any) in the next tile:
-			// only the first contributor of this tile can be on its second piece
-			const double* src = base + ((int64_t)2 * first + sk_first_local) * (GM * GN) + e;
-			acc = *reinterpret_cast<const d2_t*>(src);
-			src += (int64_t)(2 - sk_first_local) * (GM * GN);
-			for (int q = 1; q < count; q++, src += 2 * (GM * GN)) acc += *reinterpret_cast<const d2_t*>(src);
-		}
-		*reinterpret_cast<d2_t*>(ct + (int64_t)(e / GN) * ldc + (e % GN)) = acc;
-	}
+	});
 }
 
 static int g_num_cu = 0;
@@ -311,20 +173,6 @@ extern "C" int64_t nrm_gram_workspace_bytes(void) {
 	}
 	// at most nwg/2 aligned tiles x 2 parts (= nwg slabs for any parts) plus two stream-K slabs per workgroup
 	return (int64_t)3 * (2 * g_num_cu) * GM * GN * (int64_t)sizeof(double);
-}
-
-// Tiles that precede super-block row `bi` in the gram_tile_coords order.
-static int64_t gram_tiles_before(int64_t bi, int symmetric, int64_t ntm, int64_t ntn) {
-	const int64_t nbn = (ntn + GSB - 1) / GSB;
-	int64_t t = 0;
-	for (int64_t b = 0; b < bi; b++) {
-		const int64_t h = std::min<int64_t>(GSB, ntm - b * GSB);
-		for (int64_t bj = symmetric ? b : 0; bj < nbn; bj++) {
-			const int64_t w = std::min<int64_t>(GSB, ntn - bj * GSB);
-			t += (symmetric && b == bj) ? h * (h + 1) / 2 : h * w;
-		}
-	}
-	return t;
 }
 
 extern "C" int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,
@@ -356,43 +204,11 @@ extern "C" int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m
 		NRM_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
 		if (g_num_cu <= 0) g_num_cu = 256;
 	}
-	const int64_t ntm = m_pad / GM, ntn = n_pad / GN;
-	NRM_REQUIRE((symmetric ? ntn * (ntn + 1) / 2 : ntm * ntn) < (1LL << 30), "nrm_gram_f64: problem too large for one launch");
-	const int64_t tile0 = gram_tiles_before(row0 / (GSB * GM), symmetric, ntm, ntn);
-	const int64_t tiles = gram_tiles_before((row1 + GSB * GM - 1) / (GSB * GM), symmetric, ntm, ntn) - tile0;
-	NRM_REQUIRE(tiles < (1LL << 30) && k_pad / GK < (1LL << 30), "nrm_gram_f64: problem too large for one launch");
-	GramSched s;
-	s.tile0 = (int)tile0;
-	s.m_rows = (int)((m_rows > 0 && m_rows < m_pad) ? m_rows : m_pad);
-	s.n_rows = (int)((n_rows > 0 && n_rows < n_pad) ? n_rows : n_pad);
-	s.ntm = (int)ntm;
-	s.ntn = (int)ntn;
-	s.nkt = (int)(k_pad / GK);
-	s.nwg = 2 * g_num_cu;
-	s.nwg -= s.nwg % 8;
-	// three phases, every workgroup does the same amount of work in each:
-	//  1. whole tiles, one per workgroup per wave (K-lockstep, plain stores);
-	//  2. of the remaining rem < nwg tiles, nwg/parts tiles are cut into `parts` equal K ranges (still K-aligned within a
-	//     part, so workgroups of an XCD keep sharing slabs through L2);
-	//  3. the rest is cut into equal unit ranges (stream-K; different K offsets, no sharing -- kept small).
-	const int64_t waves = tiles / s.nwg, rem = tiles - waves * s.nwg;
-	s.tiles_dp = (int)(waves * s.nwg);
-	s.parts = 1;
-	s.tiles_al = 0;
-	for (int parts = 2; parts <= 8 && s.nkt >= 8 * parts; parts *= 2)
-		if (rem >= s.nwg / parts) {
-			s.parts = parts;
-			s.tiles_al = s.nwg / parts;
-			break;
-		}
-	int64_t sk = rem - s.tiles_al;
-	s.tiles_sk = (int)sk;
-	const int64_t units = sk * s.nkt;
-	s.units_per_wg = (int)((units + s.nwg - 1) / s.nwg);
 	NRM_REQUIRE(d_work != nullptr, "nrm_gram_f64: workspace of nrm_gram_workspace_bytes() bytes required");
-	s.work = (double*)d_work;
+	GramSched s;
+	NRM_TRY_RC(gram_plan(s, m_pad, n_pad, k_pad / GK, symmetric, m_rows, n_rows, row0, row1, 2 * g_num_cu, (double*)d_work));
 	hipLaunchKernelGGL(k_gram_f64, dim3((unsigned)s.nwg), dim3(256), 0, (hipStream_t)stream, d_a, d_b, lda, ldb, d_dot, ldd, symmetric, s);
 	if (s.tiles_al + s.tiles_sk > 0)
-		hipLaunchKernelGGL(k_gram_fixup, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
+		hipLaunchKernelGGL(k_gram_fixup<0>, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_f64");
 }

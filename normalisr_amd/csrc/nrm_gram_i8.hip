@@ -1,0 +1,283 @@
+// K2 (integer engine): dot[i,j] = sum_k A[i,k] B[j,k] EXACTLY for fixed-point operands, on the int8 matrix cores
+// (v_mfma_i32_32x32x32_i8: 3.9 POP/s measured on this chip against 72 TFLOP/s for v_mfma_f64_16x16x4_f64).
+// Replaces np.matmul(dy1, dx1.T) at association.py:234 like nrm_gram.hip does; same tile order, schedule and fix-up.
+//
+// Arithmetic.  Row i of an operand is scaled by a power of two so that |x| <= 2^e_i and rounded ONCE to a fixed-point
+// integer q = rint(x 2^(B - e_i)), B = 8 NS - 2 bits (NS = 6 slices: 46 bits, i.e. 1.4e-14 of the row's largest entry --
+// the rounding an fp64 dot product of ~1e4 terms carries anyway; NS = 5: 38 bits).  q is cut into NS balanced radix-256
+// digits d_s in [-128, 127] (top digit within +-64): q = sum_s d_s 256^s.  Then
+//     q_i . q_j = sum_{s,t} 256^(s+t) sum_k d_is[k] d_jt[k]
+// and every inner sum is an int8 x int8 -> int32 contraction that the matrix cores compute without any rounding.  Slice
+// pairs with s + t < NS - 1 are dropped (each sits near 2^-(8 NS + 2) of full scale); the
+// NS (NS + 1) / 2 pairs kept are accumulated into ONE int32 accumulator set per weight w = s + t (NS sets): |d d'| <= 2^14,
+// at most NS pairs per set, so 2^14 NS K < 2^31 bounds a chunk to K <= 16 384 cells, after which the sets are combined in
+// fp64 (sum_w acc_w 256^w, exact products by powers of two) and added to the output.  Chunks and the partial pieces of the
+// stream-K schedule are combined in fp64 in a fixed order: bitwise reproducible from run to run like the fp64 kernel.
+// Accuracy: the dropped digit products are the error, not the quantisation -- measured |delta r| <= 3e-14 (2e-15 typical at
+// 10 000 Gaussian cells; it grows with (max / rms)^2 of the rows and as 1 / sqrt(cells)), P-values to 4e-10 relative; on the
+// diagonal (identical rows) the dropped squares add coherently (4e-13), which nobody reads (sums of squares come from K1).
+//
+// Operand layout (written by k_quantize_rows, read back by plain DMA): plane s holds, for every block of 32 rows and every
+// k-step of 32 cells, one 1 KB image [row][32 bytes] whose two 16-byte halves of row r are swapped when (r >> 3) & 1 -- the
+// bank-conflict-free order for the MFMA operand reads (lane l reads 16 bytes of row l & 31, half l >> 5; a dot product
+// does not care which 16 of the 32 cells an instruction takes first as long as both operands agree).  One DMA instruction
+// (global_load_lds_dwordx4, issued from inline asm: see nrm_gram_skinny.hip) moves one such image: contiguous 1 KB.
+//
+// Geometry: workgroup tile 128 x 128, 8 waves (2 per SIMD) of 64 rows x 32 columns = 2 MFMA tiles, 2 * 16 * NS
+// accumulator registers; a stage is one k-step of both operand panels (8 NS KB), ring of 3 stages (144 KB at NS = 6),
+// every wave issues NS DMA instructions per stage (the NS slices of one 32-row block), one barrier per stage.
+// Inner loop alone, operands resident in LDS (tools/i8gram_probe.hip): 3.5 POP/s = 231 fp64-equivalent TFLOP/s at NS = 5,
+// 170 at NS = 6, against 68 executed by the fp64 kernel.
+#include "nrm_gram_sched.h"
+
+#define QK 32        // cells per k-step (one MFMA)
+#define QCHUNK 512   // k-steps per int32 accumulation chunk (16 384 cells)
+#define QD 3         // stages in the LDS ring
+#ifndef QI_EXP
+#define QI_EXP 0     // timing experiments (tools/build_exp.sh): 1 no DMA, 2 every DMA from k-steps 0-3 (L2 resident), 4 no barrier
+#endif
+
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef int i16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void q_dma16(const void* gsrc, unsigned lds_dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+				 : "=&s"(keep)
+				 : "v"(gsrc), "s"(lds_dst)
+				 : "memory");
+}
+
+// ---- quantiser: fp64 rows -> NS digit planes in the tiled layout + one exponent per row ----------------------------
+// One wave per row (4 rows per workgroup, consecutive rows of one 32-row block).  x = q 2^exps[row] + rounding.
+template <int NS>
+__global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict__ X, int64_t kx, int64_t ldx, char* __restrict__ Q,
+													   int64_t plane_bytes, int64_t nks, int* __restrict__ exps) {
+	constexpr int B = 8 * NS - 2;
+	const int lane = threadIdx.x & 63;
+	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const double* x = X + row * ldx;
+	double mx = 0.0;
+	for (int64_t k = (int64_t)lane * 2; k < kx; k += 128) {
+		const d2_t v = *reinterpret_cast<const d2_t*>(x + k);
+		mx = fmax(mx, fmax(fabs(v[0]), fabs(v[1])));
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+	int e = 0;
+	if (mx > 0.0 && mx < INFINITY) (void)frexp(mx, &e);  // mx = m 2^e, m in [0.5, 1): |x| < 2^e
+	const int sh = e - B;
+	if (lane == 0) exps[row] = sh;
+	const int64_t ib = row >> 5;
+	const int r = (int)(row & 31);
+	char* qrow = Q + (ib * nks) * 1024 + (2 * r) * 16;
+	const int flip = (r >> 3) & 1;
+	for (int64_t k = (int64_t)lane * 4; k < nks * QK; k += 256) {
+		double v[4] = {0.0, 0.0, 0.0, 0.0};
+		if (k < kx) {  // kx is a multiple of 16: a group of 4 cells is inside or outside as a whole
+			const d2_t a = *reinterpret_cast<const d2_t*>(x + k), b = *reinterpret_cast<const d2_t*>(x + k + 2);
+			v[0] = a[0];
+			v[1] = a[1];
+			v[2] = b[0];
+			v[3] = b[1];
+		}
+		long long q[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) q[i] = (long long)rint(ldexp(v[i], -sh));  // non-finite input: caught by K1's sum of squares / K3's flags
+		const int64_t ks = k >> 5;
+		const int kk = (int)(k & 31);
+		char* dst = qrow + ks * 1024 + (((kk >> 4) ^ flip) << 4) + (kk & 15);
+#pragma unroll
+		for (int s = 0; s < NS; s++) {
+			unsigned w = 0;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const long long d = (s == NS - 1) ? q[i] : (long long)(signed char)(q[i] & 0xff);
+				q[i] = (q[i] - d) >> 8;
+				w |= ((unsigned)d & 0xffu) << (8 * i);
+			}
+			*reinterpret_cast<unsigned*>(dst + s * plane_bytes) = w;
+		}
+	}
+}
+
+// ---- one tile piece: k-steps [k0, k1) of tile (ti, tj) -------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const char* __restrict__ QB, int64_t plane_a, int64_t plane_b,
+											  int64_t nks, const int* __restrict__ ea, const int* __restrict__ eb, double* __restrict__ C,
+											  int64_t ldc, int ti, int tj, int k0, int k1, double* __restrict__ slab, int m_rows, int n_rows,
+											  int symmetric, const char* lds, unsigned lds0) {
+	constexpr int STAGE = 8 * NS * 1024;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wid >> 2, wn = wid & 3;  // 2 x 4 waves of 64 rows x 32 columns
+	// DMA role: wave `wid` moves the NS digit images of 32-row block (wid & 3) of operand (wid >> 2) of every stage
+	const char* src0 = (wid < 4 ? QA + (((int64_t)ti * 4 + wid) * nks) * 1024 : QB + (((int64_t)tj * 4 + (wid - 4)) * nks) * 1024) + lane * 16;
+	const int64_t plane = wid < 4 ? plane_a : plane_b;
+	const unsigned dst0 = lds0 + wid * NS * 1024;
+	auto issue = [&](int buf, int ks) {
+		if (QI_EXP & 1) return;
+		if (QI_EXP & 2) ks &= 3;
+#pragma unroll
+		for (int s = 0; s < NS; s++) q_dma16(src0 + s * plane + (int64_t)ks * 1024, dst0 + buf * STAGE + s * 1024);
+	};
+	i16_t acc[NS][2];
+	auto clear = [&]() {
+#pragma unroll
+		for (int w = 0; w < NS; w++)
+#pragma unroll
+			for (int i = 0; i < 2; i++)
+#pragma unroll
+				for (int j = 0; j < 16; j++) acc[w][i][j] = 0;
+	};
+	// operand reads: lane l takes the 16 bytes of row l & 31 stored at half (l >> 5) ^ ((row >> 3) & 1)
+	const int r = lane & 31;
+	const int pos = (2 * r + ((lane >> 5) ^ ((r >> 3) & 1))) * 16;
+	const int aoff = (wm * 2) * NS * 1024 + pos;       // + i * NS * 1024 + s * 1024
+	const int boff = (4 + wn) * NS * 1024 + pos;       // + s * 1024
+	// output addressing of this wave's two 32 x 32 tiles: lane holds column lane & 31, rows (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+	const int row_w = ti * GM + wm * 64, col_w = tj * GN + wn * 32;
+	const bool diag = symmetric && ti == tj;
+	bool want[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++) want[i] = slab || (row_w + i * 32 < m_rows && col_w < n_rows && (!diag || col_w + 31 >= row_w + i * 32));
+	double* cbase;
+	int64_t pitch;
+	if (slab) {
+		cbase = slab + (wm * 64) * GN + wn * 32;
+		pitch = GN;
+	} else {
+		cbase = C + (int64_t)row_w * ldc + col_w;
+		pitch = ldc;
+	}
+	const int eb_l = eb[col_w + (lane & 31)];
+	auto flush = [&](bool first) {
+#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			if (!want[i]) continue;
+#pragma unroll
+			for (int q = 0; q < 16; q++) {
+				const int rr = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+				double v = 0.0;
+#pragma unroll
+				for (int w = NS - 1; w >= 0; w--) v = fma((double)acc[w][i][q], (double)(1ull << (8 * w)), v);  // exact: |acc| < 2^31, powers of two
+				v = ldexp(v, ea[row_w + rr] + eb_l + 8 * (NS - 1));
+				double* o = cbase + (int64_t)rr * pitch + (lane & 31);
+				*o = first ? v : *o + v;
+			}
+		}
+	};
+	clear();
+	__syncthreads();  // previous piece done with LDS
+	if (k0 < k1) issue(0, k0);
+	if (k0 + 1 < k1) issue(1, k0 + 1);
+	int in_chunk = 0;
+	bool first = true;
+	for (int ks = k0; ks < k1; ks++) {
+		const int buf = (ks - k0) % QD;
+		if (ks + 1 < k1)
+			asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");  // this wave's images of stage ks have landed (stage ks + 1 may be in flight)
+		else
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (!(QI_EXP & 4)) __syncthreads();  // everyone's have; all waves are done reading stage ks - 1, whose buffer is refilled now
+		// (issuing the refill from waves 4-7 half way through their MFMAs instead -- so that one wave of every SIMD computes while
+		//  its partner queues DMA -- was measured: the branch inside the unrolled MFMA block costs far more than it hides)
+		if (ks + 2 < k1) issue((ks - k0 + 2) % QD, ks + 2);
+		const char* st = lds + buf * STAGE;
+		i4_t fa[NS][2], fb[NS];
+#pragma unroll
+		for (int s = 0; s < NS; s++) {
+#pragma unroll
+			for (int i = 0; i < 2; i++) fa[s][i] = *reinterpret_cast<const i4_t*>(st + aoff + (i * NS + s) * 1024);
+			fb[s] = *reinterpret_cast<const i4_t*>(st + boff + s * 1024);
+		}
+#pragma unroll
+		for (int s = 0; s < NS; s++)
+#pragma unroll
+			for (int t = 0; t < NS; t++)
+				if (s + t >= NS - 1) {
+#pragma unroll
+					for (int i = 0; i < 2; i++)
+						acc[s + t - (NS - 1)][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][i], fb[t], acc[s + t - (NS - 1)][i], 0, 0, 0);
+				}
+		if (++in_chunk == QCHUNK && ks + 1 < k1) {  // int32 headroom used up: combine in fp64, start a new chunk
+			flush(first);
+			first = false;
+			clear();
+			in_chunk = 0;
+		}
+	}
+	flush(first);
+}
+
+template <int NS>
+__global__ void __launch_bounds__(512) k_gram_i8(const char* __restrict__ QA, const char* __restrict__ QB, int64_t plane_a, int64_t plane_b,
+												 int64_t nks, const int* __restrict__ ea, const int* __restrict__ eb, double* __restrict__ C,
+												 int64_t ldc, int symmetric, GramSched s) {
+	__shared__ __attribute__((aligned(1024))) char lds[QD * 8 * NS * 1024];
+	typedef __attribute__((address_space(3))) char* lds_ptr_t;
+	const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)lds);
+	gram_for_each_piece(s, [&](int t, int k0, int k1, double* slab) {
+		int ti, tj;
+		gram_tile_coords(s.tile0 + t, symmetric, s.ntm, s.ntn, ti, tj);
+		gram_piece_i8<NS>(QA, QB, plane_a, plane_b, nks, ea, eb, C, ldc, ti, tj, k0, k1, slab, s.m_rows, s.n_rows, symmetric, lds, lds0);
+	});
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------------------------------
+static int g_num_cu_q = 0;
+
+extern "C" int64_t nrm_quant_bytes(int64_t rows_pad, int64_t k_pad, int nslices) {
+	if (rows_pad < 0 || k_pad < 0 || nslices < 1) return 0;
+	const int64_t nks = (k_pad + QK - 1) / QK;
+	return (rows_pad / 32) * nks * 1024 * nslices;
+}
+
+extern "C" int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_t ldx, int nslices, void* d_q, int32_t* d_exp,
+								 void* stream) {
+	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_quantize_rows: 5 or 6 slices");
+	NRM_REQUIRE(rows_pad >= 0 && rows_pad % GM == 0 && k_pad > 0 && k_pad % 16 == 0 && ldx >= k_pad && ldx % 2 == 0,
+				"nrm_quantize_rows: rows must be padded to %d, cells to 16", GM);
+	if (rows_pad == 0) return NRM_OK;
+	NRM_REQUIRE(d_x && d_q && d_exp && (uintptr_t)d_x % 16 == 0 && (uintptr_t)d_q % 16 == 0, "nrm_quantize_rows: null or misaligned pointer");
+	const int64_t nks = (k_pad + QK - 1) / QK;
+	const int64_t plane = (rows_pad / 32) * nks * 1024;
+	dim3 grid((unsigned)(rows_pad / 4));
+	if (nslices == 5)
+		hipLaunchKernelGGL(k_quantize_rows<5>, grid, dim3(256), 0, (hipStream_t)stream, d_x, k_pad, ldx, (char*)d_q, plane, nks, d_exp);
+	else
+		hipLaunchKernelGGL(k_quantize_rows<6>, grid, dim3(256), 0, (hipStream_t)stream, d_x, k_pad, ldx, (char*)d_q, plane, nks, d_exp);
+	return nrm_check_launch("k_quantize_rows");
+}
+
+extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, const void* d_qb, const int32_t* d_eb, int64_t m_pad, int64_t n_pad,
+								int64_t k_pad, int nslices, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows,
+								int64_t row0, int64_t row1, void* d_work, void* stream) {
+	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_gram_i8: 5 or 6 slices");
+	NRM_REQUIRE(m_pad >= 0 && n_pad >= 0 && k_pad > 0 && m_pad % GM == 0 && n_pad % GN == 0, "nrm_gram_i8: sizes must be padded to %d", GM);
+	NRM_REQUIRE(ldd >= n_pad && ldd % 2 == 0, "nrm_gram_i8: pitch too small");
+	NRM_REQUIRE(!symmetric || m_pad == n_pad, "nrm_gram_i8: symmetric needs square output");
+	NRM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= m_pad && row0 % (GSB * GM) == 0 && (row1 % (GSB * GM) == 0 || row1 == m_pad),
+				"nrm_gram_i8_band: rows [row0, row1) must be cut at multiples of %d", GSB * GM);
+	if (m_pad == 0 || n_pad == 0 || row0 == row1) return NRM_OK;
+	NRM_REQUIRE(d_qa && d_qb && d_ea && d_eb && d_dot && d_work, "nrm_gram_i8: null pointer");
+	if (g_num_cu_q == 0) {
+		int dev = 0;
+		NRM_HIP(hipGetDevice(&dev));
+		NRM_HIP(hipDeviceGetAttribute(&g_num_cu_q, hipDeviceAttributeMultiprocessorCount, dev));
+		if (g_num_cu_q <= 0) g_num_cu_q = 256;
+	}
+	const int64_t nks = (k_pad + QK - 1) / QK;
+	const int64_t plane_a = (m_pad / 32) * nks * 1024, plane_b = (n_pad / 32) * nks * 1024;
+	GramSched s;
+	NRM_TRY_RC(gram_plan(s, m_pad, n_pad, nks, symmetric, m_rows, n_rows, row0, row1, g_num_cu_q, (double*)d_work));  // one workgroup per CU
+	if (nslices == 5)
+		hipLaunchKernelGGL(k_gram_i8<5>, dim3((unsigned)s.nwg), dim3(512), 0, (hipStream_t)stream, (const char*)d_qa, (const char*)d_qb, plane_a,
+						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s);
+	else
+		hipLaunchKernelGGL(k_gram_i8<6>, dim3((unsigned)s.nwg), dim3(512), 0, (hipStream_t)stream, (const char*)d_qa, (const char*)d_qb, plane_a,
+						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s);
+	if (s.tiles_al + s.tiles_sk > 0)
+		hipLaunchKernelGGL(k_gram_fixup<1>, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
+	return nrm_check_launch("k_gram_i8");
+}

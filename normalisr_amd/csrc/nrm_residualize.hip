@@ -143,11 +143,20 @@ struct Vec4Load<double> {
 	}
 };
 
-template <typename T, int CB>
+// Fixed-point output for the integer Gram engine (csrc/nrm_gram_i8.hip): digit planes in its tiled layout and one exponent per
+// row, written straight from K1 so that the fp64 residuals never make the round trip through HBM (NS = 0: none).
+struct QuantOut {
+	char* q;              // NS planes of plane_bytes each
+	int64_t plane_bytes;
+	int64_t nks;          // k-steps of 32 cells
+	int* exps;            // x = digits * 2^exps[row]
+};
+
+template <typename T, int CB, int NS>
 __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
 														 const double* __restrict__ c, int nc, int64_t ldc,
 														 const double* __restrict__ dci, int active, double* __restrict__ out,
-														 int64_t ldo, double* __restrict__ ss, double* __restrict__ coef) {
+														 int64_t ldo, double* __restrict__ ss, double* __restrict__ coef, QuantOut qo) {
 	__shared__ double s_part[4][RES_R * CB];
 	extern __shared__ double s_dyn[];
 	double* const ta = s_dyn;                    // [RES_R][nc]  x_i C^T
@@ -219,11 +228,8 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 		}
 		__syncthreads();
 	}
-	double sq[RES_R];
-#pragma unroll
-	for (int r = 0; r < RES_R; r++) sq[r] = 0.0;
-	for (int64_t k = (int64_t)tid * 4; k < ldo; k += 1024) {
-		double v[RES_R][4];
+	// residual of 4 consecutive cells k..k+3 of the workgroup's rows (zeros past the end of the row and for padding rows)
+	auto residual4 = [&](int64_t k, double (&v)[RES_R][4]) {
 		if (k < n4) {
 #pragma unroll
 			for (int r = 0; r < RES_R; r++) Vec4Load<T>::ld(xr[r] + k, v[r]);
@@ -253,13 +259,28 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			}
 		}
 #pragma unroll
-		for (int r = 0; r < RES_R; r++) {
+		for (int r = 0; r < RES_R; r++)
 			if (!live[r]) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
-			double* o = out + (row0 + r) * ldo + k;
-			*reinterpret_cast<double2*>(o) = make_double2(v[r][0], v[r][1]);
-			*reinterpret_cast<double2*>(o + 2) = make_double2(v[r][2], v[r][3]);
+	};
+	double sq[RES_R], mx[RES_R];
 #pragma unroll
-			for (int i = 0; i < 4; i++) sq[r] = fma(v[r][i], v[r][i], sq[r]);
+	for (int r = 0; r < RES_R; r++) sq[r] = mx[r] = 0.0;
+	const int64_t kend = out ? ldo : ((n + 3) & ~(int64_t)3);
+	for (int64_t k = (int64_t)tid * 4; k < kend; k += 1024) {
+		double v[RES_R][4];
+		residual4(k, v);
+#pragma unroll
+		for (int r = 0; r < RES_R; r++) {
+			if (out) {
+				double* o = out + (row0 + r) * ldo + k;
+				*reinterpret_cast<double2*>(o) = make_double2(v[r][0], v[r][1]);
+				*reinterpret_cast<double2*>(o + 2) = make_double2(v[r][2], v[r][3]);
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				sq[r] = fma(v[r][i], v[r][i], sq[r]);
+				if (NS) mx[r] = fmax(mx[r], fabs(v[r][i]));
+			}
 		}
 	}
 #pragma unroll
@@ -269,51 +290,140 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 	}
 	__syncthreads();
 	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
+	if (NS) {
+		// second sweep (the rows are in L2): the same residuals again, rounded once to (8 NS - 2)-bit fixed point relative to the
+		// row's largest entry and cut into NS balanced base-256 digits (see nrm_gram_i8.hip for the layout)
+		constexpr int B = 8 * NS - 2;
+		__shared__ double s_mx[4][RES_R];
+		__shared__ int s_sh[RES_R];
+#pragma unroll
+		for (int r = 0; r < RES_R; r++) {
+			double v = mx[r];
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+			if (lane == 0) s_mx[wid][r] = v;
+		}
+		__syncthreads();
+		if (tid < RES_R) {
+			const double m = fmax(fmax(s_mx[0][tid], s_mx[1][tid]), fmax(s_mx[2][tid], s_mx[3][tid]));
+			int e = 0;
+			if (m > 0.0 && m < INFINITY) (void)frexp(m, &e);
+			s_sh[tid] = e - B;
+			qo.exps[row0 + tid] = e - B;
+		}
+		__syncthreads();
+		int sh[RES_R];
+		char* qrow[RES_R];
+		int flip[RES_R];
+#pragma unroll
+		for (int r = 0; r < RES_R; r++) {
+			sh[r] = s_sh[r];
+			const int64_t row = row0 + r;
+			const int rr = (int)(row & 31);
+			qrow[r] = qo.q + ((row >> 5) * qo.nks) * 1024 + (2 * rr) * 16;
+			flip[r] = (rr >> 3) & 1;
+		}
+		for (int64_t k = (int64_t)tid * 4; k < qo.nks * 32; k += 1024) {
+			double v[RES_R][4];
+			if (k < n)
+				residual4(k, v);
+			else {
+#pragma unroll
+				for (int r = 0; r < RES_R; r++) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
+			}
+			const int64_t ks = k >> 5;
+			const int kk = (int)(k & 31);
+#pragma unroll
+			for (int r = 0; r < RES_R; r++) {
+				long long q[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) q[i] = (long long)rint(ldexp(v[r][i], -sh[r]));
+				char* dst = qrow[r] + ks * 1024 + (((kk >> 4) ^ flip[r]) << 4) + (kk & 15);
+#pragma unroll
+				for (int s = 0; s < (NS ? NS : 1); s++) {
+					unsigned w = 0;
+#pragma unroll
+					for (int i = 0; i < 4; i++) {
+						const long long d = (s == NS - 1) ? q[i] : (long long)(signed char)(q[i] & 0xff);
+						q[i] = (q[i] - d) >> 8;
+						w |= ((unsigned)d & 0xffu) << (8 * i);
+					}
+					*reinterpret_cast<unsigned*>(dst + s * qo.plane_bytes) = w;
+				}
+			}
+		}
+	}
 }
 
 template <typename T>
 static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, int64_t ldx, const double* c, int nc, int64_t ldc,
 							   const double* dci, int active, double* out, int64_t ldo, int64_t rows_pad, double* ss, double* coef,
-							   hipStream_t st) {
+							   int nslices, QuantOut qo, hipStream_t st) {
 	dim3 grid((unsigned)(rows_pad / RES_R));
 	const size_t lds = (size_t)2 * RES_R * (nc > 0 ? nc : 1) * sizeof(double);
-	auto go = [&](auto kern) {
+	auto go = [&](auto kern, auto... extra) {
 		if (lds > 48 * 1024)  // beyond the default dynamic-LDS window (more than 768 covariates)
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef);
+		hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, x, rows, n, ldx, c, nc, ldc, dci, active, out, ldo, ss, coef, extra...);
 	};
 	if (!vec)
 		go(k_residualize<T>);
-	else if (nc <= 4)
-		go(k_residualize_v4<T, 4>);
+	else if (nslices == 6)
+		nc <= 4 ? go(k_residualize_v4<T, 4, 6>, qo) : go(k_residualize_v4<T, 8, 6>, qo);
+	else if (nslices == 5)
+		nc <= 4 ? go(k_residualize_v4<T, 4, 5>, qo) : go(k_residualize_v4<T, 8, 5>, qo);
 	else
-		go(k_residualize_v4<T, 8>);
+		nc <= 4 ? go(k_residualize_v4<T, 4, 0>, qo) : go(k_residualize_v4<T, 8, 0>, qo);
 }
 
-extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c,
-							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
-							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
+static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
+							const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
+							int nslices, void* d_q, int32_t* d_exp, void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
 	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
 	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
 	NRM_REQUIRE(rank >= 0 && rank <= nc, "dcr higher than covariate dimension.");
 	NRM_REQUIRE(rows_pad >= rows && rows_pad % RES_R == 0, "nrm_residualize: rows_pad must cover rows and be a multiple of %d", RES_R);
-	NRM_REQUIRE(ldo >= n, "nrm_residualize: output pitch smaller than cell count");
-	NRM_REQUIRE(d_out && d_ss, "nrm_residualize: null output");
+	NRM_REQUIRE(d_out ? ldo >= n : nslices != 0, "nrm_residualize: output pitch smaller than cell count (or no output requested)");
+	NRM_REQUIRE(d_ss, "nrm_residualize: null output");
 	if (rows_pad == 0) return NRM_OK;
 	NRM_REQUIRE(d_x || rows == 0, "nrm_residualize: null input");
 	int active = (rank > 0 && nc > 0) ? 1 : 0;
 	NRM_REQUIRE(!active || (d_c && d_dci && ldc >= n), "Unmatching dx/dy/dc dimensions.");
 	const int64_t xa = 16 / (x_dtype == NRM_F64 ? 8 : 4);
-	const bool vec = (ldx % xa == 0) && ((uintptr_t)d_x % 16 == 0) && (ldo % 4 == 0) && ((uintptr_t)d_out % 16 == 0) &&
+	const bool vec = (ldx % xa == 0) && ((uintptr_t)d_x % 16 == 0) && (!d_out || ((ldo % 4 == 0) && ((uintptr_t)d_out % 16 == 0))) &&
 					 (!active || (ldc % 2 == 0 && (uintptr_t)d_c % 16 == 0));
+	QuantOut qo = {nullptr, 0, 0, nullptr};
+	if (nslices) {
+		NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_residualize_q: 5 or 6 slices");
+		NRM_REQUIRE(vec, "nrm_residualize_q: needs 16-byte aligned rows (use nrm_residualize + nrm_quantize_rows otherwise)");
+		NRM_REQUIRE(rows_pad % 128 == 0 && d_q && d_exp && (uintptr_t)d_q % 16 == 0, "nrm_residualize_q: rows_pad %% 128 == 0 and digit buffers required");
+		const int64_t k_pad = (n + 15) / 16 * 16;
+		qo.nks = (k_pad + 31) / 32;
+		qo.plane_bytes = (rows_pad / 32) * qo.nks * 1024;
+		qo.q = (char*)d_q;
+		qo.exps = d_exp;
+	}
 	if (x_dtype == NRM_F64)
 		launch_residualize<double>(vec, (const double*)d_x, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, d_out, ldo, rows_pad, d_ss, d_coef,
-								   (hipStream_t)stream);
+								   nslices, qo, (hipStream_t)stream);
 	else
 		launch_residualize<float>(vec, (const float*)d_x, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, d_out, ldo, rows_pad, d_ss, d_coef,
-								  (hipStream_t)stream);
+								  nslices, qo, (hipStream_t)stream);
 	return nrm_check_launch("k_residualize");
+}
+
+extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c,
+							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
+							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
+	NRM_REQUIRE(d_out != nullptr, "nrm_residualize: null output");
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
+								 int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss,
+								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, void* stream) {
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp, stream);
 }
 
 // Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS

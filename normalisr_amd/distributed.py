@@ -131,6 +131,7 @@ class HipBackend:
 		from .engine import get_engine
 		self.eng = get_engine(device)
 		self.torch = self.eng.torch
+		self._blocks = {}
 
 	def covariates(self, dc):
 		"""dc: (nc, n) device or host array -> replicated fp64 device covariates, pseudo-inverse, rank."""
@@ -145,10 +146,24 @@ class HipBackend:
 		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad)
 		return r.data, r.ss
 
-	def gram(self, a, b, symmetric, rows_a=None, rows_b=None):
+	def begin_step(self):
+		self._blocks = {}  # residual blocks of this step and their fixed-point digit planes (quantised once per block and step)
+
+	def _block(self, t, rows):
 		from .engine import Residualized
-		return self.eng.gram(Residualized(a.shape[0] if rows_a is None else rows_a, a.shape[1], a, None, None),
-							 Residualized(b.shape[0] if rows_b is None else rows_b, b.shape[1], b, None, None), symmetric)
+		key = (t.data_ptr(), tuple(t.shape), rows)
+		if key not in self._blocks:
+			self._blocks[key] = Residualized(t.shape[0] if rows is None else rows, t.shape[1], t, None, None)
+		return self._blocks[key]
+
+	def prepare(self, t, rows=None):
+		"""Digit planes of a residual block for the integer Gram engine (nothing to do for the fp64 kernel)."""
+		ns = self.eng.gram_slices(t.shape[1])
+		if ns:
+			self.eng.quantized(self._block(t, rows), ns)
+
+	def gram(self, a, b, symmetric, rows_a=None, rows_b=None):
+		return self.eng.gram(self._block(a, rows_a), self._block(b, rows_b), symmetric, nslices=self.eng.gram_slices(a.shape[1]))
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
 		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags)
@@ -190,7 +205,7 @@ class CoexPlan:
 		self.outputs = []
 		self.flags = None
 		self._pending = []
-		self._ev = dict(residualize=[], exchange=[], gram=[], sweep=[])
+		self._ev = dict(residualize=[], exchange=[], quantize=[], gram=[], sweep=[])
 		self._timed_steps = 0
 		# what travels over xGMI: the fp64 residual blocks, or -- when the input is narrower than fp64 -- the raw input
 		# blocks (half the bytes for fp32; partner blocks are then residualised again locally, K1 is HBM-cheap)
@@ -258,9 +273,14 @@ class CoexPlan:
 		ny = self.rows
 		if nx == 0:
 			return
+		self._prepare(timed, (a, nx), (b, ny))
 		dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym, nx, ny))
 		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
 		outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
+
+	def _prepare(self, timed, *blocks):
+		if hasattr(self.be, 'prepare'):
+			self._timed('quantize', timed, lambda: [self.be.prepare(t, rows) for t, rows in blocks])
 
 	def _partners_merged(self, outs, timed):
 		"""All full block pairs (rank, rank+k), k = 1..K, as ONE rectangular problem: the partners' raw rows are a contiguous
@@ -272,6 +292,7 @@ class CoexPlan:
 			self.all_x[W * R:(W + wrap) * R].copy_(self.all_x[:wrap * R])
 		xs = self.all_x[(self.rank + 1) * R:(self.rank + 1 + K) * R]
 		pd, pss = self._timed('residualize', timed, lambda: self.be.residualize(xs, self.cov, _round_up(K * R, ROW_TILE)))
+		self._prepare(timed, (self._data, R), (pd, K * R))
 		dot = self._timed('gram', timed, lambda: self.be.gram(self._data, pd, False, R, K * R))
 		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, self._ss, pss, R, K * R, self.n, self.dof, False, self.out_dtype, self.flags))
 		for j in range(K):
@@ -281,6 +302,8 @@ class CoexPlan:
 	def step(self, timed=False):
 		if timed:
 			self._timed_steps += 1
+		if hasattr(self.be, 'begin_step'):
+			self.be.begin_step()
 		self._pending = []
 		if self.world > 1 and self.exchange_raw:
 			self._pending = self._exchange(None, None)  # raw rows travel: nothing to wait for, start before K1

@@ -49,12 +49,13 @@ def host_blas(limit=8):
 
 
 class Residualized:
-	"""Residualised rows resident in HBM, plus their sums of squares and OLS coefficients."""
+	"""Residualised rows resident in HBM -- as fp64 (`data`) and / or as the fixed-point digit planes of the integer Gram
+	engine (`_quant`) -- plus their sums of squares and OLS coefficients."""
 
-	def __init__(self, rows, n, data, ss, coef):
+	def __init__(self, rows, n, data, ss, coef, shape=None):
 		self.rows, self.n = rows, n
 		self.data, self.ss, self.coef = data, ss, coef
-		self.rows_pad, self.k_pad = data.shape
+		self.rows_pad, self.k_pad = data.shape if shape is None else shape
 
 
 class Engine:
@@ -150,8 +151,9 @@ class Engine:
 			return None, None
 		return self.upload(np.asarray(dc, dtype=np.float64)), self.upload(np.asarray(dci, dtype=np.float64).reshape(nc, nc))
 
-	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None):
-		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n)."""
+	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True):
+		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n).  nslices = 5 / 6: also (keep_fp64=False: only) the
+		fixed-point digit planes of the integer Gram engine, written by K1 itself."""
 		torch = self.torch
 		with torch.cuda.device(self.device):
 			if isinstance(x, np.ndarray):
@@ -160,6 +162,23 @@ class Engine:
 			nc = 0 if d_c is None else d_c.shape[0]
 			rp = _round_up(max(rows, 1), ROW_TILE) if rows_pad is None else rows_pad
 			kp = _round_up(n, K_TILE)
+			esz = x.element_size()
+			fused = bool(nslices) and rp % ROW_TILE == 0 and x.stride(1) == 1 and (x.stride(0) * esz) % 16 == 0 and x.data_ptr() % 16 == 0 and (
+				d_c is None or ((d_c.stride(0) * 8) % 16 == 0 and d_c.data_ptr() % 16 == 0))
+			if fused:
+				ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
+				coef = self.zeros((rows, nc), torch.float64) if want_coef else None
+				out = torch.empty((rp, kp), dtype=torch.float64, device=self.device) if keep_fp64 else None
+				planes = torch.empty((int(self.lib.nrm_quant_bytes(rp, kp, nslices)), ), dtype=torch.uint8, device=self.device)
+				exps = torch.empty((rp, ), dtype=torch.int32, device=self.device)
+				_lib.check(self.lib.nrm_residualize_q(
+					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
+					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
+					0 if d_dci is None else d_dci.data_ptr(), int(rank), 0 if out is None else out.data_ptr(), kp, rp, ss.data_ptr(),
+					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), self._stream()))
+				r = Residualized(rows, n, out, ss, coef, shape=(rp, kp))
+				r._quant = (planes, exps, nslices)
+				return r
 			out = torch.empty((rp, kp), dtype=torch.float64, device=self.device)
 			ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
 			coef = self.zeros((rows, nc), torch.float64) if want_coef else None
@@ -170,8 +189,40 @@ class Engine:
 				out.data_ptr(), kp, rp, ss.data_ptr(), 0 if coef is None else coef.data_ptr(), self._stream()))
 		return Residualized(rows, n, out, ss, coef)
 
-	def gram(self, a, b, symmetric, dot=None, rows=None):
-		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T on the fp64 matrix cores.  rows=(row0, row1): only that band of dot."""
+	I8_MIN_CELLS = 2048
+
+	@classmethod
+	def gram_slices(cls, n_cells):
+		"""Digit slices of the integer Gram engine for the association path: NRM_GRAM=i8 (default, 6 slices = 46-bit fixed point),
+		i8x5 (5 slices = 38 bits, faster), f64 (the fp64 matrix-core kernel).  Below I8_MIN_CELLS cells the fp64 kernel is used
+		anyway: the problem is small, and the integer engine's error in Pearson r (its dropped low-order digit products,
+		~2e-15 at 10 000 cells) grows as 1 / sqrt(n_cells)."""
+		import os
+		mode = os.environ.get('NRM_GRAM', 'i8')
+		if mode not in ('i8', 'i8x5', 'f64'):
+			raise ValueError('NRM_GRAM must be i8, i8x5 or f64')
+		return {'i8': 6, 'i8x5': 5, 'f64': 0}[mode] if n_cells >= cls.I8_MIN_CELLS else 0
+
+	def quantized(self, r, nslices):
+		"""Fixed-point digit planes and row exponents of residualised rows (cached on the Residualized object; written by K1
+		itself when it could, see residualize)."""
+		torch = self.torch
+		q = getattr(r, '_quant', None)
+		if q is None or q[2] != nslices:
+			assert r.data is not None, 'no fp64 residuals to quantise'  # (keep_fp64=False rows carry their digit planes)
+			with torch.cuda.device(self.device):
+				planes = torch.empty((int(self.lib.nrm_quant_bytes(r.rows_pad, r.k_pad, nslices)), ), dtype=torch.uint8, device=self.device)
+				exps = torch.empty((r.rows_pad, ), dtype=torch.int32, device=self.device)
+				_lib.check(self.lib.nrm_quantize_rows(r.data.data_ptr(), r.rows_pad, r.k_pad, r.data.stride(0), nslices, planes.data_ptr(),
+													  exps.data_ptr(), self._stream()))
+			q = (planes, exps, nslices)
+			r._quant = q
+		return q
+
+	def gram(self, a, b, symmetric, dot=None, rows=None, nslices=0):
+		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T.  nslices = 0: fp64 matrix cores (nrm_gram.hip); 5 / 6: the exact
+		fixed-point engine on the int8 matrix cores (nrm_gram_i8.hip), used by the association path for expression-like rows.
+		rows=(row0, row1): only that band of dot."""
 		torch = self.torch
 		with torch.cuda.device(self.device):
 			if dot is None:
@@ -179,6 +230,13 @@ class Engine:
 			if self._gram_work is None:
 				self._gram_work = torch.empty((int(self.lib.nrm_gram_workspace_bytes()) // 8, ), dtype=torch.float64, device=self.device)
 			row0, row1 = (0, a.rows_pad) if rows is None else rows
+			if nslices:
+				qa = self.quantized(a, nslices)
+				qb = qa if b is a else self.quantized(b, nslices)
+				_lib.check(self.lib.nrm_gram_i8_band(qa[0].data_ptr(), qa[1].data_ptr(), qb[0].data_ptr(), qb[1].data_ptr(), a.rows_pad, b.rows_pad,
+													 a.k_pad, nslices, dot.data_ptr(), dot.stride(0), 1 if symmetric else 0, int(a.rows), int(b.rows),
+													 int(row0), int(row1), self._gram_work.data_ptr(), self._stream()))
+				return dot
 			_lib.check(self.lib.nrm_gram_f64_band(a.data.data_ptr(), b.data.data_ptr(), a.rows_pad, b.rows_pad, a.k_pad,
 												  a.data.stride(0), b.data.stride(0), dot.data_ptr(), dot.stride(0),
 												  1 if symmetric else 0, int(a.rows), int(b.rows), int(row0), int(row1),
@@ -218,7 +276,7 @@ class Engine:
 			if self._copy is None:
 				self._copy = torch.cuda.Stream(device=self.device)
 			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
-			rx = self.residualize(dx, d_c, d_dci, rank)
+			rx = self.residualize(dx, d_c, d_dci, rank, nslices=self.gram_slices(n))
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			ssy = torch.empty((ny, ), dtype=torch.float64, device=self.device)
@@ -232,8 +290,8 @@ class Engine:
 				arrived.record(self._copy)
 				main.wait_event(arrived)
 				yc.record_stream(main)
-				ry = self.residualize(yc, d_c, d_dci, rank)
-				dot = self.gram(rx, ry, False)
+				ry = self.residualize(yc, d_c, d_dci, rank, nslices=self.gram_slices(n), keep_fp64=False)
+				dot = self.gram(rx, ry, False, nslices=self.gram_slices(n))
 				_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), rx.ss.data_ptr(), ry.ss.data_ptr(), nx, b - a, int(n),
 													float(dof), 0, int(stat_kind), p.data_ptr() + a * esz, stat.data_ptr() + a * esz, 0, 0,
 													_code(out_dtype), ny, flags.data_ptr(), self._stream()))
@@ -286,7 +344,7 @@ class Engine:
 				flags = self.zeros((2, ), torch.int32)
 				done = []
 				for a, b in zip(cuts[:-1], cuts[1:]):
-					self.gram(rx, ry, samexy, dot=dot, rows=(a, rx.rows_pad if b == nx else b))
+					self.gram(rx, ry, samexy, dot=dot, rows=(a, rx.rows_pad if b == nx else b), nslices=self.gram_slices(n))
 					_lib.check(self.lib.nrm_assoc_sweep_band(dot.data_ptr(), dot.stride(0), rx.ss.data_ptr(), ry.ss.data_ptr(), nx, ny, int(n),
 															 float(dof), 1 if samexy else 0, int(stat_kind), p.data_ptr(), stat.data_ptr(), 0, 0,
 															 _code(out_dtype), max(ny, 1), flags.data_ptr(), a, b, self._stream()))
@@ -468,8 +526,9 @@ class Engine:
 		if not (samexy or device_out or resident or want_rt or want_alpha) and self.chunked_ok(dy):
 			return self.association_de_chunked(dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov)
 		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
-		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha)
-		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha)
+		ns = self.gram_slices(n)  # integer engine: K1 writes the digit planes itself and the fp64 residuals are never stored
+		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha, nslices=ns, keep_fp64=not ns)
+		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha, nslices=ns, keep_fp64=not ns)
 		host = None
 		if not (device_out or resident or want_rt or want_alpha) and self.banded_ok(nx, ny, out_dtype):
 			# the result arrays are page-locked by a helper thread while K1/K2 run.  Started only now, after the uploads: a
@@ -480,7 +539,7 @@ class Engine:
 			p, stat = self.association_banded(rx, ry, samexy, nx, ny, n, dof, stat_kind, out_dtype, host)
 			return dict(p=p, stat=stat, alpha=None, varx=None if samexy else self.variances(rx.ss, nx, n, out_dtype),
 						vary=self.variances(ry.ss, ny, n, out_dtype), dof=dof)
-		dot = self.gram(rx, ry, samexy)
+		dot = self.gram(rx, ry, samexy, nslices=self.gram_slices(n))
 		p, stat, r, t, flags = self.sweep(dot, rx.ss, ry.ss, nx, ny, n, dof, samexy, stat_kind, out_dtype, want_rt)
 		alpha = None
 		if want_alpha:

@@ -15,6 +15,19 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6  # north-star tolerance on r, t, p
 R_FLOOR = 1e-12  # |r| below this is rounding noise of an fp64 dot product over <=1e5 cells
+# Problems with >= 2048 cells run K2 on the integer engine (46-bit fixed point, csrc/nrm_gram_i8.hip).  Its error in Pearson r
+# -- the low-order digit products it drops -- was measured at <= 3e-14 over the shapes tested here (2e-15 typical at 10 000
+# Gaussian cells, more for sparse binary designs), so r, t, gamma and the covariance meet 1e-6 relative for |r| >= 1e-7 and
+# 1e-13 absolute (in units of r) below; P-values are unaffected (d ln p / d r = -dof r: 4e-10 measured).  NRM_GRAM=f64 selects
+# the fp64 matrix-core kernel, which meets R_FLOOR (test_gram_engines_on_config1_shape runs all engines).
+I8_FLOOR = 1e-7
+
+
+def gamma_close(gam, vx, vy, ref, vxr, vyr, floor):
+	"""gamma (association.py:234) compared as Pearson r = gamma sqrt(var_x / var_y), the scale the floors above refer to."""
+	r = np.asarray(gam, dtype=np.float64) * np.sqrt(np.asarray(vx, dtype=np.float64)[:, None] / np.asarray(vy, dtype=np.float64)[None, :])
+	rr = np.asarray(ref, dtype=np.float64) * np.sqrt(np.asarray(vxr, dtype=np.float64)[:, None] / np.asarray(vyr, dtype=np.float64)[None, :])
+	return close(r, rr, floor=floor)
 P_TINY = 2.3e-308  # below: subnormal, compared absolutely
 
 
@@ -493,14 +506,16 @@ def test_randomised_shapes_vs_oracle(norm):
 				assert close(g, go, 1e-6, 1e-6) and close(vy, vyo, 1e-6) and close(vx, vxo, 1e-6), tag
 			else:
 				assert p_close(p, po), tag
-				assert close(g, go, floor=1e-11) and close(vy, vyo, 1e-9) and close(vx, vxo, 1e-9) and close(a, ao, 1e-6, 1e-8), tag
+				assert (gamma_close(g, vx, vy, go, vxo, vyo, I8_FLOOR) if n >= 2048 else close(g, go, floor=1e-11)), tag
+				assert close(vy, vyo, 1e-9) and close(vx, vxo, 1e-9) and close(a, ao, 1e-6, 1e-8), tag
 		if ny > 1:
 			p, d, v = norm.coex(dy, dc)
 			pc, dcov, vc = oracle.coex(up(dy), up(dc))
 			if f32:
 				assert close(p, pc, 1e-6, 1e-38) and close(d, dcov, 1e-6, 1e-6), (ny, n, nc, f32, dup)
 			else:
-				assert p_close(p, pc) and close(d, dcov, floor=1e-12), (ny, n, nc, f32, dup)
+				sc = np.sqrt(np.outer(vc, vc)) if n >= 2048 else 1.0
+				assert p_close(p, pc) and close(d / sc, dcov / sc, floor=I8_FLOOR if n >= 2048 else 1e-12), (ny, n, nc, f32, dup)
 			assert (np.diag(p) == 0).all() and (p == p.T).all()
 
 
@@ -641,14 +656,14 @@ def test_large_cell_counts_vs_oracle(norm):
 	assert close(p, po, 1e-6, 1e-38) and close(gam, go, 1e-6, 1e-7) and close(vt, vto, 1e-6)
 	# same data in fp64: the north-star tolerance without the final fp32 rounding
 	p, gam, a, vg, vt = norm.de(dg.astype(np.float64), dt.astype(np.float64), dc.astype(np.float64))
-	assert p_close(p, po) and close(gam, go, floor=1e-12)
+	assert p_close(p, po) and gamma_close(gam, vg, vt[0], go, vgo, vto[0], I8_FLOOR)
 	n, nx, ny, nc = 50000, 256, 900, 5
 	dc = np.vstack([rng.standard_normal((nc - 1, n)), np.ones((1, n))])
 	dg = (rng.random((nx, n)) < 0.01).astype(np.float64)
 	dt = rng.standard_normal((ny, n)) + 0.5 * (rng.standard_normal((ny, 6)) @ dg[:6])
 	p, gam, a, vg, vt = norm.de(dg, dt, dc)
 	po, go, ao, vgo, vto = oracle.de(dg, dt, dc)
-	assert p_close(p, po) and close(gam, go, floor=1e-12) and close(vg, vgo, 1e-10) and close(vt, vto, 1e-10)
+	assert p_close(p, po) and gamma_close(gam, vg, vt[0], go, vgo, vto[0], I8_FLOOR) and close(vg, vgo, 1e-10) and close(vt, vto, 1e-10)
 
 
 def test_schedule_regimes_many_tiles(norm, monkeypatch):

@@ -281,7 +281,7 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 def test_bench_default_line_carries_the_other_configs():
 	"""The default N=1 line: configs[1] as `value` plus de_c3 / de_c4 / coex_c5 under extra_workloads, each with its roofline."""
 	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
-	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'] == 'f64'
+	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
 	ex = out['extra_workloads']
 	assert set(ex) == {'de_c3', 'de_c4', 'coex_c5'}, ex
 	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'mfma' and ex['coex_c5']['roofline']['bound'] == 'mfma'
@@ -329,3 +329,34 @@ def test_single1_many_covariates(golden, norm):
 	p, gam, a, vg, vt = norm.de(g['s1c_dg'], g['dt'][:16], g['s1c_dc'], single=1, lowmem=False)
 	assert p_close(p, g['s1c_p']) and close(gam, g['s1c_gamma'], floor=1e-12) and close(a, g['s1c_alpha'], floor=1e-9)
 	assert close(vg, g['s1c_varg'], 1e-9) and close(vt, g['s1c_vart'], 1e-9)
+
+
+@pytest.mark.parametrize('engine', ['i8', 'i8x5', 'f64'])
+def test_gram_engines_on_config1_shape(engine, monkeypatch):
+	"""The three K2 engines on the same seeded coex / de problems at 10 000 cells (BASELINE configs[1] cell count, 1 500 genes):
+	the fp64 matrix-core kernel meets the fp64 floors; the 46-bit integer engine 1e-6 relative on r for |r| >= 1e-7 and on every
+	P-value; the 38-bit one (i8x5) 1e-6 on P-values and 1e-6 relative on r for |r| >= 2e-5."""
+	from normalisr_amd.association import association_tests
+	from test_gpu_parity import I8_FLOOR, gamma_close
+	monkeypatch.setenv('NRM_GRAM', engine)
+	floor = dict(f64=1e-12, i8=I8_FLOOR, i8x5=2e-5)[engine]
+	rng = np.random.default_rng(2020)
+	ng, n = 1500, 10000
+	dt = rng.normal(size=(ng, n)) * rng.uniform(0.3, 3, (ng, 1)) + 0.3 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n)) + 5
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	po, do, ao, vxo, vo = oracle.association_tests(dt[:300], None, dc)
+	res = association_tests(dt, None, dc, return_stats=True)
+	p, d, st = res[0][:300, :300], res[1][:300, :300], res[5]
+	sc = np.sqrt(np.outer(vo, vo))
+	assert p_close(p, po) and close(d / sc, do / sc, floor=floor) and close(res[4][:300], vo, 1e-12)
+	ro, to = oracle.pearson_r_t(do, vo, vo, st['dof'])
+	off = ~np.eye(300, dtype=bool)
+	assert close(st['r'][:300, :300][off], ro[off], floor=floor) and close(st['t'][:300, :300][off], to[off], floor=floor * 100)
+	assert (np.diag(res[0]) == 0).all() and (res[0] == res[0].T).all() and (res[1] == res[1].T).all()
+	dg = (rng.random((40, n)) < 0.2).astype(np.float64)
+	monkeypatch.setenv('NRM_DE_PATH', 'general')
+	p, g, a, vx, vy = association_tests(dg, dt[:400], dc, return_dot=False)
+	po, go, ao, vxo, vyo = oracle.association_tests(dg, dt[:400], dc, return_dot=False)
+	assert p_close(p, po) and gamma_close(g, vx, vy, go, vxo, vyo, floor) and close(vx, vxo, 1e-12) and close(vy, vyo, 1e-12)
+	again = association_tests(dg, dt[:400], dc, return_dot=False)  # bitwise reproducible from run to run (no atomics, fixed combination order)
+	assert np.array_equal(again[0], p) and np.array_equal(again[1], g)
