@@ -117,12 +117,14 @@ int64_t nrm_gram_workspace_bytes(void);
  *       zero padded) -> d_q (nrm_quant_bytes() bytes: digit planes in the kernel's tiled layout) and d_exp (rows_pad) int32 with
  *       x = q * 2^exp.
  *   nrm_gram_i8_band: as nrm_gram_f64_band with quantised operands (d_qb == d_qa, d_eb == d_ea for symmetric problems).
+ *       plane_*_bytes: distance between an operand's digit planes, 0 = dense (m_pad / 32 * ceil(k_pad / 32) KB); an operand may be
+ *       a block of 32-row groups of a larger quantised matrix: pass the pointer of its first group and the larger matrix's pitch.
  */
 int64_t nrm_quant_bytes(int64_t rows_pad, int64_t k_pad, int nslices);
 int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_t ldx, int nslices, void* d_q, int32_t* d_exp, void* stream);
-int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, const void* d_qb, const int32_t* d_eb, int64_t m_pad, int64_t n_pad,
-					 int64_t k_pad, int nslices, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0,
-					 int64_t row1, void* d_work, void* stream);
+int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
+					 int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
+					 int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream);
 
 /*
  * P-value plan: host-side constants of p = I_{1-R^2}(dof/2, 1/2) for one dof

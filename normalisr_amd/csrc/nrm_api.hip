@@ -335,7 +335,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	for (int64_t a = 0; a < nx; a += band) {
 		const int64_t b = std::min(nx, a + band);
 		if (nslices)
-			NRM_TRY(nrm_gram_i8_band(qx.p, ex.as<int32_t>(), samexy ? qx.p : qy.p, samexy ? ex.as<int32_t>() : ey.as<int32_t>(), mp, np_, kp, nslices,
+			NRM_TRY(nrm_gram_i8_band(qx.p, ex.as<int32_t>(), 0, samexy ? qx.p : qy.p, samexy ? ex.as<int32_t>() : ey.as<int32_t>(), 0, mp, np_, kp, nslices,
 									 dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, a, b == nx ? mp : b, gwork.p, st));
 		else
 			NRM_TRY(nrm_gram_f64_band(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, a, b == nx ? mp : b, gwork.p, st));

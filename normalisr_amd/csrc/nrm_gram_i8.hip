@@ -250,9 +250,9 @@ extern "C" int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_
 	return nrm_check_launch("k_quantize_rows");
 }
 
-extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, const void* d_qb, const int32_t* d_eb, int64_t m_pad, int64_t n_pad,
-								int64_t k_pad, int nslices, double* d_dot, int64_t ldd, int symmetric, int64_t m_rows, int64_t n_rows,
-								int64_t row0, int64_t row1, void* d_work, void* stream) {
+extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
+								int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
+								int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream) {
 	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_gram_i8: 5 or 6 slices");
 	NRM_REQUIRE(m_pad >= 0 && n_pad >= 0 && k_pad > 0 && m_pad % GM == 0 && n_pad % GN == 0, "nrm_gram_i8: sizes must be padded to %d", GM);
 	NRM_REQUIRE(ldd >= n_pad && ldd % 2 == 0, "nrm_gram_i8: pitch too small");
@@ -268,7 +268,9 @@ extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, const voi
 		if (g_num_cu_q <= 0) g_num_cu_q = 256;
 	}
 	const int64_t nks = (k_pad + QK - 1) / QK;
-	const int64_t plane_a = (m_pad / 32) * nks * 1024, plane_b = (n_pad / 32) * nks * 1024;
+	// distance between digit planes: dense by default; larger when the operand is a block of rows of a bigger quantised matrix
+	const int64_t plane_a = plane_a_bytes ? plane_a_bytes : (m_pad / 32) * nks * 1024, plane_b = plane_b_bytes ? plane_b_bytes : (n_pad / 32) * nks * 1024;
+	NRM_REQUIRE(plane_a >= (m_pad / 32) * nks * 1024 && plane_b >= (n_pad / 32) * nks * 1024, "nrm_gram_i8: plane pitch smaller than the operand");
 	GramSched s;
 	NRM_TRY_RC(gram_plan(s, m_pad, n_pad, nks, symmetric, m_rows, n_rows, row0, row1, g_num_cu_q, (double*)d_work));  // one workgroup per CU
 	if (nslices == 5)

@@ -125,13 +125,13 @@ class SharedArrays:
 
 
 class HipBackend:
-	"""Block operations on the local GPU through the C ABI (normalisr_amd.engine)."""
+	"""Block operations on the local GPU through the C ABI (normalisr_amd.engine).  A block is a Residualized: fp64 residual rows
+	(fp64 Gram kernel) or the fixed-point digit planes K1 wrote for the integer engine, plus its sums of squares."""
 
 	def __init__(self, device):
 		from .engine import get_engine
 		self.eng = get_engine(device)
 		self.torch = self.eng.torch
-		self._blocks = {}
 
 	def covariates(self, dc):
 		"""dc: (nc, n) device or host array -> replicated fp64 device covariates, pseudo-inverse, rank."""
@@ -143,40 +143,54 @@ class HipBackend:
 
 	def residualize(self, x, cov, rows_pad):
 		d_c, d_dci, dcr = cov
-		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad)
-		return r.data, r.ss
+		ns = self.eng.gram_slices(x.shape[1])
+		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad, nslices=ns, keep_fp64=not ns)
+		if ns and getattr(r, '_quant', None) is None:  # rows K1 could not quantise itself (unaligned): separate pass
+			self.eng.quantized(r, ns)
+		return r, r.ss
 
-	def begin_step(self):
-		self._blocks = {}  # residual blocks of this step and their fixed-point digit planes (quantised once per block and step)
+	def rows(self, blk, lo, hi, rows=None):
+		return self.eng.row_block(blk, lo, hi, rows)
 
-	def _block(self, t, rows):
+	def payload(self, blk):
+		"""What travels to the other ranks for this block: its digit planes and row exponents (6 bytes per value at 6 slices
+		against 8 for fp64 residuals), or the fp64 residuals for the fp64 engine."""
+		q = getattr(blk, '_quant', None)
+		return [q[0], q[1]] if q is not None else [blk.data]
+
+	def from_payload(self, parts, rows, rows_pad, n, k_pad, ss):
 		from .engine import Residualized
-		key = (t.data_ptr(), tuple(t.shape), rows)
-		if key not in self._blocks:
-			self._blocks[key] = Residualized(t.shape[0] if rows is None else rows, t.shape[1], t, None, None)
-		return self._blocks[key]
-
-	def prepare(self, t, rows=None):
-		"""Digit planes of a residual block for the integer Gram engine (nothing to do for the fp64 kernel)."""
-		ns = self.eng.gram_slices(t.shape[1])
-		if ns:
-			self.eng.quantized(self._block(t, rows), ns)
+		if len(parts) == 2:
+			blk = Residualized(rows, n, None, ss, None, shape=(rows_pad, k_pad))
+			blk._quant = (parts[0], parts[1], self.eng.gram_slices(n))
+			return blk
+		return Residualized(rows, n, parts[0], ss, None, shape=(rows_pad, k_pad))
 
 	def gram(self, a, b, symmetric, rows_a=None, rows_b=None):
-		return self.eng.gram(self._block(a, rows_a), self._block(b, rows_b), symmetric, nslices=self.eng.gram_slices(a.shape[1]))
+		return self.eng.gram(a, b, symmetric, nslices=self.eng.gram_slices(a.n))
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
 		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags)
 		return p, stat, flags
-
-	def empty(self, shape):
-		return self.torch.empty(shape, dtype=self.torch.float64, device=self.eng.device)
 
 	def event(self):
 		return self.torch.cuda.Event(enable_timing=True)
 
 	def sync(self):
 		self.torch.cuda.synchronize(self.eng.device)
+
+
+class TensorBlocks:
+	"""Mixin for backends whose blocks are plain (rows_pad, k_pad) tensors (the numpy backend of the CPU tests)."""
+
+	def rows(self, blk, lo, hi, rows=None):
+		return blk[lo:hi]
+
+	def payload(self, blk):
+		return [blk]
+
+	def from_payload(self, parts, rows, rows_pad, n, k_pad, ss):
+		return parts[0]
 
 
 class CoexPlan:
@@ -205,10 +219,10 @@ class CoexPlan:
 		self.outputs = []
 		self.flags = None
 		self._pending = []
-		self._ev = dict(residualize=[], exchange=[], quantize=[], gram=[], sweep=[])
+		self._ev = dict(residualize=[], exchange=[], gram=[], sweep=[])
 		self._timed_steps = 0
-		# what travels over xGMI: the fp64 residual blocks, or -- when the input is narrower than fp64 -- the raw input
-		# blocks (half the bytes for fp32; partner blocks are then residualised again locally, K1 is HBM-cheap)
+		# what travels over xGMI: fp32 input -> the RAW rows (4 bytes per value; partner blocks are residualised again locally,
+		# K1 is HBM-cheap); fp64 input -> the residualised blocks as the backend packs them (6 bytes per value as digit planes)
 		self.exchange_raw = world > 1 and backend is None and 'float32' in str(dt_local.dtype)
 		if world > 1 and backend is None:
 			# every rank must own the same number of rows of the same dtype: a mismatch would hang the all-gather or
@@ -217,16 +231,12 @@ class CoexPlan:
 			shapes = _all_gather_ints([self.rows, self.n, code], group, dt_local.device)
 			if not (shapes == shapes[0]).all():
 				raise ValueError('Sharded coex needs the same (rows, cells, dtype) on every rank; got {}'.format(shapes.tolist()))
-		if world > 1:
-			if self.exchange_raw:
-				# blocks 0..world-1 as gathered, then copies of the first blocks so that the partners rank+1..rank+K of any
-				# rank are one contiguous run of rows (one K1, one K2 and one K3 launch for all of them)
-				self.n_partners = (world - 1) // 2
-				self.all_x = self.be.torch.empty(((world + self.n_partners) * self.rows, self.n), dtype=dt_local.dtype, device=dt_local.device)
-				self._blocks = {}
-			else:
-				self.all_data = self.be.empty((world * self.rows_pad, self.k_pad))
-				self.all_ss = self.be.empty((world * self.rows_pad, ))
+		self._gathered = None
+		if world > 1 and self.exchange_raw:
+			# blocks 0..world-1 as gathered, then copies of the first blocks so that the partners rank+1..rank+K of any
+			# rank are one contiguous run of rows (one K1, one K2 and one K3 launch for all of them)
+			self.n_partners = (world - 1) // 2
+			self.all_x = self.be.torch.empty(((world + self.n_partners) * self.rows, self.n), dtype=dt_local.dtype, device=dt_local.device)
 
 	def _timed(self, name, timed, fn):
 		if not timed:
@@ -238,49 +248,50 @@ class CoexPlan:
 		self._ev[name].append((e0, e1))
 		return out
 
-	def _exchange(self, data, ss):
-		"""Start the all-gather of residual blocks and sums of squares; returns handles to wait on (RCCL runs it on its
-		own stream, so the diagonal block pair -- local data only -- is contracted while the shards travel over xGMI)."""
+	def _exchange(self, blk, ss):
+		"""Start the all-gather of this rank's block; returns handles to wait on (RCCL runs it on its own stream, so the
+		diagonal block pair -- local data only -- is contracted while the shards travel over xGMI)."""
 		import torch.distributed as dist
+		torch = self.be.torch
 		nccl = dist.get_backend(self.group) == 'nccl'
+		self._partner = {}
 		if self.exchange_raw:
-			self._blocks = {}
 			if nccl:
 				return [dist.all_gather_into_tensor(self.all_x[:self.world * self.rows], self.x, group=self.group, async_op=True)]
 			dist.all_gather(list(self.all_x[:self.world * self.rows].view(self.world, self.rows, self.n).unbind(0)), self.x.contiguous(), group=self.group)
 			return []
+		parts = [t.contiguous() for t in self.be.payload(blk)] + [ss.contiguous()]
+		if self._gathered is None or any(g.shape[1:] != t.shape or g.dtype != t.dtype for g, t in zip(self._gathered, parts)):
+			self._gathered = [torch.empty((self.world, ) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in parts]
 		if nccl:
-			return [dist.all_gather_into_tensor(self.all_data, data, group=self.group, async_op=True),
-					dist.all_gather_into_tensor(self.all_ss, ss, group=self.group, async_op=True)]
-		dist.all_gather(list(self.all_data.view(self.world, self.rows_pad, self.k_pad).unbind(0)), data, group=self.group)
-		dist.all_gather(list(self.all_ss.view(self.world, self.rows_pad).unbind(0)), ss, group=self.group)
+			return [dist.all_gather_into_tensor(g, t, group=self.group, async_op=True) for g, t in zip(self._gathered, parts)]
+		for g, t in zip(self._gathered, parts):
+			dist.all_gather(list(g.unbind(0)), t, group=self.group)
 		return []
 
 	def block(self, b):
 		if self.world == 1 or b == self.rank:
-			return self._data, self._ss  # own block: local buffers (valid before the exchange has landed)
-		if self.exchange_raw:
-			if b not in self._blocks:  # partner block arrived raw: residualise it here (once per step)
-				self._blocks[b] = self.be.residualize(self.all_x[b * self.rows:(b + 1) * self.rows], self.cov, self.rows_pad)
-			return self._blocks[b]
-		return (self.all_data[b * self.rows_pad:(b + 1) * self.rows_pad], self.all_ss[b * self.rows_pad:(b + 1) * self.rows_pad])
+			return self._blk, self._ss  # own block: local buffers (valid before the exchange has landed)
+		if b not in self._partner:
+			if self.exchange_raw:  # partner block arrived raw: residualise it here (once per step)
+				self._partner[b] = self.be.residualize(self.all_x[b * self.rows:(b + 1) * self.rows], self.cov, self.rows_pad)
+			else:
+				ss = self._gathered[-1][b]
+				self._partner[b] = (self.be.from_payload([g[b] for g in self._gathered[:-1]], self.rows, self.rows_pad, self.n, self.k_pad, ss), ss)
+		return self._partner[b]
 
 	def _pair(self, outs, timed, bi, bj, lo, hi, sym):
 		a, ssa = self.block(bi)
 		b, ssb = self.block(bj)
-		a, ssa = a[lo:hi], ssa[lo:hi]
 		nx = max(0, min(hi, self.rows) - lo)
 		ny = self.rows
 		if nx == 0:
 			return
-		self._prepare(timed, (a, nx), (b, ny))
+		if lo != 0 or hi != self.rows_pad:
+			a, ssa = self.be.rows(a, lo, hi, nx), ssa[lo:hi]
 		dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym, nx, ny))
 		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
 		outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
-
-	def _prepare(self, timed, *blocks):
-		if hasattr(self.be, 'prepare'):
-			self._timed('quantize', timed, lambda: [self.be.prepare(t, rows) for t, rows in blocks])
 
 	def _partners_merged(self, outs, timed):
 		"""All full block pairs (rank, rank+k), k = 1..K, as ONE rectangular problem: the partners' raw rows are a contiguous
@@ -292,8 +303,7 @@ class CoexPlan:
 			self.all_x[W * R:(W + wrap) * R].copy_(self.all_x[:wrap * R])
 		xs = self.all_x[(self.rank + 1) * R:(self.rank + 1 + K) * R]
 		pd, pss = self._timed('residualize', timed, lambda: self.be.residualize(xs, self.cov, _round_up(K * R, ROW_TILE)))
-		self._prepare(timed, (self._data, R), (pd, K * R))
-		dot = self._timed('gram', timed, lambda: self.be.gram(self._data, pd, False, R, K * R))
+		dot = self._timed('gram', timed, lambda: self.be.gram(self._blk, pd, False, R, K * R))
 		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, self._ss, pss, R, K * R, self.n, self.dof, False, self.out_dtype, self.flags))
 		for j in range(K):
 			outs.append(dict(bi=self.rank, bj=(self.rank + 1 + j) % W, row_lo=0, nx=R, ny=R, symmetric=False,
@@ -302,15 +312,14 @@ class CoexPlan:
 	def step(self, timed=False):
 		if timed:
 			self._timed_steps += 1
-		if hasattr(self.be, 'begin_step'):
-			self.be.begin_step()
 		self._pending = []
+		self._partner = {}
 		if self.world > 1 and self.exchange_raw:
 			self._pending = self._exchange(None, None)  # raw rows travel: nothing to wait for, start before K1
-		data, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
-		self._data, self._ss = data, ss
+		blk, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
+		self._blk, self._ss = blk, ss
 		if self.world > 1 and not self.exchange_raw:
-			self._pending = self._exchange(data, ss)
+			self._pending = self._exchange(blk, ss)
 		outs = []
 		merged = self.exchange_raw and self.n_partners >= 1 and os.environ.get('NRM_MERGE_PARTNERS', '1') != '0'
 		merged_done = False

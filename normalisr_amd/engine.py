@@ -219,6 +219,18 @@ class Engine:
 			r._quant = q
 		return q
 
+	def row_block(self, r, lo, hi, rows=None):
+		"""Rows [lo, hi) (multiples of ROW_TILE) of residualised rows as an operand of their own: a view, nothing is copied."""
+		assert lo % ROW_TILE == 0 and hi % ROW_TILE == 0 and 0 <= lo < hi <= r.rows_pad
+		sub = Residualized(max(0, min(hi, r.rows) - lo) if rows is None else rows, r.n, None if r.data is None else r.data[lo:hi],
+						   None if r.ss is None else r.ss[lo:hi], None, shape=(hi - lo, r.k_pad))
+		q = getattr(r, '_quant', None)
+		if q is not None:
+			nks = (r.k_pad + 31) // 32
+			dense = (r.rows_pad // 32) * nks * 1024
+			sub._quant = (q[0][(lo // 32) * nks * 1024:], q[1][lo:hi], q[2], q[3] if len(q) > 3 else dense)
+		return sub
+
 	def gram(self, a, b, symmetric, dot=None, rows=None, nslices=0):
 		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T.  nslices = 0: fp64 matrix cores (nrm_gram.hip); 5 / 6: the exact
 		fixed-point engine on the int8 matrix cores (nrm_gram_i8.hip), used by the association path for expression-like rows.
@@ -233,9 +245,10 @@ class Engine:
 			if nslices:
 				qa = self.quantized(a, nslices)
 				qb = qa if b is a else self.quantized(b, nslices)
-				_lib.check(self.lib.nrm_gram_i8_band(qa[0].data_ptr(), qa[1].data_ptr(), qb[0].data_ptr(), qb[1].data_ptr(), a.rows_pad, b.rows_pad,
-													 a.k_pad, nslices, dot.data_ptr(), dot.stride(0), 1 if symmetric else 0, int(a.rows), int(b.rows),
-													 int(row0), int(row1), self._gram_work.data_ptr(), self._stream()))
+				pitch = lambda q: q[3] if len(q) > 3 else 0  # plane pitch of a row block of a larger quantised matrix (0 = dense)
+				_lib.check(self.lib.nrm_gram_i8_band(qa[0].data_ptr(), qa[1].data_ptr(), pitch(qa), qb[0].data_ptr(), qb[1].data_ptr(), pitch(qb),
+													 a.rows_pad, b.rows_pad, a.k_pad, nslices, dot.data_ptr(), dot.stride(0), 1 if symmetric else 0,
+													 int(a.rows), int(b.rows), int(row0), int(row1), self._gram_work.data_ptr(), self._stream()))
 				return dot
 			_lib.check(self.lib.nrm_gram_f64_band(a.data.data_ptr(), b.data.data_ptr(), a.rows_pad, b.rows_pad, a.k_pad,
 												  a.data.stride(0), b.data.stride(0), dot.data_ptr(), dot.stride(0),

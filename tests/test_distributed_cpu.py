@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 from conftest import ROOT, relerr
-from normalisr_amd.distributed import CoexPlan, block_pair_schedule, schedule_covers_all_pairs
+from normalisr_amd.distributed import CoexPlan, TensorBlocks, block_pair_schedule, schedule_covers_all_pairs
 
 
 @pytest.mark.parametrize('world', [1, 2, 3, 4, 5, 8])
@@ -25,7 +25,7 @@ def test_schedule_covers_every_pair_once(world):
 	assert max(work) - min(work) <= 128 + 1e-9
 
 
-class OracleBackend:
+class OracleBackend(TensorBlocks):
 	"""Block operations in numpy (oracle arithmetic) on CPU torch tensors, for gloo tests only."""
 
 	def __init__(self):
@@ -63,9 +63,6 @@ class OracleBackend:
 			p = np.triu(p, 1) + np.triu(p, 1).T
 			stat = np.triu(stat, 1) + np.triu(stat, 1).T
 		return p.astype(out_dtype), stat.astype(out_dtype), flags
-
-	def empty(self, shape):
-		return self.torch.zeros(shape, dtype=self.torch.float64)
 
 	def event(self):
 		raise NotImplementedError

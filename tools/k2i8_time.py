@@ -26,7 +26,7 @@ for ns in ([int(sys.argv[4])] if len(sys.argv) > 4 else [6, 5]):
 	def quant():
 		_lib.check(lib.nrm_quantize_rows(a.data_ptr(), mp, kp, kp, ns, q.data_ptr(), ex.data_ptr(), st))
 	def run():
-		_lib.check(lib.nrm_gram_i8_band(q.data_ptr(), ex.data_ptr(), q.data_ptr(), ex.data_ptr(), mp, mp, kp, ns, dot.data_ptr(), mp, 1, ng, ng, 0, mp, work.data_ptr(), st))
+		_lib.check(lib.nrm_gram_i8_band(q.data_ptr(), ex.data_ptr(), 0, q.data_ptr(), ex.data_ptr(), 0, mp, mp, kp, ns, dot.data_ptr(), mp, 1, ng, ng, 0, mp, work.data_ptr(), st))
 	dot.fill_(float('nan'))
 	quant()
 	run()
