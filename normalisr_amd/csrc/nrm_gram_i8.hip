@@ -11,7 +11,8 @@
 // pairs with s + t < NS - 1 are dropped (each sits near 2^-(8 NS + 2) of full scale); the
 // NS (NS + 1) / 2 pairs kept are accumulated into ONE int32 accumulator set per weight w = s + t (NS sets): |d d'| <= 2^14,
 // at most NS pairs per set, so 2^14 NS K < 2^31 bounds a chunk to K <= 16 384 cells, after which the sets are combined in
-// fp64 (sum_w acc_w 256^w, exact products by powers of two) and added to the output.  Chunks and the partial pieces of the
+// fp64 (sum_w acc_w 256^w formed as two exact 64-bit integers joined by one fma: the correctly rounded exact value) and added
+// to the output.  Chunks and the partial pieces of the
 // stream-K schedule are combined in fp64 in a fixed order: bitwise reproducible from run to run like the fp64 kernel.
 // Accuracy: the dropped digit products are the error, not the quantisation -- measured |delta r| <= 3e-14 (2e-15 typical at
 // 10 000 Gaussian cells; it grows with (max / rms)^2 of the rows and as 1 / sqrt(cells)), P-values to 4e-10 relative; on the
@@ -158,9 +159,17 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 #pragma unroll
 			for (int q = 0; q < 16; q++) {
 				const int rr = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-				double v = 0.0;
+				// sum_w acc_w 256^w as two exact 64-bit integers (weights 0..2 and 3..NS-1: each below 2^49), so that the one
+				// fma that joins them is the only rounding: the chunk's value is the correctly rounded exact integer
+				long long lo = 0, hi = 0;
 #pragma unroll
-				for (int w = NS - 1; w >= 0; w--) v = fma((double)acc[w][i][q], (double)(1ull << (8 * w)), v);  // exact: |acc| < 2^31, powers of two
+				for (int w = 0; w < NS; w++) {
+					if (w < 3)
+						lo += (long long)acc[w][i][q] << (8 * w);
+					else
+						hi += (long long)acc[w][i][q] << (8 * (w - 3));
+				}
+				double v = fma((double)hi, 16777216.0, (double)lo);
 				v = ldexp(v, ea[row_w + rr] + eb_l + 8 * (NS - 1));
 				double* o = cbase + (int64_t)rr * pitch + (lane & 31);
 				*o = first ? v : *o + v;

@@ -360,3 +360,112 @@ def test_gram_engines_on_config1_shape(engine, monkeypatch):
 	assert p_close(p, po) and gamma_close(g, vx, vy, go, vxo, vyo, floor) and close(vx, vxo, 1e-12) and close(vy, vyo, 1e-12)
 	again = association_tests(dg, dt[:400], dc, return_dot=False)  # bitwise reproducible from run to run (no atomics, fixed combination order)
 	assert np.array_equal(again[0], p) and np.array_equal(again[1], g)
+
+
+def test_integer_gram_is_exact_for_its_fixed_point_operands(eng):
+	"""nrm_quantize_rows + nrm_gram_i8 at kernel level: the digit planes reproduce round(x 2^-exp) exactly, and the contraction
+	equals the integer arithmetic it stands for -- sum over the kept digit pairs (s + t >= NS - 1) of 256^(s+t) d_s . d_t, computed
+	here in Python integers and rounded once -- bit for bit.  Shapes: cells not a multiple of 32, more than one int32
+	chunk (16 384 cells), rows of all zeros, rows with one huge entry, a rectangular (non-symmetric) problem."""
+	import torch
+	from normalisr_amd import _lib
+	lib = eng.lib
+	rng = np.random.default_rng(77)
+	for ns, n in ((6, 1000), (5, 1000), (6, 16384 + 48)):
+		mp, np_, kp = 128, 256, (n + 15) // 16 * 16
+		a = np.zeros((mp, kp))
+		b = np.zeros((np_, kp))
+		a[:100, :n] = rng.standard_normal((100, n)) * np.exp(rng.normal(size=(100, 1)) * 3)
+		b[:200, :n] = rng.standard_normal((200, n)) + 0.5 * a[:1, :n]
+		a[5] = 0
+		a[6, :n] = 1e-30 * rng.standard_normal(n)
+		a[7, 17] = 1e12
+		b[9, :n] = np.where(rng.random(n) < 0.01, 1.0, 0.0)
+		st = eng._stream()
+		quant = []
+		for m in (a, b):
+			d_m = torch.from_numpy(m).cuda()
+			q = torch.empty(int(lib.nrm_quant_bytes(m.shape[0], kp, ns)), dtype=torch.uint8, device='cuda')
+			ex = torch.empty(m.shape[0], dtype=torch.int32, device='cuda')
+			_lib.check(lib.nrm_quantize_rows(d_m.data_ptr(), m.shape[0], kp, kp, ns, q.data_ptr(), ex.data_ptr(), st))
+			quant.append((q, ex))
+		work = torch.empty(int(lib.nrm_gram_workspace_bytes()) // 8, dtype=torch.float64, device='cuda')
+		dot = torch.full((mp, np_), float('nan'), dtype=torch.float64, device='cuda')
+		_lib.check(lib.nrm_gram_i8_band(quant[0][0].data_ptr(), quant[0][1].data_ptr(), 0, quant[1][0].data_ptr(), quant[1][1].data_ptr(), 0, mp, np_, kp,
+										ns, dot.data_ptr(), np_, 0, 100, 200, 0, mp, work.data_ptr(), st))
+		got = dot.cpu().numpy()
+		# host model of the same arithmetic
+		nks = (kp + 31) // 32
+		def digits(m, q, ex):
+			e = ex.cpu().numpy().astype(np.int64)
+			planes = q.cpu().numpy().view(np.int8).reshape(ns, m.shape[0] // 32, nks, 32, 2, 16)
+			d = np.empty((ns, m.shape[0], nks * 32), dtype=np.int64)
+			for r in range(32):  # row r of a block: its halves are swapped when (r >> 3) & 1
+				flip = (r >> 3) & 1
+				rows = planes[:, :, :, r]  # (ns, blocks, nks, 2, 16)
+				if flip:
+					rows = rows[:, :, :, ::-1]
+				d[:, r::32] = rows.reshape(ns, m.shape[0] // 32, nks * 32)
+			qint = sum(d[s] << (8 * s) for s in range(ns))
+			want = np.rint(np.ldexp(np.pad(m, ((0, 0), (0, nks * 32 - kp))), -e[:, None])).astype(np.int64)
+			assert np.array_equal(qint, want) and np.abs(d[:-1]).max() <= 128 and np.abs(d[-1]).max() <= 64
+			return d, e
+		da, ea = digits(a, *quant[0])
+		db, eb = digits(b, *quant[1])
+		ref = np.zeros((100, 200), dtype=object)
+		for s in range(ns):
+			for t in range(ns):
+				if s + t >= ns - 1:
+					ref = ref + (da[s][:100] @ db[t][:200].T).astype(object) * (1 << (8 * (s + t)))  # digit products fit int64; the weights do not
+		ref = np.array([[float(v) for v in row] for row in ref])  # correctly rounded conversion of the exact integers
+		ref = np.ldexp(ref, (ea[:100, None] + eb[None, :200]))
+		assert np.isfinite(got[:100, :200]).all()
+		# small problems are cut into stream-K pieces along the cells and chunks are added in fp64: one rounding per piece
+		scale = np.sqrt((a[:100]**2).sum(axis=1))[:, None] * np.sqrt((b[:200]**2).sum(axis=1))[None, :]
+		assert float(np.max(np.abs(got[:100, :200] - ref) / np.maximum(scale, 1e-300))) < 1e-15, (ns, n)
+		assert (got[5, :200] == 0).all()
+
+
+def test_integer_gram_whole_tiles_are_correctly_rounded(eng):
+	"""One tile per workgroup and one int32 chunk (no partial pieces): every output is the CORRECTLY ROUNDED value of the exact
+	integer sum of the kept digit products -- checked bit for bit on sampled entries against Python integers."""
+	import torch
+	from normalisr_amd import _lib
+	lib = eng.lib
+	ns, n, m = 6, 96, 2048  # 16 x 16 = 256 tiles: the whole-tile phase of the schedule on 256 workgroups
+	rng = np.random.default_rng(78)
+	a = rng.standard_normal((m, n)) * np.exp(rng.normal(size=(m, 1)))
+	b = rng.standard_normal((m, n)) + 0.3 * a
+	st = eng._stream()
+	quant = []
+	for x in (a, b):
+		d_x = torch.from_numpy(x).cuda()
+		q = torch.empty(int(lib.nrm_quant_bytes(m, n, ns)), dtype=torch.uint8, device='cuda')
+		ex = torch.empty(m, dtype=torch.int32, device='cuda')
+		_lib.check(lib.nrm_quantize_rows(d_x.data_ptr(), m, n, n, ns, q.data_ptr(), ex.data_ptr(), st))
+		quant.append((q, ex))
+	work = torch.empty(int(lib.nrm_gram_workspace_bytes()) // 8, dtype=torch.float64, device='cuda')
+	dot = torch.empty((m, m), dtype=torch.float64, device='cuda')
+	_lib.check(lib.nrm_gram_i8_band(quant[0][0].data_ptr(), quant[0][1].data_ptr(), 0, quant[1][0].data_ptr(), quant[1][1].data_ptr(), 0, m, m, n, ns,
+									dot.data_ptr(), m, 0, m, m, 0, m, work.data_ptr(), st))
+	got = dot.cpu().numpy()
+	ea, eb = (q[1].cpu().numpy().astype(np.int64) for q in quant)
+	qa, qb = (np.rint(np.ldexp(x, -e[:, None])).astype(np.int64) for x, e in ((a, ea), (b, eb)))
+	def digits(q):
+		out = []
+		for s in range(ns):
+			d = q.copy() if s == ns - 1 else ((q & 0xff) ^ 0x80) - 0x80
+			q = (q - d) >> 8
+			out.append(d)
+		return out
+	da, db = digits(qa), digits(qb)
+	rows = rng.integers(0, m, 400)
+	cols = rng.integers(0, m, 400)
+	for i, j in zip(rows, cols):
+		exact = 0
+		for s in range(ns):
+			for t in range(ns):
+				if s + t >= ns - 1:
+					exact += int(np.dot(da[s][i], db[t][j])) << (8 * (s + t))
+		want = float(np.ldexp(float(exact), int(ea[i] + eb[j])))
+		assert got[i, j] == want, (int(i), int(j), float(got[i, j]).hex(), want.hex())
