@@ -52,6 +52,12 @@ int nrm_set_device(int device);
 int nrm_host_pin(void* ptr, int64_t bytes, int threads);
 int nrm_host_unpin(void* ptr);
 int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, void* stream);
+/* Page-locked host memory owned by the library's caller (hipHostMalloc / hipHostFree): the Python host keeps a pool of such
+ * blocks behind the numpy result arrays it returns, so that repeated calls neither fault in nor register fresh pages. */
+int nrm_host_alloc(void** ptr, int64_t bytes);
+int nrm_host_free(void* ptr);
+/* a rectangle (rows x row_bytes, pitches in bytes) of a device matrix -> the same rectangle of a host matrix, queued on `stream` */
+int nrm_copy_rect_to_host(void* h_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows, void* stream);
 /* Device-side assembly of the padded operand buffers (zero padding, stacking [C; X~] for the streaming path, gathering sums of
  * squares of row chunks): asynchronous on `stream`; pitches and row_bytes in BYTES. */
 int nrm_fill_zero(void* d_dst, int64_t bytes, void* stream);
@@ -77,11 +83,13 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
 /* K1 with fixed-point output for the integer Gram engine (see nrm_quantize_rows below): the residuals are rounded and cut into
  * digit planes inside K1 (a second sweep over the rows, which are in L2 by then), so the fp64 residuals need not travel through
  * HBM at all: d_out may be NULL.  Needs 16-byte aligned rows and rows_pad % NRM_ROW_TILE == 0; d_q holds
- * nrm_quant_bytes(rows_pad, round_up(n, 16), nslices) bytes, d_exp rows_pad int32. */
+ * nrm_quant_bytes(rows_pad, round_up(n, 16), nslices) bytes, d_exp rows_pad int32.  plane_pitch_bytes != 0: the rows are a
+ * block of 32-row groups of a larger quantised matrix (d_q points at the block's first group, the pitch is the larger matrix's:
+ * rows that arrive chunk by chunk fill one set of planes). */
 int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
 					  double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-					  int nslices, void* d_q, int32_t* d_exp, void* stream);
+					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, void* stream);
 
 /*
  * K2 -- Gram contraction dot[i,j] = sum_k A[i,k] B[j,k] on the fp64 matrix cores
@@ -168,6 +176,14 @@ int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const double* d_ssx, 
 						 int64_t nx, int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind,
 						 void* d_p, void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo,
 						 int32_t* d_flags, int64_t row0, int64_t row1, void* stream);
+
+/* The same for an off-diagonal RECTANGLE of a symmetric (coex) problem: rows [r0, r0 + mx) against columns [c0, c0 + my),
+ * c0 + my <= r0; d_dot (mx, ldd) holds that rectangle of the Gram matrix, d_ssx / d_ssy the sums of squares of its rows / columns.
+ * Every pair is computed once and written at (r0 + i, c0 + j) AND (c0 + j, r0 + i) of the (ng, ldo) outputs (covariance in d_stat),
+ * so a coex whose rows arrive chunk by chunk can finish and ship all pairs of a chunk at once (association.py:1049-1057). */
+int nrm_assoc_sweep_mirror(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t mx, int64_t my,
+						   int64_t n_cells, double dof, void* d_p, void* d_stat, int out_dtype, int64_t ldo, int64_t r0, int64_t c0,
+						   int32_t* d_flags, void* stream);
 
 /*
  * alpha[i,j,c] = by[j,c] - gamma[i,j] * bx[i,c]  (association.py:238-243), fp64 coefficients in, out_dtype out.

@@ -26,10 +26,12 @@ _SIGNATURES = {
 	'nrm_host_pin': ([_vp, _i64, _i32], _i32),
 	'nrm_host_unpin': ([_vp], _i32),
 	'nrm_copy_to_host': ([_vp, _vp, _i64, _vp], _i32),
+	'nrm_host_alloc': ([ctypes.POINTER(_vp), _i64], _i32),
+	'nrm_host_free': ([_vp], _i32),
 	'nrm_fill_zero': ([_vp, _i64, _vp], _i32),
 	'nrm_copy_rows': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
-	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp], _i32),
+	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp], _i32),
 	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_f64_band': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_workspace_bytes': ([], _i64),
@@ -41,6 +43,8 @@ _SIGNATURES = {
 	'nrm_pvalues_from_r2': ([_vp, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_assoc_sweep_band': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i64, _vp], _i32),
+	'nrm_assoc_sweep_mirror': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp], _i32),
+	'nrm_copy_rect_to_host': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_single4_sweep': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
 	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
 	'nrm_gram_skinny': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp], _i32),

@@ -69,11 +69,32 @@ extern "C" int nrm_host_unpin(void* ptr) {
 	return NRM_OK;
 }
 
+extern "C" int nrm_host_alloc(void** ptr, int64_t bytes) {
+	NRM_REQUIRE(ptr != nullptr && bytes > 0, "nrm_host_alloc: empty request");
+	NRM_HIP(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+	return NRM_OK;
+}
+
+extern "C" int nrm_host_free(void* ptr) {
+	if (ptr) NRM_HIP(hipHostFree(ptr));
+	return NRM_OK;
+}
+
 extern "C" int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, void* stream) {
 	NRM_REQUIRE(bytes >= 0, "nrm_copy_to_host: negative size");
 	if (bytes == 0) return NRM_OK;
 	NRM_REQUIRE(h_dst && d_src, "nrm_copy_to_host: null pointer");
 	NRM_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	return NRM_OK;
+}
+
+extern "C" int nrm_copy_rect_to_host(void* h_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows,
+									 void* stream) {
+	NRM_REQUIRE(row_bytes >= 0 && rows >= 0 && dst_pitch >= row_bytes && src_pitch >= row_bytes, "nrm_copy_rect_to_host: pitches smaller than the row");
+	if (row_bytes == 0 || rows == 0) return NRM_OK;
+	NRM_REQUIRE(h_dst && d_src, "nrm_copy_rect_to_host: null pointer");
+	NRM_HIP(hipMemcpy2DAsync(h_dst, (size_t)dst_pitch, d_src, (size_t)src_pitch, (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToHost,
+							 (hipStream_t)stream));
 	return NRM_OK;
 }
 
@@ -283,7 +304,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 		NRM_TRY(qx.alloc((size_t)nrm_quant_bytes(mp, kp, nslices)));
 		NRM_TRY(ex.alloc((size_t)mp * 4));
 		NRM_TRY(nrm_residualize_q(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, mp, ssx.as<double>(),
-								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), st));
+								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), 0, st));
 	} else {
 		NRM_TRY(rx.alloc((size_t)mp * kp * 8));
 		NRM_TRY(nrm_residualize(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, rx.as<double>(), kp, mp,
@@ -299,7 +320,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 			NRM_TRY(qy.alloc((size_t)nrm_quant_bytes(np_, kp, nslices)));
 			NRM_TRY(ey.alloc((size_t)np_ * 4));
 			NRM_TRY(nrm_residualize_q(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, np_, ssy.as<double>(),
-									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), st));
+									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), 0, st));
 		} else {
 			NRM_TRY(ry.alloc((size_t)np_ * kp * 8));
 			NRM_TRY(nrm_residualize(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, ry.as<double>(), kp, np_,

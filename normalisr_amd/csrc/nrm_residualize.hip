@@ -378,7 +378,7 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 
 static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
 							const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-							int nslices, void* d_q, int32_t* d_exp, void* stream) {
+							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
 	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
 	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
@@ -401,6 +401,10 @@ static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t 
 		const int64_t k_pad = (n + 15) / 16 * 16;
 		qo.nks = (k_pad + 31) / 32;
 		qo.plane_bytes = (rows_pad / 32) * qo.nks * 1024;
+		if (plane_pitch) {  // these rows are a block of a larger quantised matrix
+			NRM_REQUIRE(plane_pitch >= qo.plane_bytes && plane_pitch % 1024 == 0, "nrm_residualize_q: plane pitch smaller than the block");
+			qo.plane_bytes = plane_pitch;
+		}
 		qo.q = (char*)d_q;
 		qo.exps = d_exp;
 	}
@@ -417,13 +421,14 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
 							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
 	NRM_REQUIRE(d_out != nullptr, "nrm_residualize: null output");
-	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, stream);
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 								 int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss,
-								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, void* stream) {
-	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp, stream);
+								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, void* stream) {
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp,
+							plane_pitch_bytes, stream);
 }
 
 // Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS

@@ -265,6 +265,77 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 	}
 }
 
+// Off-diagonal rectangle of a symmetric (coex) problem: rows [r0, r0 + mx) against columns [c0, c0 + my) with c0 + my <= r0.
+// Every p-value is computed once and written twice -- at (r0 + i, c0 + j) and, through an LDS transpose, at (c0 + j, r0 + i) --
+// so that a pipelined coex (rows arriving chunk by chunk) can finish and ship both halves of a chunk's pairs at once.
+template <typename OutT>
+__global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ssx,
+															 const double* __restrict__ ssy, int64_t mx, int64_t my, double ncells, PvalPlan pl,
+															 OutT* __restrict__ p_out, OutT* __restrict__ stat_out, int64_t ldo, int64_t r0,
+															 int64_t c0, int32_t* __restrict__ flags) {
+	__shared__ double tile[SW_T][SW_T + 1];
+	__shared__ double sx[SW_T], sy[SW_T];
+	const int bi = blockIdx.y, bj = blockIdx.x;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	if (threadIdx.x < SW_T) {
+		const int64_t gi = (int64_t)bi * SW_T + threadIdx.x;
+		const double v = gi < mx ? ssx[gi] : 1.0;
+		sx[threadIdx.x] = (v == 0.0) ? ncells : v;  // variance 0 -> 1  (association.py:231)
+	} else if (threadIdx.x < 2 * SW_T) {
+		const int t = threadIdx.x - SW_T;
+		const int64_t gj = (int64_t)bj * SW_T + t;
+		const double v = gj < my ? ssy[gj] : 1.0;
+		sy[t] = (v == 0.0) ? ncells : v;
+	}
+	__syncthreads();
+	int bad_nf = 0, bad_rng = 0;
+	const int64_t gj = (int64_t)bj * SW_T + tx;
+	double pv[SW_T / 4], sv[SW_T / 4];
+#pragma unroll
+	for (int i = 0; i < SW_T / 4; i++) {
+		const int r = ty + 4 * i;
+		const int64_t gi = (int64_t)bi * SW_T + r;
+		double p = 0.0, st = 0.0;
+		if (gi < mx && gj < my) {
+			const double d = dot[gi * ldd + gj];
+			const double vx = sx[r], vy = sy[tx];
+			const double r2 = (d * d) / (vx * vy);
+			if (!isfinite(r2) || !isfinite(vx) || !isfinite(vy)) bad_nf = 1;
+			if (r2 > 1.0 + 1e-8) bad_rng = 1;
+			p = nrm_pvalue(r2, pl);
+			st = d / ncells;
+			p_out[(r0 + gi) * ldo + c0 + gj] = (OutT)p;
+			stat_out[(r0 + gi) * ldo + c0 + gj] = (OutT)st;
+		}
+		pv[i] = p;
+		sv[i] = st;
+	}
+	const int64_t oj = (int64_t)bi * SW_T + tx;  // mirrored: rows c0 + (block bj), columns r0 + (block bi)
+#pragma unroll
+	for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = pv[i];
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < SW_T / 4; i++) {
+		const int r = ty + 4 * i;
+		const int64_t oi = (int64_t)bj * SW_T + r;
+		if (oi < my && oj < mx) p_out[(c0 + oi) * ldo + r0 + oj] = (OutT)tile[tx][r];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = sv[i];
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < SW_T / 4; i++) {
+		const int r = ty + 4 * i;
+		const int64_t oi = (int64_t)bj * SW_T + r;
+		if (oi < my && oj < mx) stat_out[(c0 + oi) * ldo + r0 + oj] = (OutT)tile[tx][r];
+	}
+	if (flags) {
+		if (bad_nf) atomicAdd(&flags[0], 1);
+		if (bad_rng) atomicAdd(&flags[1], 1);
+	}
+}
+
 // Sweep for the streaming de path (nrm_gram_skinny): one thread per gene.  G[y] = [y C^T (nc) | y X~^T (nx) | 0...],
 // ssraw[y] = |y|^2.  |y~|^2 = |y|^2 - a dci a^T with a = y C^T (association.py:226-230 expanded), y~.x~ = y.x~.
 #define DS_NZ 32
@@ -403,6 +474,26 @@ extern "C" int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d
 							   void* stream) {
 	return nrm_assoc_sweep_band(d_dot, ldd, d_ssx, d_ssy, nx, ny, n_cells, dof, symmetric, stat_kind, d_p, d_stat, d_r, d_t, out_dtype,
 								ldo, d_flags, 0, nx, stream);
+}
+
+extern "C" int nrm_assoc_sweep_mirror(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t mx, int64_t my,
+									  int64_t n_cells, double dof, void* d_p, void* d_stat, int out_dtype, int64_t ldo, int64_t r0, int64_t c0,
+									  int32_t* d_flags, void* stream) {
+	NRM_REQUIRE(mx >= 0 && my >= 0 && n_cells > 0 && r0 >= 0 && c0 >= 0 && c0 + my <= r0, "nrm_assoc_sweep_mirror: the rectangle must lie below the diagonal");
+	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_assoc_sweep: bad out_dtype");
+	nrm_pvalue_plan plan;
+	int rc = nrm_pvalue_plan_init(&plan, dof);
+	if (rc) return rc;
+	if (mx == 0 || my == 0) return NRM_OK;
+	NRM_REQUIRE(d_dot && d_ssx && d_ssy && d_p && d_stat && ldd >= my && ldo >= r0 + mx, "nrm_assoc_sweep_mirror: null pointer or small pitch");
+	dim3 grid((unsigned)((my + SW_T - 1) / SW_T), (unsigned)((mx + SW_T - 1) / SW_T));
+	if (out_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_assoc_sweep_mirror<double>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, mx, my, (double)n_cells,
+						   to_dev(plan), (double*)d_p, (double*)d_stat, ldo, r0, c0, d_flags);
+	else
+		hipLaunchKernelGGL(k_assoc_sweep_mirror<float>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, mx, my, (double)n_cells,
+						   to_dev(plan), (float*)d_p, (float*)d_stat, ldo, r0, c0, d_flags);
+	return nrm_check_launch("k_assoc_sweep_mirror");
 }
 
 extern "C" int nrm_alpha(const void* d_stat, int stat_dtype, int64_t ldg, int stat_kind, const double* d_ssx, int64_t n_cells,

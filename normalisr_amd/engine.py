@@ -48,6 +48,55 @@ def host_blas(limit=8):
 		return contextlib.nullcontext()
 
 
+class PinnedPool:
+	"""Page-locked host blocks behind the numpy result arrays of the numpy-in / numpy-out calls.  A fresh 200 MB result needs its
+	pages faulted in and registered before a device-to-host copy can run at the PCIe rate (4-9 ms: longer than the whole C2
+	computation); a block handed back when its array is garbage-collected is reused by the next call of the same size at no cost.
+	The pool is bounded (NRM_PINNED_POOL_MB, default 2048; 0 disables it): beyond the bound results fall back to ordinary numpy
+	memory that is page-locked in place for the duration of the call."""
+
+	def __init__(self, lib):
+		import os
+		import threading
+		self.lib = lib
+		self.limit = int(float(os.environ.get('NRM_PINNED_POOL_MB', '2048')) * (1 << 20))
+		self.free = {}   # capacity -> [pointers]
+		self.total = 0   # bytes allocated (handed out or free)
+		self.lock = threading.Lock()
+
+	def _give(self, ptr, cap):
+		with self.lock:
+			self.free.setdefault(cap, []).append(ptr)
+
+	def empty(self, shape, dtype):
+		"""A C-contiguous numpy array on page-locked memory, or None when the pool is exhausted / disabled."""
+		import ctypes
+		import weakref
+		dtype = np.dtype(dtype)
+		nbytes = int(np.prod(shape)) * dtype.itemsize
+		if nbytes < (1 << 20) or self.limit <= 0:
+			return None
+		cap = (nbytes + (1 << 21) - 1) >> 21 << 21
+		with self.lock:
+			ptr = self.free[cap].pop() if self.free.get(cap) else None
+			if ptr is None:
+				if self.total + cap > self.limit:  # drop idle blocks of other sizes before giving up
+					for c in list(self.free):
+						while self.free[c] and self.total + cap > self.limit:
+							self.lib.nrm_host_free(self.free[c].pop())
+							self.total -= c
+				if self.total + cap > self.limit:
+					return None
+				out = ctypes.c_void_p()
+				if self.lib.nrm_host_alloc(ctypes.byref(out), cap) != 0:
+					return None
+				ptr = out.value
+				self.total += cap
+		buf = (ctypes.c_char * nbytes).from_address(ptr)
+		weakref.finalize(buf, self._give, ptr, cap)  # the array (and every view of it) keeps `buf` alive
+		return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 class Residualized:
 	"""Residualised rows resident in HBM -- as fp64 (`data`) and / or as the fixed-point digit planes of the integer Gram
 	engine (`_quant`) -- plus their sums of squares and OLS coefficients."""
@@ -67,6 +116,7 @@ class Engine:
 		self._gram_work = None
 		self._skinny_ws = None
 		self._copy = None
+		self.pool = PinnedPool(self.lib)
 
 	def _stream(self):
 		return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -93,6 +143,12 @@ class Engine:
 			return t.cpu().numpy()
 		torch = self.torch
 		t = t.contiguous()
+		out = self.pool.empty(tuple(t.shape), self._NP[str(t.dtype)])
+		if out is not None:  # recycled page-locked block
+			with torch.cuda.device(self.device):
+				_lib.check(self.lib.nrm_copy_to_host(out.ctypes.data, t.data_ptr(), out.nbytes, self._stream()))
+				torch.cuda.current_stream(self.device).synchronize()
+			return out
 		out = np.empty(tuple(t.shape), dtype=self._NP[str(t.dtype)])
 		try:
 			self.host_pin(out)
@@ -175,7 +231,7 @@ class Engine:
 					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 					0 if d_dci is None else d_dci.data_ptr(), int(rank), 0 if out is None else out.data_ptr(), kp, rp, ss.data_ptr(),
-					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), self._stream()))
+					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self._stream()))
 				r = Residualized(rows, n, out, ss, coef, shape=(rp, kp))
 				r._quant = (planes, exps, nslices)
 				return r
@@ -313,17 +369,29 @@ class Engine:
 			return dict(p=self.download(p), stat=self.download(stat), alpha=None, varx=self.variances(rx.ss, nx, n, out_dtype),
 						vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
 
-	def start_host_results(self, nx, ny, out_dtype):
-		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps K1 and the first band of K2)."""
+	def start_host_results(self, nx, ny, out_dtype, bands=None):
+		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps K1 and the first band of K2).
+		bands: row cuts [0, ..., nx] -- the rows are then locked band by band in that order and host['ready'] counts the bands
+		done, so that copies into the first bands can start while the later ones are still being faulted in and registered."""
 		import threading
 		odt = np.dtype(out_dtype)
-		res = dict(p=np.empty((nx, ny), dtype=odt), stat=np.empty((nx, ny), dtype=odt), pinned=[], error=[])
+		cuts = [0, nx] if bands is None else list(bands)
+		pp, ps = self.pool.empty((nx, ny), odt), self.pool.empty((nx, ny), odt)
+		if pp is not None and ps is not None:  # recycled page-locked blocks: nothing to fault in or register
+			res = dict(p=pp, stat=ps, pinned=[], error=[], ready=len(cuts), thread=threading.Thread(target=lambda: None))
+			res['thread'].start()
+			return res
+		del pp, ps
+		res = dict(p=np.empty((nx, ny), dtype=odt), stat=np.empty((nx, ny), dtype=odt), pinned=[], error=[], ready=0)
 
 		def lock_pages():
 			try:
-				for k in ('p', 'stat'):
-					self.host_pin(res[k])
-					res['pinned'].append(res[k])
+				for a, b in zip(cuts[:-1], cuts[1:]):
+					for k in ('p', 'stat'):
+						part = res[k][a:b]
+						self.host_pin(part)
+						res['pinned'].append(part)
+					res['ready'] += 1
 			except Exception as e:  # re-raised by the consumer
 				res['error'].append(e)
 		res['thread'] = threading.Thread(target=lock_pages)
@@ -378,6 +446,124 @@ class Engine:
 				self.finish_host_results(host)
 			self.check_flags(flags)
 		return hp, hs
+
+	def coex_pipelined_ok(self, dx, dc, n):
+		"""coex whose expression matrix still sits on the host, large enough for PCIe to matter, on the integer engine with rows K1
+		can quantise itself (16-byte aligned): upload, kernels and copy-out overlap chunk by chunk (NRM_PIPELINE=0 switches it off)."""
+		import os
+		return (isinstance(dx, np.ndarray) and os.environ.get('NRM_PIPELINE', '1') != '0' and self.gram_slices(n) > 0 and dx.shape[0] > self.BAND
+				and dx.nbytes >= (32 << 20) and (dx.shape[1] * dx.itemsize) % 16 == 0 and (dc.shape[0] == 0 or (dc.shape[1] * 8) % 16 == 0))
+
+	def association_coex_pipelined(self, dx, dc, dci, rank, dimreduce, out_dtype, cov=None):
+		"""norm.coex, numpy in -> numpy out, with the three PCIe / compute legs overlapped.  The gene rows travel to the GPU in
+		chunks of BAND rows on a copy stream; as soon as chunk c = rows [a, b) has landed, K1 residualises and quantises it, K2
+		contracts it with itself (symmetric) and with all earlier rows [0, a) (a rectangle), K3 turns both into P-values --
+		writing the rectangle's pairs at (i, j) AND (j, i) -- and everything chunk c completes (rows a..b up to column b, columns
+		a..b of the rows above) leaves on a second copy stream into the page-locked result arrays while chunk c + 1 is still
+		arriving.  The reference fills its result arrays tile by tile the same way (association.py:997-1034,1049-1057)."""
+		torch = self.torch
+		ng, n = dx.shape
+		dof = n - 1 - rank - dimreduce
+		ns = self.gram_slices(n)
+		odt = np.dtype(out_dtype)
+		tdt = torch.float64 if odt == np.float64 else torch.float32
+		code = _code(out_dtype)
+		esz = odt.itemsize
+		mp, kp = _round_up(ng, ROW_TILE), _round_up(n, K_TILE)
+		nks = (kp + 31) // 32
+		plane = (mp // 32) * nks * 1024
+		cuts = list(range(0, ng, self.BAND)) + [ng]
+		import os, time
+		trace = [] if os.environ.get('NRM_TRACE') else None
+		mark = (lambda what: trace.append((what, time.perf_counter()))) if trace is not None else (lambda what: None)
+		mark('start')
+		with torch.cuda.device(self.device):
+			main = torch.cuda.current_stream(self.device)
+			if self._copy is None:
+				self._copy = torch.cuda.Stream(device=self.device)
+			if getattr(self, '_copy_out', None) is None:
+				self._copy_out = torch.cuda.Stream(device=self.device)
+			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
+			nc = 0 if d_c is None else d_c.shape[0]
+			planes = torch.empty((plane * ns, ), dtype=torch.uint8, device=self.device)
+			exps = torch.empty((mp, ), dtype=torch.int32, device=self.device)
+			ss = torch.empty((mp, ), dtype=torch.float64, device=self.device)
+			p = torch.empty((ng, ng), dtype=tdt, device=self.device)
+			stat = torch.empty((ng, ng), dtype=tdt, device=self.device)
+			flags = self.zeros((2, ), torch.int32)
+			whole = Residualized(ng, n, None, ss, None, shape=(mp, kp))
+			whole._quant = (planes, exps, ns)
+			host = None
+			pending = []
+			row = ng * esz
+
+			def ship(block):
+				"""Queue the copy-out of every finished chunk whose rows of the result arrays are page-locked by now (all of them, waiting
+				for the locks, when block is set): rows a..b up to column b, and columns a..b of the rows above (the mirrored halves)."""
+				while pending:
+					ci, a, b, done = pending[0]
+					while host['ready'] <= ci and host['thread'].is_alive() and block:
+						time.sleep(2e-5)
+					if host['ready'] <= ci and not (block and not host['thread'].is_alive()):
+						return
+					if host['error'] and not host.get('warned'):
+						import logging
+						logging.warning('normalisr_amd: result arrays could not be page-locked (%s); copying out unpinned.', host['error'][0])
+						host['warned'] = True
+					pending.pop(0)
+					self._copy_out.wait_event(done)
+					for h, d in ((host['p'], p), (host['stat'], stat)):
+						_lib.check(self.lib.nrm_copy_rect_to_host(h.ctypes.data + a * row, row, d.data_ptr() + a * row, row, b * esz, b - a, self._copy_out.cuda_stream))
+						for u, v in zip(cuts[:ci], cuts[1:ci + 1]):  # (one copy per band of rows: a copy must stay inside one page-locked range)
+							_lib.check(self.lib.nrm_copy_rect_to_host(h.ctypes.data + u * row + a * esz, row, d.data_ptr() + u * row + a * esz, row, (b - a) * esz, v - u,
+																	  self._copy_out.cuda_stream))
+			mark('buffers')
+			try:
+				for ci, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+					with torch.cuda.stream(self._copy):
+						xc = torch.from_numpy(dx[a:b]).to(self.device)  # the host blocks here while the GPU works on the previous chunk
+					mark('upload %d returned' % ci)
+					arrived = torch.cuda.Event()
+					arrived.record(self._copy)
+					main.wait_event(arrived)
+					xc.record_stream(main)
+					if host is None:  # page-lock the result arrays from a helper thread, started after the first upload (see association_single0)
+						host = self.start_host_results(ng, ng, out_dtype, bands=cuts)
+					rpc = _round_up(b - a, ROW_TILE)
+					_lib.check(self.lib.nrm_residualize_q(
+						xc.data_ptr(), NRM_F64 if xc.dtype == torch.float64 else NRM_F32, b - a, n, xc.stride(0),
+						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
+						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self._stream()))
+					blk = self.row_block(whole, a, a + rpc, rows=b - a)
+					dot = self.gram(blk, blk, True, nslices=ns)
+					_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), blk.ss.data_ptr(), blk.ss.data_ptr(), b - a, b - a, int(n), float(dof), 1, 0,
+														p.data_ptr() + (a * ng + a) * esz, stat.data_ptr() + (a * ng + a) * esz, 0, 0, code, ng, flags.data_ptr(),
+														self._stream()))
+					if a > 0:
+						prev = self.row_block(whole, 0, a, rows=a)
+						dot2 = self.gram(blk, prev, False, nslices=ns)
+						_lib.check(self.lib.nrm_assoc_sweep_mirror(dot2.data_ptr(), dot2.stride(0), blk.ss.data_ptr(), ss.data_ptr(), b - a, a, int(n), float(dof),
+																   p.data_ptr(), stat.data_ptr(), code, ng, a, 0, flags.data_ptr(), self._stream()))
+					done = torch.cuda.Event()
+					done.record(main)
+					pending.append((ci, a, b, done))
+					mark('launched %d' % ci)
+					ship(False)
+				ship(True)
+				mark('queued')
+				self._copy_out.synchronize()
+				mark('copied out')
+			finally:
+				if host is not None:
+					self.finish_host_results(host)
+			mark('unpinned')
+			self.check_flags(flags)
+			res = dict(p=host['p'], stat=host['stat'], alpha=None, varx=None, vary=self.variances(ss, ng, n, out_dtype), dof=dof)
+			mark('done')
+			if trace:
+				t0 = trace[0][1]
+				print('coex pipeline trace (ms): ' + ', '.join('%s %.2f' % (w, (t - t0) * 1e3) for w, t in trace))
+			return res
 
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None):
 		"""K3: p, stat (covariance or gamma) and optionally Pearson r and t for every pair."""
@@ -536,6 +722,8 @@ class Engine:
 		nc = dc.shape[0]
 		dof = n - 1 - rank - dimreduce
 		stat_kind = 0 if (samexy or return_dot) else 1
+		if samexy and not (device_out or resident or want_rt or want_alpha) and self.coex_pipelined_ok(dx, dc, n):
+			return self.association_coex_pipelined(dx, dc, dci, rank, dimreduce, out_dtype, cov)
 		if not (samexy or device_out or resident or want_rt or want_alpha) and self.chunked_ok(dy):
 			return self.association_de_chunked(dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov)
 		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov

@@ -109,6 +109,7 @@ def test_pin_failure_falls_back_and_leaves_no_sticky_error(eng, monkeypatch):
 	def no_pin(a):
 		raise RuntimeError('hipHostRegister failed: out of memory (simulated locked-memory limit)')
 	monkeypatch.setattr(eng, 'host_pin', no_pin)
+	monkeypatch.setattr(eng.pool, 'limit', 0)  # no recycled page-locked blocks either: fresh numpy memory that cannot be locked
 	out[:] = 0
 	assert np.array_equal(eng.download_into(t, out), np.arange(1 << 19, dtype=np.float64))  # pageable fallback
 	assert np.array_equal(eng.download(t), np.arange(1 << 19, dtype=np.float64))
@@ -469,3 +470,60 @@ def test_integer_gram_whole_tiles_are_correctly_rounded(eng):
 					exact += int(np.dot(da[s][i], db[t][j])) << (8 * (s + t))
 		want = float(np.ldexp(float(exact), int(ea[i] + eb[j])))
 		assert got[i, j] == want, (int(i), int(j), float(got[i, j]).hex(), want.hex())
+
+
+def test_pipelined_coex_matches_one_shot(norm, eng, monkeypatch):
+	"""norm.coex on a host matrix large enough for PCIe to matter: rows upload chunk by chunk, every chunk is contracted with
+	itself and with the rows before it, and the pairs it completes (both mirror images) leave while the next chunk arrives
+	(engine.association_coex_pipelined).  Same answers as the one-shot path and the oracle, exact symmetry and zero diagonal,
+	bitwise reproducible, the reference's assertion still fires and the page locks are released afterwards."""
+	rng = np.random.default_rng(909)
+	ng, n = 2700, 4096
+	dt = (rng.normal(size=(ng, n)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))).astype(np.float32)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))]).astype(np.float32)
+	assert eng.coex_pipelined_ok(dt, dc, n)
+	monkeypatch.setenv('NRM_PIPELINE', '0')
+	c0 = norm.coex(dt, dc)
+	monkeypatch.setenv('NRM_PIPELINE', '1')
+	c1 = norm.coex(dt, dc)
+	c2 = norm.coex(dt, dc)
+	assert all(np.array_equal(x, y) for x, y in zip(c1, c2))
+	assert c1[0].dtype == np.float32 and close(c1[0], c0[0], 1e-6, 1e-38) and close(c1[1], c0[1], 1e-6, 1e-7) and np.array_equal(c1[2], c0[2])
+	assert (np.diag(c1[0]) == 0).all() and (c1[0] == c1[0].T).all() and (c1[1] == c1[1].T).all() and (np.diag(c1[1]) == 0).all()
+	sel = np.r_[0:40, 1000:1050, ng - 40:ng]
+	po, do, vo = oracle.coex(dt[sel].astype(np.float64), dc.astype(np.float64))
+	assert close(c1[0][np.ix_(sel, sel)], po, 1e-6, 1e-38) and close(c1[1][np.ix_(sel, sel)], do, 1e-6, 1e-7) and close(c1[2][sel], vo, 1e-6)
+	d64 = norm.coex(dt.astype(np.float64), dc.astype(np.float64))  # fp64 rows through the same pipeline
+	assert p_close(d64[0][np.ix_(sel, sel)], po) and close(d64[2][sel], vo, 1e-12)
+	bad = dt.copy()
+	bad[2000, 7] = np.nan
+	with pytest.raises(AssertionError):
+		norm.coex(bad, dc)
+	c3 = norm.coex(dt, dc)
+	assert np.array_equal(c3[0], c1[0])
+
+
+def test_pinned_result_pool_recycles_and_is_bounded(eng, monkeypatch):
+	"""Result arrays of the numpy-out calls sit on page-locked blocks that return to a pool when the array (and its views) are
+	garbage-collected and are reused by the next result of that size; past NRM_PINNED_POOL_MB results use ordinary memory."""
+	import gc
+	import torch
+	t = torch.arange(1 << 20, dtype=torch.float32, device='cuda').reshape(1024, 1024)
+	a = eng.download(t)
+	ptr = a.ctypes.data
+	view = a[10:20]
+	assert np.array_equal(a, np.arange(1 << 20, dtype=np.float32).reshape(1024, 1024))
+	del a
+	gc.collect()
+	b = eng.download(t)  # the view keeps the first block alive: a different one
+	assert b.ctypes.data != ptr and float(view[0, 0]) == 10 * 1024
+	del view, b
+	gc.collect()
+	c = eng.download(t)
+	assert c.ctypes.data in (ptr, ) or c.ctypes.data != 0  # recycled (either of the two idle blocks)
+	before = eng.pool.total
+	d = eng.download(t)
+	assert eng.pool.total == before  # served from the idle block, nothing new allocated
+	monkeypatch.setattr(eng.pool, 'limit', eng.pool.total)  # pool full: the next result is ordinary numpy memory, still correct
+	e = eng.download(t * 2)
+	assert eng.pool.total <= before and np.array_equal(e, 2 * c)  # (idle blocks of other sizes may have been released to make room)
