@@ -85,11 +85,13 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
  * HBM at all: d_out may be NULL.  Needs 16-byte aligned rows and rows_pad % NRM_ROW_TILE == 0; d_q holds
  * nrm_quant_bytes(rows_pad, round_up(n, 16), nslices) bytes, d_exp rows_pad int32.  plane_pitch_bytes != 0: the rows are a
  * block of 32-row groups of a larger quantised matrix (d_q points at the block's first group, the pitch is the larger matrix's:
- * rows that arrive chunk by chunk fill one set of planes). */
+ * rows that arrive chunk by chunk fill one set of planes).  d_cmax (nc) = max_k |C[c,k]| of every covariate row, or NULL: with it
+ * the fixed-point scale of a row comes from the bound max|x| + sum_c |b_c| max|C_c| >= max|residual| and the rows are swept twice
+ * instead of three times. */
 int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
 					  double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, void* stream);
+					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax, void* stream);
 
 /*
  * K2 -- Gram contraction dot[i,j] = sum_k A[i,k] B[j,k] on the fp64 matrix cores

@@ -1,6 +1,7 @@
 // C ABI glue: error reporting, device selection and the whole-problem host entry
 // (numpy buffers in, numpy buffers out) that stands where association_tests() does
 // (association.py:761-771,1093) for single=0.
+#include <cmath>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -260,7 +261,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	hipStream_t st = nullptr;
 	const int64_t kp = round_up(n, NRM_K_TILE), mp = round_up(nx, NRM_ROW_TILE), np_ = round_up(ny, NRM_ROW_TILE);
 
-	DevBuf dx, dy, dc, dci, rx, ry, ssx, ssy, bx, by, dot, flags, op, ostat, oalpha, orr, ot;
+	DevBuf cmax, dx, dy, dc, dci, rx, ry, ssx, ssy, bx, by, dot, flags, op, ostat, oalpha, orr, ot;
 	// the caller's result arrays are page-locked in place by a helper thread while K1/K2 run (started after the uploads:
 	// a hipHostRegister racing a pageable H2D copy was measured to stall that copy by ~20 ms)
 	const size_t ob = (size_t)nx * ny * esize(out_dtype);
@@ -277,6 +278,11 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 			for (size_t i = 0; i < c64.size(); i++) c64[i] = ((const float*)h_dc)[i];
 		NRM_TRY(dc.alloc(c64.size() * 8));
 		NRM_HIP(hipMemcpy(dc.p, c64.data(), c64.size() * 8, hipMemcpyHostToDevice));
+		std::vector<double> cm((size_t)nc, 0.0);  // max |C_c| per covariate row: K1's bound on the residuals it quantises
+		for (int64_t c = 0; c < nc; c++)
+			for (int64_t k = 0; k < n; k++) cm[(size_t)c] = std::max(cm[(size_t)c], std::fabs(c64[(size_t)(c * n + k)]));
+		NRM_TRY(cmax.alloc((size_t)nc * 8));
+		NRM_HIP(hipMemcpy(cmax.p, cm.data(), (size_t)nc * 8, hipMemcpyHostToDevice));
 		NRM_TRY(dci.alloc((size_t)nc * nc * 8));
 		NRM_REQUIRE(h_dci != nullptr || rank == 0, "Unmatching dci dimensions.");
 		if (h_dci) NRM_HIP(hipMemcpy(dci.p, h_dci, (size_t)nc * nc * 8, hipMemcpyHostToDevice));
@@ -304,7 +310,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 		NRM_TRY(qx.alloc((size_t)nrm_quant_bytes(mp, kp, nslices)));
 		NRM_TRY(ex.alloc((size_t)mp * 4));
 		NRM_TRY(nrm_residualize_q(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, mp, ssx.as<double>(),
-								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), 0, st));
+								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr, st));
 	} else {
 		NRM_TRY(rx.alloc((size_t)mp * kp * 8));
 		NRM_TRY(nrm_residualize(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, rx.as<double>(), kp, mp,
@@ -320,7 +326,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 			NRM_TRY(qy.alloc((size_t)nrm_quant_bytes(np_, kp, nslices)));
 			NRM_TRY(ey.alloc((size_t)np_ * 4));
 			NRM_TRY(nrm_residualize_q(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, np_, ssy.as<double>(),
-									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), 0, st));
+									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr, st));
 		} else {
 			NRM_TRY(ry.alloc((size_t)np_ * kp * 8));
 			NRM_TRY(nrm_residualize(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, ry.as<double>(), kp, np_,

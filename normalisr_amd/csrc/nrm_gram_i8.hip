@@ -189,8 +189,9 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 		else
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (!(QI_EXP & 4)) __syncthreads();  // everyone's have; all waves are done reading stage ks - 1, whose buffer is refilled now
-		// (issuing the refill from waves 4-7 half way through their MFMAs instead -- so that one wave of every SIMD computes while
-		//  its partner queues DMA -- was measured: the branch inside the unrolled MFMA block costs far more than it hides)
+		// (measured and rejected, C2, 2.24 ms as is: issuing the refill from waves 4-7 half way through their MFMAs so that one wave
+		//  of every SIMD computes while its partner queues DMA -- 4.05 ms; issuing it after the operand reads -- 7.1 ms, the asm
+		//  statement's memory clobber drains every read before the first MFMA; s_setprio(1) around the MFMA block -- 11 ms)
 		if (ks + 2 < k1) issue((ks - k0 + 2) % QD, ks + 2);
 		const char* st = lds + buf * STAGE;
 		i4_t fa[NS][2], fb[NS];

@@ -150,6 +150,7 @@ struct QuantOut {
 	int64_t plane_bytes;
 	int64_t nks;          // k-steps of 32 cells
 	int* exps;            // x = digits * 2^exps[row]
+	const double* cmax;   // (nc) largest |C_c| of every covariate row: bounds the residuals without a sweep of their own
 };
 
 template <typename T, int CB, int NS>
@@ -172,6 +173,9 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 		live[r] = row0 + r < rows;
 		xr[r] = x + (live[r] ? (row0 + r) : 0) * ldx;
 	}
+	double xmax[RES_R];  // largest |x| of each row, gathered on the way (NS only)
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) xmax[r] = 0.0;
 	if (active) {
 		for (int c0 = 0; c0 < nc; c0 += CB) {
 			double acc[RES_R][CB];
@@ -183,6 +187,12 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 				double xv[RES_R][4];
 #pragma unroll
 				for (int r = 0; r < RES_R; r++) Vec4Load<T>::ld(xr[r] + k, xv[r]);
+				if (NS && c0 == 0) {
+#pragma unroll
+					for (int r = 0; r < RES_R; r++)
+#pragma unroll
+						for (int i = 0; i < 4; i++) xmax[r] = fmax(xmax[r], fabs(xv[r][i]));
+				}
 #pragma unroll
 				for (int q = 0; q < CB; q++) {
 					if (c0 + q < nc) {
@@ -196,6 +206,10 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 				}
 			}
 			for (int64_t k = n4 + tid; k < n; k += 256) {  // tail cells when n % 4 != 0
+				if (NS && c0 == 0) {
+#pragma unroll
+					for (int r = 0; r < RES_R; r++) xmax[r] = fmax(xmax[r], fabs((double)xr[r][k]));
+				}
 #pragma unroll
 				for (int q = 0; q < CB; q++) {
 					if (c0 + q < nc) {
@@ -262,75 +276,83 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 		for (int r = 0; r < RES_R; r++)
 			if (!live[r]) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
 	};
-	double sq[RES_R], mx[RES_R];
+	// Fixed-point scale of each row (NS only): 2^e >= the largest |residual|.  With covariates a bound does: |x - b C| <= max|x|
+	// + sum_c |b_c| max|C_c| (max|x| was gathered in the first sweep, max|C_c| comes from the caller) -- it overestimates the true
+	// maximum by a small factor, i.e. costs a bit or two of the 8 NS - 2, and saves a sweep over the row.  Without covariates
+	// (or without the caller's maxima) the residuals are swept once more for their maximum.
+	__shared__ double s_mx[4][RES_R];
+	__shared__ int s_sh[RES_R];
+	int sh[RES_R];
+	if (NS) {
+		constexpr int B = 8 * NS - 2;
+		const bool bounded = active && qo.cmax != nullptr;
+		if (!bounded) {
 #pragma unroll
-	for (int r = 0; r < RES_R; r++) sq[r] = mx[r] = 0.0;
-	const int64_t kend = out ? ldo : ((n + 3) & ~(int64_t)3);
-	for (int64_t k = (int64_t)tid * 4; k < kend; k += 1024) {
-		double v[RES_R][4];
-		residual4(k, v);
+			for (int r = 0; r < RES_R; r++) xmax[r] = 0.0;
+			for (int64_t k = (int64_t)tid * 4; k < ((n + 3) & ~(int64_t)3); k += 1024) {
+				double v[RES_R][4];
+				residual4(k, v);
 #pragma unroll
-		for (int r = 0; r < RES_R; r++) {
-			if (out) {
-				double* o = out + (row0 + r) * ldo + k;
-				*reinterpret_cast<double2*>(o) = make_double2(v[r][0], v[r][1]);
-				*reinterpret_cast<double2*>(o + 2) = make_double2(v[r][2], v[r][3]);
-			}
+				for (int r = 0; r < RES_R; r++)
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
-				sq[r] = fma(v[r][i], v[r][i], sq[r]);
-				if (NS) mx[r] = fmax(mx[r], fabs(v[r][i]));
+					for (int i = 0; i < 4; i++) xmax[r] = fmax(xmax[r], fabs(v[r][i]));
 			}
 		}
-	}
-#pragma unroll
-	for (int r = 0; r < RES_R; r++) {
-		double v = wave_sum(sq[r]);
-		if (lane == 0) s_ss[wid][r] = v;
-	}
-	__syncthreads();
-	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
-	if (NS) {
-		// second sweep (the rows are in L2): the same residuals again, rounded once to (8 NS - 2)-bit fixed point relative to the
-		// row's largest entry and cut into NS balanced base-256 digits (see nrm_gram_i8.hip for the layout)
-		constexpr int B = 8 * NS - 2;
-		__shared__ double s_mx[4][RES_R];
-		__shared__ int s_sh[RES_R];
 #pragma unroll
 		for (int r = 0; r < RES_R; r++) {
-			double v = mx[r];
+			double v = xmax[r];
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
 			if (lane == 0) s_mx[wid][r] = v;
 		}
 		__syncthreads();
 		if (tid < RES_R) {
-			const double m = fmax(fmax(s_mx[0][tid], s_mx[1][tid]), fmax(s_mx[2][tid], s_mx[3][tid]));
+			double m = fmax(fmax(s_mx[0][tid], s_mx[1][tid]), fmax(s_mx[2][tid], s_mx[3][tid]));
+			if (bounded)
+				for (int q = 0; q < nc; q++) m = fma(fabs(tb[tid * nc + q]), qo.cmax[q], m);
 			int e = 0;
-			if (m > 0.0 && m < INFINITY) (void)frexp(m, &e);
+			if (m > 0.0 && m < INFINITY) (void)frexp(m, &e);  // m = f 2^e, f in [0.5, 1): every |residual| < 2^e
 			s_sh[tid] = e - B;
 			qo.exps[row0 + tid] = e - B;
 		}
 		__syncthreads();
-		int sh[RES_R];
-		char* qrow[RES_R];
-		int flip[RES_R];
+#pragma unroll
+		for (int r = 0; r < RES_R; r++) sh[r] = s_sh[r];
+	}
+	char* qrow[RES_R];
+	int flip[RES_R];
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) {
+		const int64_t row = row0 + r;
+		const int rr = (int)(row & 31);
+		qrow[r] = NS ? qo.q + ((row >> 5) * qo.nks) * 1024 + (2 * rr) * 16 : nullptr;
+		flip[r] = (rr >> 3) & 1;
+	}
+	// last sweep (the rows are in L2 / MALL by now): residual, zero padding, sum of squares and -- NS -- the residual rounded
+	// once to (8 NS - 2)-bit fixed point and cut into NS balanced base-256 digits (layout: nrm_gram_i8.hip)
+	double sq[RES_R];
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) sq[r] = 0.0;
+	const int64_t kres = out ? ldo : ((n + 3) & ~(int64_t)3), kq = NS ? qo.nks * 32 : 0;
+	for (int64_t k = (int64_t)tid * 4; k < (kres > kq ? kres : kq); k += 1024) {
+		double v[RES_R][4];
+		if (k < n)
+			residual4(k, v);
+		else {
+#pragma unroll
+			for (int r = 0; r < RES_R; r++) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
+		}
 #pragma unroll
 		for (int r = 0; r < RES_R; r++) {
-			sh[r] = s_sh[r];
-			const int64_t row = row0 + r;
-			const int rr = (int)(row & 31);
-			qrow[r] = qo.q + ((row >> 5) * qo.nks) * 1024 + (2 * rr) * 16;
-			flip[r] = (rr >> 3) & 1;
-		}
-		for (int64_t k = (int64_t)tid * 4; k < qo.nks * 32; k += 1024) {
-			double v[RES_R][4];
-			if (k < n)
-				residual4(k, v);
-			else {
-#pragma unroll
-				for (int r = 0; r < RES_R; r++) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
+			if (out && k < ldo) {
+				double* o = out + (row0 + r) * ldo + k;
+				*reinterpret_cast<double2*>(o) = make_double2(v[r][0], v[r][1]);
+				*reinterpret_cast<double2*>(o + 2) = make_double2(v[r][2], v[r][3]);
 			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) sq[r] = fma(v[r][i], v[r][i], sq[r]);
+		}
+		if (NS && k < kq) {
 			const int64_t ks = k >> 5;
 			const int kk = (int)(k & 31);
 #pragma unroll
@@ -353,6 +375,13 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			}
 		}
 	}
+#pragma unroll
+	for (int r = 0; r < RES_R; r++) {
+		double v = wave_sum(sq[r]);
+		if (lane == 0) s_ss[wid][r] = v;
+	}
+	__syncthreads();
+	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
 }
 
 template <typename T>
@@ -378,7 +407,7 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 
 static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
 							const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, void* stream) {
+							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, const double* d_cmax, void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
 	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
 	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
@@ -393,7 +422,7 @@ static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t 
 	const int64_t xa = 16 / (x_dtype == NRM_F64 ? 8 : 4);
 	const bool vec = (ldx % xa == 0) && ((uintptr_t)d_x % 16 == 0) && (!d_out || ((ldo % 4 == 0) && ((uintptr_t)d_out % 16 == 0))) &&
 					 (!active || (ldc % 2 == 0 && (uintptr_t)d_c % 16 == 0));
-	QuantOut qo = {nullptr, 0, 0, nullptr};
+	QuantOut qo = {nullptr, 0, 0, nullptr, d_cmax};
 	if (nslices) {
 		NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_residualize_q: 5 or 6 slices");
 		NRM_REQUIRE(vec, "nrm_residualize_q: needs 16-byte aligned rows (use nrm_residualize + nrm_quantize_rows otherwise)");
@@ -421,14 +450,15 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
 							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
 	NRM_REQUIRE(d_out != nullptr, "nrm_residualize: null output");
-	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, stream);
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 								 int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss,
-								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, void* stream) {
+								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax,
+								 void* stream) {
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp,
-							plane_pitch_bytes, stream);
+							plane_pitch_bytes, d_cmax, stream);
 }
 
 // Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS
@@ -476,12 +506,16 @@ __global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ 
 	}
 }
 
-__global__ void __launch_bounds__(64) k_rw_sum(const double* __restrict__ part, int nblocks, int rows, double* __restrict__ ss) {
-	const int r = threadIdx.x;
-	if (r >= rows) return;
+// one workgroup per row: the per-block partial sums are added in a fixed (strided, then tree) order -- bitwise reproducible
+__global__ void __launch_bounds__(256) k_rw_sum(const double* __restrict__ part, int nblocks, int rows, double* __restrict__ ss) {
+	__shared__ double s_w[4];
+	const int r = blockIdx.x;
 	double acc = 0.0;
-	for (int b = 0; b < nblocks; b++) acc += part[(int64_t)b * RW_ROWS + r];
-	ss[r] = acc;
+	for (int b = threadIdx.x; b < nblocks; b += 256) acc += part[(int64_t)b * RW_ROWS + r];
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) ss[r] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
@@ -501,6 +535,6 @@ extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, 
 	else
 		hipLaunchKernelGGL(k_residualize_wide<float>, grid, dim3(256), 0, st, (const float*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
 						   d_dci, active, d_out, ldo, d_work, d_coef);
-	hipLaunchKernelGGL(k_rw_sum, dim3(1), dim3(64), 0, st, d_work, (int)grid.x, (int)rows, d_ss);
+	hipLaunchKernelGGL(k_rw_sum, dim3((unsigned)rows), dim3(256), 0, st, d_work, (int)grid.x, (int)rows, d_ss);
 	return nrm_check_launch("k_residualize_wide");
 }

@@ -117,6 +117,7 @@ class Engine:
 		self._skinny_ws = None
 		self._copy = None
 		self.pool = PinnedPool(self.lib)
+		self._cmax = {}
 
 	def _stream(self):
 		return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -205,7 +206,17 @@ class Engine:
 		nc = dc.shape[0]
 		if nc == 0:
 			return None, None
-		return self.upload(np.asarray(dc, dtype=np.float64)), self.upload(np.asarray(dci, dtype=np.float64).reshape(nc, nc))
+		dc64 = np.asarray(dc, dtype=np.float64)
+		d_c = self.upload(dc64)
+		# largest |C_c| of every covariate row: lets K1 bound the residuals it quantises without sweeping them for their maximum
+		self._cmax = {k: v for k, v in self._cmax.items() if v[0]() is not None}
+		import weakref
+		self._cmax[d_c.data_ptr()] = (weakref.ref(d_c), self.upload(np.abs(dc64).max(axis=1)))
+		return d_c, self.upload(np.asarray(dci, dtype=np.float64).reshape(nc, nc))
+
+	def cmax_ptr(self, d_c):
+		e = None if d_c is None else self._cmax.get(d_c.data_ptr())
+		return e[1].data_ptr() if e is not None and e[0]() is d_c else 0
 
 	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True):
 		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n).  nslices = 5 / 6: also (keep_fp64=False: only) the
@@ -231,7 +242,7 @@ class Engine:
 					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 					0 if d_dci is None else d_dci.data_ptr(), int(rank), 0 if out is None else out.data_ptr(), kp, rp, ss.data_ptr(),
-					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self._stream()))
+					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self.cmax_ptr(d_c), self._stream()))
 				r = Residualized(rows, n, out, ss, coef, shape=(rp, kp))
 				r._quant = (planes, exps, nslices)
 				return r
@@ -533,7 +544,7 @@ class Engine:
 					_lib.check(self.lib.nrm_residualize_q(
 						xc.data_ptr(), NRM_F64 if xc.dtype == torch.float64 else NRM_F32, b - a, n, xc.stride(0),
 						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
-						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self._stream()))
+						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c), self._stream()))
 					blk = self.row_block(whole, a, a + rpc, rows=b - a)
 					dot = self.gram(blk, blk, True, nslices=ns)
 					_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), blk.ss.data_ptr(), blk.ss.data_ptr(), b - a, b - a, int(n), float(dof), 1, 0,
@@ -655,9 +666,18 @@ class Engine:
 			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
 			# design rows: a = x C^T through the streaming Gram (all CUs), then x~ = x - (a dci) C spread along the cells
 			k32 = _round_up(n, 128)
-			z = self.zeros((32, k32), torch.float64)  # Z = [C; X~; 0]: stacked on the device through the C ABI
-			if nc:
-				self.copy_rows(z, d_c)
+			# Z = [C; X~; 0], stacked on the device through the C ABI.  The covariate rows do not change between calls on the same
+			# covariates (a DePlan's steps): the buffer is kept and only the rows past the covariates are rewritten.
+			zc = getattr(self, '_zcache', None)
+			if zc is not None and zc[0]() is d_c and d_c is not None and zc[1].shape[1] == k32:
+				z = zc[1]
+				_lib.check(self.lib.nrm_fill_zero(z[nc:].data_ptr(), (32 - nc) * k32 * 8, self._stream()))
+			else:
+				z = self.zeros((32, k32), torch.float64)
+				if nc:
+					self.copy_rows(z, d_c)
+					import weakref
+					self._zcache = (weakref.ref(d_c), z)
 			xd = self._rows_padded16(as_input(dx) if isinstance(dx, np.ndarray) else dx)
 			xcode = NRM_F64 if xd.dtype == torch.float64 else NRM_F32
 			gx = torch.empty((256, 32), dtype=torch.float64, device=self.device)
