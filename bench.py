@@ -339,11 +339,12 @@ def main():
 				for f in PMC_FILES:
 					try:
 						with open(f) as fh:
-							out['roofline']['traffic'] = json.load(fh)[out['roofline']['kernel']]['hbm_bytes_per_launch']
+							pm = json.load(fh)
+							out['roofline']['traffic'] = next(v for k, v in pm.items() if k.split('<')[0] == out['roofline']['kernel'])['hbm_bytes_per_launch']
 						out['roofline']['traffic_unit'] = 'bytes/launch'
 						out['roofline']['traffic_source'] = '{} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(os.path.relpath(f, ROOT))
 						break
-					except (OSError, KeyError, ValueError):
+					except (OSError, KeyError, ValueError, StopIteration):
 						continue
 			return out
 		if which == 'coex_c5':
@@ -388,7 +389,7 @@ def main():
 		for w in names:
 			try:
 				torch.cuda.empty_cache()
-				r = run(w, args.extras_steps, 2)
+				r = run(w, args.steps if w == 'de_c3' else args.extras_steps, 3 if w == 'de_c3' else 2)  # (the 2 ms step: enough of them to time)
 				r['n_gpus'] = world
 				extras[w] = r
 			except Exception as e:  # reported, never fatal for the headline

@@ -21,7 +21,7 @@ def main(dirs):
 	for d in dirs:
 		for f in glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True):
 			df = pd.read_csv(f)
-			df['kernel'] = df['Kernel_Name'].str.extract(r'\b(k_[a-z0-9_]+)')
+			df['kernel'] = df['Kernel_Name'].str.extract(r'\b(k_[a-z0-9_]+(?:<[^>]*>)?)')  # template arguments kept: instantiations differ
 			rows.append(df[df['kernel'].notna()])
 	df = pd.concat(rows)
 	mean = df.groupby(['kernel', 'Counter_Name'])['Counter_Value'].mean().unstack()
@@ -30,8 +30,9 @@ def main(dirs):
 		e = {c: float(v) for c, v in r.items() if v == v}
 		if 'FETCH_SIZE' in e:
 			e['fetch_bytes_raw'] = e['FETCH_SIZE'] * 1024
-			e['fetch_bytes'] = e['fetch_bytes_raw'] * (2 if WIDE.get(k, False) else 1)
-			e['fetch_corrected_x2'] = bool(WIDE.get(k, False))
+			wide = WIDE.get(k.split('<')[0], False)
+			e['fetch_bytes'] = e['fetch_bytes_raw'] * (2 if wide else 1)
+			e['fetch_corrected_x2'] = bool(wide)
 		if 'WRITE_SIZE' in e:
 			e['write_bytes'] = e['WRITE_SIZE'] * 1024
 		if 'fetch_bytes' in e and 'write_bytes' in e:
