@@ -116,6 +116,11 @@ def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0):
 	return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def SLICES(n_cells):
+	from normalisr_amd.engine import Engine
+	return Engine.gram_slices(n_cells)
+
+
 def ARITH(n_cells):
 	"""`dtype` of the JSON line: the arithmetic the dominant kernel computes in."""
 	from normalisr_amd.engine import Engine
@@ -224,8 +229,8 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 			   scaling='weak', dtype=ARITH(n),
 			   config=dict(workload=label.format(genes=ng, cells=n), genes=ng, cells=n, covariates=3, tests_per_step=tests,
 						   parallelism='gene-row blocks x{}'.format(world), exchange=None if world == 1 else (
-							   'all-gather of raw fp32 blocks' if plan.exchange_raw else 'all-gather of fp64 residual blocks'),
-						   exchange_bytes_per_rank=None if world == 1 else int((world - 1) * rows_local * n * (esz if plan.exchange_raw else 8))),
+							   'all-gather of raw fp32 blocks' if plan.exchange_raw else 'all-gather of residual blocks as fixed-point digit planes + exponents + sums of squares'),
+						   exchange_bytes_per_rank=None if world == 1 else int((world - 1) * rows_local * n * (esz if plan.exchange_raw else (SLICES(n) or 8)))),
 			   roofline=gram_roofline(n, flops, gram_ms, plan.rows_pad, plan.k_pad),
 			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region')
 	return out, plan
