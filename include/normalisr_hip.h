@@ -212,14 +212,18 @@ int nrm_alpha(const void* d_stat, int stat_dtype, int64_t ldg, int stat_kind, co
  * zero padded up to ldo; d_ss (rows) sums of squares; d_coef (rows, nc) or NULL the OLS coefficients. */
 int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 						 int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
-						 double* d_ss, double* d_coef, double* d_work /* 32 * ceil(ldo/1024) doubles */, void* stream);
+						 double* d_ss, double* d_coef, double* d_work /* 32 * ceil(ldo/1024) doubles */,
+						 int const_last /* != 0: the LAST covariate is the constant row: its product sits in column 31 of d_ga */, void* stream);
 int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64_t n, int64_t lda, const double* d_z, int64_t ldz,
 					int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, int64_t nz /* used rows of Z (<= 32); <= 16 selects the half-width variant */,
+					double const_row_value /* != 0: G[:, 31] = value * sum_k Y[y,k], the product with a constant covariate row (the
+					intercept) that the caller left out of Z: a vector-ALU sum instead of a 4-row matrix-core group; 0: none */,
 					void* d_work, void* stream);
 int64_t nrm_gram_skinny_workspace_bytes(void);  /* scratch for d_work (deterministic combination of partial pieces) */
 int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
 					   int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,
-					   void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags, void* stream);
+					   void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags,
+					   int const_last /* as above: covariate nc-1 in column 31, the design rows from column nc-1 on */, void* stream);
 
 /*
  * single=4 sweep (competition-aware DE, association.py:421-576 in closed form).

@@ -46,10 +46,10 @@ _SIGNATURES = {
 	'nrm_assoc_sweep_mirror': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp], _i32),
 	'nrm_copy_rect_to_host': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_single4_sweep': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
-	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
-	'nrm_gram_skinny': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp], _i32),
+	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp], _i32),
+	'nrm_gram_skinny': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_gram_skinny_workspace_bytes': ([], _i64),
-	'nrm_de_small_sweep': ([_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp], _i32),
+	'nrm_de_small_sweep': ([_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp], _i32),
 	'nrm_single1_sweep': ([_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_binnet': ([_vp, _i32, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_binnet_rows': ([_vp, _i32, _i64, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),

@@ -45,6 +45,8 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 struct SkinnySched {
 	int nkt, tiles_dp, tiles_sk, units_per_wg, nwg;
 	int tm;        // rows per workgroup tile
+	double cval;   // != 0: column 31 of G receives cval * sum_k Y[y,k] -- the product with a CONSTANT Z row (the intercept)
+	               // taken out of Z and summed on the vector ALU (one add per value) instead of a 4-row matrix-core group
 	double* work;  // per partial piece: a (tm x 32) slab of G followed by tm sums of squares; two pieces per workgroup
 };
 
@@ -233,9 +235,10 @@ __global__ void __launch_bounds__(TM * 4 / RT + 64 * NL) k_gram_skinny(const T* 
 		for (int i = 0; i < RT; i++)
 #pragma unroll
 			for (int g = 0; g < (NQ ? NQ : 1); g++) accq[i][g] = 0.0;
-		double sq[RT];
+		double sq[RT], sy[RT];
 #pragma unroll
-		for (int i = 0; i < RT; i++) sq[i] = 0.0;
+		for (int i = 0; i < RT; i++) sq[i] = sy[i] = 0.0;
+		const bool sumcol = s.cval != 0.0;
 		struct Ops {
 			LdsSlab<T> cur[RT];
 			double zf[NT][4];
@@ -283,6 +286,7 @@ __global__ void __launch_bounds__(TM * 4 / RT + 64 * NL) k_gram_skinny(const T* 
 					double a = o.cur[i].get(st);
 					if (SK_EXP & 32) a = __hiloint2double(__float_as_int((float)a), 0x3ff00000);  // experiment: no v_cvt_f64_f32
 					if (!(SK_EXP & 4)) sq[i] = fma(a, a, sq[i]);
+					if (sumcol) sy[i] += a;
 					if (SK_EXP & 1) {
 						acc[i][0][st] += a;  // keeps the operand reads alive without the matrix cores
 					} else {
@@ -336,6 +340,12 @@ __global__ void __launch_bounds__(TM * 4 / RT + 64 * NL) k_gram_skinny(const T* 
 			v += __shfl_xor(v, 16, 64);
 			v += __shfl_xor(v, 32, 64);
 			if (lg == 0) sbase[i * 16 + l15] = v;
+			if (sumcol) {  // (after the column stores above: the last column is this wave's to overwrite)
+				double w = sy[i];
+				w += __shfl_xor(w, 16, 64);
+				w += __shfl_xor(w, 32, 64);
+				if (lg == 0) gbase[(int64_t)(i * 16 + l15) * SKN + (SKN - 1)] = s.cval * w;
+			}
 		}
 	}
 }
@@ -377,7 +387,8 @@ extern "C" int64_t nrm_gram_skinny_workspace_bytes(void) {
 }
 
 extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64_t n, int64_t lda, const double* d_z, int64_t ldz,
-							   int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, int64_t nz, void* d_work, void* stream) {
+							   int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, int64_t nz, double const_row_value, void* d_work,
+							   void* stream) {
 	NRM_REQUIRE(a_dtype == NRM_F32 || a_dtype == NRM_F64, "nrm_gram_skinny: bad dtype");
 	NRM_REQUIRE(rows > 0 && n > 0 && lda >= n, "Incorrect dx/dy/dc size.");
 	const int64_t n16 = (n + 15) / 16 * 16;
@@ -398,6 +409,8 @@ extern "C" int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64
 	SkinnySched s;
 	s.work = (double*)d_work;
 	s.tm = SK2_TM;
+	s.cval = const_row_value;
+	NRM_REQUIRE(const_row_value == 0.0 || nz < SKN, "nrm_gram_skinny: a constant row needs the last column of G free (nz <= 31)");
 	const int64_t tiles = rows_pad / s.tm;
 	s.nkt = (int)(k_pad / SKC);
 	s.nwg = g_num_cu_s;  // one workgroup per CU (its LDS ring takes 130-160 KB)

@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ 
 														   const double* __restrict__ c, int nc, int64_t ldc,
 														   const double* __restrict__ ga /* (rows, 32) */, const double* __restrict__ dci,
 														   int active, double* __restrict__ out, int64_t ldo, double* __restrict__ ss_part,
-														   double* __restrict__ coef) {
+														   double* __restrict__ coef, int const_last) {
 	__shared__ double s_b[RW_ROWS][RW_ROWS];
 	__shared__ double s_w[4];
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ 
 		for (int i = tid; i < rows * nc; i += 256) {
 			const int r = i / nc, q = i % nc;
 			double v = 0.0;
-			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], ga[r * 32 + e], v);
+			for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], ga[r * 32 + ((const_last && e == nc - 1) ? 31 : e)], v);
 			s_b[r][q] = v;
 			if (coef && blockIdx.x == 0) coef[r * nc + q] = v;
 		}
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) k_rw_sum(const double* __restrict__ part,
 
 extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 									int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
-									double* d_ss, double* d_coef, double* d_work, void* stream) {
+									double* d_ss, double* d_coef, double* d_work, int const_last, void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize_wide: bad dtype");
 	NRM_REQUIRE(rows > 0 && rows <= RW_ROWS && nc >= 0 && nc <= RW_ROWS, "nrm_residualize_wide: at most %d rows and covariates", RW_ROWS);
 	NRM_REQUIRE(n > 0 && ldx >= n && ldo >= n && d_x && d_out && d_ss, "Incorrect dx/dy/dc size.");
@@ -531,10 +531,10 @@ extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, 
 	dim3 grid((unsigned)((ldo + 1023) / 1024));
 	if (x_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_residualize_wide<double>, grid, dim3(256), 0, st, (const double*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
-						   d_dci, active, d_out, ldo, d_work, d_coef);
+						   d_dci, active, d_out, ldo, d_work, d_coef, const_last);
 	else
 		hipLaunchKernelGGL(k_residualize_wide<float>, grid, dim3(256), 0, st, (const float*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
-						   d_dci, active, d_out, ldo, d_work, d_coef);
+						   d_dci, active, d_out, ldo, d_work, d_coef, const_last);
 	hipLaunchKernelGGL(k_rw_sum, dim3((unsigned)rows), dim3(256), 0, st, d_work, (int)grid.x, (int)rows, d_ss);
 	return nrm_check_launch("k_residualize_wide");
 }

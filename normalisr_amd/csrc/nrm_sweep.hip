@@ -346,12 +346,28 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 														 int stat_kind, PvalPlan pl, OutT* __restrict__ p_out, OutT* __restrict__ stat_out,
 														 OutT* __restrict__ r_out, OutT* __restrict__ t_out, int64_t ldo,
 														 double* __restrict__ ssy_out, double* __restrict__ by_out,
-														 int32_t* __restrict__ flags) {
+														 int32_t* __restrict__ flags, int const_last) {
 	const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (y >= ny) return;
 	double g[DS_NZ];
+	// columns of G: covariates, then design rows.  const_last: the last covariate (a constant row summed on the vector ALU by
+	// nrm_gram_skinny) sits in column 31 and the design rows start one column earlier: put everything back in order
+	{
+		double raw[DS_NZ];
 #pragma unroll
-	for (int c = 0; c < DS_NZ; c++) g[c] = G[y * DS_NZ + c];
+		for (int c = 0; c < DS_NZ; c++) raw[c] = G[y * DS_NZ + c];
+#pragma unroll
+		for (int c = 0; c < DS_NZ; c++) {
+			double v = raw[c];
+			if (const_last) {
+				if (c == nc - 1)
+					v = raw[DS_NZ - 1];
+				else if (c >= nc)
+					v = c >= 1 ? raw[c - 1] : 0.0;
+			}
+			g[c] = v;
+		}
+	}
 	double q = 0.0;
 	if (rank_pos) {
 #pragma unroll
@@ -518,8 +534,9 @@ extern "C" int nrm_alpha(const void* d_stat, int stat_dtype, int64_t ldg, int st
 
 extern "C" int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
 								  int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,
-								  void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags, void* stream) {
+								  void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags, int const_last, void* stream) {
 	NRM_REQUIRE(nx > 0 && ny > 0 && nc >= 0 && nx + nc <= DS_NZ, "nrm_de_small_sweep: needs nx + nc <= %d", DS_NZ);
+	NRM_REQUIRE(!const_last || nc >= 1, "nrm_de_small_sweep: const_last needs a covariate");
 	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_de_small_sweep: bad out_dtype");
 	NRM_REQUIRE(d_g && d_ssraw && d_ssx && d_p && d_stat && d_ssy && ldo >= ny, "nrm_de_small_sweep: null pointer or small pitch");
 	NRM_REQUIRE(!(rank > 0 && nc > 0) || d_dci, "Unmatching dci dimensions.");
@@ -531,10 +548,10 @@ extern "C" int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, cons
 	if (out_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_de_small_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_g, d_ssraw, d_dci, (int)nc, rank_pos, d_ssx,
 						   (int)nx, ny, (double)n_cells, dof, stat_kind, to_dev(plan), (double*)d_p, (double*)d_stat, (double*)d_r,
-						   (double*)d_t, ldo, d_ssy, d_by, d_flags);
+						   (double*)d_t, ldo, d_ssy, d_by, d_flags, const_last);
 	else
 		hipLaunchKernelGGL(k_de_small_sweep<float>, grid, dim3(256), 0, (hipStream_t)stream, d_g, d_ssraw, d_dci, (int)nc, rank_pos, d_ssx,
 						   (int)nx, ny, (double)n_cells, dof, stat_kind, to_dev(plan), (float*)d_p, (float*)d_stat, (float*)d_r,
-						   (float*)d_t, ldo, d_ssy, d_by, d_flags);
+						   (float*)d_t, ldo, d_ssy, d_by, d_flags, const_last);
 	return nrm_check_launch("k_de_small_sweep");
 }

@@ -211,8 +211,15 @@ class Engine:
 		# largest |C_c| of every covariate row: lets K1 bound the residuals it quantises without sweeping them for their maximum
 		self._cmax = {k: v for k, v in self._cmax.items() if v[0]() is not None}
 		import weakref
-		self._cmax[d_c.data_ptr()] = (weakref.ref(d_c), self.upload(np.abs(dc64).max(axis=1)))
+		const = np.nonzero((dc64 == dc64[:, :1]).all(axis=1) & (dc64[:, 0] != 0))[0]  # constant rows (the intercept)
+		self._cmax[d_c.data_ptr()] = (weakref.ref(d_c), self.upload(np.abs(dc64).max(axis=1)), int(const[0]) if const.size else -1,
+									 float(dc64[const[0], 0]) if const.size else 0.0)
 		return d_c, self.upload(np.asarray(dci, dtype=np.float64).reshape(nc, nc))
+
+	def constant_row(self, d_c):
+		"""(index, value) of a constant covariate row of device covariates uploaded through covariates(), or (-1, 0)."""
+		e = None if d_c is None else self._cmax.get(d_c.data_ptr())
+		return (e[2], e[3]) if e is not None and e[0]() is d_c else (-1, 0.0)
 
 	def cmax_ptr(self, d_c):
 		e = None if d_c is None else self._cmax.get(d_c.data_ptr())
@@ -657,6 +664,7 @@ class Engine:
 	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
 								 resident=False):
 		"""de with nx + nc <= 32: stream the raw expression rows once (HBM-bound), see csrc/nrm_gram_skinny.hip."""
+		import os
 		torch = self.torch
 		nx, n = dx.shape
 		ny, nc = dy.shape[0], dc.shape[0]
@@ -664,20 +672,40 @@ class Engine:
 		tdt = torch.float64 if np.dtype(out_dtype) == np.float64 else torch.float32
 		with torch.cuda.device(self.device):
 			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
+			# A constant covariate row (the intercept) leaves Z: its product with every expression row is a plain sum, taken on the
+			# vector ALU by the streaming kernel (column 31 of G) instead of occupying a matrix-core row group.  The covariates are
+			# reordered so that it comes last; dci is permuted with them (b' = P b: no rank assumption), alpha is put back in order.
+			ci, cval = self.constant_row(d_c)
+			if os.environ.get('NRM_CONST_ROW', '1') == '0' or nc + nx > 31 + (ci >= 0):
+				ci, cval = -1, 0.0
+			perm = None
+			if ci >= 0:
+				perm = [c for c in range(nc) if c != ci] + [ci]
+				pc = getattr(self, '_cperm', None)
+				if pc is None or pc[0]() is not d_c:  # (kept with the covariates: no upload inside a step that is replayed as a graph)
+					import weakref
+					pc = (weakref.ref(d_c), d_c[perm].contiguous(),
+						  self.upload(np.ascontiguousarray(np.asarray(dci, dtype=np.float64).reshape(nc, nc)[np.ix_(perm, perm)])))
+					self._cperm = pc
+				d_cz, d_dciz = pc[1], pc[2]
+			else:
+				d_cz, d_dciz = d_c, d_dci
+			ncz = nc - (1 if ci >= 0 else 0)  # covariate rows that stay in Z
 			# design rows: a = x C^T through the streaming Gram (all CUs), then x~ = x - (a dci) C spread along the cells
 			k32 = _round_up(n, 128)
 			# Z = [C; X~; 0], stacked on the device through the C ABI.  The covariate rows do not change between calls on the same
 			# covariates (a DePlan's steps): the buffer is kept and only the rows past the covariates are rewritten.
 			zc = getattr(self, '_zcache', None)
-			if zc is not None and zc[0]() is d_c and d_c is not None and zc[1].shape[1] == k32:
+			if zc is not None and zc[0]() is d_c and d_c is not None and zc[1].shape[1] == k32 and zc[2] == ci:
 				z = zc[1]
-				_lib.check(self.lib.nrm_fill_zero(z[nc:].data_ptr(), (32 - nc) * k32 * 8, self._stream()))
+				_lib.check(self.lib.nrm_fill_zero(z[ncz:].data_ptr(), (32 - ncz) * k32 * 8, self._stream()))
 			else:
 				z = self.zeros((32, k32), torch.float64)
+				if ncz:
+					self.copy_rows(z, d_cz[:ncz])
 				if nc:
-					self.copy_rows(z, d_c)
 					import weakref
-					self._zcache = (weakref.ref(d_c), z)
+					self._zcache = (weakref.ref(d_c), z, ci)
 			xd = self._rows_padded16(as_input(dx) if isinstance(dx, np.ndarray) else dx)
 			xcode = NRM_F64 if xd.dtype == torch.float64 else NRM_F32
 			gx = torch.empty((256, 32), dtype=torch.float64, device=self.device)
@@ -685,22 +713,23 @@ class Engine:
 			active = rank > 0 and nc > 0
 			if active:
 				_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
-													ssx_raw.data_ptr(), 256, nc, self._skinny_work().data_ptr(), self._stream()))
-			xt = z[nc:nc + nx]  # the residualised design rows are written straight into their rows of Z (zero padded up to k32)
+													ssx_raw.data_ptr(), 256, max(ncz, 1), float(cval), self._skinny_work().data_ptr(), self._stream()))
+			xt = z[ncz:ncz + nx]  # the residualised design rows are written straight into their rows of Z (zero padded up to k32)
 			rw_work = torch.empty((32 * ((k32 + 1023) // 1024), ), dtype=torch.float64, device=self.device)
 			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
 			coefx = self.zeros((nx, nc), torch.float64) if want_alpha else None
-			_lib.check(self.lib.nrm_residualize_wide(xd.data_ptr(), xcode, nx, n, xd.stride(0), 0 if d_c is None else d_c.data_ptr(), nc,
-													 0 if d_c is None else d_c.stride(0), gx.data_ptr(), 0 if d_dci is None else d_dci.data_ptr(),
+			_lib.check(self.lib.nrm_residualize_wide(xd.data_ptr(), xcode, nx, n, xd.stride(0), 0 if d_cz is None else d_cz.data_ptr(), nc,
+													 0 if d_cz is None else d_cz.stride(0), gx.data_ptr(), 0 if d_dciz is None else d_dciz.data_ptr(),
 													 int(rank), xt.data_ptr(), k32, ssx.data_ptr(), 0 if coefx is None else coefx.data_ptr(),
-													 rw_work.data_ptr(), self._stream()))
+													 rw_work.data_ptr(), 1 if ci >= 0 else 0, self._stream()))
 			rx = Residualized(nx, n, xt, ssx, coefx)
 			y = self._rows_padded16(dy)
 			ny_pad = _round_up(ny, 256)
 			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
 			ssraw = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), NRM_F64 if y.dtype == torch.float64 else NRM_F32, ny, n, y.stride(0),
-												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, nc + nx, self._skinny_work().data_ptr(), self._stream()))
+												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, ncz + nx, float(cval), self._skinny_work().data_ptr(),
+												self._stream()))
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
@@ -709,14 +738,18 @@ class Engine:
 			by = self.zeros((ny, nc), torch.float64) if (want_alpha and nc) else None
 			flags = self.zeros((2, ), torch.int32)
 			stat_kind = 0 if return_dot else 1
-			_lib.check(self.lib.nrm_de_small_sweep(g.data_ptr(), ssraw.data_ptr(), 0 if d_dci is None else d_dci.data_ptr(), nc, int(rank),
+			_lib.check(self.lib.nrm_de_small_sweep(g.data_ptr(), ssraw.data_ptr(), 0 if d_dciz is None else d_dciz.data_ptr(), nc, int(rank),
 												   rx.ss.data_ptr(), nx, ny, n, float(dof), stat_kind, p.data_ptr(), stat.data_ptr(),
 												   0 if r is None else r.data_ptr(), 0 if t is None else t.data_ptr(), _code(out_dtype),
-												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), self._stream()))
+												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), 1 if ci >= 0 else 0, self._stream()))
 			alpha = None
 			if want_alpha:
 				if nc > 0:
 					alpha = self.alpha(stat, stat_kind, rx.ss, n, rx.coef, by, nc).cpu().numpy()
+					if perm is not None:  # coefficients came out in the reordered covariate order
+						back = np.empty(nc, dtype=np.int64)
+						back[perm] = np.arange(nc)
+						alpha = np.ascontiguousarray(alpha[..., back])
 				else:
 					alpha = np.zeros((nx, ny, nc), dtype=out_dtype)
 			if resident:  # resident pipeline: nothing leaves the device, the caller checks `flags` when it reads the results
