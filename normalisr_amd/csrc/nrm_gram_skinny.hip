@@ -134,7 +134,6 @@ __global__ void __launch_bounds__(TM * 4 / RT + 64 * NL) k_gram_skinny(const T* 
 	constexpr int CZ0 = NZI / NL, NZHI = NZI % NL;  // Z instructions are dealt round-robin: loaders < NZHI issue CZ0 + 1, the others CZ0
 	static_assert(NSL >= 1 && NZI * ZRPI <= 32 && ZCH <= 32 && D >= 2 && D <= 4 && SB * D <= 512, "unsupported stage geometry");
 	static_assert(NY % NL == 0 && 2 * (NYL + CZ0 + 1) < 64, "loader split / vmcnt field");
-	static_assert(YRPI % YCH == 0, "the loader assumes one swizzle per lane for every instruction");
 	__shared__ __attribute__((aligned(1024))) char ylds[D * YSTAGE];
 	__shared__ __attribute__((aligned(1024))) char zlds[D * ZSTAGE];
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -192,7 +191,9 @@ __global__ void __launch_bounds__(TM * 4 / RT + 64 * NL) k_gram_skinny(const T* 
 				const int64_t r = (int64_t)t * TM + rr;
 				ysrc[j] = A + (r < rows ? r : 0) * lda + (jp ^ (rr & (YCH - 1))) * EPC;
 			}
-			const int ycell = (jp ^ (jr & (YCH - 1))) * EPC;  // first cell (within a stage) of this lane's chunk: YRPI * j is a multiple of YCH or YCH of it
+			int ycell[NYL];  // first cell (within a stage) of the chunk this lane fetches with instruction j
+#pragma unroll
+			for (int j = 0; j < NYL; j++) ycell[j] = (jp ^ ((YRPI * (li + j * NL) + jr) & (YCH - 1))) * EPC;
 			const double* zsrc[CZ0 + 1];
 #pragma unroll
 			for (int q = 0; q < CZ0 + 1; q++) {
@@ -206,9 +207,9 @@ __global__ void __launch_bounds__(TM * 4 / RT + 64 * NL) k_gram_skinny(const T* 
 #pragma unroll
 				for (int q = 0; q < CZ0; q++) sk_dma16(zsrc[q] + k0, zlds0 + buf * ZSTAGE + (li + q * NL) * 1024);
 				if (zhi) sk_dma16(zsrc[CZ0] + k0, zlds0 + buf * ZSTAGE + (li + CZ0 * NL) * 1024);
-				const bool past = k0 + SC > n16 && k0 + ycell >= n16;  // chunk past the (16-padded) row end: fetch anything valid, its slab is skipped
+				const bool tail = k0 + SC > n16;  // a chunk past the (16-padded) row end: fetch anything valid, its slab is skipped
 #pragma unroll
-				for (int j = 0; j < NYL; j++) sk_dma16(past ? A : ysrc[j] + k0, ylds0 + buf * YSTAGE + (li + j * NL) * 1024);
+				for (int j = 0; j < NYL; j++) sk_dma16((tail && k0 + ycell[j] >= n16) ? A : ysrc[j] + k0, ylds0 + buf * YSTAGE + (li + j * NL) * 1024);
 			};
 			for (int d = 0; d < D - 1; d++)
 				if (st0 + d < st1) issue(d, (int64_t)(st0 + d) * SC);

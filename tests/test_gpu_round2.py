@@ -527,3 +527,23 @@ def test_pinned_result_pool_recycles_and_is_bounded(eng, monkeypatch):
 	monkeypatch.setattr(eng.pool, 'limit', eng.pool.total)  # pool full: the next result is ordinary numpy memory, still correct
 	e = eng.download(t * 2)
 	assert eng.pool.total <= before and np.array_equal(e, 2 * c)  # (idle blocks of other sizes may have been released to make room)
+
+
+def test_sharded_wrappers_in_a_single_process(norm):
+	"""distributed.coex / coex_binnet / de without a process group (world 1): the same row completion, shared-array assembly and
+	row-block binnet as the multi-rank runs, equal to the plain API."""
+	from normalisr_amd import distributed as nd
+	rng = np.random.default_rng(1212)
+	ng, n = 700, 2500
+	dt = rng.normal(size=(ng, n)) + 0.4 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n))
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))])
+	p, d, v = nd.coex(dt, dc)
+	pr, dr, vr = norm.coex(dt, dc)
+	assert np.array_equal(p, pr) and np.array_equal(d, dr) and np.array_equal(v, vr)
+	net = nd.coex_binnet(dt, dc, 0.2)
+	assert net.dtype == np.bool_ and np.array_equal(net, oracle.binnet(pr, 0.2))
+	dg = (rng.random((3, n)) < 0.3).astype(np.float64)
+	dg[1] = 0
+	got = nd.de(dg, dt, dc)
+	ref = norm.de(dg, dt, dc)
+	assert got[2] is None and all(np.array_equal(a, b) for a, b in zip((got[0], got[1], got[3], got[4]), (ref[0], ref[1], ref[3], ref[4])))
