@@ -24,13 +24,20 @@ def main(dirs):
 			df['kernel'] = df['Kernel_Name'].str.extract(r'\b(k_[a-z0-9_]+(?:<[^>]*>)?)')  # template arguments kept: instantiations differ
 			rows.append(df[df['kernel'].notna()])
 	df = pd.concat(rows)
+	# one instantiation launched on inputs of very different size with the same persistent grid (the de step's 20000-gene
+	# pass and its 1-row grouping pass) is reported as two classes split at the geometric mean of its durations, never
+	# averaged together
+	df['ns'] = df['End_Timestamp'] - df['Start_Timestamp']
+	span = df.groupby('kernel')['ns'].agg(['min', 'max'])
+	cut = {k: (r['min'] * r['max'])**0.5 if r['max'] > 5 * r['min'] else None for k, r in span.iterrows()}
+	df['kernel'] = [k if cut[k] is None else k + (' @long' if ns > cut[k] else ' @short') for k, ns in zip(df['kernel'], df['ns'])]
 	mean = df.groupby(['kernel', 'Counter_Name'])['Counter_Value'].mean().unstack()
 	out = {}
 	for k, r in mean.iterrows():
 		e = {c: float(v) for c, v in r.items() if v == v}
 		if 'FETCH_SIZE' in e:
 			e['fetch_bytes_raw'] = e['FETCH_SIZE'] * 1024
-			wide = WIDE.get(k.split('<')[0], False)
+			wide = WIDE.get(k.split('<')[0].split(' ')[0], False)
 			e['fetch_bytes'] = e['fetch_bytes_raw'] * (2 if wide else 1)
 			e['fetch_corrected_x2'] = bool(wide)
 		if 'WRITE_SIZE' in e:
