@@ -28,7 +28,12 @@
 // accumulator registers; a stage is one k-step of both operand panels (8 NS KB), ring of 3 stages (144 KB at NS = 6),
 // every wave issues NS DMA instructions per stage (the NS slices of one 32-row block), one barrier per stage.
 // Inner loop alone, operands resident in LDS (tools/i8gram_probe.hip): 3.5 POP/s = 231 fp64-equivalent TFLOP/s at NS = 5,
-// 170 at NS = 6, against 68 executed by the fp64 kernel.
+// 170 at NS = 6, against 68 executed by the fp64 kernel.  The chip clocks down under int8 MFMA load (tools/clock_probe.sh:
+// 1.80 GHz effective in this kernel, 2.34 GHz in the fp64 kernel), so cycles saved come back partly as clock.
+// Measured and rejected (C2, 2.15-2.25 ms as is): two 4-wave workgroups per CU on 128 x 64 half tiles with a ring of 2 (2.64 ms;
+// removing barrier and vmcnt waits altogether gains only 3 %: lockstep is not the cost); issuing the refill from waves 4-7 half
+// way through their MFMAs (4.05 ms, the branch breaks the MFMA block); a memory-clobbering asm between operand reads and MFMAs
+// (7.1 ms: every read drains first); s_setprio(1) around the MFMA block (11 ms).
 #include "nrm_gram_sched.h"
 
 #define QK 32        // cells per k-step (one MFMA)
@@ -47,6 +52,15 @@ __device__ __forceinline__ void q_dma16(const void* gsrc, unsigned lds_dst) {
 				 : "=&s"(keep)
 				 : "v"(gsrc), "s"(lds_dst)
 				 : "memory");
+}
+
+// the same without the compiler-level memory clobber, for use between sched_barriers inside the MFMA stream (ordering against
+// the LDS reads of later k-steps is carried by the vmcnt wait and the workgroup barrier, both of which clobber memory)
+__device__ __forceinline__ void q_dma16_nc(const void* gsrc, unsigned lds_dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+				 : "=&s"(keep)
+				 : "v"(gsrc), "s"(lds_dst));
 }
 
 // ---- quantiser: fp64 rows -> NS digit planes in the tiled layout + one exponent per row ----------------------------
@@ -116,11 +130,14 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 	const char* src0 = (wid < 4 ? QA + (((int64_t)ti * 4 + wid) * nks) * 1024 : QB + (((int64_t)tj * 4 + (wid - 4)) * nks) * 1024) + lane * 16;
 	const int64_t plane = wid < 4 ? plane_a : plane_b;
 	const unsigned dst0 = lds0 + wid * NS * 1024;
-	auto issue = [&](int buf, int ks) {
+	auto issue_one = [&](int buf, int ks, int s) {
 		if (QI_EXP & 1) return;
 		if (QI_EXP & 2) ks &= 3;
+		q_dma16_nc(src0 + s * plane + (int64_t)ks * 1024, dst0 + buf * STAGE + s * 1024);
+	};
+	auto issue = [&](int buf, int ks) {
 #pragma unroll
-		for (int s = 0; s < NS; s++) q_dma16(src0 + s * plane + (int64_t)ks * 1024, dst0 + buf * STAGE + s * 1024);
+		for (int s = 0; s < NS; s++) issue_one(buf, ks, s);
 	};
 	i16_t acc[NS][2];
 	auto clear = [&]() {
@@ -178,38 +195,53 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 	};
 	clear();
 	__syncthreads();  // previous piece done with LDS
-	if (k0 < k1) issue(0, k0);
-	if (k0 + 1 < k1) issue(1, k0 + 1);
+	if (k0 >= k1) return;  // (the schedule has no empty pieces)
+	issue(0, k0);
+	issue(1, min(k0 + 1, k1 - 1));
 	int in_chunk = 0;
 	bool first = true;
 	for (int ks = k0; ks < k1; ks++) {
 		const int buf = (ks - k0) % QD;
-		if (ks + 1 < k1)
-			asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");  // this wave's images of stage ks have landed (stage ks + 1 may be in flight)
-		else
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");  // this wave's images of stage ks have landed (stage ks + 1 may be in flight)
 		if (!(QI_EXP & 4)) __syncthreads();  // everyone's have; all waves are done reading stage ks - 1, whose buffer is refilled now
-		// (measured and rejected, C2, 2.24 ms as is: issuing the refill from waves 4-7 half way through their MFMAs so that one wave
-		//  of every SIMD computes while its partner queues DMA -- 4.05 ms; issuing it after the operand reads -- 7.1 ms, the asm
-		//  statement's memory clobber drains every read before the first MFMA; s_setprio(1) around the MFMA block -- 11 ms)
-		if (ks + 2 < k1) issue((ks - k0 + 2) % QD, ks + 2);
+		// The k-step by hand: row s of the digit-pair triangle (pairs (s, t >= NS-1-s): 2 (s + 1) MFMAs) needs fa[s] and fb[NS-1-s]
+		// for the first time; they are read one row ahead, and ONE refill DMA of stage ks + 2 is issued after each row (the last in
+		// the middle of the longest row).  A DMA instruction costs its wave 60-190 issue cycles; bunched behind the barrier with
+		// the 18 operand reads -- as this loop was at first -- neither wave of the SIMD feeds the matrix core meanwhile; spread out,
+		// each falls into the 32 cycles the partner wave's MFMA holds the pipe anyway.  sched_barrier pins the order.
 		const char* st = lds + buf * STAGE;
+		// past the end of the piece the refill re-fetches the last stage into the free buffer: no branch in the MFMA stream, and the
+		// count of DMAs in flight is the same at every step (drained after the loop)
+		const int nbuf = (ks - k0 + 2) % QD, nks = min(ks + 2, k1 - 1);
 		i4_t fa[NS][2], fb[NS];
-#pragma unroll
-		for (int s = 0; s < NS; s++) {
+		auto read_row = [&](int s) {
 #pragma unroll
 			for (int i = 0; i < 2; i++) fa[s][i] = *reinterpret_cast<const i4_t*>(st + aoff + (i * NS + s) * 1024);
-			fb[s] = *reinterpret_cast<const i4_t*>(st + boff + s * 1024);
+			fb[NS - 1 - s] = *reinterpret_cast<const i4_t*>(st + boff + (NS - 1 - s) * 1024);
+		};
+		auto mfma_row = [&](int s, int t0, int t1) {
+#pragma unroll
+			for (int t = t0; t < t1; t++)
+#pragma unroll
+				for (int i = 0; i < 2; i++)
+					acc[s + t - (NS - 1)][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][i], fb[t], acc[s + t - (NS - 1)][i], 0, 0, 0);
+		};
+		auto dma = [&](int j) {
+			__builtin_amdgcn_sched_barrier(0);
+			issue_one(nbuf, nks, j);
+			__builtin_amdgcn_sched_barrier(0);
+		};
+		read_row(0);
+		read_row(1);
+#pragma unroll
+		for (int s = 0; s < NS - 1; s++) {
+			mfma_row(s, NS - 1 - s, NS);
+			dma(s);
+			if (s + 2 < NS) read_row(s + 2);
 		}
-#pragma unroll
-		for (int s = 0; s < NS; s++)
-#pragma unroll
-			for (int t = 0; t < NS; t++)
-				if (s + t >= NS - 1) {
-#pragma unroll
-					for (int i = 0; i < 2; i++)
-						acc[s + t - (NS - 1)][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][i], fb[t], acc[s + t - (NS - 1)][i], 0, 0, 0);
-				}
+		mfma_row(NS - 1, 0, NS / 2);
+		dma(NS - 1);
+		mfma_row(NS - 1, NS / 2, NS);
 		if (++in_chunk == QCHUNK && ks + 1 < k1) {  // int32 headroom used up: combine in fp64, start a new chunk
 			flush(first);
 			first = false;
@@ -217,6 +249,7 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 			in_chunk = 0;
 		}
 	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the refills issued past the end: nothing may land after the workgroup has gone
 	flush(first);
 }
 
