@@ -14,7 +14,7 @@ worst = dict(p=0.0, d=0.0)
 t0 = time.time()
 for it in range(cases):
 	ng = int(rng.choice([1, 2, 127, 128, 129, 500, 1023, 1025, 1500, 2049, 2600, 3100]))
-	n = int(rng.choice([24, 97, 160, 333, 1000, 2001, 4096]))
+	n = int(rng.choice([24, 97, 160, 333, 1000, 2001, 2048, 2052, 3001, 4096, 6000]))  # >= 2048 and a multiple of 4: integer Gram engine
 	nc = int(rng.integers(0, 11))
 	if n <= nc + 3:
 		continue
