@@ -173,7 +173,13 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 	closed-form device paths in normalisr_amd.single1 / .single4.  bsx, bsy, nth, bs4 are accepted and ignored (see module docstring).
 	With return_stats=True a sixth element {'r':..., 't':..., 'dof':...} is appended.  With device_out=True (single=0 only)
 	the two (n_x, n_y) matrices are returned as torch tensors resident in HBM (e.g. to feed binnet without crossing PCIe).
+	device=<index> runs the call on that GPU instead of the current one (also engine.use_device, NORMALISR_DEVICE).
 	"""
+	device = ka.pop('device', None)
+	if device is not None:
+		with _engine.use_device(device):
+			return association_tests(dx, dy, dc, bsx=bsx, bsy=bsy, nth=nth, lowmem=lowmem, return_dot=return_dot, single=single, bs4=bs4,
+									 return_stats=return_stats, device_out=device_out, **ka)
 	bs = ka.pop('bs', None)  # the reference's docstring promises `bs` (coex.py:38) but crashes on it (SURVEY Q8)
 	if bs is not None and not bsx and not bsy:
 		bsx = bsy = bs

@@ -8,6 +8,9 @@ Data layout in HBM:
   dot                 fp64 [m_pad][n_pad]
   outputs p / stat    out dtype [nx][ny]
 """
+import os
+import threading
+
 import numpy as np
 
 from . import _lib
@@ -56,8 +59,6 @@ class PinnedPool:
 	memory that is page-locked in place for the duration of the call."""
 
 	def __init__(self, lib):
-		import os
-		import threading
 		self.lib = lib
 		self.limit = int(float(os.environ.get('NRM_PINNED_POOL_MB', '2048')) * (1 << 20))
 		self.free = {}   # capacity -> [pointers]
@@ -271,7 +272,6 @@ class Engine:
 		i8x5 (5 slices = 38 bits, faster), f64 (the fp64 matrix-core kernel).  Below I8_MIN_CELLS cells the fp64 kernel is used
 		anyway: the problem is small, and the integer engine's error in Pearson r (its dropped low-order digit products,
 		~2e-15 at 10 000 cells) grows as 1 / sqrt(n_cells)."""
-		import os
 		mode = os.environ.get('NRM_GRAM', 'i8')
 		if mode not in ('i8', 'i8x5', 'f64'):
 			raise ValueError('NRM_GRAM must be i8, i8x5 or f64')
@@ -335,7 +335,6 @@ class Engine:
 	def banded_ok(self, nx, ny, out_dtype):
 		"""Pipeline K2 -> K3 -> copy-out by row bands when there is more than one band and the results are large enough
 		for the PCIe leg to matter (NRM_PIPELINE=0 switches it off)."""
-		import os
 		if os.environ.get('NRM_PIPELINE', '1') == '0':
 			return False
 		return nx > self.BAND and 2 * nx * ny * np.dtype(out_dtype).itemsize >= (16 << 20)
@@ -345,7 +344,6 @@ class Engine:
 	def chunked_ok(self, dy):
 		"""de whose expression matrix still sits on the host and is large: upload it in row chunks on a second stream
 		so that K1/K2/K3 of chunk c run while chunk c+1 crosses PCIe (NRM_PIPELINE=0 switches it off)."""
-		import os
 		return (isinstance(dy, np.ndarray) and dy.nbytes >= 2 * self.CHUNK_BYTES and os.environ.get('NRM_PIPELINE', '1') != '0')
 
 	def association_de_chunked(self, dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov=None):
@@ -391,7 +389,6 @@ class Engine:
 		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps K1 and the first band of K2).
 		bands: row cuts [0, ..., nx] -- the rows are then locked band by band in that order and host['ready'] counts the bands
 		done, so that copies into the first bands can start while the later ones are still being faulted in and registered."""
-		import threading
 		odt = np.dtype(out_dtype)
 		cuts = [0, nx] if bands is None else list(bands)
 		pp, ps = self.pool.empty((nx, ny), odt), self.pool.empty((nx, ny), odt)
@@ -468,7 +465,6 @@ class Engine:
 	def coex_pipelined_ok(self, dx, dc, n):
 		"""coex whose expression matrix still sits on the host, large enough for PCIe to matter, on the integer engine with rows K1
 		can quantise itself (16-byte aligned): upload, kernels and copy-out overlap chunk by chunk (NRM_PIPELINE=0 switches it off)."""
-		import os
 		return (isinstance(dx, np.ndarray) and os.environ.get('NRM_PIPELINE', '1') != '0' and self.gram_slices(n) > 0 and dx.shape[0] > self.BAND
 				and dx.nbytes >= (32 << 20) and (dx.shape[1] * dx.itemsize) % 16 == 0 and (dc.shape[0] == 0 or (dc.shape[1] * 8) % 16 == 0))
 
@@ -491,7 +487,7 @@ class Engine:
 		nks = (kp + 31) // 32
 		plane = (mp // 32) * nks * 1024
 		cuts = list(range(0, ng, self.BAND)) + [ng]
-		import os, time
+		import time
 		trace = [] if os.environ.get('NRM_TRACE') else None
 		mark = (lambda what: trace.append((what, time.perf_counter()))) if trace is not None else (lambda what: None)
 		mark('start')
@@ -652,7 +648,6 @@ class Engine:
 
 	def de_streaming_ok(self, dx, dy, dc):
 		"""The streaming path (K2s) applies to de with few design rows and 16-byte aligned expression rows."""
-		import os
 		mode = os.environ.get('NRM_DE_PATH', 'auto')
 		if dy is None or mode == 'general':
 			return False
@@ -664,7 +659,6 @@ class Engine:
 	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
 								 resident=False):
 		"""de with nx + nc <= 32: stream the raw expression rows once (HBM-bound), see csrc/nrm_gram_skinny.hip."""
-		import os
 		torch = self.torch
 		nx, n = dx.shape
 		ny, nc = dy.shape[0], dc.shape[0]
@@ -815,11 +809,37 @@ class Engine:
 
 
 _engines = {}
+_selected = threading.local()
+
+
+class use_device:
+	"""Context manager: every entry point called inside runs on GPU `device` (an index) instead of the current one.
+	association_tests / coex / de / binnet / normvar take it as their `device=` keyword; NORMALISR_DEVICE sets the process
+	default.  (The reference has no devices; SURVEY section 5 lists this as the one build-only option.)"""
+
+	def __init__(self, device):
+		self.device = None if device is None else int(device)
+
+	def __enter__(self):
+		self.prev = getattr(_selected, 'device', None)
+		if self.device is not None:
+			_selected.device = self.device
+		return self
+
+	def __exit__(self, *exc):
+		_selected.device = self.prev
+		return False
 
 
 def get_engine(device=None):
 	torch = _torch()
+	if device is None:
+		device = getattr(_selected, 'device', None)
+	if device is None and os.environ.get('NORMALISR_DEVICE', '') != '':
+		device = int(os.environ['NORMALISR_DEVICE'])
 	idx = torch.cuda.current_device() if device is None else int(device)
+	if not 0 <= idx < torch.cuda.device_count():
+		raise ValueError('GPU {} requested, {} visible'.format(idx, torch.cuda.device_count()))
 	if idx not in _engines:
 		_engines[idx] = Engine(idx)
 	return _engines[idx]

@@ -547,3 +547,28 @@ def test_sharded_wrappers_in_a_single_process(norm):
 	got = nd.de(dg, dt, dc)
 	ref = norm.de(dg, dt, dc)
 	assert got[2] is None and all(np.array_equal(a, b) for a, b in zip((got[0], got[1], got[3], got[4]), (ref[0], ref[1], ref[3], ref[4])))
+
+
+def test_device_selection(norm, monkeypatch):
+	"""device= / engine.use_device / NORMALISR_DEVICE pick the GPU of a single-process call (SURVEY section 5's one build-only
+	option); an index that is not visible is refused before anything runs."""
+	import normalisr_amd.engine as engine
+	rng = np.random.default_rng(3)
+	dt = rng.normal(size=(40, 200))
+	dc = np.ones((1, 200))
+	base = norm.coex(dt, dc)
+	sel = norm.coex(dt, dc, device=0)
+	assert all(np.array_equal(a, b) for a, b in zip(base, sel))
+	with engine.use_device(0):
+		assert engine.get_engine().device.index == 0
+		r = norm.de((rng.random((2, 200)) < 0.5).astype(float), dt, dc)
+		assert np.isfinite(r[0]).all()
+	import torch
+	bad = torch.cuda.device_count()
+	with pytest.raises(ValueError):
+		norm.coex(dt, dc, device=bad)
+	monkeypatch.setenv('NORMALISR_DEVICE', str(bad))
+	with pytest.raises(ValueError):
+		norm.coex(dt, dc)
+	monkeypatch.setenv('NORMALISR_DEVICE', '0')
+	assert all(np.array_equal(a, b) for a, b in zip(base, norm.coex(dt, dc)))
