@@ -229,7 +229,9 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 			   scaling='weak', dtype=ARITH(n),
 			   config=dict(workload=label.format(genes=ng, cells=n), genes=ng, cells=n, covariates=3, tests_per_step=tests,
 						   parallelism='gene-row blocks x{}'.format(world), exchange=None if world == 1 else (
-							   'all-gather of raw fp32 blocks' if plan.exchange_raw else 'all-gather of residual blocks as fixed-point digit planes + exponents + sums of squares'),
+							   'all-gather of raw fp32 blocks' if plan.exchange_raw else
+							   'fixed-point digit planes in {} cell chunks, one all-gather each, block pairs accumulated as the chunks land'.format(plan.chunks)
+							   if plan.chunks else 'all-gather of residual blocks as fixed-point digit planes + exponents + sums of squares'),
 						   exchange_bytes_per_rank=None if world == 1 else int((world - 1) * rows_local * n * (esz if plan.exchange_raw else (SLICES(n) or 8)))),
 			   roofline=gram_roofline(n, flops, gram_ms, plan.rows_pad, plan.k_pad),
 			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region')

@@ -92,6 +92,14 @@ int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
 					  double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
 					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax, void* stream);
+/* The same with the digit planes cut along the cells into chunks of 32 * chunk_ksteps cells: chunk c is a dense quantised operand
+ * of its own (nslices planes of rows_pad / 32 * chunk_ksteps KB) at d_q + c * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices);
+ * all chunks share d_exp; the last chunk is zero padded.  The sharded coex path (normalisr_amd/distributed.py; the N > 1 form of
+ * association.py:890-909) sends the chunks to the other GPUs one after another and contracts each as it lands. */
+int nrm_residualize_q_chunked(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
+							  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
+							  int64_t rows_pad, double* d_ss, int nslices, void* d_q, int32_t* d_exp,
+							  int64_t chunk_ksteps, const double* d_cmax, void* stream);
 
 /*
  * K2 -- Gram contraction dot[i,j] = sum_k A[i,k] B[j,k] on the fp64 matrix cores
@@ -135,6 +143,11 @@ int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_
 int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
 					 int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
 					 int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream);
+/* One cell chunk (k_pad = its cells) of a contraction whose operands arrive in chunks: accumulate != 0 adds the chunk's exact
+ * partial dot products to d_dot in fp64 instead of overwriting it. */
+int nrm_gram_i8_chunk(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
+					  int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
+					  int symmetric, int64_t m_rows, int64_t n_rows, int accumulate, void* d_work, void* stream);
 
 /*
  * P-value plan: host-side constants of p = I_{1-R^2}(dof/2, 1/2) for one dof

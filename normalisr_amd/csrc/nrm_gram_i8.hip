@@ -121,7 +121,7 @@ template <int NS>
 __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const char* __restrict__ QB, int64_t plane_a, int64_t plane_b,
 											  int64_t nks, const int* __restrict__ ea, const int* __restrict__ eb, double* __restrict__ C,
 											  int64_t ldc, int ti, int tj, int k0, int k1, double* __restrict__ slab, int m_rows, int n_rows,
-											  int symmetric, const char* lds, unsigned lds0) {
+											  int symmetric, int accumulate, const char* lds, unsigned lds0) {
 	constexpr int STAGE = 8 * NS * 1024;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,7 +189,7 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 				double v = fma((double)hi, 16777216.0, (double)lo);
 				v = ldexp(v, ea[row_w + rr] + eb_l + 8 * (NS - 1));
 				double* o = cbase + (int64_t)rr * pitch + (lane & 31);
-				*o = first ? v : *o + v;
+				*o = (first && !(accumulate && !slab)) ? v : *o + v;
 			}
 		}
 	};
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(512) k_gram_i8(const char* __restrict__ QA, co
 	gram_for_each_piece(s, [&](int t, int k0, int k1, double* slab) {
 		int ti, tj;
 		gram_tile_coords(s.tile0 + t, symmetric, s.ntm, s.ntn, ti, tj);
-		gram_piece_i8<NS>(QA, QB, plane_a, plane_b, nks, ea, eb, C, ldc, ti, tj, k0, k1, slab, s.m_rows, s.n_rows, symmetric, lds, lds0);
+		gram_piece_i8<NS>(QA, QB, plane_a, plane_b, nks, ea, eb, C, ldc, ti, tj, k0, k1, slab, s.m_rows, s.n_rows, symmetric, s.accumulate, lds, lds0);
 	});
 }
 
@@ -293,9 +293,9 @@ extern "C" int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_
 	return nrm_check_launch("k_quantize_rows");
 }
 
-extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
-								int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
-								int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream) {
+static int gram_i8_impl(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
+						int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
+						int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, int accumulate, void* d_work, void* stream) {
 	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_gram_i8: 5 or 6 slices");
 	NRM_REQUIRE(m_pad >= 0 && n_pad >= 0 && k_pad > 0 && m_pad % GM == 0 && n_pad % GN == 0, "nrm_gram_i8: sizes must be padded to %d", GM);
 	NRM_REQUIRE(ldd >= n_pad && ldd % 2 == 0, "nrm_gram_i8: pitch too small");
@@ -316,6 +316,7 @@ extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t p
 	NRM_REQUIRE(plane_a >= (m_pad / 32) * nks * 1024 && plane_b >= (n_pad / 32) * nks * 1024, "nrm_gram_i8: plane pitch smaller than the operand");
 	GramSched s;
 	NRM_TRY_RC(gram_plan(s, m_pad, n_pad, nks, symmetric, m_rows, n_rows, row0, row1, g_num_cu_q, (double*)d_work));  // one workgroup per CU
+	s.accumulate = accumulate ? 1 : 0;
 	if (nslices == 5)
 		hipLaunchKernelGGL(k_gram_i8<5>, dim3((unsigned)s.nwg), dim3(512), 0, (hipStream_t)stream, (const char*)d_qa, (const char*)d_qb, plane_a,
 						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s);
@@ -325,4 +326,20 @@ extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t p
 	if (s.tiles_al + s.tiles_sk > 0)
 		hipLaunchKernelGGL(k_gram_fixup<1>, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_i8");
+}
+
+extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
+								int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
+								int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream) {
+	return gram_i8_impl(d_qa, d_ea, plane_a_bytes, d_qb, d_eb, plane_b_bytes, m_pad, n_pad, k_pad, nslices, d_dot, ldd, symmetric, m_rows, n_rows, row0,
+						row1, 0, d_work, stream);
+}
+
+// One cell chunk of a contraction whose operands arrive in pieces along the cells (sharded coex: the digit planes of the other
+// ranks' blocks travel chunk by chunk): accumulate != 0 adds this chunk's exact partial dot products to d_dot in fp64.
+extern "C" int nrm_gram_i8_chunk(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
+								 int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
+								 int symmetric, int64_t m_rows, int64_t n_rows, int accumulate, void* d_work, void* stream) {
+	return gram_i8_impl(d_qa, d_ea, plane_a_bytes, d_qb, d_eb, plane_b_bytes, m_pad, n_pad, k_pad, nslices, d_dot, ldd, symmetric, m_rows, n_rows, 0,
+						m_pad, accumulate, d_work, stream);
 }

@@ -60,6 +60,7 @@ struct GramSched {
 	int units_per_wg;
 	int nwg;        // persistent workgroups (multiple of 8)
 	int tile0;      // first tile of this launch in the gram_tile_coords order (band launches)
+	int accumulate; // add to C instead of overwriting it (cell-chunked launches of the sharded path)
 	double* work;   // slabs of partial pieces: [tiles_al*parts] then [2 per workgroup]
 };
 
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int6
 			src += (int64_t)(2 - sk_first_local) * (GM * GN);
 			for (int q = 1; q < count; q++, src += 2 * (GM * GN)) acc += *reinterpret_cast<const d2_t*>(src);
 		}
-		*reinterpret_cast<d2_t*>(ct + (int64_t)(e / GN) * ldc + (e % GN)) = acc;
+		d2_t* o = reinterpret_cast<d2_t*>(ct + (int64_t)(e / GN) * ldc + (e % GN));
+		*o = s.accumulate ? *o + acc : acc;
 	}
 }
 
@@ -177,6 +179,7 @@ static inline int gram_plan(GramSched& s, int64_t m_pad, int64_t n_pad, int64_t 
 	const int64_t tiles = gram_tiles_before((row1 + GSB * GM - 1) / (GSB * GM), symmetric, ntm, ntn) - tile0;
 	NRM_REQUIRE(tiles < (1LL << 30) && nkt < (1LL << 30), "nrm_gram: problem too large for one launch");
 	s.tile0 = (int)tile0;
+	s.accumulate = 0;
 	s.m_rows = (int)((m_rows > 0 && m_rows < m_pad) ? m_rows : m_pad);
 	s.n_rows = (int)((n_rows > 0 && n_rows < n_pad) ? n_rows : n_pad);
 	s.ntm = (int)ntm;

@@ -149,6 +149,8 @@ struct QuantOut {
 	char* q;              // NS planes of plane_bytes each
 	int64_t plane_bytes;
 	int64_t nks;          // k-steps of 32 cells
+	int64_t cks;          // k-steps per cell chunk (== nks: one chunk); chunk c is an operand of its own at q + c * chunk_bytes
+	int64_t chunk_bytes;
 	int* exps;            // x = digits * 2^exps[row]
 	const double* cmax;   // (nc) largest |C_c| of every covariate row: bounds the residuals without a sweep of their own
 };
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 	for (int r = 0; r < RES_R; r++) {
 		const int64_t row = row0 + r;
 		const int rr = (int)(row & 31);
-		qrow[r] = NS ? qo.q + ((row >> 5) * qo.nks) * 1024 + (2 * rr) * 16 : nullptr;
+		qrow[r] = NS ? qo.q + ((row >> 5) * qo.cks) * 1024 + (2 * rr) * 16 : nullptr;
 		flip[r] = (rr >> 3) & 1;
 	}
 	// last sweep (the rows are in L2 / MALL by now): residual, zero padding, sum of squares and -- NS -- the residual rounded
@@ -353,8 +355,9 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			for (int i = 0; i < 4; i++) sq[r] = fma(v[r][i], v[r][i], sq[r]);
 		}
 		if (NS && k < kq) {
-			const int64_t ks = k >> 5;
 			const int kk = (int)(k & 31);
+			const int ks_all = (int)(k >> 5), chunk = ks_all / (int)qo.cks;
+			const int64_t ks = (int64_t)(ks_all - chunk * (int)qo.cks) + chunk * (qo.chunk_bytes >> 10);  // in KB images from q
 #pragma unroll
 			for (int r = 0; r < RES_R; r++) {
 				long long q[4];
@@ -407,7 +410,7 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 
 static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
 							const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, const double* d_cmax, void* stream) {
+							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, int64_t chunk_ksteps, const double* d_cmax, void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
 	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
 	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
@@ -422,14 +425,21 @@ static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t 
 	const int64_t xa = 16 / (x_dtype == NRM_F64 ? 8 : 4);
 	const bool vec = (ldx % xa == 0) && ((uintptr_t)d_x % 16 == 0) && (!d_out || ((ldo % 4 == 0) && ((uintptr_t)d_out % 16 == 0))) &&
 					 (!active || (ldc % 2 == 0 && (uintptr_t)d_c % 16 == 0));
-	QuantOut qo = {nullptr, 0, 0, nullptr, d_cmax};
+	QuantOut qo = {nullptr, 0, 0, 0, 0, nullptr, d_cmax};
 	if (nslices) {
 		NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_residualize_q: 5 or 6 slices");
 		NRM_REQUIRE(vec, "nrm_residualize_q: needs 16-byte aligned rows (use nrm_residualize + nrm_quantize_rows otherwise)");
 		NRM_REQUIRE(rows_pad % 128 == 0 && d_q && d_exp && (uintptr_t)d_q % 16 == 0, "nrm_residualize_q: rows_pad %% 128 == 0 and digit buffers required");
 		const int64_t k_pad = (n + 15) / 16 * 16;
 		qo.nks = (k_pad + 31) / 32;
-		qo.plane_bytes = (rows_pad / 32) * qo.nks * 1024;
+		qo.cks = qo.nks;
+		if (chunk_ksteps > 0) {  // cell chunks of chunk_ksteps k-steps, each a dense operand of its own; the last one zero padded
+			NRM_REQUIRE(plane_pitch == 0, "nrm_residualize_q_chunked: chunks are dense");
+			qo.cks = chunk_ksteps;
+			qo.nks = (qo.nks + qo.cks - 1) / qo.cks * qo.cks;
+		}
+		qo.plane_bytes = (rows_pad / 32) * qo.cks * 1024;
+		qo.chunk_bytes = nslices * qo.plane_bytes;
 		if (plane_pitch) {  // these rows are a block of a larger quantised matrix
 			NRM_REQUIRE(plane_pitch >= qo.plane_bytes && plane_pitch % 1024 == 0, "nrm_residualize_q: plane pitch smaller than the block");
 			qo.plane_bytes = plane_pitch;
@@ -450,7 +460,7 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
 							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
 	NRM_REQUIRE(d_out != nullptr, "nrm_residualize: null output");
-	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, nullptr, stream);
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, 0, nullptr, stream);
 }
 
 extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
@@ -458,7 +468,19 @@ extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int
 								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax,
 								 void* stream) {
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp,
-							plane_pitch_bytes, d_cmax, stream);
+							plane_pitch_bytes, 0, d_cmax, stream);
+}
+
+// The same with the digit planes cut along the cells into chunks of chunk_ksteps * 32 cells: chunk c is a dense quantised
+// operand of its own (nslices planes of rows_pad / 32 * chunk_ksteps KB) at d_q + c * nslices * plane bytes, all chunks share
+// the row exponents.  The sharded coex path sends the chunks one after another and contracts each as it lands
+// (nrm_gram_i8_chunk).  d_q: ceil(ceil(k_pad / 32) / chunk_ksteps) * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices) bytes.
+extern "C" int nrm_residualize_q_chunked(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
+										 int64_t ldc, const double* d_dci, int rank, int64_t rows_pad, double* d_ss, int nslices, void* d_q,
+										 int32_t* d_exp, int64_t chunk_ksteps, const double* d_cmax, void* stream) {
+	NRM_REQUIRE(chunk_ksteps > 0 && chunk_ksteps < (1 << 24), "nrm_residualize_q_chunked: bad chunk size");
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, nullptr, 0, rows_pad, d_ss, nullptr, nslices, d_q, d_exp, 0,
+							chunk_ksteps, d_cmax, stream);
 }
 
 // Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS

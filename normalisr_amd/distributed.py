@@ -3,9 +3,9 @@ over xGMI).  The reference's only parallelism is a thread-pool map over independ
 tiles (association.py:890-909,997; parallel.py:12-74); here the same independence is used across GPUs.
 
 coex (dy=None): gene-row block b lives on rank b.  Each rank residualises its own block (covariates are
-tiny and replicated), then ONE exchange step -- an all-gather of the residualised blocks and their sums
-of squares -- after which rank b contracts block pairs (b, b+k mod N), k = 0..floor(N/2); for even N
-the k = N/2 pair is shared half/half by its two owners.  Every unordered block pair is computed exactly
+tiny and replicated) and all-gathers it -- as fixed-point digit planes in cell chunks, contracted chunk by
+chunk as they land (CoexPlan._step_chunked), or in one piece -- and rank b contracts block pairs
+(b, b+k mod N), k = 0..floor(N/2); for even N the k = N/2 pair is shared half/half by its two owners.  Every unordered block pair is computed exactly
 once (association.py:893-894 keeps x0 <= y0 the same way).  K (cells) is never split across GPUs, so
 there is no all-reduce.  xGMI is point-to-point: an all-gather in which every GPU pushes its shard to its
 7 peers at once uses all links in parallel (shard bytes / ~153 GB/s).
@@ -179,9 +179,16 @@ class HipBackend:
 		d_c, d_dci = self.eng.covariates(dc64, dci)
 		return d_c, d_dci, dcr
 
-	def residualize(self, x, cov, rows_pad):
+	def chunkable(self, x, cov):
+		"""The digit planes of these rows can be written (and sent) in cell chunks: integer engine and 16-byte aligned rows."""
+		return bool(self.eng.gram_slices(x.shape[1])) and self.eng.k1_quantises(x, cov[0])
+
+	def residualize(self, x, cov, rows_pad, chunks=0):
 		d_c, d_dci, dcr = cov
 		ns = self.eng.gram_slices(x.shape[1])
+		if chunks:
+			r = self.eng.residualize_chunked(x, d_c, d_dci, dcr, rows_pad, ns, chunks)
+			return r, r.ss
 		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad, nslices=ns, keep_fp64=not ns)
 		if ns and getattr(r, '_quant', None) is None:  # rows K1 could not quantise itself (unaligned): separate pass
 			self.eng.quantized(r, ns)
@@ -207,6 +214,24 @@ class HipBackend:
 	def gram(self, a, b, symmetric, rows_a=None, rows_b=None):
 		return self.eng.gram(a, b, symmetric, nslices=self.eng.gram_slices(a.n))
 
+	# cell-chunked blocks (the pipelined exchange): every chunk is an operand of its own, the row exponents are shared
+	def n_chunks(self, blk):
+		return len(blk._quant[0])
+
+	def chunk_payload(self, blk):
+		"""(tensors of the chunks, in cell order; tensors that travel once: the row exponents)."""
+		return list(blk._quant[0]), [blk._quant[1]]
+
+	def from_chunks(self, chunks, once, like, ss):
+		from .engine import Residualized
+		blk = Residualized(like.rows, like.n, None, ss, None, shape=(like.rows_pad, like.k_pad))
+		blk._quant = (list(chunks), once[0], like._quant[2])
+		blk.cks = like.cks
+		return blk
+
+	def gram_chunk(self, a, b, symmetric, chunk, dot, accumulate):
+		return self.eng.gram_chunk(a, b, symmetric, chunk, dot, accumulate)
+
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
 		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags)
 		return p, stat, flags
@@ -229,6 +254,29 @@ class TensorBlocks:
 
 	def from_payload(self, parts, rows, rows_pad, n, k_pad, ss):
 		return parts[0]
+
+	# cell chunks of a (rows_pad, k_pad) tensor: column ranges of equal width
+	def chunkable(self, x, cov):
+		return True
+
+	def _cell_ranges(self, blk):
+		w = -(-blk.shape[1] // self._nchunks)
+		return [(c, min(blk.shape[1], c + w)) for c in range(0, blk.shape[1], w)]
+
+	def n_chunks(self, blk):
+		return len(self._cell_ranges(blk))
+
+	def chunk_payload(self, blk):
+		return [blk[:, a:b].contiguous() for a, b in self._cell_ranges(blk)], []
+
+	def from_chunks(self, chunks, once, like, ss):
+		import torch
+		return torch.cat(list(chunks), dim=1)
+
+	def gram_chunk(self, a, b, symmetric, chunk, dot, accumulate):
+		c0, c1 = self._cell_ranges(a)[chunk]
+		part = a[:, c0:c1] @ b[:, c0:c1].T
+		return dot + part if accumulate else part
 
 
 class CoexPlan:
@@ -259,16 +307,32 @@ class CoexPlan:
 		self._pending = []
 		self._ev = dict(residualize=[], exchange=[], gram=[], sweep=[])
 		self._timed_steps = 0
-		# what travels over xGMI: fp32 input -> the RAW rows (4 bytes per value; partner blocks are residualised again locally,
-		# K1 is HBM-cheap); fp64 input -> the residualised blocks as the backend packs them (6 bytes per value as digit planes)
-		self.exchange_raw = world > 1 and backend is None and 'float32' in str(dt_local.dtype)
+		# What travels over xGMI (NRM_EXCHANGE = auto | chunks | blocks | raw):
+		#  chunks (auto, whenever the rows go to the integer engine): this rank's fixed-point digit planes, cut along the cells
+		#    into NRM_EXCHANGE_CHUNKS pieces that are all-gathered one after another; the block pairs are contracted chunk by
+		#    chunk as the pieces land (exact partial sums, added in fp64), so only the first piece's flight is exposed and the
+		#    partner blocks are never residualised again;
+		#  raw (auto otherwise for fp32 input): the raw rows, 4 bytes per value, residualised again by the receiver;
+		#  blocks (auto otherwise): the residualised blocks in one piece, as the backend packs them.
+		mode = os.environ.get('NRM_EXCHANGE', 'auto')
+		if mode not in ('auto', 'chunks', 'blocks', 'raw'):
+			raise ValueError('NRM_EXCHANGE must be auto, chunks, blocks or raw')
+		self.chunks = 0
+		if world > 1 and mode in ('auto', 'chunks') and hasattr(self.be, 'gram_chunk') and self.be.chunkable(dt_local, self.cov):
+			# chunk launches of fewer than ~128 k-steps (4096 cells) cost more than they hide (tools/time_chunks.py: a 1792 x 1792
+			# block pair over 10 000 cells takes 1.04x in 2 chunks, 1.33x in 4, 2.0x in 8; at 100 000 cells 4 chunks are free)
+			min_ks = int(os.environ.get('NRM_EXCHANGE_MIN_KSTEPS', '128'))
+			self.chunks = max(1, min(int(os.environ.get('NRM_EXCHANGE_CHUNKS', '8')), ((self.k_pad + 31) // 32) // max(1, min_ks)))
+		elif world > 1 and mode == 'chunks':
+			raise ValueError('NRM_EXCHANGE=chunks needs the integer Gram engine and 16-byte aligned rows')
+		self.exchange_raw = world > 1 and backend is None and not self.chunks and mode != 'blocks' and 'float32' in str(dt_local.dtype)
 		if world > 1 and backend is None:
 			# every rank must own the same number of rows of the same dtype: a mismatch would hang the all-gather or
-			# mis-slice the gathered rows, and ranks with different dtypes would issue different collectives
+			# mis-slice the gathered rows, and ranks with different dtypes (or exchange modes) would issue different collectives
 			code = {'torch.float32': 0, 'torch.float64': 1}.get(str(dt_local.dtype), 2)
-			shapes = _all_gather_ints([self.rows, self.n, code], group, dt_local.device)
+			shapes = _all_gather_ints([self.rows, self.n, code, self.chunks], group, dt_local.device)
 			if not (shapes == shapes[0]).all():
-				raise ValueError('Sharded coex needs the same (rows, cells, dtype) on every rank; got {}'.format(shapes.tolist()))
+				raise ValueError('Sharded coex needs the same (rows, cells, dtype, exchange) on every rank; got {}'.format(shapes.tolist()))
 		self._gathered = None
 		if world > 1 and self.exchange_raw:
 			# blocks 0..world-1 as gathered, then copies of the first blocks so that the partners rank+1..rank+K of any
@@ -311,7 +375,10 @@ class CoexPlan:
 		if self.world == 1 or b == self.rank:
 			return self._blk, self._ss  # own block: local buffers (valid before the exchange has landed)
 		if b not in self._partner:
-			if self.exchange_raw:  # partner block arrived raw: residualise it here (once per step)
+			if self.chunks:  # views of the gather buffers: the chunks land one after another
+				ss = self._g_once[-1][b]
+				self._partner[b] = (self.be.from_chunks([g[b] for g in self._g_chunks], [g[b] for g in self._g_once[:-1]], self._blk, ss), ss)
+			elif self.exchange_raw:  # partner block arrived raw: residualise it here (once per step)
 				self._partner[b] = self.be.residualize(self.all_x[b * self.rows:(b + 1) * self.rows], self.cov, self.rows_pad)
 			else:
 				ss = self._gathered[-1][b]
@@ -347,11 +414,81 @@ class CoexPlan:
 			outs.append(dict(bi=self.rank, bj=(self.rank + 1 + j) % W, row_lo=0, nx=R, ny=R, symmetric=False,
 							 p=p[:, j * R:(j + 1) * R], stat=stat[:, j * R:(j + 1) * R]))
 
+	def _operands(self, bi, bj, lo, hi):
+		a, ssa = self.block(bi)
+		b, ssb = self.block(bj)
+		nx = max(0, min(hi, self.rows) - lo)
+		if nx and (lo != 0 or hi != self.rows_pad):
+			a, ssa = self.be.rows(a, lo, hi, nx), ssa[lo:hi]
+		return a, ssa, b, ssb, nx
+
+	def _step_chunked(self, timed):
+		"""One pass with the pipelined exchange: K1 writes this rank's digit planes in cell chunks; every chunk is all-gathered
+		by its own collective, queued back to back on RCCL's stream; the own (diagonal) block pair is contracted while the first
+		chunk travels, then every other pair of this rank chunk by chunk as the pieces land."""
+		import torch.distributed as dist
+		be = self.be
+		blk, ss = self._timed('residualize', timed, lambda: be.residualize(self.x, self.cov, self.rows_pad, chunks=self.chunks))
+		self._blk, self._ss = blk, ss
+		S = be.n_chunks(blk)
+		chunks, once = be.chunk_payload(blk)
+		chunks = [t.contiguous() for t in chunks]
+		once = [t.contiguous() for t in once] + [ss.contiguous()]
+		fits = lambda gs, ts: gs is not None and len(gs) == len(ts) and all(g.shape[1:] == t.shape and g.dtype == t.dtype for g, t in zip(gs, ts))
+		if not (fits(getattr(self, '_g_chunks', None), chunks) and fits(getattr(self, '_g_once', None), once)):
+			new = lambda t: t.new_empty((self.world, ) + tuple(t.shape))
+			self._g_chunks, self._g_once = [new(t) for t in chunks], [new(t) for t in once]
+		nccl = dist.get_backend(self.group) == 'nccl'
+
+		def gather(g, t):
+			if nccl:
+				return [dist.all_gather_into_tensor(g, t, group=self.group, async_op=True)]
+			dist.all_gather(list(g.unbind(0)), t, group=self.group)
+			return []
+
+		def wait(handles):
+			def w():
+				for h in handles:
+					h.wait()
+			if handles:
+				self._timed('exchange', timed, w)  # the part of the flight that compute did not hide
+		h_once = [h for g, t in zip(self._g_once, once) for h in gather(g, t)]
+		h_chunk = [gather(g, t) for g, t in zip(self._g_chunks, chunks)]
+		outs = []
+
+		def finish(e, ops, dot):
+			bi, bj, lo, hi, sym = e
+			a, ssa, b, ssb, nx = ops
+			p, stat, self.flags = self._timed('sweep', timed, lambda: be.sweep(dot, ssa, ssb, nx, self.rows, self.n, self.dof, sym, self.out_dtype, self.flags))
+			outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=self.rows, symmetric=sym, p=p, stat=stat))
+		own = [e for e in self.sched if e[0] == self.rank and e[1] == self.rank]
+		rest = [e for e in self.sched if not (e[0] == self.rank and e[1] == self.rank)]
+		for e in own:  # local data only: runs while the chunks travel
+			ops = self._operands(*e[:4])
+			dot = None
+			for c in range(S):
+				dot = self._timed('gram', timed, lambda: be.gram_chunk(ops[0], ops[2], e[4], c, dot, c > 0))
+			finish(e, ops, dot)
+		wait(h_once)
+		todo = [(e, self._operands(*e[:4])) for e in rest]
+		todo = [(e, ops) for e, ops in todo if ops[4] > 0]
+		dots = [None] * len(todo)
+		for c in range(S):
+			wait(h_chunk[c])
+			for i, (e, ops) in enumerate(todo):
+				dots[i] = self._timed('gram', timed, lambda: be.gram_chunk(ops[0], ops[2], e[4], c, dots[i], c > 0))
+		for (e, ops), dot in zip(todo, dots):
+			finish(e, ops, dot)
+		self.outputs = outs
+		return outs
+
 	def step(self, timed=False):
 		if timed:
 			self._timed_steps += 1
 		self._pending = []
 		self._partner = {}
+		if self.world > 1 and self.chunks:
+			return self._step_chunked(timed)
 		if self.world > 1 and self.exchange_raw:
 			self._pending = self._exchange(None, None)  # raw rows travel: nothing to wait for, start before K1
 		blk, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))

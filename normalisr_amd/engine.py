@@ -106,6 +106,7 @@ class Residualized:
 		self.rows, self.n = rows, n
 		self.data, self.ss, self.coef = data, ss, coef
 		self.rows_pad, self.k_pad = data.shape if shape is None else shape
+		self.cks = None  # chunked digit planes: k-steps (32 cells) per chunk; _quant[0] is then the list of chunk operands
 
 
 class Engine:
@@ -238,8 +239,7 @@ class Engine:
 			rp = _round_up(max(rows, 1), ROW_TILE) if rows_pad is None else rows_pad
 			kp = _round_up(n, K_TILE)
 			esz = x.element_size()
-			fused = bool(nslices) and rp % ROW_TILE == 0 and x.stride(1) == 1 and (x.stride(0) * esz) % 16 == 0 and x.data_ptr() % 16 == 0 and (
-				d_c is None or ((d_c.stride(0) * 8) % 16 == 0 and d_c.data_ptr() % 16 == 0))
+			fused = bool(nslices) and rp % ROW_TILE == 0 and self.k1_quantises(x, d_c)
 			if fused:
 				ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
 				coef = self.zeros((rows, nc), torch.float64) if want_coef else None
@@ -263,6 +263,53 @@ class Engine:
 				0 if d_dci is None else d_dci.data_ptr(), int(rank),
 				out.data_ptr(), kp, rp, ss.data_ptr(), 0 if coef is None else coef.data_ptr(), self._stream()))
 		return Residualized(rows, n, out, ss, coef)
+
+	@staticmethod
+	def k1_quantises(x, d_c=None):
+		"""K1 writes the digit planes itself when the rows (and covariates) are 16-byte aligned."""
+		return x.stride(1) == 1 and (x.stride(0) * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0 and (
+			d_c is None or ((d_c.stride(0) * 8) % 16 == 0 and d_c.data_ptr() % 16 == 0))
+
+	def residualize_chunked(self, x, d_c, d_dci, rank, rows_pad, nslices, chunks):
+		"""K1 with the digit planes cut along the cells into (at most) `chunks` operands of equal size that share the row
+		exponents (nrm_residualize_q_chunked): what the sharded coex path sends to the other GPUs piece by piece."""
+		torch = self.torch
+		with torch.cuda.device(self.device):
+			rows, n = x.shape
+			nc = 0 if d_c is None else d_c.shape[0]
+			kp = _round_up(n, K_TILE)
+			nks = (kp + 31) // 32
+			cks = (nks + max(1, chunks) - 1) // max(1, chunks)
+			nchunks = (nks + cks - 1) // cks
+			cb = int(self.lib.nrm_quant_bytes(rows_pad, 32 * cks, nslices))
+			planes = torch.empty((nchunks * cb, ), dtype=torch.uint8, device=self.device)
+			exps = torch.empty((rows_pad, ), dtype=torch.int32, device=self.device)
+			ss = torch.empty((rows_pad, ), dtype=torch.float64, device=self.device)
+			_lib.check(self.lib.nrm_residualize_q_chunked(
+				x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
+				0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
+				0 if d_dci is None else d_dci.data_ptr(), int(rank), rows_pad, ss.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(),
+				cks, self.cmax_ptr(d_c), self._stream()))
+		r = Residualized(rows, n, None, ss, None, shape=(rows_pad, kp))
+		r._quant = ([planes[c * cb:(c + 1) * cb] for c in range(nchunks)], exps, nslices)
+		r.cks = cks
+		return r
+
+	def gram_chunk(self, a, b, symmetric, chunk, dot, accumulate):
+		"""K2 over one cell chunk of chunked operands (residualize_chunked): dot (+)= a_chunk @ b_chunk.T, exact per chunk."""
+		torch = self.torch
+		with torch.cuda.device(self.device):
+			if dot is None:
+				dot = torch.empty((a.rows_pad, b.rows_pad), dtype=torch.float64, device=self.device)
+			if self._gram_work is None:
+				self._gram_work = torch.empty((int(self.lib.nrm_gram_workspace_bytes()) // 8, ), dtype=torch.float64, device=self.device)
+			qa, qb = a._quant, b._quant
+			assert a.cks is not None and a.cks == b.cks and qa[2] == qb[2]
+			pitch = lambda q: q[3] if len(q) > 3 else 0
+			_lib.check(self.lib.nrm_gram_i8_chunk(qa[0][chunk].data_ptr(), qa[1].data_ptr(), pitch(qa), qb[0][chunk].data_ptr(), qb[1].data_ptr(), pitch(qb),
+												  a.rows_pad, b.rows_pad, 32 * a.cks, qa[2], dot.data_ptr(), dot.stride(0), 1 if symmetric else 0,
+												  int(a.rows), int(b.rows), 1 if accumulate else 0, self._gram_work.data_ptr(), self._stream()))
+		return dot
 
 	I8_MIN_CELLS = 2048
 
@@ -300,9 +347,11 @@ class Engine:
 						   None if r.ss is None else r.ss[lo:hi], None, shape=(hi - lo, r.k_pad))
 		q = getattr(r, '_quant', None)
 		if q is not None:
-			nks = (r.k_pad + 31) // 32
+			nks = (r.k_pad + 31) // 32 if r.cks is None else r.cks
 			dense = (r.rows_pad // 32) * nks * 1024
-			sub._quant = (q[0][(lo // 32) * nks * 1024:], q[1][lo:hi], q[2], q[3] if len(q) > 3 else dense)
+			first = (lo // 32) * nks * 1024
+			sub._quant = (q[0][first:] if r.cks is None else [t[first:] for t in q[0]], q[1][lo:hi], q[2], q[3] if len(q) > 3 else dense)
+			sub.cks = r.cks
 		return sub
 
 	def gram(self, a, b, symmetric, dot=None, rows=None, nslices=0):

@@ -40,7 +40,8 @@ class OracleBackend(TensorBlocks):
 			dci, dcr = np.zeros((dc.shape[0], ) * 2), 0
 		return dc, dci, dcr
 
-	def residualize(self, x, cov, rows_pad):
+	def residualize(self, x, cov, rows_pad, chunks=0):
+		self._nchunks = max(1, chunks)
 		dc, dci, dcr = cov
 		x = np.asarray(x, dtype=np.float64)
 		r = x - (dci @ (dc @ x.T)).T @ dc if dcr > 0 else x
@@ -83,6 +84,7 @@ def _worker(rank, world, port, q):
 	R = ng // world
 	plan = CoexPlan(dt[rank * R:(rank + 1) * R], dc, rank=rank, world=world, group=dist.group.WORLD, backend=OracleBackend(),
 					out_dtype=np.float64)
+	assert plan.chunks == (4 if os.environ['NRM_EXCHANGE'] == 'chunks' else 0)
 	plan.step()
 	res = plan.assemble()
 	if rank == 0:
@@ -99,11 +101,16 @@ def _free_port():
 	return p
 
 
-@pytest.mark.parametrize('world', [2, 3, 4])
-def test_gloo_sharded_coex_matches_single_process(world):
+@pytest.mark.parametrize('world,exchange', [(2, 'chunks'), (3, 'chunks'), (4, 'chunks'), (2, 'blocks'), (3, 'blocks')])
+def test_gloo_sharded_coex_matches_single_process(world, exchange, monkeypatch):
 	"""Exchange, schedule, completion of every rank's row block by point-to-point messages (mirrored blocks, the half-split
-	pair of an even world) and assembly through arrays shared by the ranks -- nothing is pickled through rank 0."""
+	pair of an even world) and assembly through arrays shared by the ranks -- nothing is pickled through rank 0.
+	exchange = chunks: the pipelined form (4 cell chunks gathered one after another, block pairs accumulated chunk by chunk);
+	blocks: one all-gather of whole residualised blocks."""
 	import torch.multiprocessing as mp
+	monkeypatch.setenv('NRM_EXCHANGE', exchange)  # inherited by the spawned ranks
+	monkeypatch.setenv('NRM_EXCHANGE_MIN_KSTEPS', '1')
+	monkeypatch.setenv('NRM_EXCHANGE_CHUNKS', '4')
 	ctx = mp.get_context('spawn')
 	q = ctx.Queue()
 	port = _free_port()

@@ -276,7 +276,11 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
 	assert out['n_gpus'] == 2 and out['ranks_seen_by_collective'] == 2 and out['value'] > 0
 	assert out['roofline']['bound'] == 'mfma' and out['roofline']['kernel_ms'] > 0 and 'exchange' in out['kernels_ms']
-	assert out['config']['exchange'] == 'all-gather of raw fp32 blocks'
+	assert out['config']['exchange'] == 'all-gather of raw fp32 blocks'  # below 2048 cells: fp64 engine, raw rows travel
+	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--genes', '1200', '--cells', '8192', '--no-extras'],
+					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
+	assert out['n_gpus'] == 2 and out['value'] > 0 and 'in 2 cell chunks' in out['config']['exchange']
+	assert out['kernels_ms']['gram'] > 0 and out['kernels_ms']['exchange'] >= 0
 
 
 def test_bench_default_line_carries_the_other_configs():
@@ -572,3 +576,67 @@ def test_device_selection(norm, monkeypatch):
 		norm.coex(dt, dc)
 	monkeypatch.setenv('NORMALISR_DEVICE', '0')
 	assert all(np.array_equal(a, b) for a, b in zip(base, norm.coex(dt, dc)))
+
+
+def _chunked_worker(rank, world, port, q, dtype, n):
+	import torch
+	import torch.distributed as dist
+	sys.path.insert(0, ROOT)
+	from normalisr_amd.distributed import CoexPlan
+	dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
+	torch.cuda.set_device(0)
+	rng = np.random.default_rng(79)
+	R = 200 if world < 4 else 130
+	ng = R * world
+	dt = (rng.normal(size=(ng, n)) * rng.uniform(0.3, 3, (ng, 1)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n)) + 2).astype(dtype)
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(dtype)
+	plan = CoexPlan(torch.from_numpy(dt[rank * R:(rank + 1) * R]).cuda(), torch.from_numpy(dc).cuda(), rank=rank, world=world, group=dist.group.WORLD)
+	assert plan.chunks == 4 and not plan.exchange_raw
+	plan.step()
+	first = [(o['bi'], o['bj'], o['row_lo'], o['p'].clone(), o['stat'].clone()) for o in plan.outputs]
+	plan.step(timed=True)  # buffers are reused; the result must not depend on what the previous step left in them
+	for (bi, bj, lo, p, st), o in zip(first, plan.outputs):
+		assert (bi, bj, lo) == (o['bi'], o['bj'], o['row_lo']) and torch.equal(p, o['p']) and torch.equal(st, o['stat'])
+	kb = plan.kernel_breakdown()
+	assert kb['gram'] > 0 and kb['residualize'] > 0
+	res = plan.assemble()
+	if rank == 0:
+		q.put(tuple(np.array(a) for a in res))
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,dtype', [(2, 'float32'), (3, 'float64'), (4, 'float64'), (4, 'float32')])
+def test_sharded_coex_pipelined_chunk_exchange(world, dtype, monkeypatch):
+	"""The default N>1 exchange of rows that go to the integer engine: K1 writes the digit planes in 4 cell chunks, every chunk is
+	all-gathered on its own and the block pairs (incl. the half-split pair of an even world) are accumulated chunk by chunk with
+	nrm_gram_i8_chunk.  `world` processes share the one GPU over gloo; result against the single-process oracle."""
+	import socket
+	import torch.multiprocessing as mp
+	monkeypatch.setenv('NRM_EXCHANGE_MIN_KSTEPS', '8')  # 2304 cells = 72 k-steps -> 4 chunks of 18
+	monkeypatch.setenv('NRM_EXCHANGE_CHUNKS', '4')
+	n = 2304
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	ctx = mp.get_context('spawn')
+	q = ctx.Queue()
+	procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, q, dtype, n)) for r in range(world)]
+	for p in procs:
+		p.start()
+	P, D, V = q.get(timeout=300)
+	for p in procs:
+		p.join(timeout=120)
+		assert p.exitcode == 0
+	rng = np.random.default_rng(79)
+	R = 200 if world < 4 else 130
+	ng = R * world
+	dt = (rng.normal(size=(ng, n)) * rng.uniform(0.3, 3, (ng, 1)) + 0.5 * rng.normal(size=(ng, 1)) * rng.normal(size=(1, n)) + 2).astype(dtype)
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones((1, n))]).astype(dtype)
+	po, do, vo = oracle.coex(dt.astype(np.float64), dc.astype(np.float64))
+	from test_gpu_parity import I8_FLOOR
+	sd = np.sqrt(np.outer(vo, vo))
+	assert P.dtype == np.dtype(dtype)
+	assert (close(P, po, 1e-6, 1e-38) if dtype == 'float32' else p_close(P, po, 1e-6)) and close(D / sd, do / sd, 1e-6, I8_FLOOR) and close(V, vo, 1e-6)
+	assert (np.diag(P) == 0).all() and (P == P.T).all() and (D == D.T).all()
