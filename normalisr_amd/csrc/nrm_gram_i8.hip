@@ -34,6 +34,7 @@
 // removing barrier and vmcnt waits altogether gains only 3 %: lockstep is not the cost); issuing the refill from waves 4-7 half
 // way through their MFMAs (4.05 ms, the branch breaks the MFMA block); a memory-clobbering asm between operand reads and MFMAs
 // (7.1 ms: every read drains first); s_setprio(1) around the MFMA block (11 ms).
+#include <type_traits>
 #include "nrm_gram_sched.h"
 
 #define QK 32        // cells per k-step (one MFMA)
@@ -156,9 +157,12 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 	// output addressing of this wave's two 32 x 32 tiles: lane holds column lane & 31, rows (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
 	const int row_w = ti * GM + wm * 64, col_w = tj * GN + wn * 32;
 	const bool diag = symmetric && ti == tj;
+	// 32 x 32 sub-tiles that are pure padding, or below the diagonal of a symmetric problem, are neither stored nor -- when both of
+	// a wave's are -- computed (5000 genes: the last tile row and column hold 8 valid rows of 128); nobody reads them (K3 sweeps
+	// valid rows and, symmetric, the upper triangle), also not through the slabs of split tiles
 	bool want[2];
 #pragma unroll
-	for (int i = 0; i < 2; i++) want[i] = slab || (row_w + i * 32 < m_rows && col_w < n_rows && (!diag || col_w + 31 >= row_w + i * 32));
+	for (int i = 0; i < 2; i++) want[i] = row_w + i * 32 < m_rows && col_w < n_rows && (!diag || col_w + 31 >= row_w + i * 32);
 	double* cbase;
 	int64_t pitch;
 	if (slab) {
@@ -200,6 +204,10 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 	issue(1, min(k0 + 1, k1 - 1));
 	int in_chunk = 0;
 	bool first = true;
+	// two copies of the k loop (compute / only feed the ring), chosen per piece: a branch INSIDE the loop makes the compiler shuffle the 192 accumulator registers
+	// on every iteration (26 ms instead of 2.2 on C2)
+	auto kloop = [&](auto mask) {
+	constexpr int MASK = decltype(mask)::value;  // which of the wave's two 32-row halves are computed
 	for (int ks = k0; ks < k1; ks++) {
 		const int buf = (ks - k0) % QD;
 		asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NS) : "memory");  // this wave's images of stage ks have landed (stage ks + 1 may be in flight)
@@ -216,7 +224,8 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 		i4_t fa[NS][2], fb[NS];
 		auto read_row = [&](int s) {
 #pragma unroll
-			for (int i = 0; i < 2; i++) fa[s][i] = *reinterpret_cast<const i4_t*>(st + aoff + (i * NS + s) * 1024);
+			for (int i = 0; i < 2; i++)
+				if (MASK >> i & 1) fa[s][i] = *reinterpret_cast<const i4_t*>(st + aoff + (i * NS + s) * 1024);
 			fb[NS - 1 - s] = *reinterpret_cast<const i4_t*>(st + boff + (NS - 1 - s) * 1024);
 		};
 		auto mfma_row = [&](int s, int t0, int t1) {
@@ -224,31 +233,42 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 			for (int t = t0; t < t1; t++)
 #pragma unroll
 				for (int i = 0; i < 2; i++)
-					acc[s + t - (NS - 1)][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][i], fb[t], acc[s + t - (NS - 1)][i], 0, 0, 0);
+					if (MASK >> i & 1)
+						acc[s + t - (NS - 1)][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s][i], fb[t], acc[s + t - (NS - 1)][i], 0, 0, 0);
 		};
 		auto dma = [&](int j) {
 			__builtin_amdgcn_sched_barrier(0);
 			issue_one(nbuf, nks, j);
 			__builtin_amdgcn_sched_barrier(0);
 		};
-		read_row(0);
-		read_row(1);
+		if (MASK) {
+			read_row(0);
+			read_row(1);
 #pragma unroll
-		for (int s = 0; s < NS - 1; s++) {
-			mfma_row(s, NS - 1 - s, NS);
-			dma(s);
-			if (s + 2 < NS) read_row(s + 2);
+			for (int s = 0; s < NS - 1; s++) {
+				mfma_row(s, NS - 1 - s, NS);
+				dma(s);
+				if (s + 2 < NS) read_row(s + 2);
+			}
+			mfma_row(NS - 1, 0, NS / 2);
+			dma(NS - 1);
+			mfma_row(NS - 1, NS / 2, NS);
+		} else {  // this wave only feeds the ring
+#pragma unroll
+			for (int s = 0; s < NS; s++) dma(s);
 		}
-		mfma_row(NS - 1, 0, NS / 2);
-		dma(NS - 1);
-		mfma_row(NS - 1, NS / 2, NS);
-		if (++in_chunk == QCHUNK && ks + 1 < k1) {  // int32 headroom used up: combine in fp64, start a new chunk
+		if (MASK && ++in_chunk == QCHUNK && ks + 1 < k1) {  // int32 headroom used up: combine in fp64, start a new chunk
 			flush(first);
 			first = false;
 			clear();
 			in_chunk = 0;
 		}
 	}
+	};
+	if (want[0] || want[1])  // (copies for one half only, masks 1 and 2, measured: no gain over computing both)
+		kloop(std::integral_constant<int, 3>{});
+	else
+		kloop(std::integral_constant<int, 0>{});
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the refills issued past the end: nothing may land after the workgroup has gone
 	flush(first);
 }
