@@ -36,6 +36,7 @@
 // (7.1 ms: every read drains first); s_setprio(1) around the MFMA block (11 ms).
 #include <type_traits>
 #include "nrm_gram_sched.h"
+#include "nrm_digits.h"
 
 #define QK 32        // cells per k-step (one MFMA)
 #define QCHUNK 512   // k-steps per int32 accumulation chunk (16 384 cells)
@@ -97,23 +98,13 @@ __global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict_
 			v[2] = b[0];
 			v[3] = b[1];
 		}
-		long long q[4];
-#pragma unroll
-		for (int i = 0; i < 4; i++) q[i] = (long long)rint(ldexp(v[i], -sh));  // non-finite input: caught by K1's sum of squares / K3's flags
+		unsigned w[NS];
+		nrm_digits4<NS>(v, sh, w);  // non-finite input: caught by K1's sum of squares / K3's flags
 		const int64_t ks = k >> 5;
 		const int kk = (int)(k & 31);
 		char* dst = qrow + ks * 1024 + (((kk >> 4) ^ flip) << 4) + (kk & 15);
 #pragma unroll
-		for (int s = 0; s < NS; s++) {
-			unsigned w = 0;
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				const long long d = (s == NS - 1) ? q[i] : (long long)(signed char)(q[i] & 0xff);
-				q[i] = (q[i] - d) >> 8;
-				w |= ((unsigned)d & 0xffu) << (8 * i);
-			}
-			*reinterpret_cast<unsigned*>(dst + s * plane_bytes) = w;
-		}
+		for (int s = 0; s < NS; s++) *reinterpret_cast<unsigned*>(dst + s * plane_bytes) = w[s];
 	}
 }
 

@@ -10,6 +10,7 @@
 // One workgroup (256 threads) owns RES_R consecutive rows so that every covariate element fetched
 // from L2 is used RES_R times; covariates are swept in chunks of RES_CB to bound registers.
 #include "nrm_common.h"
+#include "nrm_digits.h"
 
 #define RES_R 4
 #define RES_CB 8
@@ -360,21 +361,11 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			const int64_t ks = (int64_t)(ks_all - chunk * (int)qo.cks) + chunk * (qo.chunk_bytes >> 10);  // in KB images from q
 #pragma unroll
 			for (int r = 0; r < RES_R; r++) {
-				long long q[4];
-#pragma unroll
-				for (int i = 0; i < 4; i++) q[i] = (long long)rint(ldexp(v[r][i], -sh[r]));
+				unsigned w[NS ? NS : 1];
+				nrm_digits4<(NS ? NS : 1)>(v[r], sh[r], w);
 				char* dst = qrow[r] + ks * 1024 + (((kk >> 4) ^ flip[r]) << 4) + (kk & 15);
 #pragma unroll
-				for (int s = 0; s < (NS ? NS : 1); s++) {
-					unsigned w = 0;
-#pragma unroll
-					for (int i = 0; i < 4; i++) {
-						const long long d = (s == NS - 1) ? q[i] : (long long)(signed char)(q[i] & 0xff);
-						q[i] = (q[i] - d) >> 8;
-						w |= ((unsigned)d & 0xffu) << (8 * i);
-					}
-					*reinterpret_cast<unsigned*>(dst + s * qo.plane_bytes) = w;
-				}
+				for (int s = 0; s < (NS ? NS : 1); s++) *reinterpret_cast<unsigned*>(dst + s * qo.plane_bytes) = w[s];
 			}
 		}
 	}
