@@ -144,10 +144,14 @@ int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t plane_a_byte
 					 int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
 					 int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream);
 /* One cell chunk (k_pad = its cells) of a contraction whose operands arrive in chunks: accumulate != 0 adds the chunk's exact
- * partial dot products to d_dot in fp64 instead of overwriting it. */
+ * partial dot products to d_dot in fp64 instead of overwriting it.  b_block_rows != 0: operand B is n_pad / b_block_rows blocks
+ * (cyclically from block b_first of b_count) of a gathered buffer, block b a dense quantised operand of b_block_rows padded rows
+ * at d_qb + b * b_block_stride_bytes with its exponents at d_eb + b * b_block_rows: all full partner blocks of a rank in one
+ * launch (the N > 1 form of the x0 <= y0 tile loop, association.py:890-909). */
 int nrm_gram_i8_chunk(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
 					  int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
-					  int symmetric, int64_t m_rows, int64_t n_rows, int accumulate, void* d_work, void* stream);
+					  int symmetric, int64_t m_rows, int64_t n_rows, int accumulate, int64_t b_block_rows, int64_t b_block_stride_bytes,
+					  int b_first, int b_count, void* d_work, void* stream);
 
 /*
  * P-value plan: host-side constants of p = I_{1-R^2}(dof/2, 1/2) for one dof

@@ -39,7 +39,7 @@ _SIGNATURES = {
 	'nrm_quant_bytes': ([_i64, _i64, _i32], _i64),
 	'nrm_quantize_rows': ([_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp], _i32),
 	'nrm_gram_i8_band': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),
-	'nrm_gram_i8_chunk': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp], _i32),
+	'nrm_gram_i8_chunk': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _vp], _i32),
 	'nrm_pvalue_plan_init': ([ctypes.POINTER(PvaluePlan), _dbl], _i32),
 	'nrm_pvalue_plan_init_many': ([_vp, _i64, _vp, _i64], _i32),
 	'nrm_pvalues_from_r2': ([_vp, _i64, _dbl, _vp, _vp], _i32),

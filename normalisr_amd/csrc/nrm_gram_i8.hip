@@ -108,18 +108,34 @@ __global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict_
 	}
 }
 
+// Operand B as a run of equally sized blocks of a gathered buffer (sharded coex: the partner ranks' digit planes, one block per
+// rank, block b at b * stride, visited cyclically from `first`): tile column tj lies in block (first + tj * 128 / rows) % count.
+// rows == 0: B is one dense operand.
+struct BBlocks {
+	int rows;        // padded rows per block (multiple of 128)
+	int first, count;
+	int64_t stride;  // bytes between blocks
+};
+
 // ---- one tile piece: k-steps [k0, k1) of tile (ti, tj) -------------------------------------------------------------
 template <int NS>
 __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const char* __restrict__ QB, int64_t plane_a, int64_t plane_b,
 											  int64_t nks, const int* __restrict__ ea, const int* __restrict__ eb, double* __restrict__ C,
 											  int64_t ldc, int ti, int tj, int k0, int k1, double* __restrict__ slab, int m_rows, int n_rows,
-											  int symmetric, int accumulate, const char* lds, unsigned lds0) {
+											  int symmetric, int accumulate, BBlocks bb, const char* lds, unsigned lds0) {
 	constexpr int STAGE = 8 * NS * 1024;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wid >> 2, wn = wid & 3;  // 2 x 4 waves of 64 rows x 32 columns
 	// DMA role: wave `wid` moves the NS digit images of 32-row block (wid & 3) of operand (wid >> 2) of every stage
-	const char* src0 = (wid < 4 ? QA + (((int64_t)ti * 4 + wid) * nks) * 1024 : QB + (((int64_t)tj * 4 + (wid - 4)) * nks) * 1024) + lane * 16;
+	const char* qb_t = QB + ((int64_t)tj * 4 * nks) * 1024;  // the tile's 128 rows of B and their exponents
+	const int* eb_t = eb + tj * GN;
+	if (bb.rows) {
+		const int blk = tj * GN / bb.rows, within = tj * GN - blk * bb.rows, wb = (bb.first + blk) % bb.count;
+		qb_t = QB + wb * bb.stride + ((int64_t)(within / 32) * nks) * 1024;
+		eb_t = eb + wb * bb.rows + within;
+	}
+	const char* src0 = (wid < 4 ? QA + (((int64_t)ti * 4 + wid) * nks) * 1024 : qb_t + ((int64_t)(wid - 4) * nks) * 1024) + lane * 16;
 	const int64_t plane = wid < 4 ? plane_a : plane_b;
 	const unsigned dst0 = lds0 + wid * NS * 1024;
 	auto issue_one = [&](int buf, int ks, int s) {
@@ -163,7 +179,7 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 		cbase = C + (int64_t)row_w * ldc + col_w;
 		pitch = ldc;
 	}
-	const int eb_l = eb[col_w + (lane & 31)];
+	const int eb_l = eb_t[wn * 32 + (lane & 31)];
 	auto flush = [&](bool first) {
 #pragma unroll
 		for (int i = 0; i < 2; i++) {
@@ -267,14 +283,14 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 template <int NS>
 __global__ void __launch_bounds__(512) k_gram_i8(const char* __restrict__ QA, const char* __restrict__ QB, int64_t plane_a, int64_t plane_b,
 												 int64_t nks, const int* __restrict__ ea, const int* __restrict__ eb, double* __restrict__ C,
-												 int64_t ldc, int symmetric, GramSched s) {
+												 int64_t ldc, int symmetric, GramSched s, BBlocks bb) {
 	__shared__ __attribute__((aligned(1024))) char lds[QD * 8 * NS * 1024];
 	typedef __attribute__((address_space(3))) char* lds_ptr_t;
 	const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)lds);
 	gram_for_each_piece(s, [&](int t, int k0, int k1, double* slab) {
 		int ti, tj;
 		gram_tile_coords(s.tile0 + t, symmetric, s.ntm, s.ntn, ti, tj);
-		gram_piece_i8<NS>(QA, QB, plane_a, plane_b, nks, ea, eb, C, ldc, ti, tj, k0, k1, slab, s.m_rows, s.n_rows, symmetric, s.accumulate, lds, lds0);
+		gram_piece_i8<NS>(QA, QB, plane_a, plane_b, nks, ea, eb, C, ldc, ti, tj, k0, k1, slab, s.m_rows, s.n_rows, symmetric, s.accumulate, bb, lds, lds0);
 	});
 }
 
@@ -306,7 +322,7 @@ extern "C" int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_
 
 static int gram_i8_impl(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
 						int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
-						int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, int accumulate, void* d_work, void* stream) {
+						int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, int accumulate, BBlocks bb, void* d_work, void* stream) {
 	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_gram_i8: 5 or 6 slices");
 	NRM_REQUIRE(m_pad >= 0 && n_pad >= 0 && k_pad > 0 && m_pad % GM == 0 && n_pad % GN == 0, "nrm_gram_i8: sizes must be padded to %d", GM);
 	NRM_REQUIRE(ldd >= n_pad && ldd % 2 == 0, "nrm_gram_i8: pitch too small");
@@ -323,17 +339,19 @@ static int gram_i8_impl(const void* d_qa, const int32_t* d_ea, int64_t plane_a_b
 	}
 	const int64_t nks = (k_pad + QK - 1) / QK;
 	// distance between digit planes: dense by default; larger when the operand is a block of rows of a bigger quantised matrix
-	const int64_t plane_a = plane_a_bytes ? plane_a_bytes : (m_pad / 32) * nks * 1024, plane_b = plane_b_bytes ? plane_b_bytes : (n_pad / 32) * nks * 1024;
-	NRM_REQUIRE(plane_a >= (m_pad / 32) * nks * 1024 && plane_b >= (n_pad / 32) * nks * 1024, "nrm_gram_i8: plane pitch smaller than the operand");
+	const int64_t plane_a = plane_a_bytes ? plane_a_bytes : (m_pad / 32) * nks * 1024,
+				  plane_b = plane_b_bytes ? plane_b_bytes : ((bb.rows ? bb.rows : n_pad) / 32) * nks * 1024;
+	NRM_REQUIRE(plane_a >= (m_pad / 32) * nks * 1024 && plane_b >= ((bb.rows ? bb.rows : n_pad) / 32) * nks * 1024,
+				"nrm_gram_i8: plane pitch smaller than the operand");
 	GramSched s;
 	NRM_TRY_RC(gram_plan(s, m_pad, n_pad, nks, symmetric, m_rows, n_rows, row0, row1, g_num_cu_q, (double*)d_work));  // one workgroup per CU
 	s.accumulate = accumulate ? 1 : 0;
 	if (nslices == 5)
 		hipLaunchKernelGGL(k_gram_i8<5>, dim3((unsigned)s.nwg), dim3(512), 0, (hipStream_t)stream, (const char*)d_qa, (const char*)d_qb, plane_a,
-						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s);
+						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s, bb);
 	else
 		hipLaunchKernelGGL(k_gram_i8<6>, dim3((unsigned)s.nwg), dim3(512), 0, (hipStream_t)stream, (const char*)d_qa, (const char*)d_qb, plane_a,
-						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s);
+						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s, bb);
 	if (s.tiles_al + s.tiles_sk > 0)
 		hipLaunchKernelGGL(k_gram_fixup<1>, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_i8");
@@ -343,14 +361,25 @@ extern "C" int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t p
 								int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
 								int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream) {
 	return gram_i8_impl(d_qa, d_ea, plane_a_bytes, d_qb, d_eb, plane_b_bytes, m_pad, n_pad, k_pad, nslices, d_dot, ldd, symmetric, m_rows, n_rows, row0,
-						row1, 0, d_work, stream);
+						row1, 0, BBlocks{0, 0, 1, 0}, d_work, stream);
 }
 
 // One cell chunk of a contraction whose operands arrive in pieces along the cells (sharded coex: the digit planes of the other
 // ranks' blocks travel chunk by chunk): accumulate != 0 adds this chunk's exact partial dot products to d_dot in fp64.
+// b_block_rows != 0: operand B is b_blocks consecutive blocks (cyclically from b_first, of b_count) of a gathered buffer, each a
+// dense quantised operand of b_block_rows padded rows at d_qb + block * b_block_stride_bytes with its exponents at
+// d_eb + block * b_block_rows; n_pad = b_blocks * b_block_rows -- all full partner blocks of a rank in ONE launch.
 extern "C" int nrm_gram_i8_chunk(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
 								 int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
-								 int symmetric, int64_t m_rows, int64_t n_rows, int accumulate, void* d_work, void* stream) {
+								 int symmetric, int64_t m_rows, int64_t n_rows, int accumulate, int64_t b_block_rows, int64_t b_block_stride_bytes,
+								 int b_first, int b_count, void* d_work, void* stream) {
+	BBlocks bb{0, 0, 1, 0};
+	if (b_block_rows) {
+		NRM_REQUIRE(!symmetric && b_block_rows > 0 && b_block_rows % GN == 0 && n_pad % b_block_rows == 0 && b_count > 0 && b_first >= 0 &&
+						b_first < b_count && n_pad / b_block_rows <= b_count && b_block_stride_bytes % 16 == 0 && b_block_rows < (1 << 30),
+					"nrm_gram_i8_chunk: bad block description of operand B");
+		bb = BBlocks{(int)b_block_rows, b_first, b_count, b_block_stride_bytes};
+	}
 	return gram_i8_impl(d_qa, d_ea, plane_a_bytes, d_qb, d_eb, plane_b_bytes, m_pad, n_pad, k_pad, nslices, d_dot, ldd, symmetric, m_rows, n_rows, 0,
-						m_pad, accumulate, d_work, stream);
+						m_pad, accumulate, bb, d_work, stream);
 }

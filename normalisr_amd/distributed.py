@@ -232,6 +232,10 @@ class HipBackend:
 	def gram_chunk(self, a, b, symmetric, chunk, dot, accumulate):
 		return self.eng.gram_chunk(a, b, symmetric, chunk, dot, accumulate)
 
+	def gram_chunk_blocks(self, a, g_chunk, g_once, first, count, chunk, dot, accumulate):
+		"""All full partner blocks first .. first + count - 1 (cyclic) of the gather buffers against `a` in one launch."""
+		return self.eng.gram_chunk_blocks(a, g_chunk, g_once[0], first, count, chunk, dot, accumulate)
+
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
 		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags)
 		return p, stat, flags
@@ -470,13 +474,30 @@ class CoexPlan:
 				dot = self._timed('gram', timed, lambda: be.gram_chunk(ops[0], ops[2], e[4], c, dot, c > 0))
 			finish(e, ops, dot)
 		wait(h_once)
+		# the full partner blocks rank+1 .. rank+K are consecutive (cyclically) in the gather buffers: ONE launch per chunk for
+		# all of them (K x more tiles per launch keep the persistent schedule in its whole-tile regime); what is left -- the
+		# half-split pair of an even world -- goes pair by pair
+		full = [e for e in rest if e[0] == self.rank and e[2] == 0 and e[3] == self.rows_pad and not e[4]]
+		K = len(full)
+		merged = K >= 2 and hasattr(be, 'gram_chunk_blocks') and os.environ.get('NRM_MERGE_PARTNERS', '1') != '0' and [
+			e[1] for e in full] == [(self.rank + 1 + j) % self.world for j in range(K)]
+		if merged:
+			rest = [e for e in rest if e not in full]
 		todo = [(e, self._operands(*e[:4])) for e in rest]
 		todo = [(e, ops) for e, ops in todo if ops[4] > 0]
 		dots = [None] * len(todo)
+		mdot = None
 		for c in range(S):
 			wait(h_chunk[c])
+			if merged:
+				mdot = self._timed('gram', timed, lambda: be.gram_chunk_blocks(blk, self._g_chunks[c], self._g_once, (self.rank + 1) % self.world, K, c,
+																			   mdot, c > 0))
 			for i, (e, ops) in enumerate(todo):
 				dots[i] = self._timed('gram', timed, lambda: be.gram_chunk(ops[0], ops[2], e[4], c, dots[i], c > 0))
+		if merged:
+			for j, e in enumerate(full):
+				ssb = self._g_once[-1][e[1]]
+				finish(e, (blk, ss, None, ssb, self.rows), mdot[:, j * self.rows_pad:(j + 1) * self.rows_pad])
 		for (e, ops), dot in zip(todo, dots):
 			finish(e, ops, dot)
 		self.outputs = outs

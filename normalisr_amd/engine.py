@@ -308,7 +308,26 @@ class Engine:
 			pitch = lambda q: q[3] if len(q) > 3 else 0
 			_lib.check(self.lib.nrm_gram_i8_chunk(qa[0][chunk].data_ptr(), qa[1].data_ptr(), pitch(qa), qb[0][chunk].data_ptr(), qb[1].data_ptr(), pitch(qb),
 												  a.rows_pad, b.rows_pad, 32 * a.cks, qa[2], dot.data_ptr(), dot.stride(0), 1 if symmetric else 0,
-												  int(a.rows), int(b.rows), 1 if accumulate else 0, self._gram_work.data_ptr(), self._stream()))
+												  int(a.rows), int(b.rows), 1 if accumulate else 0, 0, 0, 0, 1, self._gram_work.data_ptr(), self._stream()))
+		return dot
+
+	def gram_chunk_blocks(self, a, g_chunk, g_exps, first, count, chunk, dot, accumulate):
+		"""The same against `count` consecutive blocks (cyclically from block `first`) of a gathered buffer in ONE launch:
+		g_chunk (world, chunk bytes) holds every rank's digit planes of this cell chunk, g_exps (world, rows_pad) their row
+		exponents.  dot: (a.rows_pad, count * a.rows_pad), block j in columns [j rows_pad, (j + 1) rows_pad)."""
+		torch = self.torch
+		with torch.cuda.device(self.device):
+			world, rp = g_exps.shape
+			if dot is None:
+				dot = torch.empty((a.rows_pad, count * rp), dtype=torch.float64, device=self.device)
+			if self._gram_work is None:
+				self._gram_work = torch.empty((int(self.lib.nrm_gram_workspace_bytes()) // 8, ), dtype=torch.float64, device=self.device)
+			qa = a._quant
+			pitch = lambda q: q[3] if len(q) > 3 else 0
+			_lib.check(self.lib.nrm_gram_i8_chunk(qa[0][chunk].data_ptr(), qa[1].data_ptr(), pitch(qa), g_chunk.data_ptr(), g_exps.data_ptr(), 0,
+												  a.rows_pad, count * rp, 32 * a.cks, qa[2], dot.data_ptr(), dot.stride(0), 0, int(a.rows), 0,
+												  1 if accumulate else 0, rp, g_chunk.stride(0) * g_chunk.element_size(), int(first), int(world),
+												  self._gram_work.data_ptr(), self._stream()))
 		return dot
 
 	I8_MIN_CELLS = 2048

@@ -606,11 +606,12 @@ def _chunked_worker(rank, world, port, q, dtype, n):
 	dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,dtype', [(2, 'float32'), (3, 'float64'), (4, 'float64'), (4, 'float32')])
+@pytest.mark.parametrize('world,dtype', [(2, 'float32'), (3, 'float64'), (4, 'float64'), (4, 'float32'), (5, 'float32'), (8, 'float64')])
 def test_sharded_coex_pipelined_chunk_exchange(world, dtype, monkeypatch):
 	"""The default N>1 exchange of rows that go to the integer engine: K1 writes the digit planes in 4 cell chunks, every chunk is
 	all-gathered on its own and the block pairs (incl. the half-split pair of an even world) are accumulated chunk by chunk with
-	nrm_gram_i8_chunk.  `world` processes share the one GPU over gloo; result against the single-process oracle."""
+	nrm_gram_i8_chunk -- from 5 ranks on all full partner blocks of a rank in one launch per chunk (cyclic run of the gather
+	buffer).  `world` processes share the one GPU over gloo; result against the single-process oracle."""
 	import socket
 	import torch.multiprocessing as mp
 	monkeypatch.setenv('NRM_EXCHANGE_MIN_KSTEPS', '8')  # 2304 cells = 72 k-steps -> 4 chunks of 18

@@ -49,3 +49,20 @@ for S in Ss:
 	err = ((dot[:rows, :rows] - ref[:rows, :rows]).abs().max() / ref[:rows, :rows].abs().max()).item()
 	tkc = timeit(lambda: eng.residualize_chunked(x, d_c, d_dci, dcr, rp, 6, S))
 	print('  %d chunks of %d k-steps: %.3f ms (%.2fx), K1 chunked %.3f ms, max rel diff %.1e' % (nch, ac.cks, timeit(run), timeit(run) / t1, tkc, err))
+
+# all K full partner blocks of a rank in one launch per chunk (gram_chunk_blocks), as CoexPlan does from 5 ranks on
+K = 3
+print('merged: %d x (%d x %d) block pairs per launch' % (K, rows, rows))
+for S in Ss:
+	ac = eng.residualize_chunked(x, d_c, d_dci, dcr, rp, 6, S)
+	nch = len(ac._quant[0])
+	world = K + 1
+	g_chunks = [torch.stack([ac._quant[0][c]] * world) for c in range(nch)]
+	g_exps = torch.stack([ac._quant[1]] * world)
+	md = torch.empty((rp, K * rp), dtype=torch.float64, device='cuda')
+
+	def runm():
+		for c in range(nch):
+			eng.gram_chunk_blocks(ac, g_chunks[c], g_exps, 1, K, c, md, c > 0)
+	t = timeit(runm)
+	print('  %d chunks: %.3f ms for %d pairs = %.3f ms per pair (%.2fx one launch per pair)' % (nch, t, K, t / K, t / K / t1))
