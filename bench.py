@@ -347,7 +347,10 @@ def main():
 					try:
 						with open(f) as fh:
 							pm = json.load(fh)
-							out['roofline']['traffic'] = next(v for k, v in pm.items() if k.split('<')[0] == out['roofline']['kernel'])['hbm_bytes_per_launch']
+							entry = next(v for k, v in pm.items() if k.split('<')[0] == out['roofline']['kernel'])
+							out['roofline']['traffic'] = entry['hbm_bytes_per_launch']
+							if 'effective_clock_ghz' in entry:  # the chip clocks down under int8 MFMA load: the nominal peak assumes 2.4 GHz
+								out['roofline']['effective_clock_ghz_profiled'] = round(entry['effective_clock_ghz'], 3)
 						out['roofline']['traffic_unit'] = 'bytes/launch'
 						out['roofline']['traffic_source'] = '{} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(os.path.relpath(f, ROOT))
 						break

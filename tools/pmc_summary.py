@@ -32,6 +32,9 @@ def main(dirs):
 	cut = {k: (r['min'] * r['max'])**0.5 if r['max'] > 5 * r['min'] else None for k, r in span.iterrows()}
 	df['kernel'] = [k if cut[k] is None else k + (' @long' if ns > cut[k] else ' @short') for k, ns in zip(df['kernel'], df['ns'])]
 	mean = df.groupby(['kernel', 'Counter_Name'])['Counter_Value'].mean().unstack()
+	# effective shader clock (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / duration
+	gui = df[df['Counter_Name'] == 'GRBM_GUI_ACTIVE']
+	clock = (gui['Counter_Value'] / 8 / gui['ns'].clip(lower=1)).groupby(gui['kernel']).mean() if len(gui) else {}
 	out = {}
 	for k, r in mean.iterrows():
 		e = {c: float(v) for c, v in r.items() if v == v}
@@ -44,6 +47,8 @@ def main(dirs):
 			e['write_bytes'] = e['WRITE_SIZE'] * 1024
 		if 'fetch_bytes' in e and 'write_bytes' in e:
 			e['hbm_bytes_per_launch'] = e['fetch_bytes'] + e['write_bytes']
+		if k in clock:
+			e['effective_clock_ghz'] = float(clock[k])
 		out[k] = e
 	json.dump(out, sys.stdout, indent=1)
 

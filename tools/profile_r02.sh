@@ -15,6 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/c2_SQ -o pmc -- $B --steps 3 --warmup 1 > /dev/null 2> $O/c2_SQ.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/c3_SQ -o pmc -- $B --workload de_c3 --steps 3 --warmup 1 > /dev/null 2> $O/c3_SQ.err
-python3 tools/pmc_summary.py $O/c2_FETCH_SIZE $O/c2_WRITE_SIZE $O/c2_SQ > $O/r02_pmc_c2.json
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/c2_CLK -o pmc -- $B --steps 10 --warmup 2 > /dev/null 2> $O/c2_CLK.err
+python3 tools/pmc_summary.py $O/c2_FETCH_SIZE $O/c2_WRITE_SIZE $O/c2_SQ $O/c2_CLK > $O/r02_pmc_c2.json
 python3 tools/pmc_summary.py $O/c3_FETCH_SIZE $O/c3_WRITE_SIZE $O/c3_SQ > $O/r02_pmc_de_c3.json
 find $O -name "*kernel_stats.csv" | head; head -c 1500 $O/r02_pmc_c2.json
