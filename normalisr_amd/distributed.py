@@ -316,13 +316,17 @@ class CoexPlan:
 		#    into NRM_EXCHANGE_CHUNKS pieces that are all-gathered one after another; the block pairs are contracted chunk by
 		#    chunk as the pieces land (exact partial sums, added in fp64), so only the first piece's flight is exposed and the
 		#    partner blocks are never residualised again;
-		#  raw (auto otherwise for fp32 input): the raw rows, 4 bytes per value, residualised again by the receiver;
+		#  raw (auto for fp32 input on 2-3 ranks, or when the rows do not go to the integer engine): the raw rows, 4 bytes per value,
+		#    residualised again by the receiver;
 		#  blocks (auto otherwise): the residualised blocks in one piece, as the backend packs them.
 		mode = os.environ.get('NRM_EXCHANGE', 'auto')
 		if mode not in ('auto', 'chunks', 'blocks', 'raw'):
 			raise ValueError('NRM_EXCHANGE must be auto, chunks, blocks or raw')
 		self.chunks = 0
-		if world > 1 and mode in ('auto', 'chunks') and hasattr(self.be, 'gram_chunk') and self.be.chunkable(dt_local, self.cov):
+		# auto: with 2 or 3 ranks a GPU talks over one or two of its seven xGMI links and the step is bound by the bytes on the
+		# wire, not by how well they hide -- fp32 rows then travel raw (4 bytes per value against 6 as digit planes)
+		few_links = mode == 'auto' and world <= 3 and backend is None and 'float32' in str(dt_local.dtype)
+		if world > 1 and mode in ('auto', 'chunks') and not few_links and hasattr(self.be, 'gram_chunk') and self.be.chunkable(dt_local, self.cov):
 			# chunk launches of fewer than ~128 k-steps (4096 cells) cost more than they hide (tools/time_chunks.py: a 1792 x 1792
 			# block pair over 10 000 cells takes 1.04x in 2 chunks, 1.33x in 4, 2.0x in 8; at 100 000 cells 4 chunks are free)
 			min_ks = int(os.environ.get('NRM_EXCHANGE_MIN_KSTEPS', '128'))

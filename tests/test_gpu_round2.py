@@ -279,6 +279,9 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 	assert out['config']['exchange'] == 'all-gather of raw fp32 blocks'  # below 2048 cells: fp64 engine, raw rows travel
 	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--genes', '1200', '--cells', '8192', '--no-extras'],
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
+	assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['exchange'] == 'all-gather of raw fp32 blocks'  # auto on 2 ranks
+	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--genes', '1200', '--cells', '8192', '--no-extras'],
+					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1', NRM_EXCHANGE='chunks'))
 	assert out['n_gpus'] == 2 and out['value'] > 0 and 'in 2 cell chunks' in out['config']['exchange']
 	assert out['kernels_ms']['gram'] > 0 and out['kernels_ms']['exchange'] >= 0
 
@@ -616,6 +619,7 @@ def test_sharded_coex_pipelined_chunk_exchange(world, dtype, monkeypatch):
 	import torch.multiprocessing as mp
 	monkeypatch.setenv('NRM_EXCHANGE_MIN_KSTEPS', '8')  # 2304 cells = 72 k-steps -> 4 chunks of 18
 	monkeypatch.setenv('NRM_EXCHANGE_CHUNKS', '4')
+	monkeypatch.setenv('NRM_EXCHANGE', 'chunks')  # (auto sends fp32 rows raw on 2-3 ranks)
 	n = 2304
 	s = socket.socket()
 	s.bind(('127.0.0.1', 0))
