@@ -45,8 +45,7 @@ def gram_roofline(n_cells, flops, gram_ms, rows_pad, k_pad):
 	kernel's measured duration.  The integer engine (>= 2048 cells) spends nslices (nslices + 1) / 2 int8 multiply-adds per
 	fp64-equivalent one, so its peak is the dense int8 MFMA peak divided by that count; the fp64 kernel is priced against the
 	fp64 MFMA peak.  Both are also shown against the fp32 MFMA peak the north star names."""
-	from normalisr_amd.engine import Engine
-	ns = Engine.gram_slices(n_cells)
+	ns = SLICES(n_cells)
 	achieved = flops / (gram_ms * 1e-3) / 1e12
 	if ns:
 		pairs = ns * (ns + 1) // 2
@@ -117,14 +116,15 @@ def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0):
 
 
 def SLICES(n_cells):
+	"""Digit planes of the integer Gram engine at this cell count under the current NRM_GRAM (0: the fp64 Gram kernel)."""
 	from normalisr_amd.engine import Engine
-	return Engine.gram_slices(n_cells)
+	mode = os.environ.get('NRM_GRAM', 'i8')
+	return {'i8': 6, 'i8x5': 5, 'f64': 0}[mode] if Engine.I8_MIN_CELLS <= n_cells < Engine.I8_MAX_CELLS else 0
 
 
 def ARITH(n_cells):
 	"""`dtype` of the JSON line: the arithmetic the dominant kernel computes in."""
-	from normalisr_amd.engine import Engine
-	ns = Engine.gram_slices(n_cells)
+	ns = SLICES(n_cells)
 	return 'i8 digits x i8 -> i32 exact, {}-bit fixed point, f64 combine (f64 residuals, sums of squares and P-values)'.format(8 * ns - 2) if ns else 'f64'
 
 

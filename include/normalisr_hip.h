@@ -87,11 +87,19 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
  * block of 32-row groups of a larger quantised matrix (d_q points at the block's first group, the pitch is the larger matrix's:
  * rows that arrive chunk by chunk fill one set of planes).  d_cmax (nc) = max_k |C[c,k]| of every covariate row, or NULL: with it
  * the fixed-point scale of a row comes from the bound max|x| + sum_c |b_c| max|C_c| >= max|residual| and the rows are swept twice
- * instead of three times. */
+ * instead of three times -- as long as that bound lies within 12x of the residuals' rms (estimated in the first sweep); rows whose
+ * mean dwarfs their spread, or whose covariates nearly cancel, are swept for their true maximum so that the overestimate never
+ * costs more than a few of the 8 * nslices - 2 bits.
+ * d_fix (rows_pad, NRM_FIX_STRIDE) fp64 or NULL: one record per row for K3 (nrm_assoc_sweep* below): the digit sums of the planes
+ * whose products the integer engine leaves out (K3 adds the product of the digit means back exactly) and the two numbers of the
+ * accuracy guard, c = sqrt(max digit variance / |q|^2) and g = sqrt(n) / (2 |q|); see csrc/nrm_fix.h.  The reference computes this
+ * contraction in fp64 (association.py:224-235); the records are what lets the integer engine certify, pair by pair, that its
+ * P-values agree with that to the stated tolerance.  Rows of fewer than 2^22 cells. */
+#define NRM_FIX_STRIDE 8
 int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
 					  double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax, void* stream);
+					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax, double* d_fix, void* stream);
 /* The same with the digit planes cut along the cells into chunks of 32 * chunk_ksteps cells: chunk c is a dense quantised operand
  * of its own (nslices planes of rows_pad / 32 * chunk_ksteps KB) at d_q + c * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices);
  * all chunks share d_exp; the last chunk is zero padded.  The sharded coex path (normalisr_amd/distributed.py; the N > 1 form of
@@ -99,7 +107,7 @@ int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int
 int nrm_residualize_q_chunked(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
 							  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
 							  int64_t rows_pad, double* d_ss, int nslices, void* d_q, int32_t* d_exp,
-							  int64_t chunk_ksteps, const double* d_cmax, void* stream);
+							  int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* stream);
 
 /*
  * K2 -- Gram contraction dot[i,j] = sum_k A[i,k] B[j,k] on the fp64 matrix cores
@@ -139,7 +147,8 @@ int64_t nrm_gram_workspace_bytes(void);
  *       a block of 32-row groups of a larger quantised matrix: pass the pointer of its first group and the larger matrix's pitch.
  */
 int64_t nrm_quant_bytes(int64_t rows_pad, int64_t k_pad, int nslices);
-int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_t ldx, int nslices, void* d_q, int32_t* d_exp, void* stream);
+int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_t ldx, int nslices, void* d_q, int32_t* d_exp,
+					  double* d_fix /* row records as in nrm_residualize_q, or NULL */, int64_t n_cells /* valid cells (<= k_pad), for d_fix */, void* stream);
 int nrm_gram_i8_band(const void* d_qa, const int32_t* d_ea, int64_t plane_a_bytes, const void* d_qb, const int32_t* d_eb,
 					 int64_t plane_b_bytes, int64_t m_pad, int64_t n_pad, int64_t k_pad, int nslices, double* d_dot, int64_t ldd,
 					 int symmetric, int64_t m_rows, int64_t n_rows, int64_t row0, int64_t row1, void* d_work, void* stream);
@@ -182,19 +191,26 @@ int nrm_pvalues_from_r2(const double* d_r2, int64_t count, double dof, double* d
  *                   (association.py:1050-1057); requires nx == ny and d_ssx == d_ssy.
  *   stat_kind: 0 -> covariance x~.y~/n ("dot", association.py:1039,1048); 1 -> gamma = x~.y~/ssx (:234)
  *   outputs (nx, ldo) of dtype out_dtype; d_r / d_t may be NULL (north-star extras: Pearson r, t statistic)
- *   d_flags: int32[2] device counters, incremented for non-finite inputs [0] and R^2 > 1+1e-8 [1]
- *            (the reference's assertions at association.py:248,252); may be NULL.
+ *   d_flags: int32[4] device counters, incremented for non-finite inputs [0] and R^2 > 1+1e-8 [1]
+ *            (the reference's assertions at association.py:248,252); may be NULL when fix_nslices == 0.
+ *   fix_nslices != 0 (5 or 6: d_dot came from the integer engine with that many digit planes): d_fixx (nx, NRM_FIX_STRIDE) and
+ *            d_fixy (ny, ..) are the row records K1 wrote.  Every dot product first receives the exact correction for the coherent
+ *            part of the digit products the engine left out; then, guard_tol > 0, the pair is checked: d_flags[2] counts the pairs
+ *            whose P-value the engine's remaining error (a rigorous bound, csrc/nrm_fix.h) could move by more than guard_tol
+ *            (relative) -- the host redoes such a call on nrm_gram_f64 -- and d_flags[3] receives the largest error estimate seen
+ *            (bits of a float).
  */
 int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy,
 					int64_t nx, int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind,
 					void* d_p, void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo,
-					int32_t* d_flags, void* stream);
+					int32_t* d_flags, int fix_nslices, const double* d_fixx, const double* d_fixy, double guard_tol, void* stream);
 /* The same for the x rows [row0, row1) (multiples of 64, or nx).  Symmetric problems: the band reads only dot rows
  * < row1 and, once the bands [0, row1) have run in order, output rows [0, row1) are complete (mirrored halves included). */
 int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy,
 						 int64_t nx, int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind,
 						 void* d_p, void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo,
-						 int32_t* d_flags, int64_t row0, int64_t row1, void* stream);
+						 int32_t* d_flags, int64_t row0, int64_t row1, int fix_nslices, const double* d_fixx, const double* d_fixy,
+						 double guard_tol, void* stream);
 
 /* The same for an off-diagonal RECTANGLE of a symmetric (coex) problem: rows [r0, r0 + mx) against columns [c0, c0 + my),
  * c0 + my <= r0; d_dot (mx, ldd) holds that rectangle of the Gram matrix, d_ssx / d_ssy the sums of squares of its rows / columns.
@@ -202,7 +218,7 @@ int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const double* d_ssx, 
  * so a coex whose rows arrive chunk by chunk can finish and ship all pairs of a chunk at once (association.py:1049-1057). */
 int nrm_assoc_sweep_mirror(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t mx, int64_t my,
 						   int64_t n_cells, double dof, void* d_p, void* d_stat, int out_dtype, int64_t ldo, int64_t r0, int64_t c0,
-						   int32_t* d_flags, void* stream);
+						   int32_t* d_flags, int fix_nslices, const double* d_fixx, const double* d_fixy, double guard_tol, void* stream);
 
 /*
  * alpha[i,j,c] = by[j,c] - gamma[i,j] * bx[i,c]  (association.py:238-243), fp64 coefficients in, out_dtype out.
@@ -310,6 +326,10 @@ int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int
 /* Frees the device scratch nrm_association_tests_host keeps between calls (it is reused best-fit; calls are
  * serialised per process). */
 int nrm_release_cache(void);
+/* Verdict of the integer engine's accuracy guard for the last nrm_association_tests_host call of this thread: *hits = pairs it could
+ * not certify on the integer pass (> 0: the call was redone on the fp64 Gram kernel before returning), *worst = largest relative
+ * error estimate of a P-value among the pairs it looked at.  NRM_I8_GUARD_TOL sets the tolerance (default 2.5e-7; 0 = no guard). */
+int nrm_last_guard(int64_t* hits, double* worst);
 int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
 							   const void* h_dy, int y_dtype, int64_t ny,
 							   const void* h_dc, int c_dtype, int64_t nc, int64_t n_cells,

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, 'libnormalisr_hip.so')
 
 NRM_F32, NRM_F64 = 0, 1
 NRM_E_ARG, NRM_E_DEVICE, NRM_E_NUMERIC = -1, -2, -3
-ROW_TILE, K_TILE, PCOEF = 128, 16, 20
+ROW_TILE, K_TILE, PCOEF, FIX_STRIDE = 128, 16, 20, 8
 
 _i64, _i32, _vp, _dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
 
@@ -23,6 +23,7 @@ _SIGNATURES = {
 	'nrm_device_count': ([ctypes.POINTER(_i32)], _i32),
 	'nrm_set_device': ([_i32], _i32),
 	'nrm_release_cache': ([], _i32),
+	'nrm_last_guard': ([ctypes.POINTER(_i64), ctypes.POINTER(_dbl)], _i32),
 	'nrm_host_pin': ([_vp, _i64, _i32], _i32),
 	'nrm_host_unpin': ([_vp], _i32),
 	'nrm_copy_to_host': ([_vp, _vp, _i64, _vp], _i32),
@@ -31,21 +32,21 @@ _SIGNATURES = {
 	'nrm_fill_zero': ([_vp, _i64, _vp], _i32),
 	'nrm_copy_rows': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
-	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp], _i32),
-	'nrm_residualize_q_chunked': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp], _i32),
+	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp], _i32),
+	'nrm_residualize_q_chunked': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_f64_band': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_workspace_bytes': ([], _i64),
 	'nrm_quant_bytes': ([_i64, _i64, _i32], _i64),
-	'nrm_quantize_rows': ([_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp], _i32),
+	'nrm_quantize_rows': ([_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp], _i32),
 	'nrm_gram_i8_band': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_i8_chunk': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _vp], _i32),
 	'nrm_pvalue_plan_init': ([ctypes.POINTER(PvaluePlan), _dbl], _i32),
 	'nrm_pvalue_plan_init_many': ([_vp, _i64, _vp, _i64], _i32),
 	'nrm_pvalues_from_r2': ([_vp, _i64, _dbl, _vp, _vp], _i32),
-	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
-	'nrm_assoc_sweep_band': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i64, _vp], _i32),
-	'nrm_assoc_sweep_mirror': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp], _i32),
+	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _dbl, _vp], _i32),
+	'nrm_assoc_sweep_band': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _vp], _i32),
+	'nrm_assoc_sweep_mirror': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _dbl, _vp], _i32),
 	'nrm_copy_rect_to_host': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_single4_sweep': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
 	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp], _i32),

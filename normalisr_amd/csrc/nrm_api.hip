@@ -244,11 +244,61 @@ extern "C" int nrm_release_cache(void) {
 	return NRM_OK;
 }
 
+// Verdict of the integer engine's accuracy guard (csrc/nrm_fix.h) for the last whole-problem call of this thread: pairs it could not
+// certify on the first pass (0: the integer engine's results were returned; > 0: the call was redone on the fp64 Gram kernel),
+// and the largest error estimate of a P-value (relative) among the pairs it looked at.
+static thread_local int64_t g_guard_hits = 0;
+static thread_local double g_guard_worst = 0.0;
+
+extern "C" int nrm_last_guard(int64_t* hits, double* worst) {
+	if (hits) *hits = g_guard_hits;
+	if (worst) *worst = g_guard_worst;
+	return NRM_OK;
+}
+
+static double guard_tolerance() {
+	const char* t = getenv("NRM_I8_GUARD_TOL");  // largest relative change of a P-value the integer engine may cause (0: no guard)
+	return t ? atof(t) : 2.5e-7;
+}
+
+static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
+										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
+										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
+										  void* h_vary, void* h_r, void* h_t, int out_dtype, int nslices, int64_t* guard_hits);
+
 extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
 										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
 										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
 										  void* h_vary, void* h_r, void* h_t, int out_dtype) {
 	std::lock_guard<std::mutex> serial(g_host_entry);
+	// K2 engine as in the Python host (NRM_GRAM): exact fixed-point contraction on the int8 matrix cores (6 slices = 46 bits; i8x5: 5
+	// slices = 38 bits), or the fp64 matrix-core kernel (f64).  With the integer engine K1 writes the digit planes itself and the
+	// fp64 residuals are never stored.
+	int nslices = 6;
+	if (n < 2048 || n >= (1 << 22)) nslices = 0;  // small problems stay on the fp64 kernel (the integer engine's error in r grows as 1/sqrt(n))
+	else if (const char* g = getenv("NRM_GRAM")) {
+		if (!strcmp(g, "f64")) nslices = 0;
+		else if (!strcmp(g, "i8x5")) nslices = 5;
+		else NRM_REQUIRE(!strcmp(g, "i8"), "NRM_GRAM must be i8, i8x5 or f64");
+	}
+	if (nslices && (n % 4 != 0)) nslices = 0;  // K1's fused quantiser needs 16-byte aligned rows of the (unpadded) host matrices
+	g_guard_hits = 0;
+	g_guard_worst = 0.0;
+	int64_t hits = 0;
+	int rc = association_tests_host_impl(h_dx, x_dtype, nx, h_dy, y_dtype, ny, h_dc, c_dtype, nc, n, h_dci, rank, dimreduce, return_dot, h_p, h_stat,
+										 h_alpha, h_varx, h_vary, h_r, h_t, out_dtype, nslices, &hits);
+	if (rc == NRM_OK && hits > 0) {  // pairs the guard could not certify: the whole call again on the fp64 matrix cores
+		g_guard_hits = hits;
+		rc = association_tests_host_impl(h_dx, x_dtype, nx, h_dy, y_dtype, ny, h_dc, c_dtype, nc, n, h_dci, rank, dimreduce, return_dot, h_p, h_stat,
+										 h_alpha, h_varx, h_vary, h_r, h_t, out_dtype, 0, nullptr);
+	}
+	return rc;
+}
+
+static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
+										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
+										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
+										  void* h_vary, void* h_r, void* h_t, int out_dtype, int nslices, int64_t* guard_hits) {
 	const bool samexy = (h_dy == nullptr);
 	if (samexy) {
 		ny = nx;
@@ -293,18 +343,8 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	}
 	const bool want_alpha = h_alpha != nullptr && nc > 0;
 	NRM_REQUIRE(!(want_alpha && samexy), "alpha is not provided for dy == NULL (meaningless in the reference, association.py:1066-1068)");
-	// K2 engine as in the Python host (NRM_GRAM): exact fixed-point contraction on the int8 matrix cores (6 slices = 46 bits; i8x5: 5
-	// slices = 38 bits), or the fp64 matrix-core kernel (f64).  With the integer engine K1 writes the digit planes itself and the
-	// fp64 residuals are never stored.
-	int nslices = 6;
-	if (n < 2048) nslices = 0;  // small problems stay on the fp64 kernel (the integer engine's error in r grows as 1/sqrt(n))
-	else if (const char* g = getenv("NRM_GRAM")) {
-		if (!strcmp(g, "f64")) nslices = 0;
-		else if (!strcmp(g, "i8x5")) nslices = 5;
-		else NRM_REQUIRE(!strcmp(g, "i8"), "NRM_GRAM must be i8, i8x5 or f64");
-	}
-	if (nslices && (n % 4 != 0)) nslices = 0;  // K1's fused quantiser needs 16-byte aligned rows of the (unpadded) host matrices
-	DevBuf qx, qy, ex, ey;
+	DevBuf qx, qy, ex, ey, fx, fy;
+	const double guard_tol = guard_tolerance();
 	NRM_TRY(dx.alloc((size_t)nx * n * esize(x_dtype)));
 	NRM_HIP(hipMemcpy(dx.p, h_dx, (size_t)nx * n * esize(x_dtype), hipMemcpyHostToDevice));
 	NRM_TRY(ssx.alloc((size_t)mp * 8));
@@ -313,8 +353,10 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	if (nslices) {
 		NRM_TRY(qx.alloc((size_t)nrm_quant_bytes(mp, kp, nslices)));
 		NRM_TRY(ex.alloc((size_t)mp * 4));
+		NRM_TRY(fx.alloc((size_t)mp * 8 * 8));
 		NRM_TRY(nrm_residualize_q(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, mp, ssx.as<double>(),
-								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr, st));
+								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr,
+								  fx.as<double>(), st));
 	} else {
 		NRM_TRY(rx.alloc((size_t)mp * kp * 8));
 		NRM_TRY(nrm_residualize(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, rx.as<double>(), kp, mp,
@@ -329,8 +371,10 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 		if (nslices) {
 			NRM_TRY(qy.alloc((size_t)nrm_quant_bytes(np_, kp, nslices)));
 			NRM_TRY(ey.alloc((size_t)np_ * 4));
+			NRM_TRY(fy.alloc((size_t)np_ * 8 * 8));
 			NRM_TRY(nrm_residualize_q(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, np_, ssy.as<double>(),
-									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr, st));
+									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr,
+									  fy.as<double>(), st));
 		} else {
 			NRM_TRY(ry.alloc((size_t)np_ * kp * 8));
 			NRM_TRY(nrm_residualize(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, ry.as<double>(), kp, np_,
@@ -350,8 +394,10 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	NRM_TRY(dot.alloc((size_t)mp * np_ * 8));
 	DevBuf gwork;
 	NRM_TRY(gwork.alloc((size_t)nrm_gram_workspace_bytes()));
-	NRM_TRY(flags.alloc(8));
-	NRM_HIP(hipMemsetAsync(flags.p, 0, 8, st));
+	NRM_TRY(flags.alloc(16));
+	NRM_HIP(hipMemsetAsync(flags.p, 0, 16, st));
+	const double* fxp = nslices ? fx.as<double>() : nullptr;
+	const double* fyp = nslices ? (samexy ? fxp : fy.as<double>()) : nullptr;
 	NRM_TRY(op.alloc(ob));
 	NRM_TRY(ostat.alloc(ob));
 	if (h_r) NRM_TRY(orr.alloc(ob));
@@ -371,7 +417,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 		else
 			NRM_TRY(nrm_gram_f64_band(A, B, mp, np_, kp, kp, kp, dot.as<double>(), np_, samexy ? 1 : 0, nx, ny, a, b == nx ? mp : b, gwork.p, st));
 		NRM_TRY(nrm_assoc_sweep_band(dot.as<double>(), np_, sx, sy, nx, ny, n, dof, samexy ? 1 : 0, stat_kind, op.p, ostat.p,
-									 h_r ? orr.p : nullptr, h_t ? ot.p : nullptr, out_dtype, ny, flags.as<int32_t>(), a, b, st));
+									 h_r ? orr.p : nullptr, h_t ? ot.p : nullptr, out_dtype, ny, flags.as<int32_t>(), a, b, nslices, fxp, fyp, guard_tol, st));
 		hipEvent_t ev;
 		NRM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		cs.events.push_back(ev);
@@ -396,11 +442,18 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	}
 	NRM_HIP(hipStreamSynchronize(st));
 	NRM_HIP(hipStreamSynchronize(cs.s));
-	int32_t hf[2];
-	NRM_HIP(hipMemcpy(hf, flags.p, 8, hipMemcpyDeviceToHost));
+	int32_t hf[4];
+	NRM_HIP(hipMemcpy(hf, flags.p, 16, hipMemcpyDeviceToHost));
 	if (hf[0] || hf[1]) {
 		nrm_set_error("association results failed the reference's assertions (association.py:248,252): %d tiles non-finite, %d tiles with R^2 > 1+1e-8", hf[0], hf[1]);
 		return NRM_E_NUMERIC;
+	}
+	if (nslices) {
+		float w;
+		memcpy(&w, &hf[3], 4);
+		g_guard_worst = (double)w;
+		if (guard_hits) *guard_hits = hf[2];
+		if (hf[2] > 0 && guard_hits) return NRM_OK;  // the caller redoes the call on the fp64 kernel: nothing more to bring back from this pass
 	}
 	if (want_alpha) NRM_HIP(hipMemcpy(h_alpha, oalpha.p, ob * nc, hipMemcpyDeviceToHost));
 	// variances = ss / n with the 0 -> 1 rule (association.py:230-233), cast to the output dtype

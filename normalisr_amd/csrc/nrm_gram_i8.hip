@@ -37,6 +37,7 @@
 #include <type_traits>
 #include "nrm_gram_sched.h"
 #include "nrm_digits.h"
+#include "nrm_fix.h"
 
 #define QK 32        // cells per k-step (one MFMA)
 #define QCHUNK 512   // k-steps per int32 accumulation chunk (16 384 cells)
@@ -69,15 +70,16 @@ __device__ __forceinline__ void q_dma16_nc(const void* gsrc, unsigned lds_dst) {
 // One wave per row (4 rows per workgroup, consecutive rows of one 32-row block).  x = q 2^exps[row] + rounding.
 template <int NS>
 __global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict__ X, int64_t kx, int64_t ldx, char* __restrict__ Q,
-													   int64_t plane_bytes, int64_t nks, int* __restrict__ exps) {
+													   int64_t plane_bytes, int64_t nks, int* __restrict__ exps, double* __restrict__ fix, double n_cells) {
 	constexpr int B = 8 * NS - 2;
 	const int lane = threadIdx.x & 63;
 	const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	const double* x = X + row * ldx;
-	double mx = 0.0;
+	double mx = 0.0, ssq = 0.0;
 	for (int64_t k = (int64_t)lane * 2; k < kx; k += 128) {
 		const d2_t v = *reinterpret_cast<const d2_t*>(x + k);
 		mx = fmax(mx, fmax(fabs(v[0]), fabs(v[1])));
+		ssq = fma(v[0], v[0], fma(v[1], v[1], ssq));
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
@@ -89,6 +91,13 @@ __global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict_
 	const int r = (int)(row & 31);
 	char* qrow = Q + (ib * nks) * 1024 + (2 * r) * 16;
 	const int flip = (r >> 3) & 1;
+	int dsum[NS - 1];
+	unsigned dsq[NS - 1];
+#pragma unroll
+	for (int s = 0; s < NS - 1; s++) {
+		dsum[s] = 0;
+		dsq[s] = 0u;
+	}
 	for (int64_t k = (int64_t)lane * 4; k < nks * QK; k += 256) {
 		double v[4] = {0.0, 0.0, 0.0, 0.0};
 		if (k < kx) {  // kx is a multiple of 16: a group of 4 cells is inside or outside as a whole
@@ -105,6 +114,22 @@ __global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict_
 		char* dst = qrow + ks * 1024 + (((kk >> 4) ^ flip) << 4) + (kk & 15);
 #pragma unroll
 		for (int s = 0; s < NS; s++) *reinterpret_cast<unsigned*>(dst + s * plane_bytes) = w[s];
+#pragma unroll
+		for (int s = 0; s < NS - 1; s++) {
+			dsum[s] = __builtin_amdgcn_sdot4((int)w[s], 0x01010101, dsum[s], false);
+			dsq[s] = (unsigned)__builtin_amdgcn_sdot4((int)w[s], (int)w[s], (int)dsq[s], false);
+		}
+	}
+	if (fix) {  // the row's record for K3's correction and guard (nrm_fix.h)
+		double S[5] = {0, 0, 0, 0, 0}, Q2[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+		for (int s = 0; s < NS - 1; s++) {
+			S[s] = (double)wave_sum_i32(dsum[s]);
+			Q2[s] = (double)wave_sum_u32(dsq[s]);
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o, 64);
+		if (lane == 0) nrm_fix_record<NS>(fix + row * NRM_FIX_STRIDE, S, Q2, sh, ssq, n_cells);
 	}
 }
 
@@ -304,19 +329,20 @@ extern "C" int64_t nrm_quant_bytes(int64_t rows_pad, int64_t k_pad, int nslices)
 }
 
 extern "C" int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_t ldx, int nslices, void* d_q, int32_t* d_exp,
-								 void* stream) {
+								 double* d_fix, int64_t n_cells, void* stream) {
 	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_quantize_rows: 5 or 6 slices");
 	NRM_REQUIRE(rows_pad >= 0 && rows_pad % GM == 0 && k_pad > 0 && k_pad % 16 == 0 && ldx >= k_pad && ldx % 2 == 0,
 				"nrm_quantize_rows: rows must be padded to %d, cells to 16", GM);
 	if (rows_pad == 0) return NRM_OK;
 	NRM_REQUIRE(d_x && d_q && d_exp && (uintptr_t)d_x % 16 == 0 && (uintptr_t)d_q % 16 == 0, "nrm_quantize_rows: null or misaligned pointer");
+	NRM_REQUIRE(!d_fix || (n_cells > 0 && n_cells <= k_pad && k_pad < (1 << 22)), "nrm_quantize_rows: row records need 0 < n_cells <= k_pad < 2^22");
 	const int64_t nks = (k_pad + QK - 1) / QK;
 	const int64_t plane = (rows_pad / 32) * nks * 1024;
 	dim3 grid((unsigned)(rows_pad / 4));
 	if (nslices == 5)
-		hipLaunchKernelGGL(k_quantize_rows<5>, grid, dim3(256), 0, (hipStream_t)stream, d_x, k_pad, ldx, (char*)d_q, plane, nks, d_exp);
+		hipLaunchKernelGGL(k_quantize_rows<5>, grid, dim3(256), 0, (hipStream_t)stream, d_x, k_pad, ldx, (char*)d_q, plane, nks, d_exp, d_fix, (double)n_cells);
 	else
-		hipLaunchKernelGGL(k_quantize_rows<6>, grid, dim3(256), 0, (hipStream_t)stream, d_x, k_pad, ldx, (char*)d_q, plane, nks, d_exp);
+		hipLaunchKernelGGL(k_quantize_rows<6>, grid, dim3(256), 0, (hipStream_t)stream, d_x, k_pad, ldx, (char*)d_q, plane, nks, d_exp, d_fix, (double)n_cells);
 	return nrm_check_launch("k_quantize_rows");
 }
 

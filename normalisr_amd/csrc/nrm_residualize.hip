@@ -11,6 +11,7 @@
 // from L2 is used RES_R times; covariates are swept in chunks of RES_CB to bound registers.
 #include "nrm_common.h"
 #include "nrm_digits.h"
+#include "nrm_fix.h"
 
 #define RES_R 4
 #define RES_CB 8
@@ -154,7 +155,14 @@ struct QuantOut {
 	int64_t chunk_bytes;
 	int* exps;            // x = digits * 2^exps[row]
 	const double* cmax;   // (nc) largest |C_c| of every covariate row: bounds the residuals without a sweep of their own
+	double* fix;          // (rows_pad, NRM_FIX_STRIDE) row records for K3's correction and guard (nrm_fix.h), or nullptr
 };
+
+// Loosest fixed-point scale K1 accepts from the bound max|x| + sum_c |b_c| max|C_c| without looking: bound / rms of the residuals
+// (the rms estimated from the first sweep as |x|^2 - a.b).  Beyond it -- rows whose mean dwarfs their spread, near-collinear
+// covariates with large opposite coefficients -- the residuals are swept for their true maximum, so that no more than log2 of
+// this / (true max / rms) of the 8 NS - 2 bits are lost to the overestimate.
+#define RES_LOOSE 12.0
 
 template <typename T, int CB, int NS>
 __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
@@ -176,9 +184,9 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 		live[r] = row0 + r < rows;
 		xr[r] = x + (live[r] ? (row0 + r) : 0) * ldx;
 	}
-	double xmax[RES_R];  // largest |x| of each row, gathered on the way (NS only)
+	double xmax[RES_R], xsq[RES_R];  // largest |x| and sum of squares of each row, gathered on the way (NS only)
 #pragma unroll
-	for (int r = 0; r < RES_R; r++) xmax[r] = 0.0;
+	for (int r = 0; r < RES_R; r++) xmax[r] = xsq[r] = 0.0;
 	if (active) {
 		for (int c0 = 0; c0 < nc; c0 += CB) {
 			double acc[RES_R][CB];
@@ -194,7 +202,10 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 #pragma unroll
 					for (int r = 0; r < RES_R; r++)
 #pragma unroll
-						for (int i = 0; i < 4; i++) xmax[r] = fmax(xmax[r], fabs(xv[r][i]));
+						for (int i = 0; i < 4; i++) {
+							xmax[r] = fmax(xmax[r], fabs(xv[r][i]));
+							xsq[r] = fma(xv[r][i], xv[r][i], xsq[r]);
+						}
 				}
 #pragma unroll
 				for (int q = 0; q < CB; q++) {
@@ -211,7 +222,10 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			for (int64_t k = n4 + tid; k < n; k += 256) {  // tail cells when n % 4 != 0
 				if (NS && c0 == 0) {
 #pragma unroll
-					for (int r = 0; r < RES_R; r++) xmax[r] = fmax(xmax[r], fabs((double)xr[r][k]));
+					for (int r = 0; r < RES_R; r++) {
+						xmax[r] = fmax(xmax[r], fabs((double)xr[r][k]));
+						xsq[r] = fma((double)xr[r][k], (double)xr[r][k], xsq[r]);
+					}
 				}
 #pragma unroll
 				for (int q = 0; q < CB; q++) {
@@ -279,19 +293,51 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 		for (int r = 0; r < RES_R; r++)
 			if (!live[r]) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
 	};
-	// Fixed-point scale of each row (NS only): 2^e >= the largest |residual|.  With covariates a bound does: |x - b C| <= max|x|
-	// + sum_c |b_c| max|C_c| (max|x| was gathered in the first sweep, max|C_c| comes from the caller) -- it overestimates the true
-	// maximum by a small factor, i.e. costs a bit or two of the 8 NS - 2, and saves a sweep over the row.  Without covariates
-	// (or without the caller's maxima) the residuals are swept once more for their maximum.
-	__shared__ double s_mx[4][RES_R];
-	__shared__ int s_sh[RES_R];
+	// Fixed-point scale of each row (NS only): 2^e >= the largest |residual|.  With covariates a bound does when it is tight: |x - b C|
+	// <= max|x| + sum_c |b_c| max|C_c| (max|x| was gathered in the first sweep, max|C_c| comes from the caller) saves a sweep over the
+	// row.  It is accepted when it lies within RES_LOOSE of the residuals' rms (|x|^2 - a.b from the same sweep); otherwise, and
+	// without covariates or without the caller's maxima, the residuals are swept once more for their true maximum.
+	__shared__ double s_mx[4][RES_R], s_sq[4][RES_R];
+	__shared__ int s_sh[RES_R], s_loose;
 	int sh[RES_R];
 	if (NS) {
 		constexpr int B = 8 * NS - 2;
 		const bool bounded = active && qo.cmax != nullptr;
-		if (!bounded) {
+		auto reduce_max = [&]() {
 #pragma unroll
-			for (int r = 0; r < RES_R; r++) xmax[r] = 0.0;
+			for (int r = 0; r < RES_R; r++) {
+				double v = xmax[r], q = wave_sum(xsq[r]);
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+				if (lane == 0) {
+					s_mx[wid][r] = v;
+					s_sq[wid][r] = q;
+				}
+			}
+		};
+		if (tid == 0) s_loose = 0;
+		if (bounded) {
+			reduce_max();
+			__syncthreads();
+			if (tid < RES_R) {
+				double m = fmax(fmax(s_mx[0][tid], s_mx[1][tid]), fmax(s_mx[2][tid], s_mx[3][tid]));
+				const double sq = (s_sq[0][tid] + s_sq[1][tid]) + (s_sq[2][tid] + s_sq[3][tid]);
+				double proj = 0.0;
+				for (int q = 0; q < nc; q++) {
+					m = fma(fabs(tb[tid * nc + q]), qo.cmax[q], m);
+					proj = fma(ta[tid * nc + q], tb[tid * nc + q], proj);
+				}
+				const double est = sq - proj;  // |x~|^2 up to cancellation: trusted only while it is a fair share of |x|^2
+				if (live[tid] && !(est > 1e-8 * sq && m * m * (double)n <= (RES_LOOSE * RES_LOOSE) * est)) s_loose = 1;
+				s_mx[0][tid] = m;
+			}
+			__syncthreads();
+		}
+		const bool sweep = !bounded || s_loose != 0;  // (one decision for the workgroup's rows)
+		if (sweep) {
+			__syncthreads();
+#pragma unroll
+			for (int r = 0; r < RES_R; r++) xmax[r] = xsq[r] = 0.0;
 			for (int64_t k = (int64_t)tid * 4; k < ((n + 3) & ~(int64_t)3); k += 1024) {
 				double v[RES_R][4];
 				residual4(k, v);
@@ -300,19 +346,13 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 #pragma unroll
 					for (int i = 0; i < 4; i++) xmax[r] = fmax(xmax[r], fabs(v[r][i]));
 			}
+			reduce_max();
+			__syncthreads();
+			if (tid < RES_R) s_mx[0][tid] = fmax(fmax(s_mx[0][tid], s_mx[1][tid]), fmax(s_mx[2][tid], s_mx[3][tid]));
+			__syncthreads();
 		}
-#pragma unroll
-		for (int r = 0; r < RES_R; r++) {
-			double v = xmax[r];
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-			if (lane == 0) s_mx[wid][r] = v;
-		}
-		__syncthreads();
 		if (tid < RES_R) {
-			double m = fmax(fmax(s_mx[0][tid], s_mx[1][tid]), fmax(s_mx[2][tid], s_mx[3][tid]));
-			if (bounded)
-				for (int q = 0; q < nc; q++) m = fma(fabs(tb[tid * nc + q]), qo.cmax[q], m);
+			const double m = s_mx[0][tid];
 			int e = 0;
 			if (m > 0.0 && m < INFINITY) (void)frexp(m, &e);  // m = f 2^e, f in [0.5, 1): every |residual| < 2^e
 			s_sh[tid] = e - B;
@@ -336,6 +376,17 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 	double sq[RES_R];
 #pragma unroll
 	for (int r = 0; r < RES_R; r++) sq[r] = 0.0;
+	// digit sums and sums of squares of the planes that have dropped products (s <= NS - 2): the row record of nrm_fix.h
+	constexpr int NP = NS >= 2 ? NS - 1 : 1;
+	int dsum[RES_R][NP];
+	unsigned dsq[RES_R][NP];
+#pragma unroll
+	for (int r = 0; r < RES_R; r++)
+#pragma unroll
+		for (int s = 0; s < NP; s++) {
+			dsum[r][s] = 0;
+			dsq[r][s] = 0u;
+		}
 	const int64_t kres = out ? ldo : ((n + 3) & ~(int64_t)3), kq = NS ? qo.nks * 32 : 0;
 	for (int64_t k = (int64_t)tid * 4; k < (kres > kq ? kres : kq); k += 1024) {
 		double v[RES_R][4];
@@ -366,6 +417,11 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 				char* dst = qrow[r] + ks * 1024 + (((kk >> 4) ^ flip[r]) << 4) + (kk & 15);
 #pragma unroll
 				for (int s = 0; s < (NS ? NS : 1); s++) *reinterpret_cast<unsigned*>(dst + s * qo.plane_bytes) = w[s];
+#pragma unroll
+				for (int s = 0; s < NP; s++) {
+					dsum[r][s] = __builtin_amdgcn_sdot4((int)w[s], 0x01010101, dsum[r][s], false);
+					dsq[r][s] = (unsigned)__builtin_amdgcn_sdot4((int)w[s], (int)w[s], (int)dsq[r][s], false);
+				}
 			}
 		}
 	}
@@ -374,8 +430,33 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 		double v = wave_sum(sq[r]);
 		if (lane == 0) s_ss[wid][r] = v;
 	}
+	__shared__ long long s_ds[4][RES_R][NP], s_dq[4][RES_R][NP];
+	if (NS && qo.fix) {
+#pragma unroll
+		for (int r = 0; r < RES_R; r++)
+#pragma unroll
+			for (int s = 0; s < NP; s++) {
+				const long long a = wave_sum_i32(dsum[r][s]), b = wave_sum_u32(dsq[r][s]);
+				if (lane == 0) {
+					s_ds[wid][r][s] = a;
+					s_dq[wid][r][s] = b;
+				}
+			}
+	}
 	__syncthreads();
-	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
+	if (tid < RES_R) {
+		const double ssr = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
+		ss[row0 + tid] = ssr;
+		if (NS && qo.fix) {
+			double S[5] = {0, 0, 0, 0, 0}, Q[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+			for (int s = 0; s < NP; s++) {
+				S[s] = (double)((s_ds[0][tid][s] + s_ds[1][tid][s]) + (s_ds[2][tid][s] + s_ds[3][tid][s]));
+				Q[s] = (double)((s_dq[0][tid][s] + s_dq[1][tid][s]) + (s_dq[2][tid][s] + s_dq[3][tid][s]));
+			}
+			nrm_fix_record<NS>(qo.fix + (row0 + tid) * NRM_FIX_STRIDE, S, Q, s_sh[tid], ssr, (double)n);
+		}
+	}
 }
 
 template <typename T>
@@ -401,7 +482,8 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 
 static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
 							const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, int64_t chunk_ksteps, const double* d_cmax, void* stream) {
+							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, int64_t chunk_ksteps, const double* d_cmax, double* d_fix,
+							void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
 	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
 	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
@@ -416,9 +498,10 @@ static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t 
 	const int64_t xa = 16 / (x_dtype == NRM_F64 ? 8 : 4);
 	const bool vec = (ldx % xa == 0) && ((uintptr_t)d_x % 16 == 0) && (!d_out || ((ldo % 4 == 0) && ((uintptr_t)d_out % 16 == 0))) &&
 					 (!active || (ldc % 2 == 0 && (uintptr_t)d_c % 16 == 0));
-	QuantOut qo = {nullptr, 0, 0, 0, 0, nullptr, d_cmax};
+	QuantOut qo = {nullptr, 0, 0, 0, 0, nullptr, d_cmax, d_fix};
 	if (nslices) {
 		NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_residualize_q: 5 or 6 slices");
+		NRM_REQUIRE(n < (1 << 22), "nrm_residualize_q: the integer engine takes rows of fewer than 2^22 cells");
 		NRM_REQUIRE(vec, "nrm_residualize_q: needs 16-byte aligned rows (use nrm_residualize + nrm_quantize_rows otherwise)");
 		NRM_REQUIRE(rows_pad % 128 == 0 && d_q && d_exp && (uintptr_t)d_q % 16 == 0, "nrm_residualize_q: rows_pad %% 128 == 0 and digit buffers required");
 		const int64_t k_pad = (n + 15) / 16 * 16;
@@ -451,15 +534,16 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 							   int64_t nc, int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo,
 							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
 	NRM_REQUIRE(d_out != nullptr, "nrm_residualize: null output");
-	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, 0, nullptr, stream);
+	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, 0, nullptr,
+							nullptr, stream);
 }
 
 extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 								 int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss,
 								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax,
-								 void* stream) {
+								 double* d_fix, void* stream) {
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp,
-							plane_pitch_bytes, 0, d_cmax, stream);
+							plane_pitch_bytes, 0, d_cmax, d_fix, stream);
 }
 
 // The same with the digit planes cut along the cells into chunks of chunk_ksteps * 32 cells: chunk c is a dense quantised
@@ -468,10 +552,10 @@ extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int
 // (nrm_gram_i8_chunk).  d_q: ceil(ceil(k_pad / 32) / chunk_ksteps) * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices) bytes.
 extern "C" int nrm_residualize_q_chunked(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 										 int64_t ldc, const double* d_dci, int rank, int64_t rows_pad, double* d_ss, int nslices, void* d_q,
-										 int32_t* d_exp, int64_t chunk_ksteps, const double* d_cmax, void* stream) {
+										 int32_t* d_exp, int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* stream) {
 	NRM_REQUIRE(chunk_ksteps > 0 && chunk_ksteps < (1 << 24), "nrm_residualize_q_chunked: bad chunk size");
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, nullptr, 0, rows_pad, d_ss, nullptr, nslices, d_q, d_exp, 0,
-							chunk_ksteps, d_cmax, stream);
+							chunk_ksteps, d_cmax, d_fix, stream);
 }
 
 // Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include "nrm_pvalue.h"
+#include "nrm_fix.h"
 
 // ---- host: plan -------------------------------------------------------------------------------
 
@@ -100,24 +101,57 @@ __global__ void __launch_bounds__(256) k_pvalues_from_r2(const double* __restric
 	for (; i < count; i += stride) p[i] = nrm_pvalue(r2[i], pl);
 }
 
+#define SW_T 64
+#define SW_T_ 64
 template <typename T>
 __device__ __forceinline__ void store_out(void* base, int64_t idx, double v) {
 	reinterpret_cast<T*>(base)[idx] = (T)v;
 }
 
+// Integer-engine row records (nrm_fix.h) inside a sweep: the x rows of the workgroup's tile staged in LDS, the thread's column
+// record in registers; fix_finish publishes the guard's verdict: flags[2] += uncertified pairs, flags[3] = max error estimate
+// (float bits; positive floats order like their bit patterns).
+#define SW_FIX 7  // doubles of a record the sweeps use: u0..u4, c, g
+#define PV_FN [](double r2_, const PvalPlan& pl_) { return nrm_pvalue(r2_, pl_); }
+__device__ __forceinline__ void fix_stage_rows(const FixArgs& f, double (*sfx)[SW_FIX], int64_t row0, int64_t nrows) {
+	if (!f.fx) return;
+	for (int i = threadIdx.x; i < SW_T_ * SW_FIX; i += 256) {
+		const int r = i / SW_FIX, c = i - r * SW_FIX;
+		sfx[r][c] = (row0 + r < nrows) ? f.fx[(row0 + r) * NRM_FIX_STRIDE + c] : 0.0;
+	}
+}
+__device__ __forceinline__ FixCol fix_column(const FixArgs& f, int64_t col, int64_t ncols) {
+	FixCol y = {{0.0, 0.0, 0.0, 0.0, 0.0}, 0.0, 0.0};
+	if (f.fx && col < ncols) y = nrm_fix_col(f.fy + col * NRM_FIX_STRIDE);
+	return y;
+}
+__device__ __forceinline__ void fix_finish(const FixArgs& f, int32_t* __restrict__ flags, int bad, float worst) {
+	if (!f.fx || !flags) return;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		bad += __shfl_xor(bad, o, 64);
+		worst = fmaxf(worst, __shfl_xor(worst, o, 64));
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (bad) atomicAdd(&flags[2], bad);
+		if (worst > 0.f) atomicMax(&flags[3], __float_as_int(worst));
+	}
+}
+
 // One workgroup = one 64x64 tile of the (nx, ny) output.  The source tile of dot is staged through LDS
 // so that the mirrored half of a symmetric (coex) problem is read coalesced and transposed on chip.
-#define SW_T 64
 template <typename OutT>
 __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ dot, int64_t ldd,
 													  const double* __restrict__ ssx, const double* __restrict__ ssy,
 													  int64_t nx, int64_t ny, double ncells, double dof, int symmetric,
 													  int stat_kind, PvalPlan pl, void* __restrict__ p_out,
 													  void* __restrict__ stat_out, void* __restrict__ r_out,
-													  void* __restrict__ t_out, int64_t ldo, int32_t* __restrict__ flags, int bi0) {
+													  void* __restrict__ t_out, int64_t ldo, int32_t* __restrict__ flags, int bi0, FixArgs fix) {
 	__shared__ double tile[SW_T][SW_T + 1];
 	__shared__ double sx[SW_T], sy[SW_T];
+	__shared__ double sfx[SW_T][SW_FIX];
 	const int bi = blockIdx.y + bi0, bj = blockIdx.x;
+	fix_stage_rows(fix, sfx, (int64_t)bi * SW_T, nx);
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
 	// source tile: for coex always from the upper triangle (association.py:1050-1057)
 	const bool mirror = symmetric && bi > bj;
@@ -138,8 +172,10 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 		sy[t] = (v == 0.0) ? ncells : v;  // association.py:233
 	}
 	__syncthreads();
-	int bad_nf = 0, bad_rng = 0;
+	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
+	float worst = 0.f;
 	const int64_t gj = (int64_t)bj * SW_T + tx;
+	const FixCol fy = fix_column(fix, gj, ny);
 	for (int r = ty; r < SW_T; r += 4) {
 		const int64_t gi = (int64_t)bi * SW_T + r;
 		if (gi >= nx || gj >= ny) continue;
@@ -152,6 +188,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 			d = (r <= tx) ? tile[r][tx] : tile[tx][r];
 		else
 			d = tile[r][tx];
+		if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 		const double vx = sx[r], vy = sy[tx];
 		double r2 = (d * d) / (vx * vy);  // = gamma^2 vx / vy  (association.py:235)
 		double p, stat, rr, tt;
@@ -168,6 +205,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 			rr = d / sqrt(vx * vy);
 			double rc = fmin(r2, 1.0);
 			tt = copysign(sqrt(dof * rc / (1.0 - rc)), d);
+			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, rr, r2, p, pl, PV_FN, worst);
 		}
 		const int64_t o = gi * ldo + gj;
 		store_out<OutT>(p_out, o, p);
@@ -179,6 +217,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
 	}
+	fix_finish(fix, flags, bad_fix, worst);
 }
 
 // Symmetric (coex) sweep over the upper triangle of 64x64 tiles only: every p-value is computed once and
@@ -186,9 +225,10 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 template <typename OutT>
 __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ss,
 														  int64_t ng, int nb, double ncells, PvalPlan pl, OutT* __restrict__ p_out,
-														  OutT* __restrict__ stat_out, int64_t ldo, int32_t* __restrict__ flags, int bi0) {
+														  OutT* __restrict__ stat_out, int64_t ldo, int32_t* __restrict__ flags, int bi0, FixArgs fix) {
 	__shared__ double tile[SW_T][SW_T + 1];
 	__shared__ double sx[SW_T], sy[SW_T];
+	__shared__ double sfx[SW_T][SW_FIX];
 	int b = blockIdx.x, bi = bi0, len = nb - bi0;
 	while (b >= len) {
 		b -= len;
@@ -196,6 +236,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 		len--;
 	}
 	const int bj = bi + b;
+	fix_stage_rows(fix, sfx, (int64_t)bi * SW_T, ng);
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 	for (int r = ty; r < SW_T; r += 4) {
 		int64_t gi = (int64_t)bi * SW_T + r, gj = (int64_t)bj * SW_T + tx;
@@ -212,14 +253,17 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 		sy[t] = (v == 0.0) ? ncells : v;
 	}
 	__syncthreads();
-	int bad_nf = 0, bad_rng = 0;
+	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
+	float worst = 0.f;
 	const int64_t gj = (int64_t)bj * SW_T + tx;
+	const FixCol fy = fix_column(fix, gj, ng);
 	double pv[SW_T / 4], sv[SW_T / 4];
 #pragma unroll
 	for (int i = 0; i < SW_T / 4; i++) {
 		const int r = ty + 4 * i;
 		const int64_t gi = (int64_t)bi * SW_T + r;
 		double d = (bi == bj && r > tx) ? tile[tx][r] : tile[r][tx];
+		if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 		const double vx = sx[r], vy = sy[tx];
 		const double r2 = (d * d) / (vx * vy);
 		double p = 0.0, st = 0.0;
@@ -228,6 +272,8 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
+			if (fix.fx && fix.budget > 0.0 && (bi != bj || r < tx))  // (a diagonal block holds each of its pairs twice)
+				bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, d * rsqrt(vx * vy), r2, p, pl, PV_FN, worst);
 		}
 		pv[i] = p;
 		sv[i] = st;
@@ -263,6 +309,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
 	}
+	fix_finish(fix, flags, bad_fix, worst);
 }
 
 // Off-diagonal rectangle of a symmetric (coex) problem: rows [r0, r0 + mx) against columns [c0, c0 + my) with c0 + my <= r0.
@@ -272,11 +319,13 @@ template <typename OutT>
 __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ssx,
 															 const double* __restrict__ ssy, int64_t mx, int64_t my, double ncells, PvalPlan pl,
 															 OutT* __restrict__ p_out, OutT* __restrict__ stat_out, int64_t ldo, int64_t r0,
-															 int64_t c0, int32_t* __restrict__ flags) {
+															 int64_t c0, int32_t* __restrict__ flags, FixArgs fix) {
 	__shared__ double tile[SW_T][SW_T + 1];
 	__shared__ double sx[SW_T], sy[SW_T];
+	__shared__ double sfx[SW_T][SW_FIX];
 	const int bi = blockIdx.y, bj = blockIdx.x;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	fix_stage_rows(fix, sfx, (int64_t)bi * SW_T, mx);
 	if (threadIdx.x < SW_T) {
 		const int64_t gi = (int64_t)bi * SW_T + threadIdx.x;
 		const double v = gi < mx ? ssx[gi] : 1.0;
@@ -288,8 +337,10 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 		sy[t] = (v == 0.0) ? ncells : v;
 	}
 	__syncthreads();
-	int bad_nf = 0, bad_rng = 0;
+	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
+	float worst = 0.f;
 	const int64_t gj = (int64_t)bj * SW_T + tx;
+	const FixCol fy = fix_column(fix, gj, my);
 	double pv[SW_T / 4], sv[SW_T / 4];
 #pragma unroll
 	for (int i = 0; i < SW_T / 4; i++) {
@@ -297,13 +348,15 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 		const int64_t gi = (int64_t)bi * SW_T + r;
 		double p = 0.0, st = 0.0;
 		if (gi < mx && gj < my) {
-			const double d = dot[gi * ldd + gj];
+			double d = dot[gi * ldd + gj];
+			if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 			const double vx = sx[r], vy = sy[tx];
 			const double r2 = (d * d) / (vx * vy);
 			if (!isfinite(r2) || !isfinite(vx) || !isfinite(vy)) bad_nf = 1;
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
+			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, d * rsqrt(vx * vy), r2, p, pl, PV_FN, worst);
 			p_out[(r0 + gi) * ldo + c0 + gj] = (OutT)p;
 			stat_out[(r0 + gi) * ldo + c0 + gj] = (OutT)st;
 		}
@@ -334,6 +387,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
 	}
+	fix_finish(fix, flags, bad_fix, worst);
 }
 
 // Sweep for the streaming de path (nrm_gram_skinny): one thread per gene.  G[y] = [y C^T (nc) | y X~^T (nx) | 0...],
@@ -449,8 +503,11 @@ extern "C" int nrm_pvalues_from_r2(const double* d_r2, int64_t count, double dof
 extern "C" int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t nx,
 									int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind, void* d_p,
 									void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo, int32_t* d_flags,
-									int64_t row0, int64_t row1, void* stream) {
+									int64_t row0, int64_t row1, int fix_nslices, const double* d_fixx, const double* d_fixy, double guard_tol,
+									void* stream) {
 	NRM_REQUIRE(nx >= 0 && ny >= 0 && n_cells > 0, "nrm_assoc_sweep: bad sizes");
+	NRM_REQUIRE(fix_nslices == 0 || ((fix_nslices == 5 || fix_nslices == 6) && d_fixx && d_fixy && d_flags), "nrm_assoc_sweep: row records need 5 or 6 slices, both tables and flags");
+	const FixArgs fix = nrm_fix_args(fix_nslices ? d_fixx : nullptr, d_fixy, fix_nslices, n_cells, dof, guard_tol);
 	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_assoc_sweep: bad out_dtype");
 	NRM_REQUIRE(!symmetric || nx == ny, "nrm_assoc_sweep: symmetric needs nx == ny");
 	NRM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= nx && row0 % SW_T == 0 && (row1 % SW_T == 0 || row1 == nx),
@@ -468,33 +525,35 @@ extern "C" int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const doub
 		dim3 g((unsigned)((b1 - b0) * nb - (b1 * (b1 - 1) - b0 * (b0 - 1)) / 2));
 		if (out_dtype == NRM_F64)
 			hipLaunchKernelGGL(k_assoc_sweep_sym<double>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
-							   (double)n_cells, to_dev(plan), (double*)d_p, (double*)d_stat, ldo, d_flags, (int)b0);
+							   (double)n_cells, to_dev(plan), (double*)d_p, (double*)d_stat, ldo, d_flags, (int)b0, fix);
 		else
 			hipLaunchKernelGGL(k_assoc_sweep_sym<float>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
-							   (double)n_cells, to_dev(plan), (float*)d_p, (float*)d_stat, ldo, d_flags, (int)b0);
+							   (double)n_cells, to_dev(plan), (float*)d_p, (float*)d_stat, ldo, d_flags, (int)b0, fix);
 		return nrm_check_launch("k_assoc_sweep_sym");
 	}
 	dim3 grid((unsigned)((ny + SW_T - 1) / SW_T), (unsigned)(b1 - b0));
 	if (out_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_assoc_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
-						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags, (int)b0);
+						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags, (int)b0, fix);
 	else
 		hipLaunchKernelGGL(k_assoc_sweep<float>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, nx, ny,
-						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags, (int)b0);
+						   (double)n_cells, dof, symmetric, stat_kind, to_dev(plan), d_p, d_stat, d_r, d_t, ldo, d_flags, (int)b0, fix);
 	return nrm_check_launch("k_assoc_sweep");
 }
 
 extern "C" int nrm_assoc_sweep(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t nx,
 							   int64_t ny, int64_t n_cells, double dof, int symmetric, int stat_kind, void* d_p,
 							   void* d_stat, void* d_r, void* d_t, int out_dtype, int64_t ldo, int32_t* d_flags,
-							   void* stream) {
+							   int fix_nslices, const double* d_fixx, const double* d_fixy, double guard_tol, void* stream) {
 	return nrm_assoc_sweep_band(d_dot, ldd, d_ssx, d_ssy, nx, ny, n_cells, dof, symmetric, stat_kind, d_p, d_stat, d_r, d_t, out_dtype,
-								ldo, d_flags, 0, nx, stream);
+								ldo, d_flags, 0, nx, fix_nslices, d_fixx, d_fixy, guard_tol, stream);
 }
 
 extern "C" int nrm_assoc_sweep_mirror(const double* d_dot, int64_t ldd, const double* d_ssx, const double* d_ssy, int64_t mx, int64_t my,
 									  int64_t n_cells, double dof, void* d_p, void* d_stat, int out_dtype, int64_t ldo, int64_t r0, int64_t c0,
-									  int32_t* d_flags, void* stream) {
+									  int32_t* d_flags, int fix_nslices, const double* d_fixx, const double* d_fixy, double guard_tol, void* stream) {
+	NRM_REQUIRE(fix_nslices == 0 || ((fix_nslices == 5 || fix_nslices == 6) && d_fixx && d_fixy && d_flags), "nrm_assoc_sweep: row records need 5 or 6 slices, both tables and flags");
+	const FixArgs fix = nrm_fix_args(fix_nslices ? d_fixx : nullptr, d_fixy, fix_nslices, n_cells, dof, guard_tol);
 	NRM_REQUIRE(mx >= 0 && my >= 0 && n_cells > 0 && r0 >= 0 && c0 >= 0 && c0 + my <= r0, "nrm_assoc_sweep_mirror: the rectangle must lie below the diagonal");
 	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_assoc_sweep: bad out_dtype");
 	nrm_pvalue_plan plan;
@@ -505,10 +564,10 @@ extern "C" int nrm_assoc_sweep_mirror(const double* d_dot, int64_t ldd, const do
 	dim3 grid((unsigned)((my + SW_T - 1) / SW_T), (unsigned)((mx + SW_T - 1) / SW_T));
 	if (out_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_assoc_sweep_mirror<double>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, mx, my, (double)n_cells,
-						   to_dev(plan), (double*)d_p, (double*)d_stat, ldo, r0, c0, d_flags);
+						   to_dev(plan), (double*)d_p, (double*)d_stat, ldo, r0, c0, d_flags, fix);
 	else
 		hipLaunchKernelGGL(k_assoc_sweep_mirror<float>, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, d_ssy, mx, my, (double)n_cells,
-						   to_dev(plan), (float*)d_p, (float*)d_stat, ldo, r0, c0, d_flags);
+						   to_dev(plan), (float*)d_p, (float*)d_stat, ldo, r0, c0, d_flags, fix);
 	return nrm_check_launch("k_assoc_sweep_mirror");
 }
 

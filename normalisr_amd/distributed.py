@@ -78,6 +78,19 @@ def _all_gather_ints(values, group, device):
 	return np.stack([t.cpu().numpy() for t in out])
 
 
+def _reduce_flags(flags, group):
+	"""A call's device counters (engine.new_flags) as ONE verdict of all ranks: the counts summed, the guard's largest error
+	estimate (float bits in the last entry) maximised.  Returns the reduced tensor (on the host for gloo)."""
+	import torch.distributed as dist
+	f = flags.clone() if dist.get_backend(group) == 'nccl' else flags.cpu()
+	worst = f[3:4].clone() if f.shape[0] >= 4 else None
+	dist.all_reduce(f, group=group)
+	if worst is not None:
+		dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
+		f[3:4] = worst
+	return f
+
+
 class SharedArrays:
 	"""Result arrays visible to every rank of the node, so that each rank copies ITS finished rows straight into the
 	caller-visible output (the reference's gather loop fills one array from every tile, association.py:1005-1034) and
@@ -201,13 +214,14 @@ class HipBackend:
 		"""What travels to the other ranks for this block: its digit planes and row exponents (6 bytes per value at 6 slices
 		against 8 for fp64 residuals), or the fp64 residuals for the fp64 engine."""
 		q = getattr(blk, '_quant', None)
-		return [q[0], q[1]] if q is not None else [blk.data]
+		return [q[0], q[1], blk.fix] if q is not None else [blk.data]
 
 	def from_payload(self, parts, rows, rows_pad, n, k_pad, ss):
 		from .engine import Residualized
-		if len(parts) == 2:
+		if len(parts) == 3:  # digit planes, row exponents, row records (csrc/nrm_fix.h)
 			blk = Residualized(rows, n, None, ss, None, shape=(rows_pad, k_pad))
 			blk._quant = (parts[0], parts[1], self.eng.gram_slices(n))
+			blk.fix = parts[2]
 			return blk
 		return Residualized(rows, n, parts[0], ss, None, shape=(rows_pad, k_pad))
 
@@ -219,14 +233,15 @@ class HipBackend:
 		return len(blk._quant[0])
 
 	def chunk_payload(self, blk):
-		"""(tensors of the chunks, in cell order; tensors that travel once: the row exponents)."""
-		return list(blk._quant[0]), [blk._quant[1]]
+		"""(tensors of the chunks, in cell order; tensors that travel once: the row exponents and the row records)."""
+		return list(blk._quant[0]), [blk._quant[1], blk.fix]
 
 	def from_chunks(self, chunks, once, like, ss):
 		from .engine import Residualized
 		blk = Residualized(like.rows, like.n, None, ss, None, shape=(like.rows_pad, like.k_pad))
 		blk._quant = (list(chunks), once[0], like._quant[2])
 		blk.cks = like.cks
+		blk.fix = once[1]
 		return blk
 
 	def gram_chunk(self, a, b, symmetric, chunk, dot, accumulate):
@@ -236,8 +251,10 @@ class HipBackend:
 		"""All full partner blocks first .. first + count - 1 (cyclic) of the gather buffers against `a` in one launch."""
 		return self.eng.gram_chunk_blocks(a, g_chunk, g_once[0], first, count, chunk, dot, accumulate)
 
-	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
-		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags)
+	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None, a=None, b=None):
+		"""a, b: the blocks dot was made from (their row records feed K3's correction and guard when the integer engine made it)."""
+		fix = self.eng.fix_args(a, b) if a is not None and b is not None else None
+		p, stat, _, _, flags = self.eng.sweep(dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, 0, out_dtype, flags=flags, fix=fix)
 		return p, stat, flags
 
 	def event(self):
@@ -403,7 +420,7 @@ class CoexPlan:
 		if lo != 0 or hi != self.rows_pad:
 			a, ssa = self.be.rows(a, lo, hi, nx), ssa[lo:hi]
 		dot = self._timed('gram', timed, lambda: self.be.gram(a, b, sym, nx, ny))
-		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags))
+		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, ssa, ssb, nx, ny, self.n, self.dof, sym, self.out_dtype, self.flags, a=a, b=b))
 		outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=ny, symmetric=sym, p=p, stat=stat))
 
 	def _partners_merged(self, outs, timed):
@@ -417,7 +434,8 @@ class CoexPlan:
 		xs = self.all_x[(self.rank + 1) * R:(self.rank + 1 + K) * R]
 		pd, pss = self._timed('residualize', timed, lambda: self.be.residualize(xs, self.cov, _round_up(K * R, ROW_TILE)))
 		dot = self._timed('gram', timed, lambda: self.be.gram(self._blk, pd, False, R, K * R))
-		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, self._ss, pss, R, K * R, self.n, self.dof, False, self.out_dtype, self.flags))
+		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, self._ss, pss, R, K * R, self.n, self.dof, False, self.out_dtype, self.flags,
+																				a=self._blk, b=pd))
 		for j in range(K):
 			outs.append(dict(bi=self.rank, bj=(self.rank + 1 + j) % W, row_lo=0, nx=R, ny=R, symmetric=False,
 							 p=p[:, j * R:(j + 1) * R], stat=stat[:, j * R:(j + 1) * R]))
@@ -467,7 +485,7 @@ class CoexPlan:
 		def finish(e, ops, dot):
 			bi, bj, lo, hi, sym = e
 			a, ssa, b, ssb, nx = ops
-			p, stat, self.flags = self._timed('sweep', timed, lambda: be.sweep(dot, ssa, ssb, nx, self.rows, self.n, self.dof, sym, self.out_dtype, self.flags))
+			p, stat, self.flags = self._timed('sweep', timed, lambda: be.sweep(dot, ssa, ssb, nx, self.rows, self.n, self.dof, sym, self.out_dtype, self.flags, a=a, b=b))
 			outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=self.rows, symmetric=sym, p=p, stat=stat))
 		own = [e for e in self.sched if e[0] == self.rank and e[1] == self.rank]
 		rest = [e for e in self.sched if not (e[0] == self.rank and e[1] == self.rank)]
@@ -501,7 +519,7 @@ class CoexPlan:
 		if merged:
 			for j, e in enumerate(full):
 				ssb = self._g_once[-1][e[1]]
-				finish(e, (blk, ss, None, ssb, self.rows), mdot[:, j * self.rows_pad:(j + 1) * self.rows_pad])
+				finish(e, (blk, ss, self.block(e[1])[0], ssb, self.rows), mdot[:, j * self.rows_pad:(j + 1) * self.rows_pad])
 		for (e, ops), dot in zip(todo, dots):
 			finish(e, ops, dot)
 		self.outputs = outs
@@ -646,9 +664,7 @@ class CoexPlan:
 			return
 		f = self.flags
 		if self.world > 1:
-			import torch.distributed as dist
-			f = f.clone() if dist.get_backend(self.group) == 'nccl' else f.cpu()
-			dist.all_reduce(f, group=self.group)
+			f = _reduce_flags(f, self.group)
 		self.be.eng.check_flags(f)
 
 	def binnet_rows(self, p_rows, qcut):
@@ -747,8 +763,15 @@ class DePlan:
 
 	def results(self):
 		"""(p, gamma, varx, vary) of the last step as numpy arrays, after the reference's assertions (association.py:248,252)."""
+		from .engine import GuardHit
 		r = self.result
-		self.eng.check_flags(r['flags'])
+		try:
+			self.eng.check_flags(r['flags'])
+		except GuardHit as g:  # the integer engine could not certify every P-value: this step again, eagerly, on the fp64 Gram kernel
+			with self.eng.forced_f64():
+				r = self._run()
+				self.eng.check_flags(r['flags'])
+			self.eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
 		return (self.eng.download(r['p']), self.eng.download(r['stat']), self.eng.variances(r['ssx'], self.nx, self.n, self.out_dtype),
 				self.eng.variances(r['ssy'], self.ny, self.n, self.out_dtype))
 
@@ -775,6 +798,25 @@ def _world(group):
 	return dist.get_rank(group), dist.get_world_size(group), (group if group is not None else dist.group.WORLD)
 
 
+def _certified_coex_step(x, dc, rank, world, group, dimreduce):
+	"""One sharded coex pass whose P-values are certified: the reference's assertions and the integer engine's accuracy guard are
+	ONE decision of all ranks (the device counters are reduced over the group), and a pass the guard cannot certify is redone by
+	every rank on the fp64 Gram kernel."""
+	from .engine import GuardHit
+	plan = CoexPlan(x, dc, rank=rank, world=world, group=group, dimreduce=dimreduce)
+	plan.step()
+	try:
+		plan._flags_ok_everywhere()
+	except GuardHit as g:
+		eng = plan.be.eng
+		with eng.forced_f64():
+			plan = CoexPlan(x, dc, rank=rank, world=world, group=group, dimreduce=dimreduce)
+			plan.step()
+			plan._flags_ok_everywhere()
+		eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
+	return plan
+
+
 def coex(dt_local, dc, group=None, dimreduce=0, out_dir=None):
 	"""Sharded norm.coex for one-process-per-GPU programs: every rank passes ITS block of gene rows (same row count on
 	every rank; numpy or a torch tensor on its GPU) and the replicated covariates.  Rank 0 gets (p, dot, var) as numpy
@@ -788,9 +830,7 @@ def coex(dt_local, dc, group=None, dimreduce=0, out_dir=None):
 	import torch
 	rank, world, group = _world(group)
 	dev = torch.device('cuda', torch.cuda.current_device())
-	plan = CoexPlan(_local_rows(dt_local, dev), dc, rank=rank, world=world, group=group, dimreduce=dimreduce)
-	plan.step()
-	plan._flags_ok_everywhere()
+	plan = _certified_coex_step(_local_rows(dt_local, dev), dc, rank, world, group, dimreduce)
 	return plan.assemble(out_dir=out_dir)
 
 
@@ -802,9 +842,7 @@ def coex_binnet(dt_local, dc, qcut, group=None, dimreduce=0, out_dir=None):
 	import torch
 	rank, world, group = _world(group)
 	dev = torch.device('cuda', torch.cuda.current_device())
-	plan = CoexPlan(_local_rows(dt_local, dev), dc, rank=rank, world=world, group=group, dimreduce=dimreduce)
-	plan.step()
-	plan._flags_ok_everywhere()
+	plan = _certified_coex_step(_local_rows(dt_local, dev), dc, rank, world, group, dimreduce)
 	P, _ = plan.complete_rows()
 	net = plan.binnet_rows(P, qcut)
 	R, ng = plan.rows, world * plan.rows
@@ -835,9 +873,7 @@ def de(dg, dt_local, dc, group=None, dimreduce=0, out_dir=None):
 	counts = np.array([[plan.ny]])
 	if world > 1:
 		import torch.distributed as dist
-		f = flags.clone() if dist.get_backend(group) == 'nccl' else flags.cpu()
-		dist.all_reduce(f, group=group)  # one decision for all ranks (see CoexPlan._flags_ok_everywhere)
-		plan.result['flags'] = f
+		plan.result['flags'] = _reduce_flags(flags, group)  # one decision for all ranks (see CoexPlan._flags_ok_everywhere)
 		counts = _all_gather_ints([plan.ny], group, dev)
 	p, gam, vg, vt = plan.results()
 	starts = np.concatenate([[0], np.cumsum(counts[:, 0])])

@@ -14,7 +14,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import NRM_F32, NRM_F64, ROW_TILE, K_TILE
+from ._lib import NRM_F32, NRM_F64, ROW_TILE, K_TILE, FIX_STRIDE
 
 
 def _torch():
@@ -98,15 +98,26 @@ class PinnedPool:
 		return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
+class GuardHit(Exception):
+	"""The integer Gram engine's accuracy guard (csrc/nrm_fix.h) could not certify every P-value of a call: the caller redoes it on
+	the fp64 Gram kernel.  Internal: never reaches the user."""
+
+	def __init__(self, hits, worst):
+		Exception.__init__(self, '{} pairs not certified (largest error estimate {:.3g})'.format(hits, worst))
+		self.hits, self.worst = hits, worst
+
+
 class Residualized:
 	"""Residualised rows resident in HBM -- as fp64 (`data`) and / or as the fixed-point digit planes of the integer Gram
-	engine (`_quant`) -- plus their sums of squares and OLS coefficients."""
+	engine (`_quant`, with the row records `fix` K3 needs for them: csrc/nrm_fix.h) -- plus their sums of squares and OLS
+	coefficients."""
 
 	def __init__(self, rows, n, data, ss, coef, shape=None):
 		self.rows, self.n = rows, n
 		self.data, self.ss, self.coef = data, ss, coef
 		self.rows_pad, self.k_pad = data.shape if shape is None else shape
 		self.cks = None  # chunked digit planes: k-steps (32 cells) per chunk; _quant[0] is then the list of chunk operands
+		self.fix = None  # (rows_pad, FIX_STRIDE) fp64 row records written next to the digit planes
 
 
 class Engine:
@@ -120,6 +131,10 @@ class Engine:
 		self._copy = None
 		self.pool = PinnedPool(self.lib)
 		self._cmax = {}
+		self._force_f64 = False
+		# the integer engine's accuracy guard: largest relative change of a P-value it may cause (NRM_I8_GUARD_TOL, 0 = no guard)
+		self.guard_tol = float(os.environ.get('NRM_I8_GUARD_TOL', '2.5e-7'))
+		self.last_guard = dict(hits=0, worst=0.0, fallback=False)
 
 	def _stream(self):
 		return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -246,13 +261,16 @@ class Engine:
 				out = torch.empty((rp, kp), dtype=torch.float64, device=self.device) if keep_fp64 else None
 				planes = torch.empty((int(self.lib.nrm_quant_bytes(rp, kp, nslices)), ), dtype=torch.uint8, device=self.device)
 				exps = torch.empty((rp, ), dtype=torch.int32, device=self.device)
+				fix = torch.empty((rp, FIX_STRIDE), dtype=torch.float64, device=self.device)
 				_lib.check(self.lib.nrm_residualize_q(
 					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 					0 if d_dci is None else d_dci.data_ptr(), int(rank), 0 if out is None else out.data_ptr(), kp, rp, ss.data_ptr(),
-					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self.cmax_ptr(d_c), self._stream()))
+					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self.cmax_ptr(d_c), fix.data_ptr(),
+					self._stream()))
 				r = Residualized(rows, n, out, ss, coef, shape=(rp, kp))
 				r._quant = (planes, exps, nslices)
+				r.fix = fix
 				return r
 			out = torch.empty((rp, kp), dtype=torch.float64, device=self.device)
 			ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
@@ -285,14 +303,16 @@ class Engine:
 			planes = torch.empty((nchunks * cb, ), dtype=torch.uint8, device=self.device)
 			exps = torch.empty((rows_pad, ), dtype=torch.int32, device=self.device)
 			ss = torch.empty((rows_pad, ), dtype=torch.float64, device=self.device)
+			fix = torch.empty((rows_pad, FIX_STRIDE), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_residualize_q_chunked(
 				x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 				0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 				0 if d_dci is None else d_dci.data_ptr(), int(rank), rows_pad, ss.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(),
-				cks, self.cmax_ptr(d_c), self._stream()))
+				cks, self.cmax_ptr(d_c), fix.data_ptr(), self._stream()))
 		r = Residualized(rows, n, None, ss, None, shape=(rows_pad, kp))
 		r._quant = ([planes[c * cb:(c + 1) * cb] for c in range(nchunks)], exps, nslices)
 		r.cks = cks
+		r.fix = fix
 		return r
 
 	def gram_chunk(self, a, b, symmetric, chunk, dot, accumulate):
@@ -331,17 +351,31 @@ class Engine:
 		return dot
 
 	I8_MIN_CELLS = 2048
+	I8_MAX_CELLS = 1 << 22  # (K1's digit statistics are summed in 32 bits across 16 lanes)
 
-	@classmethod
-	def gram_slices(cls, n_cells):
+	def gram_slices(self, n_cells):
 		"""Digit slices of the integer Gram engine for the association path: NRM_GRAM=i8 (default, 6 slices = 46-bit fixed point),
 		i8x5 (5 slices = 38 bits, faster), f64 (the fp64 matrix-core kernel).  Below I8_MIN_CELLS cells the fp64 kernel is used
 		anyway: the problem is small, and the integer engine's error in Pearson r (its dropped low-order digit products,
-		~2e-15 at 10 000 cells) grows as 1 / sqrt(n_cells)."""
+		~2e-15 at 10 000 cells) grows as 1 / sqrt(n_cells).  0 as well while a call is being redone after the accuracy guard fired."""
 		mode = os.environ.get('NRM_GRAM', 'i8')
 		if mode not in ('i8', 'i8x5', 'f64'):
 			raise ValueError('NRM_GRAM must be i8, i8x5 or f64')
-		return {'i8': 6, 'i8x5': 5, 'f64': 0}[mode] if n_cells >= cls.I8_MIN_CELLS else 0
+		if self._force_f64:
+			return 0
+		return {'i8': 6, 'i8x5': 5, 'f64': 0}[mode] if self.I8_MIN_CELLS <= n_cells < self.I8_MAX_CELLS else 0
+
+	def fix_args(self, rx, ry):
+		"""(digit planes, row records of the x rows, of the y rows, guard tolerance) for the sweep of a dot product the integer engine
+		made from rx and ry; zeros for the fp64 Gram kernels."""
+		fx, fy = getattr(rx, 'fix', None), getattr(ry, 'fix', None)
+		if fx is None or fy is None or os.environ.get('NRM_I8_FIX', '1') == '0':  # (the switch exists for the tests that show what the records are for)
+			return 0, 0, 0, 0.0
+		return int(rx._quant[2]), fx.data_ptr(), fy.data_ptr(), float(self.guard_tol)
+
+	def new_flags(self):
+		"""int32[4] device counters of a call: non-finite, R^2 > 1 + 1e-8 (association.py:248,252), guard hits, largest guard estimate."""
+		return self.zeros((4, ), self.torch.int32)
 
 	def quantized(self, r, nslices):
 		"""Fixed-point digit planes and row exponents of residualised rows (cached on the Residualized object; written by K1
@@ -353,10 +387,12 @@ class Engine:
 			with torch.cuda.device(self.device):
 				planes = torch.empty((int(self.lib.nrm_quant_bytes(r.rows_pad, r.k_pad, nslices)), ), dtype=torch.uint8, device=self.device)
 				exps = torch.empty((r.rows_pad, ), dtype=torch.int32, device=self.device)
+				fix = torch.empty((r.rows_pad, FIX_STRIDE), dtype=torch.float64, device=self.device)
 				_lib.check(self.lib.nrm_quantize_rows(r.data.data_ptr(), r.rows_pad, r.k_pad, r.data.stride(0), nslices, planes.data_ptr(),
-													  exps.data_ptr(), self._stream()))
+													  exps.data_ptr(), fix.data_ptr(), int(r.n), self._stream()))
 			q = (planes, exps, nslices)
 			r._quant = q
+			r.fix = fix
 		return q
 
 	def row_block(self, r, lo, hi, rows=None):
@@ -371,6 +407,7 @@ class Engine:
 			first = (lo // 32) * nks * 1024
 			sub._quant = (q[0][first:] if r.cks is None else [t[first:] for t in q[0]], q[1][lo:hi], q[2], q[3] if len(q) > 3 else dense)
 			sub.cks = r.cks
+			sub.fix = None if r.fix is None else r.fix[lo:hi]
 		return sub
 
 	def gram(self, a, b, symmetric, dot=None, rows=None, nslices=0):
@@ -433,7 +470,7 @@ class Engine:
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			ssy = torch.empty((ny, ), dtype=torch.float64, device=self.device)
-			flags = self.zeros((2, ), torch.int32)
+			flags = self.new_flags()
 			esz = p.element_size()
 			for a in range(0, ny, rows):
 				b = min(ny, a + rows)
@@ -447,7 +484,7 @@ class Engine:
 				dot = self.gram(rx, ry, False, nslices=self.gram_slices(n))
 				_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), rx.ss.data_ptr(), ry.ss.data_ptr(), nx, b - a, int(n),
 													float(dof), 0, int(stat_kind), p.data_ptr() + a * esz, stat.data_ptr() + a * esz, 0, 0,
-													_code(out_dtype), ny, flags.data_ptr(), self._stream()))
+													_code(out_dtype), ny, flags.data_ptr(), *self.fix_args(rx, ry), self._stream()))
 				_lib.check(self.lib.nrm_copy_rows(ssy.data_ptr() + a * 8, 8 * (b - a), ry.ss.data_ptr(), 8 * (b - a), 8 * (b - a), 1, self._stream()))
 			self.check_flags(flags)
 			return dict(p=self.download(p), stat=self.download(stat), alpha=None, varx=self.variances(rx.ss, nx, n, out_dtype),
@@ -505,13 +542,13 @@ class Engine:
 				dot = torch.empty((rx.rows_pad, ry.rows_pad), dtype=torch.float64, device=self.device)
 				p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 				stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
-				flags = self.zeros((2, ), torch.int32)
+				flags = self.new_flags()
 				done = []
 				for a, b in zip(cuts[:-1], cuts[1:]):
 					self.gram(rx, ry, samexy, dot=dot, rows=(a, rx.rows_pad if b == nx else b), nslices=self.gram_slices(n))
 					_lib.check(self.lib.nrm_assoc_sweep_band(dot.data_ptr(), dot.stride(0), rx.ss.data_ptr(), ry.ss.data_ptr(), nx, ny, int(n),
 															 float(dof), 1 if samexy else 0, int(stat_kind), p.data_ptr(), stat.data_ptr(), 0, 0,
-															 _code(out_dtype), max(ny, 1), flags.data_ptr(), a, b, self._stream()))
+															 _code(out_dtype), max(ny, 1), flags.data_ptr(), a, b, *self.fix_args(rx, ry), self._stream()))
 					ev = torch.cuda.Event()
 					ev.record(main)
 					done.append(ev)
@@ -570,11 +607,13 @@ class Engine:
 			planes = torch.empty((plane * ns, ), dtype=torch.uint8, device=self.device)
 			exps = torch.empty((mp, ), dtype=torch.int32, device=self.device)
 			ss = torch.empty((mp, ), dtype=torch.float64, device=self.device)
+			fixt = torch.empty((mp, FIX_STRIDE), dtype=torch.float64, device=self.device)
 			p = torch.empty((ng, ng), dtype=tdt, device=self.device)
 			stat = torch.empty((ng, ng), dtype=tdt, device=self.device)
-			flags = self.zeros((2, ), torch.int32)
+			flags = self.new_flags()
 			whole = Residualized(ng, n, None, ss, None, shape=(mp, kp))
 			whole._quant = (planes, exps, ns)
+			whole.fix = fixt
 			host = None
 			pending = []
 			row = ng * esz
@@ -615,17 +654,18 @@ class Engine:
 					_lib.check(self.lib.nrm_residualize_q(
 						xc.data_ptr(), NRM_F64 if xc.dtype == torch.float64 else NRM_F32, b - a, n, xc.stride(0),
 						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
-						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c), self._stream()))
+						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
+						fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
 					blk = self.row_block(whole, a, a + rpc, rows=b - a)
 					dot = self.gram(blk, blk, True, nslices=ns)
 					_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), blk.ss.data_ptr(), blk.ss.data_ptr(), b - a, b - a, int(n), float(dof), 1, 0,
 														p.data_ptr() + (a * ng + a) * esz, stat.data_ptr() + (a * ng + a) * esz, 0, 0, code, ng, flags.data_ptr(),
-														self._stream()))
+														*self.fix_args(blk, blk), self._stream()))
 					if a > 0:
 						prev = self.row_block(whole, 0, a, rows=a)
 						dot2 = self.gram(blk, prev, False, nslices=ns)
 						_lib.check(self.lib.nrm_assoc_sweep_mirror(dot2.data_ptr(), dot2.stride(0), blk.ss.data_ptr(), ss.data_ptr(), b - a, a, int(n), float(dof),
-																   p.data_ptr(), stat.data_ptr(), code, ng, a, 0, flags.data_ptr(), self._stream()))
+																   p.data_ptr(), stat.data_ptr(), code, ng, a, 0, flags.data_ptr(), *self.fix_args(blk, prev), self._stream()))
 					done = torch.cuda.Event()
 					done.record(main)
 					pending.append((ci, a, b, done))
@@ -647,8 +687,9 @@ class Engine:
 				print('coex pipeline trace (ms): ' + ', '.join('%s %.2f' % (w, (t - t0) * 1e3) for w, t in trace))
 			return res
 
-	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None):
-		"""K3: p, stat (covariance or gamma) and optionally Pearson r and t for every pair."""
+	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None, fix=None):
+		"""K3: p, stat (covariance or gamma) and optionally Pearson r and t for every pair.  fix = fix_args(rx, ry) when dot came
+		from the integer engine."""
 		torch = self.torch
 		tdt = torch.float64 if np.dtype(out_dtype) == np.float64 else torch.float32
 		with torch.cuda.device(self.device):
@@ -657,12 +698,12 @@ class Engine:
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
 			t = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
 			if flags is None:
-				flags = self.zeros((2, ), torch.int32)
+				flags = self.new_flags()
 			_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), ssx.data_ptr(), ssy.data_ptr(), nx, ny,
 												int(n_cells), float(dof), 1 if symmetric else 0, int(stat_kind),
 												p.data_ptr(), stat.data_ptr(), 0 if r is None else r.data_ptr(),
 												0 if t is None else t.data_ptr(), _code(out_dtype), max(ny, 1),
-												flags.data_ptr(), self._stream()))
+												flags.data_ptr(), *(fix if fix is not None else (0, 0, 0, 0.0)), self._stream()))
 		return p, stat, r, t, flags
 
 	def alpha(self, stat, stat_kind, ssx, n_cells, bx, by, nc):
@@ -677,12 +718,19 @@ class Engine:
 										  bx.data_ptr(), by.data_ptr(), nx, ny, nc, out.data_ptr(), code, self._stream()))
 		return out
 
-	@staticmethod
-	def check_flags(flags):
+	def check_flags(self, flags):
+		"""The reference's assertions (association.py:248,252) on a call's device counters, then the verdict of the integer engine's
+		accuracy guard: pairs it could not certify raise GuardHit, which association_single0 (and the sharded drivers) answer by
+		redoing the call on the fp64 Gram kernel."""
 		f = flags.cpu().numpy()
 		if f[0] or f[1]:
 			raise AssertionError('association results failed the reference assertions (association.py:248,252): '
 								 '{} tiles with non-finite values, {} tiles with R^2 > 1+1e-8'.format(int(f[0]), int(f[1])))
+		if f.shape[0] >= 4:
+			worst = float(f[3:4].view(np.float32)[0])
+			self.last_guard = dict(hits=int(f[2]), worst=worst, fallback=False)
+			if f[2] > 0:
+				raise GuardHit(int(f[2]), worst)
 
 	def variances(self, ss, count, n_cells, out_dtype):
 		"""ss/n with the variance 0 -> 1 substitution (association.py:230-233)."""
@@ -798,7 +846,7 @@ class Engine:
 			t = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
 			ssy = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
 			by = self.zeros((ny, nc), torch.float64) if (want_alpha and nc) else None
-			flags = self.zeros((2, ), torch.int32)
+			flags = self.new_flags()
 			stat_kind = 0 if return_dot else 1
 			_lib.check(self.lib.nrm_de_small_sweep(g.data_ptr(), ssraw.data_ptr(), 0 if d_dciz is None else d_dciz.data_ptr(), nc, int(rank),
 												   rx.ss.data_ptr(), nx, ny, n, float(dof), stat_kind, p.data_ptr(), stat.data_ptr(),
@@ -827,7 +875,33 @@ class Engine:
 	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
 							device_out=False, resident=False):
 		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric).
-		cov: optional (d_c, d_dci) already on the device (repeated calls with the same covariates)."""
+		cov: optional (d_c, d_dci) already on the device (repeated calls with the same covariates).
+		A call whose P-values the integer engine's guard cannot certify (GuardHit) is redone on the fp64 Gram kernel; resident calls
+		leave that to whoever reads the flags (DePlan.results)."""
+		try:
+			return self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident)
+		except GuardHit as g:
+			import logging
+			logging.info('normalisr_amd: integer Gram engine: %s; redoing the call on the fp64 matrix cores.', g)
+			with self.forced_f64():
+				res = self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident)
+			self.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
+			return res
+
+	def forced_f64(self):
+		"""Context: every Gram product of this engine goes to the fp64 kernel (the redo after a GuardHit)."""
+		import contextlib
+
+		@contextlib.contextmanager
+		def ctx():
+			prev, self._force_f64 = self._force_f64, True
+			try:
+				yield
+			finally:
+				self._force_f64 = prev
+		return ctx()
+
+	def _association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident):
 		samexy = dy is None
 		if self.de_streaming_ok(dx, dy, dc):
 			return self.association_de_streaming(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov,
@@ -855,8 +929,8 @@ class Engine:
 			p, stat = self.association_banded(rx, ry, samexy, nx, ny, n, dof, stat_kind, out_dtype, host)
 			return dict(p=p, stat=stat, alpha=None, varx=None if samexy else self.variances(rx.ss, nx, n, out_dtype),
 						vary=self.variances(ry.ss, ny, n, out_dtype), dof=dof)
-		dot = self.gram(rx, ry, samexy, nslices=self.gram_slices(n))
-		p, stat, r, t, flags = self.sweep(dot, rx.ss, ry.ss, nx, ny, n, dof, samexy, stat_kind, out_dtype, want_rt)
+		dot = self.gram(rx, ry, samexy, nslices=ns)
+		p, stat, r, t, flags = self.sweep(dot, rx.ss, ry.ss, nx, ny, n, dof, samexy, stat_kind, out_dtype, want_rt, fix=self.fix_args(rx, ry))
 		alpha = None
 		if want_alpha:
 			if nc > 0 and not samexy:

@@ -7,7 +7,7 @@ Run in the dev container only (the reference lives at /root/reference and never 
 
 Each fixture is data only: seeded synthetic inputs plus the outputs the reference
 (normalisr v1.0.0, numpy/scipy versions recorded in meta.json) produced for them.
-Fixture names follow SURVEY.md section 8(c): G1..G7.
+Fixture names follow SURVEY.md section 8(c): G1..G7; G8..G11 were added with the components they pin.
 """
 import gzip
 import io
@@ -333,7 +333,56 @@ def g10():
 	return sklearn.__version__
 
 
+def g11_inputs(seed=11, n=4096):
+	"""Rows that are hard for a fixed-point Gram engine (the build's integer engine takes problems from 2048 cells on; the
+	reference is fp64 throughout, association.py:224-235): few distinct values per row -- log1p(Poisson) counts from very sparse
+	to dense, 0/1 rows from 0.2 % to 30 % dense --, rows whose mean dwarfs their spread, and a heavy-tailed row."""
+	rng = np.random.default_rng(seed)
+	lam = np.r_[np.geomspace(0.01, 5, 28)]
+	lat = rng.normal(size=n)
+	counts = rng.poisson(lam[:, None] * np.exp(0.4 * lat - 0.08)[None, :])
+	dens = np.geomspace(0.002, 0.3, 8)
+	binary = (rng.random((8, n)) < dens[:, None]).astype(np.float64)
+	binary[1] = np.maximum(binary[0], binary[1])  # two overlapping sparse rows: a true positive among them
+	offset = 1e4 + rng.normal(size=(6, n)) + 0.2 * lat
+	heavy = rng.standard_t(2.5, size=(2, n))
+	spike = rng.normal(size=(2, n)) * 1e-3
+	spike[0, 17] = 50.
+	spike[1, 999] = -20.
+	dt = np.vstack([np.log1p(counts.astype(np.float64)), binary, offset, heavy, spike])
+	batch = rng.integers(0, 4, n)
+	onehot = (batch[None, :] == np.arange(4)[:, None]).astype(np.float64)
+	z = rng.normal(size=n)
+	cov = dict(
+		intercept=np.ones((1, n)),
+		onehot=np.vstack([onehot, np.ones((1, n))]),  # one-hot batches plus an intercept: rank 4 of 5
+		collinear=np.vstack([z, z + 1e-2 * rng.normal(size=n), np.ones(n)]),  # cond(C C^T) ~ 4e4
+		none=np.zeros((0, n)),
+	)
+	dg = np.vstack([(rng.random((2, n)) < 0.03).astype(np.float64), (batch == 0).astype(np.float64)[None, :]])
+	return dt, cov, dg
+
+
+def g11():
+	"""Reference outputs for g11_inputs at 4096 cells: coex under every covariate set, de for three groupings."""
+	dt, cov, dg = g11_inputs()
+	out = dict(dt=dt, dg=dg)
+	for name, dc in cov.items():
+		out['dc_' + name] = dc
+		p, d, v = norm.coex(dt, dc)
+		out.update({'coex_%s_p' % name: p, 'coex_%s_dot' % name: d, 'coex_%s_var' % name: v})
+		if name == 'onehot':
+			continue  # (batch == 0) is in the span of these covariates: nothing to test
+		pd_, g, a, vg, vt = norm.de(dg, dt, dc)
+		out.update({'de_%s_p' % name: pd_, 'de_%s_gamma' % name: g, 'de_%s_varg' % name: vg, 'de_%s_vart' % name: vt})
+	save('G11_i8hard', **out)
+
+
 def main():
+	if len(sys.argv) > 1:  # selected fixtures only, e.g. `make_golden.py g11`
+		for name in sys.argv[1:]:
+			globals()[name]()
+		return
 	g1()
 	g2()
 	worst = g3()
@@ -344,6 +393,7 @@ def main():
 	g8()
 	g9()
 	skl = g10()
+	g11()
 	meta = dict(sklearn=skl, reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:

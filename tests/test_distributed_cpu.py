@@ -53,7 +53,7 @@ class OracleBackend(TensorBlocks):
 	def gram(self, a, b, symmetric, rows_a=None, rows_b=None):
 		return self.torch.from_numpy(a.numpy() @ b.numpy().T)
 
-	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None):
+	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, out_dtype, flags=None, a=None, b=None):
 		d = dot.numpy()[:nx, :ny]
 		sx, sy = ssx.numpy()[:nx].copy(), ssy.numpy()[:ny].copy()
 		sx[sx == 0] = n_cells
