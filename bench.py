@@ -164,9 +164,19 @@ class Ranks:
 		self.device = torch.device('cuda', local_rank)
 		self.group = None
 		self.ranks_seen = 1
-		if self.world > 1:
+		self.forced = os.environ.get('NRM_FORCE_EXCHANGE', '') if self.world == 1 else ''
+		if self.forced:  # the N > 1 exchange code on one rank: an RCCL group of one (see CoexPlan, NRM_FORCE_EXCHANGE)
+			import socket
+			s = socket.socket()
+			s.bind(('127.0.0.1', 0))
+			os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+			os.environ.setdefault('MASTER_PORT', str(s.getsockname()[1]))
+			s.close()
+		if self.world > 1 or self.forced:
 			import torch.distributed as dist
-			if self.backend == 'nccl':
+			if self.forced:
+				dist.init_process_group('nccl', rank=0, world_size=1, device_id=self.device)
+			elif self.backend == 'nccl':
 				dist.init_process_group('nccl', device_id=self.device)
 			else:
 				dist.init_process_group(self.backend)
@@ -188,7 +198,7 @@ class Ranks:
 		return float(t.item())
 
 	def close(self):
-		if self.world > 1:
+		if self.world > 1 or self.forced:
 			self.torch.distributed.destroy_process_group()
 
 
@@ -215,7 +225,7 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 	# N > 1: the exchange runs on RCCL's stream; timing events recorded on the launch stream were measured to slow
 	# cross-stream work of the same process on ROCm 7.2 (see the end_to_end_pcie note), so the timed region runs without
 	# them and the per-kernel breakdown comes from three extra steps after it (`kernels_ms_from`).
-	events_inside = world == 1
+	events_inside = world == 1 and not plan.multi
 	elapsed = timed_steps(rk, plan, steps, warmup, events_inside)
 	if not events_inside:
 		for _ in range(3):
@@ -228,7 +238,7 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 	out = dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
 			   scaling='weak', dtype=ARITH(n),
 			   config=dict(workload=label.format(genes=ng, cells=n), genes=ng, cells=n, covariates=3, tests_per_step=tests,
-						   parallelism='gene-row blocks x{}'.format(world), exchange=None if world == 1 else (
+						   parallelism='gene-row blocks x{}'.format(world), exchange=None if not plan.multi else (
 							   'all-gather of raw fp32 blocks' if plan.exchange_raw else
 							   'fixed-point digit planes in {} cell chunks, one all-gather each, block pairs accumulated as the chunks land'.format(plan.chunks)
 							   if plan.chunks else 'all-gather of residual blocks as fixed-point digit planes + exponents + sums of squares'),
@@ -373,7 +383,9 @@ def main():
 					 warmup=head.pop('warmup'), ms_per_step=head.pop('ms_per_step'), higher_is_better=True, scaling=head.pop('scaling'),
 					 vs_baseline=None, dtype=head.pop('dtype'), data='synthetic'), **head)
 	head['ranks_seen_by_collective'] = rk.ranks_seen
-	head['dist_backend'] = None if world == 1 else ('rccl (torch nccl backend)' if rk.backend == 'nccl' else rk.backend)
+	head['dist_backend'] = None if (world == 1 and not rk.forced) else ('rccl (torch nccl backend)' if (rk.backend == 'nccl' or rk.forced) else rk.backend)
+	if rk.forced:
+		head['forced_exchange'] = 'NRM_FORCE_EXCHANGE={}: the N > 1 exchange path on one rank (RCCL group of one; the own block pair is contracted from the gather buffers)'.format(rk.forced)
 	head['cpu_baseline'] = cpu
 	head['end_to_end_pcie'] = e2e
 

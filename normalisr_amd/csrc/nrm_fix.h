@@ -75,23 +75,25 @@ __device__ __forceinline__ double nrm_fix_corr(const double* __restrict__ ux, co
 	return acc * inv_n;
 }
 
-// The guard of one pair whose P-value p came from Pearson r (R^2 = r2): 1 when the bound on the engine's error could move p by
-// more than the budget.  |d ln p / d r| <= (sqrt(dof) + dof |r|) / (1 - R^2)^2: the hazard rate of the normal limit, which the t
-// distribution's stays under.  A P-value that is 0 on the whole interval |r| +- bound is exempt.  `worst` collects the largest
-// certified-or-not error estimate of the pairs that are not exempt (diagnostics: how close a call came to the budget).
+// The guard of one pair whose P-value p came from R^2 = r2: 1 when the bound on the engine's error could move p by more than the
+// budget.  |d ln p / d r| <= (sqrt(dof) + dof |r|) / (1 - R^2)^2: the hazard rate of the normal limit (<= 1 + t, which the t
+// distribution's stays under) times dt/dr = sqrt(dof) (1 - R^2)^-3/2.  A P-value that is 0 on the whole interval |r| +- bound is
+// exempt.  `worst` collects the largest error estimate of the pairs that are not exempt (diagnostics: how close a call came to the
+// budget).  K3 is bound by the fp64 vector ALU: the decision is two products on either side of one comparison -- |r| comes from a
+// single-precision square root rounded up, the diagnostic quotient is taken in single precision.
 template <typename Plan, typename PFn>
-__device__ __forceinline__ int nrm_fix_guard(const FixArgs& f, double cx, double gx, const FixCol& y, double rr, double r2, double p, const Plan& pl,
-											 PFn pvalue, float& worst) {
+__device__ __forceinline__ int nrm_fix_guard(const FixArgs& f, double cx, double gx, const FixCol& y, double r2, double p, double sqrt_dof,
+											 const Plan& pl, PFn pvalue, float& worst) {
 	const double dr = fma(f.kconst * cx, y.c, gx + y.g);
-	const double ar = fabs(rr);
-	const double om = fmax(1.0 - r2, 1e-150);  // t = r sqrt(dof / (1 - R^2)): dt/dr = sqrt(dof) (1 - R^2)^-3/2, hazard(t) <= 1 + t
-	const double err = dr * (sqrt(f.dof) + f.dof * ar) / (om * om);
+	const double ar = (double)(sqrtf((float)r2) * 1.0000002f);  // >= |r| (r2 below the float range: |r| < 1e-19 counts as 0)
+	const double om = fmax(1.0 - r2, 1e-150);
+	const double num = dr * fma(f.dof, ar, sqrt_dof), den = om * om;
 	int bad = 0;
-	if (err > f.budget) {
+	if (num > f.budget * den) {
 		const double lo = fmax(ar - dr, 0.0);
 		if (p != 0.0 || pvalue(lo * lo, pl) != 0.0) bad = 1;
 	}
-	if (p != 0.0 || bad) worst = fmaxf(worst, (float)err);
+	if (p != 0.0 || bad) worst = fmaxf(worst, __fdividef((float)num, (float)den));
 	return bad;
 }
 

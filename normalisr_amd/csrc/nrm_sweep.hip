@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 	__syncthreads();
 	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
 	float worst = 0.f;
+	const double sqrt_dof = sqrt(fix.dof);
 	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, ny);
 	for (int r = ty; r < SW_T; r += 4) {
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 			rr = d / sqrt(vx * vy);
 			double rc = fmin(r2, 1.0);
 			tt = copysign(sqrt(dof * rc / (1.0 - rc)), d);
-			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, rr, r2, p, pl, PV_FN, worst);
+			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, pl, PV_FN, worst);
 		}
 		const int64_t o = gi * ldo + gj;
 		store_out<OutT>(p_out, o, p);
@@ -255,6 +256,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 	__syncthreads();
 	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
 	float worst = 0.f;
+	const double sqrt_dof = sqrt(fix.dof);
 	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, ng);
 	double pv[SW_T / 4], sv[SW_T / 4];
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
 			if (fix.fx && fix.budget > 0.0 && (bi != bj || r < tx))  // (a diagonal block holds each of its pairs twice)
-				bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, d * rsqrt(vx * vy), r2, p, pl, PV_FN, worst);
+				bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, pl, PV_FN, worst);
 		}
 		pv[i] = p;
 		sv[i] = st;
@@ -339,6 +341,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 	__syncthreads();
 	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
 	float worst = 0.f;
+	const double sqrt_dof = sqrt(fix.dof);
 	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, my);
 	double pv[SW_T / 4], sv[SW_T / 4];
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
-			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, d * rsqrt(vx * vy), r2, p, pl, PV_FN, worst);
+			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, pl, PV_FN, worst);
 			p_out[(r0 + gi) * ldo + c0 + gj] = (OutT)p;
 			stat_out[(r0 + gi) * ldo + c0 + gj] = (OutT)st;
 		}

@@ -99,22 +99,34 @@ class SharedArrays:
 	directory of the caller's choice, i.e. the per-run result files.  Only the directory name travels between ranks."""
 
 	def __init__(self, specs, rank, world, group, base=None, keep=False):
+		import shutil
 		import tempfile
 		self.rank, self.world, self.group, self.keep = rank, world, group, keep
-		path = [None]
+		path = [None, None]  # (directory, error): every rank learns of a failure on rank 0 instead of waiting in the collective
 		if rank == 0:
-			if keep:
-				os.makedirs(base, exist_ok=True)
-				path[0] = base
-			else:
-				base = base or ('/dev/shm' if os.path.isdir('/dev/shm') else None)
-				path[0] = tempfile.mkdtemp(prefix='nrm_shared_', dir=base)
-			for name, (shape, dtype) in specs.items():
-				m = np.lib.format.open_memmap(os.path.join(path[0], name + '.npy'), mode='w+', dtype=np.dtype(dtype), shape=tuple(shape))
-				del m
+			try:
+				need = sum(int(np.prod(shape)) * np.dtype(dtype).itemsize + 4096 for shape, dtype in specs.values())
+				if keep:
+					os.makedirs(base, exist_ok=True)
+					path[0] = base
+				else:
+					# tmpfs reserves nothing at creation: a /dev/shm smaller than the results (64 MB by default in a container) would
+					# kill the ranks with SIGBUS on their first write -- fall back to the default temporary directory
+					base = base or ('/dev/shm' if os.path.isdir('/dev/shm') and shutil.disk_usage('/dev/shm').free > need + (64 << 20) else None)
+					path[0] = tempfile.mkdtemp(prefix='nrm_shared_', dir=base)
+				free = shutil.disk_usage(path[0]).free
+				if free < need:
+					raise OSError('result arrays need {} bytes, {} has {} free'.format(need, path[0], free))
+				for name, (shape, dtype) in specs.items():
+					m = np.lib.format.open_memmap(os.path.join(path[0], name + '.npy'), mode='w+', dtype=np.dtype(dtype), shape=tuple(shape))
+					del m
+			except Exception as e:
+				path = [None, '{}: {}'.format(type(e).__name__, e)]
 		if world > 1:
 			import torch.distributed as dist
 			dist.broadcast_object_list(path, src=0, group=group)  # a directory name, not data
+		if path[1] is not None:
+			raise RuntimeError('SharedArrays: rank 0 could not create the result arrays ({})'.format(path[1]))
 		self.dir = path[0]
 		self.arrays = {name: np.lib.format.open_memmap(os.path.join(self.dir, name + '.npy'), mode='r+') for name in specs}
 
@@ -339,27 +351,44 @@ class CoexPlan:
 		mode = os.environ.get('NRM_EXCHANGE', 'auto')
 		if mode not in ('auto', 'chunks', 'blocks', 'raw'):
 			raise ValueError('NRM_EXCHANGE must be auto, chunks, blocks or raw')
+		# NRM_FORCE_EXCHANGE = chunks | blocks | raw: take the N > 1 code path of that exchange form on ONE rank -- the collectives run
+		# (a group of one: RCCL on the one GPU of a development box), and the rank's own block pair is contracted from the GATHER
+		# BUFFERS after the waits instead of from the local block, so what the collective delivered is what is computed on
+		forced = os.environ.get('NRM_FORCE_EXCHANGE', '')
+		if forced and forced not in ('chunks', 'blocks', 'raw'):
+			raise ValueError('NRM_FORCE_EXCHANGE must be chunks, blocks or raw')
+		self.forced = bool(forced) and world == 1 and group is not None and backend is None
+		if self.forced:
+			mode = forced
+		multi = world > 1 or self.forced
+		self.multi = multi
 		self.chunks = 0
 		# auto: with 2 or 3 ranks a GPU talks over one or two of its seven xGMI links and the step is bound by the bytes on the
 		# wire, not by how well they hide -- fp32 rows then travel raw (4 bytes per value against 6 as digit planes)
 		few_links = mode == 'auto' and world <= 3 and backend is None and 'float32' in str(dt_local.dtype)
-		if world > 1 and mode in ('auto', 'chunks') and not few_links and hasattr(self.be, 'gram_chunk') and self.be.chunkable(dt_local, self.cov):
+		if multi and mode in ('auto', 'chunks') and not few_links and hasattr(self.be, 'gram_chunk') and self.be.chunkable(dt_local, self.cov):
 			# chunk launches of fewer than ~128 k-steps (4096 cells) cost more than they hide (tools/time_chunks.py: a 1792 x 1792
 			# block pair over 10 000 cells takes 1.04x in 2 chunks, 1.33x in 4, 2.0x in 8; at 100 000 cells 4 chunks are free)
 			min_ks = int(os.environ.get('NRM_EXCHANGE_MIN_KSTEPS', '128'))
 			self.chunks = max(1, min(int(os.environ.get('NRM_EXCHANGE_CHUNKS', '8')), ((self.k_pad + 31) // 32) // max(1, min_ks)))
-		elif world > 1 and mode == 'chunks':
+		elif multi and mode == 'chunks':
 			raise ValueError('NRM_EXCHANGE=chunks needs the integer Gram engine and 16-byte aligned rows')
-		self.exchange_raw = world > 1 and backend is None and not self.chunks and mode != 'blocks' and 'float32' in str(dt_local.dtype)
-		if world > 1 and backend is None:
+		self.exchange_raw = multi and backend is None and not self.chunks and mode != 'blocks' and 'float32' in str(dt_local.dtype)
+		if multi and backend is None:
 			# every rank must own the same number of rows of the same dtype: a mismatch would hang the all-gather or
 			# mis-slice the gathered rows, and ranks with different dtypes (or exchange modes) would issue different collectives
 			code = {'torch.float32': 0, 'torch.float64': 1}.get(str(dt_local.dtype), 2)
-			shapes = _all_gather_ints([self.rows, self.n, code, self.chunks], group, dt_local.device)
-			if not (shapes == shapes[0]).all():
-				raise ValueError('Sharded coex needs the same (rows, cells, dtype, exchange) on every rank; got {}'.format(shapes.tolist()))
+			shapes = _all_gather_ints([self.rows, self.n, code, self.chunks, int(self.exchange_raw)], group, dt_local.device)
+			if not (shapes[:, :3] == shapes[0, :3]).all():
+				raise ValueError('Sharded coex needs the same (rows, cells, dtype) on every rank; got {}'.format(shapes[:, :3].tolist()))
+			if not (shapes[:, 3:] == shapes[0, 3:]).all():
+				# the ranks' local views differ in alignment (one can write cell chunks, another cannot): agree on the one form every
+				# rank can produce -- whole blocks -- instead of issuing different collectives
+				if mode == 'chunks':
+					raise ValueError('NRM_EXCHANGE=chunks needs 16-byte aligned rows on every rank')
+				self.chunks, self.exchange_raw = 0, False
 		self._gathered = None
-		if world > 1 and self.exchange_raw:
+		if multi and self.exchange_raw:
 			# blocks 0..world-1 as gathered, then copies of the first blocks so that the partners rank+1..rank+K of any
 			# rank are one contiguous run of rows (one K1, one K2 and one K3 launch for all of them)
 			self.n_partners = (world - 1) // 2
@@ -397,7 +426,7 @@ class CoexPlan:
 		return []
 
 	def block(self, b):
-		if self.world == 1 or b == self.rank:
+		if not self.multi or (b == self.rank and not self.forced):
 			return self._blk, self._ss  # own block: local buffers (valid before the exchange has landed)
 		if b not in self._partner:
 			if self.chunks:  # views of the gather buffers: the chunks land one after another
@@ -489,6 +518,8 @@ class CoexPlan:
 			outs.append(dict(bi=bi, bj=bj, row_lo=lo, nx=nx, ny=self.rows, symmetric=sym, p=p, stat=stat))
 		own = [e for e in self.sched if e[0] == self.rank and e[1] == self.rank]
 		rest = [e for e in self.sched if not (e[0] == self.rank and e[1] == self.rank)]
+		if self.forced:  # (one rank standing in for many: its own pair is taken from the gather buffers like a partner's)
+			own, rest = [], own + rest
 		for e in own:  # local data only: runs while the chunks travel
 			ops = self._operands(*e[:4])
 			dot = None
@@ -530,19 +561,19 @@ class CoexPlan:
 			self._timed_steps += 1
 		self._pending = []
 		self._partner = {}
-		if self.world > 1 and self.chunks:
+		if self.multi and self.chunks:
 			return self._step_chunked(timed)
-		if self.world > 1 and self.exchange_raw:
+		if self.multi and self.exchange_raw:
 			self._pending = self._exchange(None, None)  # raw rows travel: nothing to wait for, start before K1
 		blk, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
 		self._blk, self._ss = blk, ss
-		if self.world > 1 and not self.exchange_raw:
+		if self.multi and not self.exchange_raw:
 			self._pending = self._exchange(blk, ss)
 		outs = []
 		merged = self.exchange_raw and self.n_partners >= 1 and os.environ.get('NRM_MERGE_PARTNERS', '1') != '0'
 		merged_done = False
 		for bi, bj, lo, hi, sym in self.sched:
-			if self._pending and not (bi == self.rank and bj == self.rank):
+			if self._pending and (self.forced or not (bi == self.rank and bj == self.rank)):
 				def wait():
 					for w in self._pending:
 						w.wait()
@@ -743,12 +774,13 @@ class DePlan:
 		self.result = None
 		self._ev = []
 		self._graph = StepGraph(self.eng.torch)
+		self._state = {}  # buffers of the streaming path that a captured graph points into: owned by the plan (see association_de_streaming)
 
 	def _run(self):
 		# resident step: p / gamma / sums of squares stay in HBM; results() brings them to the host and checks the flags
 		return self.eng.association_single0(self.dx, self.dy, self.dc64, self.dci, self.dcr, self.dimreduce,
 											return_dot=self.return_dot, want_alpha=False, out_dtype=self.out_dtype, cov=self.cov,
-											resident=True)
+											resident=True, state=self._state)
 
 	def step(self, timed=False):
 		torch = self.eng.torch

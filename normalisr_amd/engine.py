@@ -56,14 +56,15 @@ class PinnedPool:
 	pages faulted in and registered before a device-to-host copy can run at the PCIe rate (4-9 ms: longer than the whole C2
 	computation); a block handed back when its array is garbage-collected is reused by the next call of the same size at no cost.
 	The pool is bounded (NRM_PINNED_POOL_MB, default 2048; 0 disables it): beyond the bound results fall back to ordinary numpy
-	memory that is page-locked in place for the duration of the call."""
+	memory that is page-locked in place for the duration of the call.  Arrays handed to the caller keep their block page-locked
+	for as long as the caller holds them (up to the bound in total)."""
 
 	def __init__(self, lib):
 		self.lib = lib
 		self.limit = int(float(os.environ.get('NRM_PINNED_POOL_MB', '2048')) * (1 << 20))
 		self.free = {}   # capacity -> [pointers]
 		self.total = 0   # bytes allocated (handed out or free)
-		self.lock = threading.Lock()
+		self.lock = threading.RLock()  # re-entrant: _give runs from weakref.finalize, possibly inside a GC pass triggered under the lock
 
 	def _give(self, ptr, cap):
 		with self.lock:
@@ -756,7 +757,7 @@ class Engine:
 			buf = self.zeros((rows, n16), t.dtype)
 			self.copy_rows(buf, t.to(self.device))
 			return buf[:, :n]
-		if n16 == n and a.stride(1) == 1 and a.stride(0) % 4 == 0:
+		if n16 == n and a.stride(1) == 1 and (a.stride(0) * a.element_size()) % 16 == 0 and a.data_ptr() % 16 == 0:
 			return a
 		buf = self.zeros((rows, n16), a.dtype)
 		self.copy_rows(buf, a if a.stride(1) == 1 else a.contiguous())
@@ -773,8 +774,13 @@ class Engine:
 		return ok
 
 	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
-								 resident=False):
-		"""de with nx + nc <= 32: stream the raw expression rows once (HBM-bound), see csrc/nrm_gram_skinny.hip."""
+								 resident=False, state=None):
+		"""de with nx + nc <= 32: stream the raw expression rows once (HBM-bound), see csrc/nrm_gram_skinny.hip.
+		state: a dict owned by the caller that keeps the buffers worth keeping between calls on the same covariates (the permuted
+		covariates, the Z buffer).  A DePlan passes its own, so that the pointers its captured HIP graph holds live exactly as long
+		as the plan, whatever else runs on this engine in between; one-shot calls keep nothing."""
+		if state is None:
+			state = {}
 		torch = self.torch
 		nx, n = dx.shape
 		ny, nc = dy.shape[0], dc.shape[0]
@@ -791,12 +797,11 @@ class Engine:
 			perm = None
 			if ci >= 0:
 				perm = [c for c in range(nc) if c != ci] + [ci]
-				pc = getattr(self, '_cperm', None)
-				if pc is None or pc[0]() is not d_c:  # (kept with the covariates: no upload inside a step that is replayed as a graph)
-					import weakref
-					pc = (weakref.ref(d_c), d_c[perm].contiguous(),
+				pc = state.get('cperm')
+				if pc is None or pc[0] is not d_c:  # (kept with the covariates: no upload inside a step that is replayed as a graph)
+					pc = (d_c, d_c[perm].contiguous(),
 						  self.upload(np.ascontiguousarray(np.asarray(dci, dtype=np.float64).reshape(nc, nc)[np.ix_(perm, perm)])))
-					self._cperm = pc
+					state['cperm'] = pc
 				d_cz, d_dciz = pc[1], pc[2]
 			else:
 				d_cz, d_dciz = d_c, d_dci
@@ -805,8 +810,8 @@ class Engine:
 			k32 = _round_up(n, 128)
 			# Z = [C; X~; 0], stacked on the device through the C ABI.  The covariate rows do not change between calls on the same
 			# covariates (a DePlan's steps): the buffer is kept and only the rows past the covariates are rewritten.
-			zc = getattr(self, '_zcache', None)
-			if zc is not None and zc[0]() is d_c and d_c is not None and zc[1].shape[1] == k32 and zc[2] == ci:
+			zc = state.get('z')
+			if zc is not None and zc[0] is d_c and d_c is not None and zc[1].shape[1] == k32 and zc[2] == ci:
 				z = zc[1]
 				_lib.check(self.lib.nrm_fill_zero(z[ncz:].data_ptr(), (32 - ncz) * k32 * 8, self._stream()))
 			else:
@@ -814,8 +819,7 @@ class Engine:
 				if ncz:
 					self.copy_rows(z, d_cz[:ncz])
 				if nc:
-					import weakref
-					self._zcache = (weakref.ref(d_c), z, ci)
+					state['z'] = (d_c, z, ci)
 			xd = self._rows_padded16(as_input(dx) if isinstance(dx, np.ndarray) else dx)
 			xcode = NRM_F64 if xd.dtype == torch.float64 else NRM_F32
 			gx = torch.empty((256, 32), dtype=torch.float64, device=self.device)
@@ -873,18 +877,18 @@ class Engine:
 		return res
 
 	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
-							device_out=False, resident=False):
+							device_out=False, resident=False, state=None):
 		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric).
 		cov: optional (d_c, d_dci) already on the device (repeated calls with the same covariates).
 		A call whose P-values the integer engine's guard cannot certify (GuardHit) is redone on the fp64 Gram kernel; resident calls
 		leave that to whoever reads the flags (DePlan.results)."""
 		try:
-			return self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident)
+			return self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident, state)
 		except GuardHit as g:
 			import logging
 			logging.info('normalisr_amd: integer Gram engine: %s; redoing the call on the fp64 matrix cores.', g)
 			with self.forced_f64():
-				res = self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident)
+				res = self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident, state)
 			self.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
 			return res
 
@@ -901,11 +905,11 @@ class Engine:
 				self._force_f64 = prev
 		return ctx()
 
-	def _association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident):
+	def _association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident, state=None):
 		samexy = dy is None
 		if self.de_streaming_ok(dx, dy, dc):
 			return self.association_de_streaming(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov,
-												 resident=resident and not (want_alpha or want_rt))
+												 resident=resident and not (want_alpha or want_rt), state=state)
 		nx, n = dx.shape
 		ny = nx if samexy else dy.shape[0]
 		nc = dc.shape[0]

@@ -395,7 +395,7 @@ def test_integer_gram_is_exact_for_its_fixed_point_operands(eng):
 			d_m = torch.from_numpy(m).cuda()
 			q = torch.empty(int(lib.nrm_quant_bytes(m.shape[0], kp, ns)), dtype=torch.uint8, device='cuda')
 			ex = torch.empty(m.shape[0], dtype=torch.int32, device='cuda')
-			_lib.check(lib.nrm_quantize_rows(d_m.data_ptr(), m.shape[0], kp, kp, ns, q.data_ptr(), ex.data_ptr(), st))
+			_lib.check(lib.nrm_quantize_rows(d_m.data_ptr(), m.shape[0], kp, kp, ns, q.data_ptr(), ex.data_ptr(), 0, 0, st))
 			quant.append((q, ex))
 		work = torch.empty(int(lib.nrm_gram_workspace_bytes()) // 8, dtype=torch.float64, device='cuda')
 		dot = torch.full((mp, np_), float('nan'), dtype=torch.float64, device='cuda')
@@ -450,7 +450,7 @@ def test_integer_gram_whole_tiles_are_correctly_rounded(eng):
 		d_x = torch.from_numpy(x).cuda()
 		q = torch.empty(int(lib.nrm_quant_bytes(m, n, ns)), dtype=torch.uint8, device='cuda')
 		ex = torch.empty(m, dtype=torch.int32, device='cuda')
-		_lib.check(lib.nrm_quantize_rows(d_x.data_ptr(), m, n, n, ns, q.data_ptr(), ex.data_ptr(), st))
+		_lib.check(lib.nrm_quantize_rows(d_x.data_ptr(), m, n, n, ns, q.data_ptr(), ex.data_ptr(), 0, 0, st))
 		quant.append((q, ex))
 	work = torch.empty(int(lib.nrm_gram_workspace_bytes()) // 8, dtype=torch.float64, device='cuda')
 	dot = torch.empty((m, m), dtype=torch.float64, device='cuda')

@@ -24,7 +24,7 @@ for ns in ([int(sys.argv[4])] if len(sys.argv) > 4 else [6, 5]):
 	q = torch.empty(int(lib.nrm_quant_bytes(mp, kp, ns)), dtype=torch.uint8, device='cuda')
 	ex = torch.empty(mp, dtype=torch.int32, device='cuda')
 	def quant():
-		_lib.check(lib.nrm_quantize_rows(a.data_ptr(), mp, kp, kp, ns, q.data_ptr(), ex.data_ptr(), st))
+		_lib.check(lib.nrm_quantize_rows(a.data_ptr(), mp, kp, kp, ns, q.data_ptr(), ex.data_ptr(), 0, 0, st))
 	def run():
 		_lib.check(lib.nrm_gram_i8_band(q.data_ptr(), ex.data_ptr(), 0, q.data_ptr(), ex.data_ptr(), 0, mp, mp, kp, ns, dot.data_ptr(), mp, 1, ng, ng, 0, mp, work.data_ptr(), st))
 	dot.fill_(float('nan'))
