@@ -27,6 +27,7 @@ def build_parser():
 	p.add_argument('--clfc_out', dest='clfc_out', action='store', help='Output covariate log fold changes, (predictors, genes*covariates) row-major, TSV.')
 	p.add_argument('--vard_out', dest='vard_out', action='store', help='Output variance of each predictor unexplained by covariates, TSV.')
 	p.add_argument('--vart_out', dest='vart_out', action='store', help='Output variance of expression unexplained by covariates (predictors x genes), TSV.')
+	p.add_argument('--gpus', dest='gpus', action='store', type=int, default=1, help='GPUs of this node to shard the problem over (one process per GPU, RCCL); every rank reads only its gene rows of exp_in. Default: 1.')
 
 	p = sub.add_parser('coex', help='Co-expression analysis.')
 	p.add_argument('exp_in', help='Normalized expression matrix (genes x cells), TSV.')
@@ -38,6 +39,7 @@ def build_parser():
 	p.add_argument('--var_out', dest='var_out', action='store', help='Output variance of each gene unexplained by covariates, TSV.')
 	p.add_argument('--dot_out', dest='dot_out', action='store',
 				   help='Output covariance of gene pairs after covariate removal (inner product / cell count), TSV. Pearson R = dot/sqrt(var_i var_j).')
+	p.add_argument('--gpus', dest='gpus', action='store', type=int, default=1, help='GPUs of this node to shard the problem over (one process per GPU, RCCL); every rank reads only its gene rows of exp_in. Default: 1.')
 	p = sub.add_parser('normvar', help='Normalize variances of gene expressions and covariates.')
 	p.add_argument('lcpm_in', help='Input Bayesian logCPM matrix (genes x cells), TSV.')
 	p.add_argument('weights_in', help='Input vector of the fitted weight of each cell, TSV.')
@@ -67,6 +69,11 @@ def main(argv=None):
 	if args['cmd'] is None:
 		p0.print_help(sys.stderr)
 		return 1
+	if args.get('gpus', 1) < 1:
+		raise ValueError('--gpus must be positive')
+	if args.get('gpus', 1) > 1:  # one process per GPU, started before anything in this process touches a GPU
+		from . import launch
+		return launch.run_sharded(args['cmd'], args)
 	from . import run
 	getattr(run, args['cmd'])(args)
 	return 0

@@ -81,20 +81,33 @@ __device__ __forceinline__ double nrm_fix_corr(const double* __restrict__ ux, co
 // exempt.  `worst` collects the largest error estimate of the pairs that are not exempt (diagnostics: how close a call came to the
 // budget).  K3 is bound by the fp64 vector ALU: the decision is two products on either side of one comparison -- |r| comes from a
 // single-precision square root rounded up, the diagnostic quotient is taken in single precision.
-template <typename Plan, typename PFn>
-__device__ __forceinline__ int nrm_fix_guard(const FixArgs& f, double cx, double gx, const FixCol& y, double r2, double p, double sqrt_dof,
-											 const Plan& pl, PFn pvalue, float& worst) {
+struct FixAcc {
+	int bad;         // pairs over the budget whose P-value is not 0
+	float worst;     // largest error estimate among the pairs with a non-zero P-value
+	double lo2_min;  // pairs over the budget with P = 0: the smallest (|r| - bound)^2 among them -- P is monotone in R^2, so if P is still
+					 // 0 there, every one of them is exempt (one more P-value evaluation per thread, after its pairs: nrm_fix_close)
+};
+__device__ __forceinline__ FixAcc nrm_fix_acc() { return FixAcc{0, 0.f, INFINITY}; }
+
+__device__ __forceinline__ void nrm_fix_guard(const FixArgs& f, double cx, double gx, const FixCol& y, double r2, double p, double sqrt_dof, FixAcc& a) {
 	const double dr = fma(f.kconst * cx, y.c, gx + y.g);
 	const double ar = (double)(sqrtf((float)r2) * 1.0000002f);  // >= |r| (r2 below the float range: |r| < 1e-19 counts as 0)
 	const double om = fmax(1.0 - r2, 1e-150);
 	const double num = dr * fma(f.dof, ar, sqrt_dof), den = om * om;
-	int bad = 0;
 	if (num > f.budget * den) {
-		const double lo = fmax(ar - dr, 0.0);
-		if (p != 0.0 || pvalue(lo * lo, pl) != 0.0) bad = 1;
+		if (p != 0.0)
+			a.bad++;
+		else {
+			const double lo = fmax(ar - dr, 0.0);
+			a.lo2_min = fmin(a.lo2_min, lo * lo);
+		}
 	}
-	if (p != 0.0 || bad) worst = fmaxf(worst, __fdividef((float)num, (float)den));
-	return bad;
+	if (p != 0.0) a.worst = fmaxf(a.worst, __fdividef((float)num, (float)den));
+}
+
+template <typename Plan, typename PFn>
+__device__ __forceinline__ void nrm_fix_close(FixAcc& a, const Plan& pl, PFn pvalue) {
+	if (a.lo2_min < INFINITY && pvalue(a.lo2_min, pl) != 0.0) a.bad++;
 }
 
 // ---- K1 side: digit statistics of a row -> its record ---------------------------------------------------------------------------

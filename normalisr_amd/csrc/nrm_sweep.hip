@@ -125,8 +125,11 @@ __device__ __forceinline__ FixCol fix_column(const FixArgs& f, int64_t col, int6
 	if (f.fx && col < ncols) y = nrm_fix_col(f.fy + col * NRM_FIX_STRIDE);
 	return y;
 }
-__device__ __forceinline__ void fix_finish(const FixArgs& f, int32_t* __restrict__ flags, int bad, float worst) {
+__device__ __forceinline__ void fix_finish(const FixArgs& f, int32_t* __restrict__ flags, FixAcc& a, const PvalPlan& pl) {
 	if (!f.fx || !flags) return;
+	nrm_fix_close(a, pl, PV_FN);
+	int bad = a.bad;
+	float worst = a.worst;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
 		bad += __shfl_xor(bad, o, 64);
@@ -141,7 +144,7 @@ __device__ __forceinline__ void fix_finish(const FixArgs& f, int32_t* __restrict
 // One workgroup = one 64x64 tile of the (nx, ny) output.  The source tile of dot is staged through LDS
 // so that the mirrored half of a symmetric (coex) problem is read coalesced and transposed on chip.
 template <typename OutT>
-__global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ dot, int64_t ldd,
+__global__ void __launch_bounds__(256, 3) k_assoc_sweep(const double* __restrict__ dot, int64_t ldd,
 													  const double* __restrict__ ssx, const double* __restrict__ ssy,
 													  int64_t nx, int64_t ny, double ncells, double dof, int symmetric,
 													  int stat_kind, PvalPlan pl, void* __restrict__ p_out,
@@ -150,8 +153,14 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 	__shared__ double tile[SW_T][SW_T + 1];
 	__shared__ double sx[SW_T], sy[SW_T];
 	__shared__ double sfx[SW_T][SW_FIX];
+	__shared__ double sfc[SW_T][SW_FIX];  // symmetric problems: the records of the column genes as well (see `swap` below)
 	const int bi = blockIdx.y + bi0, bj = blockIdx.x;
 	fix_stage_rows(fix, sfx, (int64_t)bi * SW_T, nx);
+	if (symmetric && bi >= bj) {
+		FixArgs fc = fix;
+		fc.fx = fix.fx ? fix.fy : nullptr;
+		fix_stage_rows(fc, sfc, (int64_t)bj * SW_T, ny);
+	}
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
 	// source tile: for coex always from the upper triangle (association.py:1050-1057)
 	const bool mirror = symmetric && bi > bj;
@@ -172,8 +181,8 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 		sy[t] = (v == 0.0) ? ncells : v;  // association.py:233
 	}
 	__syncthreads();
-	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
-	float worst = 0.f;
+	int bad_nf = 0, bad_rng = 0;
+	FixAcc facc = nrm_fix_acc();
 	const double sqrt_dof = sqrt(fix.dof);
 	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, ny);
@@ -189,7 +198,13 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 			d = (r <= tx) ? tile[r][tx] : tile[tx][r];
 		else
 			d = tile[r][tx];
-		if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+		if (fix.fx) {
+			// The correction is symmetric in the pair but not in its rounding: an element below the diagonal of a symmetric problem
+			// takes it with the roles of its two genes swapped, i.e. exactly as its mirror image above the diagonal does, so that
+			// the results stay bitwise symmetric (association.py:1050-1057 copies the upper triangle)
+			const bool swap = symmetric && (mirror || (bi == bj && r > tx));
+			d += swap ? nrm_fix_corr(sfc[tx], nrm_fix_col(sfx[r]), fix.top, fix.inv_n) : nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+		}
 		const double vx = sx[r], vy = sy[tx];
 		double r2 = (d * d) / (vx * vy);  // = gamma^2 vx / vy  (association.py:235)
 		double p, stat, rr, tt;
@@ -206,7 +221,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 			rr = d / sqrt(vx * vy);
 			double rc = fmin(r2, 1.0);
 			tt = copysign(sqrt(dof * rc / (1.0 - rc)), d);
-			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, pl, PV_FN, worst);
+			if (fix.fx && fix.budget > 0.0) nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, facc);
 		}
 		const int64_t o = gi * ldo + gj;
 		store_out<OutT>(p_out, o, p);
@@ -218,13 +233,13 @@ __global__ void __launch_bounds__(256) k_assoc_sweep(const double* __restrict__ 
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
 	}
-	fix_finish(fix, flags, bad_fix, worst);
+	fix_finish(fix, flags, facc, pl);
 }
 
 // Symmetric (coex) sweep over the upper triangle of 64x64 tiles only: every p-value is computed once and
 // written twice (direct and mirrored through an LDS transpose), halving the special-function work.
 template <typename OutT>
-__global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ss,
+__global__ void __launch_bounds__(256, 3) k_assoc_sweep_sym(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ss,
 														  int64_t ng, int nb, double ncells, PvalPlan pl, OutT* __restrict__ p_out,
 														  OutT* __restrict__ stat_out, int64_t ldo, int32_t* __restrict__ flags, int bi0, FixArgs fix) {
 	__shared__ double tile[SW_T][SW_T + 1];
@@ -254,37 +269,37 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 		sy[t] = (v == 0.0) ? ncells : v;
 	}
 	__syncthreads();
-	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
-	float worst = 0.f;
+	int bad_nf = 0, bad_rng = 0;
+	FixAcc facc = nrm_fix_acc();
 	const double sqrt_dof = sqrt(fix.dof);
 	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, ng);
-	double pv[SW_T / 4], sv[SW_T / 4];
+	OutT pv[SW_T / 4], sv[SW_T / 4];  // (in the output type: half the registers for fp32 results)
 #pragma unroll
 	for (int i = 0; i < SW_T / 4; i++) {
 		const int r = ty + 4 * i;
 		const int64_t gi = (int64_t)bi * SW_T + r;
-		double d = (bi == bj && r > tx) ? tile[tx][r] : tile[r][tx];
+		const bool lower = bi == bj && r > tx;  // below the diagonal of a diagonal tile: filled in from its mirror image afterwards
+		double d = tile[r][tx];
 		if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 		const double vx = sx[r], vy = sy[tx];
 		const double r2 = (d * d) / (vx * vy);
 		double p = 0.0, st = 0.0;
-		if (gi < ng && gj < ng && gi != gj) {
+		if (gi < ng && gj < ng && gi != gj && !lower) {
 			if (!isfinite(r2) || !isfinite(vx) || !isfinite(vy)) bad_nf = 1;
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
-			if (fix.fx && fix.budget > 0.0 && (bi != bj || r < tx))  // (a diagonal block holds each of its pairs twice)
-				bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, pl, PV_FN, worst);
+			if (fix.fx && fix.budget > 0.0) nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, facc);
 		}
-		pv[i] = p;
-		sv[i] = st;
-		if (gi < ng && gj < ng) {
+		pv[i] = (OutT)p;
+		sv[i] = (OutT)st;
+		if (gi < ng && gj < ng && !lower) {
 			p_out[gi * ldo + gj] = (OutT)p;
 			stat_out[gi * ldo + gj] = (OutT)st;
 		}
 	}
-	if (bi != bj) {
+	{
 		const int64_t oj = (int64_t)bi * SW_T + tx;  // mirrored block: rows of block bj, columns of block bi
 		__syncthreads();
 #pragma unroll
@@ -294,7 +309,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 		for (int i = 0; i < SW_T / 4; i++) {
 			const int r = ty + 4 * i;
 			const int64_t oi = (int64_t)bj * SW_T + r;
-			if (oi < ng && oj < ng) p_out[oi * ldo + oj] = (OutT)tile[tx][r];
+			if (oi < ng && oj < ng && (bi != bj || r > tx)) p_out[oi * ldo + oj] = (OutT)tile[tx][r];
 		}
 		__syncthreads();
 #pragma unroll
@@ -304,21 +319,21 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_sym(const double* __restric
 		for (int i = 0; i < SW_T / 4; i++) {
 			const int r = ty + 4 * i;
 			const int64_t oi = (int64_t)bj * SW_T + r;
-			if (oi < ng && oj < ng) stat_out[oi * ldo + oj] = (OutT)tile[tx][r];
+			if (oi < ng && oj < ng && (bi != bj || r > tx)) stat_out[oi * ldo + oj] = (OutT)tile[tx][r];
 		}
 	}
 	if (flags) {
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
 	}
-	fix_finish(fix, flags, bad_fix, worst);
+	fix_finish(fix, flags, facc, pl);
 }
 
 // Off-diagonal rectangle of a symmetric (coex) problem: rows [r0, r0 + mx) against columns [c0, c0 + my) with c0 + my <= r0.
 // Every p-value is computed once and written twice -- at (r0 + i, c0 + j) and, through an LDS transpose, at (c0 + j, r0 + i) --
 // so that a pipelined coex (rows arriving chunk by chunk) can finish and ship both halves of a chunk's pairs at once.
 template <typename OutT>
-__global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ssx,
+__global__ void __launch_bounds__(256, 3) k_assoc_sweep_mirror(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ssx,
 															 const double* __restrict__ ssy, int64_t mx, int64_t my, double ncells, PvalPlan pl,
 															 OutT* __restrict__ p_out, OutT* __restrict__ stat_out, int64_t ldo, int64_t r0,
 															 int64_t c0, int32_t* __restrict__ flags, FixArgs fix) {
@@ -339,12 +354,12 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 		sy[t] = (v == 0.0) ? ncells : v;
 	}
 	__syncthreads();
-	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
-	float worst = 0.f;
+	int bad_nf = 0, bad_rng = 0;
+	FixAcc facc = nrm_fix_acc();
 	const double sqrt_dof = sqrt(fix.dof);
 	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, my);
-	double pv[SW_T / 4], sv[SW_T / 4];
+	OutT pv[SW_T / 4], sv[SW_T / 4];  // (in the output type: half the registers for fp32 results)
 #pragma unroll
 	for (int i = 0; i < SW_T / 4; i++) {
 		const int r = ty + 4 * i;
@@ -359,12 +374,12 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
-			if (fix.fx && fix.budget > 0.0) bad_fix += nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, pl, PV_FN, worst);
+			if (fix.fx && fix.budget > 0.0) nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, facc);
 			p_out[(r0 + gi) * ldo + c0 + gj] = (OutT)p;
 			stat_out[(r0 + gi) * ldo + c0 + gj] = (OutT)st;
 		}
-		pv[i] = p;
-		sv[i] = st;
+		pv[i] = (OutT)p;
+		sv[i] = (OutT)st;
 	}
 	const int64_t oj = (int64_t)bi * SW_T + tx;  // mirrored: rows c0 + (block bj), columns r0 + (block bi)
 #pragma unroll
@@ -390,7 +405,7 @@ __global__ void __launch_bounds__(256) k_assoc_sweep_mirror(const double* __rest
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
 	}
-	fix_finish(fix, flags, bad_fix, worst);
+	fix_finish(fix, flags, facc, pl);
 }
 
 // Sweep for the streaming de path (nrm_gram_skinny): one thread per gene.  G[y] = [y C^T (nc) | y X~^T (nx) | 0...],

@@ -688,6 +688,71 @@ class Engine:
 				print('coex pipeline trace (ms): ' + ', '.join('%s %.2f' % (w, (t - t0) * 1e3) for w, t in trace))
 			return res
 
+	def coex_blocks_resident(self, block_fn, n_genes, n, dc, dci, rank, dimreduce, out_dtype, block_rows=3840, timings=None):
+		"""coex of a matrix that is too large to sit in HBM next to its own digit planes (BASELINE configs[4]: 30 000 genes x 500 000
+		cells fp64 = 120 GB in, 90 GB of planes) on ONE GPU: the gene rows arrive block by block -- block_fn(lo, hi) returns rows
+		[lo, hi) as a device tensor, which is dropped as soon as K1 has residualised and quantised it into the resident planes -- then
+		K2 and K3 run band by band over the whole symmetric problem (the reference walks the same pair space tile by tile,
+		association.py:890-909).  Results stay in HBM: dict(p, stat = covariance, ss, flags).  block_rows: a multiple of 128."""
+		torch = self.torch
+		ns = self.gram_slices(n)
+		assert ns, 'coex_blocks_resident runs on the integer engine (2048 <= cells < 2^22)'
+		assert block_rows % ROW_TILE == 0
+		dof = n - 1 - rank - dimreduce
+		odt = np.dtype(out_dtype)
+		tdt = torch.float64 if odt == np.float64 else torch.float32
+		mp, kp = _round_up(n_genes, ROW_TILE), _round_up(n, K_TILE)
+		nks = (kp + 31) // 32
+		plane = (mp // 32) * nks * 1024
+		with torch.cuda.device(self.device):
+			ev = lambda: torch.cuda.Event(enable_timing=True)
+			marks = []
+
+			def mark(name):
+				if timings is not None:
+					e = ev()
+					e.record()
+					marks.append((name, e))
+			d_c, d_dci = self.covariates(dc, dci)
+			nc = 0 if d_c is None else d_c.shape[0]
+			planes = torch.empty((plane * ns, ), dtype=torch.uint8, device=self.device)
+			exps = torch.empty((mp, ), dtype=torch.int32, device=self.device)
+			ss = torch.empty((mp, ), dtype=torch.float64, device=self.device)
+			fixt = torch.empty((mp, FIX_STRIDE), dtype=torch.float64, device=self.device)
+			whole = Residualized(n_genes, n, None, ss, None, shape=(mp, kp))
+			whole._quant = (planes, exps, ns)
+			whole.fix = fixt
+			mark('start')
+			for a in range(0, n_genes, block_rows):
+				b = min(n_genes, a + block_rows)
+				x = block_fn(a, b)
+				assert tuple(x.shape) == (b - a, n) and self.k1_quantises(x, d_c)
+				rpc = _round_up(b - a, ROW_TILE)
+				_lib.check(self.lib.nrm_residualize_q(
+					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, b - a, n, x.stride(0),
+					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
+					0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
+					fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
+				torch.cuda.current_stream(self.device).synchronize()  # the block is released before the next one is made
+				del x
+			mark('residualised')
+			dot = torch.empty((mp, mp), dtype=torch.float64, device=self.device)
+			p = torch.empty((n_genes, n_genes), dtype=tdt, device=self.device)
+			stat = torch.empty((n_genes, n_genes), dtype=tdt, device=self.device)
+			flags = self.new_flags()
+			cuts = list(range(0, n_genes, self.BAND)) + [n_genes]
+			for a, b in zip(cuts[:-1], cuts[1:]):
+				self.gram(whole, whole, True, dot=dot, rows=(a, mp if b == n_genes else b), nslices=ns)
+				_lib.check(self.lib.nrm_assoc_sweep_band(dot.data_ptr(), dot.stride(0), ss.data_ptr(), ss.data_ptr(), n_genes, n_genes, int(n), float(dof), 1, 0,
+														 p.data_ptr(), stat.data_ptr(), 0, 0, _code(out_dtype), n_genes, flags.data_ptr(), a, b,
+														 *self.fix_args(whole, whole), self._stream()))
+			mark('swept')
+			if timings is not None:
+				torch.cuda.synchronize(self.device)
+				for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+					timings[n1] = e0.elapsed_time(e1)
+			return dict(p=p, stat=stat, ss=ss, flags=flags, dof=dof, dot=dot)
+
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None, fix=None):
 		"""K3: p, stat (covariance or gamma) and optionally Pearson r and t for every pair.  fix = fix_args(rx, ry) when dot came
 		from the integer engine."""
