@@ -3,8 +3,9 @@
 
 Headline (`value`): BASELINE.json configs[1] -- norm.coex gene x gene on 5k genes x 10k cells, fp32 input,
 3 covariates (2 random + intercept), seeded synthetic data.  A step is one full pass of
-the hot path over the matrix resident in HBM: residualise (K1) -> fp64-MFMA Gram (K2) -> per-pair sweep
-R^2 -> p, covariance (K3); outputs stay in HBM.  tests = ng(ng-1)/2 unique pairs.  For N>1 (one process per
+the hot path over the matrix resident in HBM: residualise + quantise (K1) -> Gram contraction on the int8 matrix cores, exact
+for its 46-bit fixed-point operands (K2, k_gram_i8; problems under 2048 cells: the fp64-MFMA kernel k_gram_f64) -> per-pair
+sweep R^2 -> p, covariance with the integer engine's correction and accuracy guard (K3); outputs stay in HBM.  tests = ng(ng-1)/2 unique pairs.  For N>1 (one process per
 GPU, RCCL) the gene count grows as sqrt(N) so the pairs per GPU stay fixed (weak scaling); gene-row blocks are
 residualised locally and exchanged by all-gather.
 
@@ -17,9 +18,11 @@ makes X the headline instead; `--no-extras` skips them.
 
 Launch: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when it is
 not already running under one; under `python -m torch.distributed.run ... bench.py --gpus N` it uses the
-ranks it was given.  Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gram_f64),
+ranks it was given.  Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gram_i8),
 timed live with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the
-reference's algorithm, test infrastructure) on a bounded sample on this box's host cores (N=1 only).
+reference's algorithm, test infrastructure) on a bounded sample on this box's host cores (N=1 only); the extra
+workloads carry their own, extrapolated from sampled rows.  `guard` is the verdict of the integer engine's accuracy
+guard over the timed steps (pairs it could not certify: must be 0 here).
 """
 import argparse
 import json
@@ -34,7 +37,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
 
-PMC_FILES = [os.path.join(ROOT, 'profiles', f) for f in ('r02_pmc_c2.json', 'r01_pmc_c2.json')]  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r03.sh), newest first
+PMC_FILES = {w: [os.path.join(ROOT, 'profiles', f) for f in fs] for w, fs in dict(
+	coex_c2=('r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
+	de_c4=('r03_pmc_de_c4.json', ), coex_c5=('r03_pmc_coex_c5.json', )).items()}
+
+
+def pmc_traffic(workload, roof, kernel=None):
+	"""HBM-side bytes per launch of the roofline's kernel from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)."""
+	want = kernel or roof['kernel'].split(' ')[0]
+	for f in PMC_FILES.get(workload, ()):
+		try:
+			with open(f) as fh:
+				pm = json.load(fh)
+			cands = [(k, v) for k, v in pm.items() if k.split('<')[0].split(' ')[0] == want and 'hbm_bytes_per_launch' in v]
+			if not cands:
+				continue
+			k, entry = max(cands, key=lambda kv: kv[1]['hbm_bytes_per_launch'])  # (the long dispatch class of a kernel launched on two sizes)
+			roof['traffic'] = entry['hbm_bytes_per_launch']
+			if 'effective_clock_ghz' in entry:  # the chip clocks down under int8 MFMA load: the nominal peak assumes 2.4 GHz
+				roof['effective_clock_ghz_profiled'] = round(entry['effective_clock_ghz'], 3)
+			roof['traffic_unit'] = 'bytes/launch'
+			roof['traffic_source'] = '{} [{}] (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(
+				os.path.relpath(f, ROOT), k)
+			return
+		except (OSError, KeyError, ValueError):
+			continue
 F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (= 1/2 of the 157.3 TF fp32 matrix peak of MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # the roofline BASELINE.json's north_star names
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, matrix cores): 2 x 2.5 PF
@@ -80,7 +108,7 @@ def synth_c2(ng, n, seed, device, torch, row0=0, dtype=None, loading=0.3):
 	return dt, dc
 
 
-def cpu_baseline_worker(ng, n_cells, nc, seed, min_seconds):
+def cpu_baseline_worker(ng, n_cells, nc, seed, min_seconds, extras_too=False):
 	"""Runs in a child process started with BLAS threads pinned to 1 (the reference launcher's convention,
 	bin/normalisr:3) and times the CPU oracle's tile loop with nth = all cores on the full workload."""
 	import oracle
@@ -98,20 +126,49 @@ def cpu_baseline_worker(ng, n_cells, nc, seed, min_seconds):
 		if el >= min_seconds or reps >= 50:
 			break
 	pairs = ng * (ng - 1) // 2
-	print(json.dumps(dict(value=pairs * reps / el, unit='tests/s', cores=cores, kind='port',
-						  sample='{} pass(es) of coex on {} genes x {} cells fp64 ({} pairs each) in {:.1f} s; CPU oracle tile loop '
-						  '(500x500 tiles, per-tile residualisation as association.py:224-249), thread pool nth={}, BLAS threads=1'.format(
-							  reps, ng, n_cells, pairs, el, cores))))
+	out = dict(value=pairs * reps / el, unit='tests/s', cores=cores, kind='port',
+			   sample='{} pass(es) of coex on {} genes x {} cells fp64 ({} pairs each) in {:.1f} s; CPU oracle tile loop '
+			   '(500x500 tiles, per-tile residualisation as association.py:224-249), thread pool nth={}, BLAS threads=1'.format(
+				   reps, ng, n_cells, pairs, el, cores))
+	del dt
+	extras = {}
+	if extras_too:
+		# the other BASELINE configs on SAMPLED rows (the full problems take minutes to hours on the host): rate per test of the
+		# sample, flagged as extrapolated -- the per-test cost of the reference's algorithm does not depend on how many tiles follow
+		def timed(fn, tests, what):
+			t0 = time.perf_counter()
+			fn()
+			el = time.perf_counter() - t0
+			return dict(value=tests / el, unit='tests/s', cores=cores, kind='port', extrapolated=True, sample='{} in {:.1f} s; thread pool nth={}, BLAS threads=1'.format(what, el, cores))
+		r = np.random.default_rng(3)
+		n3, g3 = 100000, min(20000, 500 * max(1, min(cores, 4)))
+		dc3 = np.vstack([r.normal(size=(19, n3)), np.ones((1, n3))])
+		dg3 = (r.random((1, n3)) < 0.5).astype(np.float64)
+		dt3 = r.normal(size=(g3, n3))
+		extras['de_c3'] = timed(lambda: oracle.de(dg3, dt3, dc3, nth=cores), g3, 'norm.de 1 x {} of the 20000 genes x {} cells, 20 covariates'.format(g3, n3))
+		del dt3, dc3
+		n4, g4 = 50000, 500 * max(1, min(cores // 2, 2))
+		dc4 = np.vstack([r.normal(size=(4, n4)), np.ones((1, n4))])
+		dg4 = (r.random((1000, n4)) < 0.01).astype(np.float64)
+		dt4 = r.normal(size=(g4, n4))
+		extras['de_c4'] = timed(lambda: oracle.de(dg4, dt4, dc4, nth=cores), 1000 * g4, 'norm.de 1000 gRNAs x {} of the 15000 genes x {} cells, 5 covariates'.format(g4, n4))
+		del dt4, dg4, dc4
+		n5, g5 = 500000, 264  # (the reference's tile size at this shape is 132)
+		dc5 = np.vstack([r.normal(size=(2, n5)), np.ones((1, n5))])
+		dt5 = r.normal(size=(g5, n5))
+		extras['coex_c5'] = timed(lambda: oracle.coex(dt5, dc5, nth=cores), g5 * (g5 - 1) // 2, 'norm.coex on {} of the 30000 genes x {} cells fp64'.format(g5, n5))
+	out['extras'] = extras
+	print(json.dumps(out))
 
 
-def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0):
+def cpu_baseline(ng, n_cells, nc, seed, min_seconds=10.0, extras=False):
 	import subprocess
 	env = dict(os.environ)
 	for k in ('OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS', 'OMP_NUM_THREADS'):
 		env[k] = '1'
 	env['HIP_VISIBLE_DEVICES'] = ''
-	r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(ng), str(n_cells), str(nc), str(seed), str(min_seconds)],
-					   env=env, stdout=subprocess.PIPE, text=True, timeout=600)
+	r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(ng), str(n_cells), str(nc), str(seed), str(min_seconds), str(int(extras))],
+					   env=env, stdout=subprocess.PIPE, text=True, timeout=900)
 	return json.loads(r.stdout.strip().splitlines()[-1])
 
 
@@ -214,6 +271,16 @@ def timed_steps(rk, plan, steps, warmup, events_inside):
 	return rk.max_over_ranks(time.perf_counter() - t0)
 
 
+def guard_verdict(flags, eng):
+	"""The integer engine's accuracy guard over every step that accumulated into `flags` (engine.new_flags): pairs whose P-value
+	it could not certify to the tolerance (a user call would have been redone on the fp64 kernel) and the largest error estimate."""
+	if flags is None or flags.shape[0] < 4:
+		return None
+	f = flags.cpu().numpy()
+	return dict(uncertified_pairs=int(f[2]), largest_relative_p_error_bound=float(f[3:4].view(np.float32)[0]), tolerance=eng.guard_tol,
+				note='rigorous bound (csrc/nrm_fix.h); 0 uncertified pairs = every P-value of the timed steps came from the integer engine')
+
+
 def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading=0.3):
 	"""Sharded coex: every rank owns `rows_local` gene rows (generated on its GPU), see normalisr_amd.distributed.CoexPlan."""
 	torch = rk.torch
@@ -244,7 +311,8 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 							   if plan.chunks else 'all-gather of residual blocks as fixed-point digit planes + exponents + sums of squares'),
 						   exchange_bytes_per_rank=None if world == 1 else int((world - 1) * rows_local * n * (esz if plan.exchange_raw else (SLICES(n) or 8)))),
 			   roofline=gram_roofline(n, flops, gram_ms, plan.rows_pad, plan.k_pad),
-			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region')
+			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region',
+			   guard=guard_verdict(plan.flags, plan.be.eng))
 	return out, plan
 
 
@@ -271,18 +339,70 @@ def bench_de(rk, nd, steps, warmup, which, covariates=20):
 	elapsed = timed_steps(rk, plan, steps, warmup, True)
 	tests = nx * ny_local * world
 	ms = plan.step_ms()
+	# per-kernel split of the step: three more steps, eager (a captured graph cannot be bracketed kernel by kernel), with the engine's
+	# event trace on
+	eng = plan.eng
+	plan._graph.enabled, plan._graph.graph = False, None
+	eng.trace = []
+	for _ in range(3):
+		plan.step()
+	torch.cuda.synchronize()
+	split = {}
+	for name, e0, e1 in eng.trace:
+		split[name] = split.get(name, 0.0) + e0.elapsed_time(e1) / 3
+	eng.trace = None
 	if plan.streaming():
 		byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
 		roof = dict(bound='hbm', kernel='k_gram_skinny + sweep (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
 					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms)
 	else:
-		roof = gram_roofline(n, 2.0 * n * nx * ny_local, ms, 0, 0)
-		roof['kernel'] += ' (whole step: K1 + quantise + K2 + K3)'
-		roof['algorithmic_bytes'] = None
+		roof = gram_roofline(n, 2.0 * n * nx * ny_local, split.get('gram', ms), 0, 0)  # K2 alone
+		roof['algorithmic_bytes'] = float(SLICES(n) or 8) * (nx + ny_local) * n
+		roof['step_ms'] = ms
 	return dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
 				scaling='strong', dtype='f64' if plan.streaming() else ARITH(n),
 				config=dict(workload='norm.de {} x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[{}])'.format(
-					nx, ny, n, nc, 2 if which == 'de_c3' else 3), parallelism='gene rows of Y x{}, no collective'.format(world)), roofline=roof)
+					nx, ny, n, nc, 2 if which == 'de_c3' else 3), parallelism='gene rows of Y x{}, no collective'.format(world)), roofline=roof,
+				kernels_ms={k: round(v, 4) for k, v in split.items()}, kernels_ms_from='3 extra eager steps after the timed region',
+				guard=guard_verdict(plan.result.get('flags'), eng))
+
+
+def bench_c5_full(rk):
+	"""BASELINE configs[4] WHOLE on one GPU: 30 000 genes x 500 000 cells fp64 (4.5e8 pairs).  The 120 GB matrix is generated and
+	dropped in blocks of 3840 gene rows; only its 90 GB of digit planes stay resident (engine.coex_blocks_resident).  value = pairs /
+	(K1 + K2 + K3 time, HIP events); generating the synthetic blocks between the K1 launches is not part of the hot path."""
+	torch = rk.torch
+	from normalisr_amd.association import _prepare_covariates
+	from normalisr_amd.engine import get_engine
+	eng = get_engine(rk.device.index)
+	ng, n = 30000, C5_CELLS
+	if torch.cuda.mem_get_info(rk.device)[1] < 200 * (1 << 30):
+		return None
+	rows = lambda lo, hi: synth_c2(hi - lo, n, 5, rk.device, torch, row0=lo, dtype=torch.float64, loading=0.05)[0]
+	dc = synth_c2(1, n, 5, rk.device, torch, dtype=torch.float64)[1].cpu().numpy()
+	dc64, dci, dcr = _prepare_covariates(dc)
+	eng.trace = []
+	rk.barrier()
+	t0 = time.perf_counter()
+	res = eng.coex_blocks_resident(rows, ng, n, dc64, dci, dcr, 0, np.float64)
+	rk.barrier()
+	wall = time.perf_counter() - t0
+	split = {}
+	for name, e0, e1 in eng.trace:
+		split[name] = split.get(name, 0.0) + e0.elapsed_time(e1)
+	eng.trace = None
+	guard = guard_verdict(res['flags'], eng)
+	del res
+	torch.cuda.empty_cache()
+	tests = ng * (ng - 1) // 2
+	ms = sum(split.values())
+	roof = gram_roofline(n, 2.0 * n * (tests + ng), split['gram'], 30080, 500000)
+	roof['note'] = 'sum of the {} band launches of k_gram_i8'.format(len([1 for t in range(0, ng, 1024)]))
+	return dict(metric='association tests/sec (gene x gene coex)', value=tests / (ms * 1e-3), unit='tests/s', steps=1, warmup=0, ms_per_step=ms,
+				scaling='single GPU', dtype=ARITH(n),
+				config=dict(workload='norm.coex gene x gene, 30000 genes x 500000 cells, fp64 input, 3 covariates (BASELINE configs[4], the WHOLE problem on one GPU)',
+							genes=ng, cells=n, tests_per_step=tests, parallelism='one GPU; input generated in blocks of 3840 rows, 90 GB of digit planes resident'),
+				roofline=roof, kernels_ms={k: round(v, 2) for k, v in split.items()}, wall_seconds_incl_generating_the_input=round(wall, 2), guard=guard)
 
 
 def main():
@@ -293,19 +413,19 @@ def main():
 	ap.add_argument('--genes', type=int, default=5000, help='genes at N=1 (scaled by sqrt(N) for N>1)')
 	ap.add_argument('--cells', type=int, default=10000)
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
-	ap.add_argument('--cpu-worker', nargs=5, default=None, help=argparse.SUPPRESS)
-	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5'],
+	ap.add_argument('--cpu-worker', nargs=6, default=None, help=argparse.SUPPRESS)
+	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu'],
 					help='headline workload: coex_c2 = BASELINE configs[1] (default); de_c3 / de_c4 / coex_c5 = configs[2] / [3] / [4] shapes')
 	ap.add_argument('--no-extras', action='store_true', help='skip the extra_workloads entries (the other BASELINE configs)')
 	ap.add_argument('--extras-steps', type=int, default=5)
-	ap.add_argument('--extras-timeout', type=float, default=240.0, help='seconds after which a stuck extra workload is abandoned and the headline line printed')
+	ap.add_argument('--extras-timeout', type=float, default=300.0, help='seconds after which a stuck extra workload is abandoned and the headline line printed')
 	ap.add_argument('--covariates', type=int, default=20, help='covariates of the de_c3 workload (<= 15 selects the half-width streaming kernel)')
 	ap.add_argument('--seed', type=int, default=2)
 	ap.add_argument('--e2e', type=int, default=2, help='repetitions of the numpy-in/numpy-out end-to-end timing (0 = skip)')
 	args = ap.parse_args()
 	if args.cpu_worker:
 		w = args.cpu_worker
-		cpu_baseline_worker(int(w[0]), int(w[1]), int(w[2]), int(w[3]), float(w[4]))
+		cpu_baseline_worker(int(w[0]), int(w[1]), int(w[2]), int(w[3]), float(w[4]), bool(int(w[5])))
 		return 0
 
 	if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -316,7 +436,7 @@ def main():
 	cpu = None
 	if world == 1 and args.cpu_seconds > 0 and args.workload == 'coex_c2':
 		# CPU baseline first, in a child process, before this process touches the GPU
-		cpu = cpu_baseline(int(round(args.genes)), args.cells, 3, args.seed, args.cpu_seconds)
+		cpu = cpu_baseline(int(round(args.genes)), args.cells, 3, args.seed, args.cpu_seconds, extras=not args.no_extras)
 
 	import torch
 	from normalisr_amd import distributed as nd
@@ -352,20 +472,7 @@ def main():
 								   'norm.coex gene x gene, {genes} genes x {cells} cells, fp32 input, 3 covariates (BASELINE configs[1]' + ('' if world == 1 else ', genes scaled by sqrt(N)') + ')')
 			out['metric'] = 'association tests/sec (gene x gene coex)'
 			if world == 1 and rows_local == 5000 and n == 10000:
-				# HBM-side bytes per k_gram_f64 launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-				for f in PMC_FILES:
-					try:
-						with open(f) as fh:
-							pm = json.load(fh)
-							entry = next(v for k, v in pm.items() if k.split('<')[0] == out['roofline']['kernel'])
-							out['roofline']['traffic'] = entry['hbm_bytes_per_launch']
-							if 'effective_clock_ghz' in entry:  # the chip clocks down under int8 MFMA load: the nominal peak assumes 2.4 GHz
-								out['roofline']['effective_clock_ghz_profiled'] = round(entry['effective_clock_ghz'], 3)
-						out['roofline']['traffic_unit'] = 'bytes/launch'
-						out['roofline']['traffic_source'] = '{} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(os.path.relpath(f, ROOT))
-						break
-					except (OSError, KeyError, ValueError, StopIteration):
-						continue
+				pmc_traffic('coex_c2', out['roofline'])
 			return out
 		if which == 'coex_c5':
 			out, plan = bench_coex(rk, nd, steps, warmup, C5_ROWS_PER_RANK, C5_CELLS, 5, torch.float64,
@@ -373,9 +480,15 @@ def main():
 								   ('; N=8 is the full 30k x 30k problem)' if world != 8 else ': the full problem)'), loading=0.05)
 			out['metric'] = 'association tests/sec (gene x gene coex)'
 			out['scaling'] = 'rows per rank fixed (block pairs per rank grow as (N+1)/2)'
+			if world == 1:
+				pmc_traffic('coex_c5', out['roofline'])
 			return out
+		if which == 'coex_c5_full_1gpu':
+			return bench_c5_full(rk)
 		out = bench_de(rk, nd, steps, warmup, which, args.covariates)
 		out['metric'] = 'association tests/sec (de)'
+		if world == 1:
+			pmc_traffic(which, out['roofline'], kernel='k_gram_skinny' if which == 'de_c3' else 'k_gram_i8')
 		return out
 
 	head = run(args.workload, args.steps, args.warmup)
@@ -386,8 +499,10 @@ def main():
 	head['dist_backend'] = None if (world == 1 and not rk.forced) else ('rccl (torch nccl backend)' if (rk.backend == 'nccl' or rk.forced) else rk.backend)
 	if rk.forced:
 		head['forced_exchange'] = 'NRM_FORCE_EXCHANGE={}: the N > 1 exchange path on one rank (RCCL group of one; the own block pair is contracted from the gather buffers)'.format(rk.forced)
+	cpu_extras = cpu.pop('extras', {}) if cpu else {}
 	head['cpu_baseline'] = cpu
 	head['end_to_end_pcie'] = e2e
+	head['frac_of_fp32_mfma_peak'] = head['roofline'].get('frac_of_fp32_mfma_peak')  # the roofline BASELINE.json's north_star names
 
 	printed = threading.Event()
 
@@ -407,12 +522,16 @@ def main():
 		dog = threading.Timer(args.extras_timeout, give_up)
 		dog.daemon = True
 		dog.start()
-		names = [w for w in ('de_c3', 'de_c4', 'coex_c5') if w != args.workload]
+		names = [w for w in ('de_c3', 'de_c4', 'coex_c5') if w != args.workload] + (['coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
 		for w in names:
 			try:
 				torch.cuda.empty_cache()
 				r = run(w, args.steps if w == 'de_c3' else args.extras_steps, 3 if w == 'de_c3' else 2)  # (the 2 ms step: enough of them to time)
+				if r is None:
+					continue
 				r['n_gpus'] = world
+				if w in cpu_extras or w.startswith('coex_c5'):
+					r['cpu_baseline'] = cpu_extras.get(w, cpu_extras.get('coex_c5'))
 				extras[w] = r
 			except Exception as e:  # reported, never fatal for the headline
 				extras[w] = dict(error='{}: {}'.format(type(e).__name__, e))

@@ -99,6 +99,27 @@ class PinnedPool:
 		return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
+class _Span:
+	"""HIP events around one kernel group on the launch stream while engine.trace is a list (bench.py's per-kernel split of steps
+	that are otherwise timed as a whole); nothing when it is None."""
+
+	def __init__(self, eng, name):
+		self.eng, self.name = eng, name
+
+	def __enter__(self):
+		if self.eng.trace is not None:
+			self.e0 = self.eng.torch.cuda.Event(enable_timing=True)
+			self.e0.record(self.eng.torch.cuda.current_stream(self.eng.device))
+		return self
+
+	def __exit__(self, *exc):
+		if self.eng.trace is not None:
+			e1 = self.eng.torch.cuda.Event(enable_timing=True)
+			e1.record(self.eng.torch.cuda.current_stream(self.eng.device))
+			self.eng.trace.append((self.name, self.e0, e1))
+		return False
+
+
 class GuardHit(Exception):
 	"""The integer Gram engine's accuracy guard (csrc/nrm_fix.h) could not certify every P-value of a call: the caller redoes it on
 	the fp64 Gram kernel.  Internal: never reaches the user."""
@@ -133,6 +154,7 @@ class Engine:
 		self.pool = PinnedPool(self.lib)
 		self._cmax = {}
 		self._force_f64 = False
+		self.trace = None  # a list collects (name, start event, end event) of K1 / K2 / K3 launches (see _Span)
 		# the integer engine's accuracy guard: largest relative change of a P-value it may cause (NRM_I8_GUARD_TOL, 0 = no guard)
 		self.guard_tol = float(os.environ.get('NRM_I8_GUARD_TOL', '2.5e-7'))
 		self.last_guard = dict(hits=0, worst=0.0, fallback=False)
@@ -246,6 +268,12 @@ class Engine:
 	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True):
 		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n).  nslices = 5 / 6: also (keep_fp64=False: only) the
 		fixed-point digit planes of the integer Gram engine, written by K1 itself."""
+		if isinstance(x, np.ndarray):
+			x = self.upload(as_input(x))
+		with _Span(self, 'residualize'):
+			return self._residualize(x, d_c, d_dci, rank, want_coef, rows_pad, nslices, keep_fp64)
+
+	def _residualize(self, x, d_c, d_dci, rank, want_coef, rows_pad, nslices, keep_fp64):
 		torch = self.torch
 		with torch.cuda.device(self.device):
 			if isinstance(x, np.ndarray):
@@ -415,6 +443,10 @@ class Engine:
 		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T.  nslices = 0: fp64 matrix cores (nrm_gram.hip); 5 / 6: the exact
 		fixed-point engine on the int8 matrix cores (nrm_gram_i8.hip), used by the association path for expression-like rows.
 		rows=(row0, row1): only that band of dot."""
+		with _Span(self, 'gram'):
+			return self._gram(a, b, symmetric, dot, rows, nslices)
+
+	def _gram(self, a, b, symmetric, dot, rows, nslices):
 		torch = self.torch
 		with torch.cuda.device(self.device):
 			if dot is None:
@@ -728,11 +760,12 @@ class Engine:
 				x = block_fn(a, b)
 				assert tuple(x.shape) == (b - a, n) and self.k1_quantises(x, d_c)
 				rpc = _round_up(b - a, ROW_TILE)
-				_lib.check(self.lib.nrm_residualize_q(
-					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, b - a, n, x.stride(0),
-					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
-					0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
-					fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
+				with _Span(self, 'residualize'):
+					_lib.check(self.lib.nrm_residualize_q(
+						x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, b - a, n, x.stride(0),
+						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
+						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
+						fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
 				torch.cuda.current_stream(self.device).synchronize()  # the block is released before the next one is made
 				del x
 			mark('residualised')
@@ -743,9 +776,10 @@ class Engine:
 			cuts = list(range(0, n_genes, self.BAND)) + [n_genes]
 			for a, b in zip(cuts[:-1], cuts[1:]):
 				self.gram(whole, whole, True, dot=dot, rows=(a, mp if b == n_genes else b), nslices=ns)
-				_lib.check(self.lib.nrm_assoc_sweep_band(dot.data_ptr(), dot.stride(0), ss.data_ptr(), ss.data_ptr(), n_genes, n_genes, int(n), float(dof), 1, 0,
-														 p.data_ptr(), stat.data_ptr(), 0, 0, _code(out_dtype), n_genes, flags.data_ptr(), a, b,
-														 *self.fix_args(whole, whole), self._stream()))
+				with _Span(self, 'sweep'):
+					_lib.check(self.lib.nrm_assoc_sweep_band(dot.data_ptr(), dot.stride(0), ss.data_ptr(), ss.data_ptr(), n_genes, n_genes, int(n), float(dof), 1, 0,
+															 p.data_ptr(), stat.data_ptr(), 0, 0, _code(out_dtype), n_genes, flags.data_ptr(), a, b,
+															 *self.fix_args(whole, whole), self._stream()))
 			mark('swept')
 			if timings is not None:
 				torch.cuda.synchronize(self.device)
@@ -758,7 +792,7 @@ class Engine:
 		from the integer engine."""
 		torch = self.torch
 		tdt = torch.float64 if np.dtype(out_dtype) == np.float64 else torch.float32
-		with torch.cuda.device(self.device):
+		with torch.cuda.device(self.device), _Span(self, 'sweep'):
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
