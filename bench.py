@@ -417,6 +417,7 @@ def main():
 	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu'],
 					help='headline workload: coex_c2 = BASELINE configs[1] (default); de_c3 / de_c4 / coex_c5 = configs[2] / [3] / [4] shapes')
 	ap.add_argument('--no-extras', action='store_true', help='skip the extra_workloads entries (the other BASELINE configs)')
+	ap.add_argument('--extras', default='', help='comma-separated subset of the extra workloads to run (default: all)')
 	ap.add_argument('--extras-steps', type=int, default=5)
 	ap.add_argument('--extras-timeout', type=float, default=300.0, help='seconds after which a stuck extra workload is abandoned and the headline line printed')
 	ap.add_argument('--covariates', type=int, default=20, help='covariates of the de_c3 workload (<= 15 selects the half-width streaming kernel)')
@@ -523,6 +524,8 @@ def main():
 		dog.daemon = True
 		dog.start()
 		names = [w for w in ('de_c3', 'de_c4', 'coex_c5') if w != args.workload] + (['coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
+		if args.extras:
+			names = [w for w in names if w in args.extras.split(',')]
 		for w in names:
 			try:
 				torch.cuda.empty_cache()

@@ -312,6 +312,10 @@ int nrm_normvar_weights(const void* d_y, int y_dtype, int64_t rows, int64_t n, i
 int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_b, const double* d_scale, void* d_out, int out_dtype,
 					  int64_t ldo, void* stream);
+/* normvar1 with explicit per-gene cell weights w2 (rows, ldw) (norm.py:150-153: row g is residualised against dc * w2[g]):
+ * out_gk = y_gk - w2_gk * sum_c b_gc C_ck, with b_g = (sum_k w2_gk^2 C_k C_k^T)^+ (sum_k w2_gk y_gk C_k) from the host. */
+int nrm_normvar_apply_w2(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_w2, int64_t ldw,
+						 const double* d_c, int64_t nc, int64_t ldc, const double* d_b, void* d_out, int out_dtype, int64_t ldo, void* stream);
 
 /*
  * Whole-problem host entry (numpy in / numpy out): the seam association_tests(dx, dy, dc, ...)

@@ -73,11 +73,20 @@ def inv_rank(m, tol=1E-8, method='auto', logger=None, mpc=0, qr=0, **ka):
 	flat = m.reshape((-1, n, n)).astype(np.float64, copy=False)
 	inv = np.empty_like(flat)
 	ranks = np.empty(flat.shape[0], dtype=int)
+	warned = False
 	for i, mat in enumerate(flat):
 		if method == 'sklearn':
 			inv[i], ranks[i] = _randomized_inverse(mat, tol, mpc, qr, ka)
 			continue
-		_, s, vh = np.linalg.svd(mat)
+		try:
+			_, s, vh = np.linalg.svd(mat)
+		except np.linalg.LinAlgError:
+			# the divide-and-conquer driver did not converge: LAPACK's gesvd, as the reference does (association.py:70-76,111-119)
+			if not warned:
+				logger.warning("Default SVD failed. Falling back to option lapack_driver='gesvd'. Expecting much slower computation.")
+				warned = True
+			from scipy.linalg import svd as _svd  # (scipy: a dependency of the reference for this very call)
+			_, s, vh = _svd(mat, lapack_driver='gesvd')
 		r = int(n - np.searchsorted(s[::-1], tol * s[0]))
 		if mpc > 0:
 			r = min(r, mpc)

@@ -11,6 +11,7 @@
 #include <thread>
 #include <vector>
 #include "nrm_common.h"
+#include "nrm_host_logic.h"
 
 static thread_local char g_err[512] = "";
 
@@ -122,58 +123,18 @@ extern "C" int nrm_copy_rows(void* d_dst, int64_t dst_pitch, const void* d_src, 
 }
 
 namespace {
-// Device scratch of the host entry, kept between calls (hipMalloc / hipFree of GB-sized buffers cost milliseconds
-// each): blocks return to a per-process pool and are reused best-fit; nrm_release_cache() frees them.
-struct DevPool {
-	struct Block {
-		void* p;
-		size_t cap;
-		bool used;
-	};
-	std::mutex mu;
-	std::vector<Block> blocks;
-	void* take(size_t bytes) {
-		std::lock_guard<std::mutex> g(mu);
-		int best = -1;
-		for (size_t i = 0; i < blocks.size(); i++)
-			if (!blocks[i].used && blocks[i].cap >= bytes && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
-		if (best >= 0 && blocks[(size_t)best].cap <= 2 * bytes + (1 << 20)) {
-			blocks[(size_t)best].used = true;
-			return blocks[(size_t)best].p;
-		}
+struct HipAlloc {
+	void* alloc(size_t bytes) {
 		void* p = nullptr;
-		if (hipMalloc(&p, bytes) != hipSuccess) {  // out of memory: drop the idle blocks and retry once
+		if (hipMalloc(&p, bytes) != hipSuccess) {
 			(void)hipGetLastError();
-			for (size_t i = 0; i < blocks.size();) {
-				if (!blocks[i].used) {
-					(void)hipFree(blocks[i].p);
-					blocks.erase(blocks.begin() + (long)i);
-				} else {
-					i++;
-				}
-			}
-			if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+			return nullptr;
 		}
-		blocks.push_back({p, bytes, true});
 		return p;
 	}
-	void give(void* p) {
-		std::lock_guard<std::mutex> g(mu);
-		for (auto& b : blocks)
-			if (b.p == p) b.used = false;
-	}
-	void release() {
-		std::lock_guard<std::mutex> g(mu);
-		for (size_t i = 0; i < blocks.size();) {
-			if (!blocks[i].used) {
-				(void)hipFree(blocks[i].p);
-				blocks.erase(blocks.begin() + (long)i);
-			} else {
-				i++;
-			}
-		}
-	}
+	void free(void* p) { (void)hipFree(p); }
 };
+typedef DevPoolT<HipAlloc> DevPool;
 DevPool g_pool;
 std::mutex g_host_entry;  // one whole-problem call at a time per process (the pool and the default stream are shared)
 

@@ -171,8 +171,8 @@ extern "C" int64_t nrm_gram_workspace_bytes(void) {
 		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cu <= 0)
 			g_num_cu = 256;
 	}
-	// at most nwg/2 aligned tiles x 2 parts (= nwg slabs for any parts) plus two stream-K slabs per workgroup
-	return (int64_t)3 * (2 * g_num_cu) * GM * GN * (int64_t)sizeof(double);
+	// (the fp64 kernel runs two workgroups per CU, the integer engine one)
+	return nrm_host_gram_workspace_doubles(2 * g_num_cu) * (int64_t)sizeof(double);
 }
 
 extern "C" int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m_pad, int64_t n_pad, int64_t k_pad, int64_t lda,

@@ -104,6 +104,51 @@ __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64
 	}
 }
 
+// normvar1 with explicit per-gene cell weights (norm.py:150-153: row g is residualised against dc * w2[g]):
+//     out_gk = y_gk - w2_gk sum_c b_gc C_ck
+template <typename T, typename OutT>
+__global__ void __launch_bounds__(256) k_nv_apply_w2(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy, const double* __restrict__ w2,
+													 int64_t ldw, const double* __restrict__ c, int nc, int64_t ldc, const double* __restrict__ b,
+													 OutT* __restrict__ out, int64_t ldo) {
+	__shared__ double s_b[NV_R][64];
+	const int tid = threadIdx.x;
+	const int64_t row0 = (int64_t)blockIdx.x * NV_R;
+	for (int i = tid; i < NV_R * nc; i += 256) {
+		const int r = i / nc, q = i % nc;
+		s_b[r][q] = row0 + r < rows ? b[(row0 + r) * nc + q] : 0.0;
+	}
+	__syncthreads();
+	for (int64_t k = tid; k < n; k += 256) {
+		double fit[NV_R];
+#pragma unroll
+		for (int r = 0; r < NV_R; r++) fit[r] = 0.0;
+		for (int q = 0; q < nc; q++) {
+			const double cv = c[(int64_t)q * ldc + k];
+#pragma unroll
+			for (int r = 0; r < NV_R; r++) fit[r] = fma(s_b[r][q], cv, fit[r]);
+		}
+#pragma unroll
+		for (int r = 0; r < NV_R; r++)
+			if (row0 + r < rows) out[(row0 + r) * ldo + k] = (OutT)((double)y[(row0 + r) * ldy + k] - w2[(row0 + r) * ldw + k] * fit[r]);
+	}
+}
+
+extern "C" int nrm_normvar_apply_w2(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_w2, int64_t ldw,
+									const double* d_c, int64_t nc, int64_t ldc, const double* d_b, void* d_out, int out_dtype, int64_t ldo, void* stream) {
+	NRM_REQUIRE((y_dtype == NRM_F32 || y_dtype == NRM_F64) && (out_dtype == NRM_F32 || out_dtype == NRM_F64), "nrm_normvar_apply_w2: bad dtype");
+	NRM_REQUIRE(rows > 0 && n > 0 && ldy >= n && ldw >= n && ldo >= n && nc > 0 && nc <= 64 && ldc >= n, "Unmatched gene or cell counts.");
+	NRM_REQUIRE(d_y && d_w2 && d_c && d_b && d_out, "nrm_normvar_apply_w2: null pointer");
+	dim3 grid((unsigned)((rows + NV_R - 1) / NV_R));
+	hipStream_t st = (hipStream_t)stream;
+#define NV_LAUNCH(TY, TO) hipLaunchKernelGGL((k_nv_apply_w2<TY, TO>), grid, dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_w2, ldw, d_c, (int)nc, ldc, d_b, (TO*)d_out, ldo)
+	if (y_dtype == NRM_F64 && out_dtype == NRM_F64) NV_LAUNCH(double, double);
+	else if (y_dtype == NRM_F64) NV_LAUNCH(double, float);
+	else if (out_dtype == NRM_F64) NV_LAUNCH(float, double);
+	else NV_LAUNCH(float, float);
+#undef NV_LAUNCH
+	return nrm_check_launch("k_nv_apply_w2");
+}
+
 extern "C" int nrm_normvar_weights(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
 								   double* d_u, double* d_v, int64_t ldo, int64_t rows_pad, double* d_s1, double* d_s2, void* stream) {
 	NRM_REQUIRE(y_dtype == NRM_F32 || y_dtype == NRM_F64, "nrm_normvar_weights: bad dtype");

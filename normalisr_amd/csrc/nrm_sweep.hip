@@ -5,70 +5,11 @@
 #include <cstring>
 #include "nrm_pvalue.h"
 #include "nrm_fix.h"
+#include "nrm_host_logic.h"
 
 // ---- host: plan -------------------------------------------------------------------------------
 
-// Taylor coefficients h_k of sqrt((s/2)/sinh(s/2)) = sum_k h_k s^(2k)
-static const double kH[] = {1.0,
-							-0.02083333333333333333333,
-							0.000390625,
-							-0.000007879670965608465608466,
-							1.696766579172178130511e-7,
-							-3.805064191721906565657e-9,
-							8.748377596315407304061e-11,
-							-2.044523359411973817584e-12,
-							4.833351797967704408319e-14,
-							-1.152434101767385923873e-15,
-							2.766052043599370042286e-17};
-
-// ln( Gamma(a+1/2)/Gamma(a) ): recurrence up to a >= 24, then the asymptotic series (DLMF 5.11.13).
-static double ln_gamma_ratio_half(double a) {
-	double shift = 0.0;
-	while (a < 24.0) {
-		shift += std::log(a / (a + 0.5));
-		a += 1.0;
-	}
-	double i = 1.0 / a, i2 = i * i;
-	double s = i * (-1.0 / 8 + i2 * (1.0 / 192 + i2 * (-1.0 / 640 + i2 * (17.0 / 14336 + i2 * (-31.0 / 18432 + i2 * (691.0 / 180224))))));
-	return 0.5 * std::log(a) + s + shift;
-}
-
-extern "C" int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof) {
-	NRM_REQUIRE(plan != nullptr, "nrm_pvalue_plan_init: null plan");
-	NRM_REQUIRE(dof > 0, "Insufficient number of cells: dof = %g must be positive", dof);
-	const int K = NRM_PCOEF / 2;  // series terms k = 0..K
-	double a = 0.5 * dof;
-	plan->a = a;
-	plan->alpha = a - 0.25;
-	plan->ln_front = ln_gamma_ratio_half(a) - 0.57236494292470008707;  // - ln(pi)/2
-	for (int j = 0; j < NRM_PCOEF; j++) plan->coef[j] = 0.0;
-	if (a < 8.0) {
-		plan->umax = 0.0;  // asymptotic series in 1/alpha not accurate enough: continued fraction only
-		return NRM_OK;
-	}
-	plan->umax = 1.5;
-	double al = plan->alpha;
-	// S = sum_k h_k alpha^-2k c'_2k,  c'_m = prod_{i<m} (i + 1/2)
-	long double S = 0;
-	for (int k = 0; k <= K; k++) {
-		long double cp = 1;
-		for (int i = 0; i < 2 * k; i++) cp *= (i + 0.5L);
-		S += (long double)kH[k] * powl(al, -2 * k) * cp;
-	}
-	// coef_j = (1/(S sqrt(pi))) sum_{k: 2k > j} h_k alpha^(j-2k) prod_{i=j+1}^{2k-1} (i + 1/2)
-	for (int j = 0; j < NRM_PCOEF; j++) {
-		long double c = 0;
-		for (int k = 1; k <= K; k++) {
-			int m = 2 * k;
-			if (j >= m) continue;
-			long double pr = 1;
-			for (int i = j + 1; i < m; i++) pr *= (i + 0.5L);
-			c += (long double)kH[k] * powl(al, j - m) * pr;
-		}
-		plan->coef[j] = (double)(c / (S * 1.7724538509055160272981674833411L));
-	}
-	return NRM_OK;
-}
+extern "C" int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof) { return nrm_pvalue_plan_init_host(plan, dof); }
 
 extern "C" int nrm_pvalue_plan_init_many(const double* dof, int64_t count, double* out, int64_t pitch) {
 	NRM_REQUIRE(count >= 0 && pitch >= (int64_t)(sizeof(nrm_pvalue_plan) / sizeof(double)), "nrm_pvalue_plan_init_many: bad sizes");

@@ -23,7 +23,7 @@ def normvar1(dt, dc, w2=None):
 	"""Remove covariates from every row of dt (norm.py:131-163).  w2 (n_gene, n_cell): row g uses dc * w2[g]."""
 	dt, dc = np.asarray(dt), np.asarray(dc)
 	if w2 is not None:
-		raise NotImplementedError('normvar1 with explicit per-gene weights: use normvar (weights of the form w**wt).')
+		return _normvar1_weighted(dt, dc, np.asarray(w2))
 	dc64 = np.asarray(dc, dtype=np.float64)
 	mi, r = inv_rank(np.matmul(dc64, dc64.T))
 	if r <= 0:
@@ -34,6 +34,58 @@ def normvar1(dt, dc, w2=None):
 	out = eng.download(res.data[:dt.shape[0], :dt.shape[1]].contiguous())
 	assert np.isfinite(out).all()
 	return out.astype(np.result_type(dt.dtype, dc.dtype, np.float32), copy=False)
+
+
+def _normvar1_weighted(dt, dc, w2, tol=1E-8):
+	"""normvar1 with w2 (norm.py:150-153): gene g against dc * w2[g].  The per-gene Gram matrices sum_k w2_gk^2 C_k C_k^T and moment
+	vectors sum_k w2_gk y_gk C_k are rows of two contractions on the fp64 matrix cores, the pseudo-inverses (integer ranks) a batched
+	SVD on the host as in normvar, the residuals one element-wise kernel (nrm_normvar_apply_w2)."""
+	nt, ns = dt.shape
+	nc = dc.shape[0]
+	if w2.shape != (nt, ns):
+		raise ValueError('w2 must have the shape of dt.')
+	if nc == 0 or nc > 63:
+		raise NotImplementedError('normvar1 on the device takes 1 to 63 covariates.')
+	out_dtype = np.dtype(np.float32) if np.result_type(dt.dtype, dc.dtype, w2.dtype, np.float32) == np.float32 else np.dtype(np.float64)
+	eng = _engine.get_engine()
+	torch = eng.torch
+	iu = np.triu_indices(nc)
+	npair = len(iu[0])
+	with torch.cuda.device(eng.device):
+		y = eng.upload(_engine.as_input(dt))
+		d_w = eng.upload(np.asarray(w2, dtype=np.float64))
+		d_c = eng.upload(np.asarray(dc, dtype=np.float64))
+		rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
+		u = torch.zeros((rp, kp), dtype=torch.float64, device=eng.device)
+		v = torch.zeros((rp, kp), dtype=torch.float64, device=eng.device)
+		u[:nt, :ns] = d_w * d_w
+		v[:nt, :ns] = d_w * y.to(torch.float64)
+		pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+		pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
+		cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+		cp[:nc, :ns] = d_c
+		R = _engine.Residualized
+		gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
+		ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
+		m = np.zeros((nt, nc, nc))
+		m[:, iu[0], iu[1]] = gm
+		m[:, iu[1], iu[0]] = gm
+		_, sv, vh = np.linalg.svd(m)
+		keep = sv >= tol * sv[:, :1]
+		if (keep.sum(axis=1) <= 0).any():
+			raise RuntimeError('Zero-rank covariates found.')
+		with np.errstate(divide='ignore'):
+			inv_s = np.where(keep, 1.0 / sv, 0.0)
+		b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)
+		tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+		out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
+		d_b = eng.upload(b)
+		_lib.check(eng.lib.nrm_normvar_apply_w2(y.data_ptr(), _lib.NRM_F64 if y.dtype == torch.float64 else _lib.NRM_F32, nt, ns, y.stride(0), d_w.data_ptr(),
+												d_w.stride(0), d_c.data_ptr(), nc, d_c.stride(0), d_b.data_ptr(), out.data_ptr(),
+												_lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, eng._stream()))
+		dtn = eng.download(out)
+	assert np.isfinite(dtn).all()
+	return dtn
 
 
 def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, normmean=False, tol=1E-8):

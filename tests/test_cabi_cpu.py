@@ -129,3 +129,24 @@ def test_cli_matrix_io_text_and_binary(tmp_path):
 	assert ns['cmd'] == 'coex' and ns['nth'] == 0 and ns['dot_out'] == 'd' and ns['var_out'] is None
 	ns = vars(p.parse_args(['binnet', 'pv', 'net', '0.05']))
 	assert ns['cmd'] == 'binnet' and ns['qcut'] == 0.05
+
+
+def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
+	"""The library's host-only logic -- the Gram kernels' persistent schedule (every k-unit of every tile covered exactly once,
+	slabs inside the workspace, bands tiling the problem), the scratch pool of the whole-problem entry, the P-value plan -- built by
+	g++ with -fsanitize=address,undefined and run on the CPU (csrc/nrm_host_logic.h is free of HIP headers for this purpose; GPU
+	sanitizers are not available on the pool)."""
+	import shutil
+	import subprocess
+	gxx = shutil.which('g++')
+	if gxx is None:
+		pytest.skip('no g++')
+	exe = str(tmp_path / 'host_sanitize')
+	src = os.path.join(ROOT, 'tests', 'host', 'host_sanitize.cpp')
+	r = subprocess.run([gxx, '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-o', exe, src],
+					   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+	if r.returncode != 0 and ('asan' in r.stdout or 'ubsan' in r.stdout or 'sanitize' in r.stdout):
+		pytest.skip('sanitizer runtimes not installed: ' + r.stdout[-200:])
+	assert r.returncode == 0, r.stdout
+	r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+	assert r.returncode == 0 and 'host logic ok' in r.stdout, r.stdout[-2000:]

@@ -120,3 +120,28 @@ def test_spd_inverse_and_partner_runs():
 			for i in range(max(0, wrap)):
 				buf[world + i] = buf[i]
 			assert buf[rank + 1:rank + 1 + K] == [(rank + 1 + j) % world for j in range(K)]
+
+
+def test_inv_rank_retries_with_gesvd(monkeypatch, caplog):
+	"""inv_rank falls back to LAPACK's gesvd when the default SVD driver does not converge, with one warning, as the reference does
+	(association.py:70-76 for one matrix, :111-119 for a stack)."""
+	import logging
+	from normalisr_amd.association import inv_rank
+	rng = np.random.default_rng(12)
+	a = rng.normal(size=(5, 40))
+	m = a @ a.T
+	want, rank = inv_rank(m)
+	real = np.linalg.svd
+	calls = []
+
+	def failing(x, *args, **ka):
+		calls.append(1)
+		raise np.linalg.LinAlgError('SVD did not converge')
+	monkeypatch.setattr(np.linalg, 'svd', failing)
+	with caplog.at_level(logging.WARNING):
+		got, r2 = inv_rank(m)
+		stack, ranks = inv_rank(np.stack([m, 2 * m, m + np.eye(5)]))
+	monkeypatch.setattr(np.linalg, 'svd', real)
+	assert r2 == rank and np.allclose(got, want, rtol=1e-10, atol=1e-14)
+	assert list(ranks) == [rank] * 3 and np.allclose(stack[1], want / 2, rtol=1e-10, atol=1e-14)
+	assert len(calls) == 4 and sum('gesvd' in r.getMessage() for r in caplog.records) == 2  # one warning per call, not per matrix
