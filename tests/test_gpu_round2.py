@@ -287,11 +287,15 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 
 
 def test_bench_default_line_carries_the_other_configs():
-	"""The default N=1 line: configs[1] as `value` plus de_c3 / de_c4 / coex_c5 under extra_workloads, each with its roofline."""
+	"""The default N=1 line: configs[1] as `value` plus de_c3 / de_c4 / coex_c5 (the per-rank slice) and configs[4] whole on this one GPU
+	under extra_workloads, each with its roofline, kernel split and the guard's verdict."""
 	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
 	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
 	ex = out['extra_workloads']
-	assert set(ex) == {'de_c3', 'de_c4', 'coex_c5'}, ex
+	assert set(ex) == {'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu'}, ex
+	assert out['guard']['uncertified_pairs'] == 0 and 0 < out['guard']['largest_relative_p_error_bound'] < out['guard']['tolerance']
+	assert ex['coex_c5_full_1gpu']['config']['tests_per_step'] == 30000 * 29999 // 2 and ex['coex_c5_full_1gpu']['guard']['uncertified_pairs'] == 0
+	assert ex['de_c4']['kernels_ms']['gram'] < ex['de_c4']['ms_per_step'] and ex['de_c4']['roofline']['kernel_ms'] == pytest.approx(ex['de_c4']['kernels_ms']['gram'], rel=0.02)
 	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'mfma' and ex['coex_c5']['roofline']['bound'] == 'mfma'
 	for k, v in ex.items():
 		assert 'error' not in v, (k, v)
