@@ -884,12 +884,60 @@ def coex_binnet(dt_local, dc, qcut, group=None, dimreduce=0, out_dir=None):
 	return None if res is None else res['net']
 
 
-def de(dg, dt_local, dc, group=None, dimreduce=0, out_dir=None):
-	"""Sharded norm.de (single=0) for one-process-per-GPU programs: every rank passes the full grouping matrix dg, ITS
+def _de_other_methods(dg, dt_local, dc, group, dimreduce, out_dir, single, ka):
+	"""Sharded de for single=1 (every grouping on the cells free of the other groupings, association.py:263-390) and single=4 (the
+	other groupings as covariates, :421-576): a gene's results depend on the design, the covariates and that gene's row only, so
+	every rank runs the single-GPU path on ITS gene rows and writes its columns of the shared result arrays; the small design-side
+	factorisations are repeated per rank (replicas of the (n_x + n_cov)^2 inverse + gene-row sharding)."""
+	from .de import de as de_local
+	rank, world, group = _world(group)
+	y = dt_local.detach().cpu().numpy() if hasattr(dt_local, 'detach') else np.asarray(dt_local)
+	dimr = dimreduce
+	counts = np.array([[y.shape[0]]])
+	if world > 1:
+		import torch
+		counts = _all_gather_ints([y.shape[0]], group, torch.device('cuda', torch.cuda.current_device()))
+	starts = np.concatenate([[0], np.cumsum(counts[:, 0])])
+	a, b = int(starts[rank]), int(starts[rank + 1])
+	if np.ndim(dimr) != 0:  # one value per gene: this rank's genes
+		dimr = np.asarray(dimr)[a:b]
+	err, res = None, None
+	try:
+		res = de_local(dg, y, dc, single=single, dimreduce=dimr, **ka)
+	except Exception as e:  # every rank must learn of it: the others would wait in the collectives below
+		err = e
+	if world > 1:
+		import torch.distributed as dist
+		bad = _coll_tensor([0 if err is None else 1], group, torch.device('cuda', torch.cuda.current_device()))
+		dist.all_reduce(bad, group=group)
+		if int(bad.item()) and err is None:
+			err = RuntimeError('sharded de (single={}) failed on another rank'.format(single))
+	if err is not None:
+		raise err
+	p, gam, alpha, vg, vt = res
+	ng0, nt = p.shape[0], int(starts[-1])
+	odt = p.dtype
+	sh = SharedArrays(dict(p=((ng0, nt), odt), gamma=((ng0, nt), odt), varg=((ng0, ), odt), vart=((ng0, nt), odt)), rank, world, group,
+					  base=out_dir, keep=out_dir is not None)
+	sh['p'][:, a:b], sh['gamma'][:, a:b], sh['vart'][:, a:b] = p, gam, vt
+	if rank == 0:
+		sh['varg'][...] = vg
+	out = sh.finish()
+	return None if out is None else (out['p'], out['gamma'], None, out['varg'], out['vart'])
+
+
+def de(dg, dt_local, dc, group=None, dimreduce=0, out_dir=None, single=0, **ka):
+	"""Sharded norm.de for one-process-per-GPU programs: every rank passes the full grouping matrix dg, ITS
 	block of gene rows of dt (numpy or a torch tensor on its GPU; the blocks may differ in size) and the replicated
 	covariates.  No collective on the data path; every rank writes its gene columns into result arrays shared by the ranks
 	and rank 0 returns (p, gamma, None, varg, vart) with the reference's contract (de.py:4-132, constant groupings
-	re-inflated), other ranks get None."""
+	re-inflated), other ranks get None.  single = 0 (resident DePlan), 1 or 4 (see _de_other_methods)."""
+	if single not in (0, 1, 4):
+		raise ValueError('Unknown value single={}'.format(single))
+	if single:
+		return _de_other_methods(dg, dt_local, dc, group, dimreduce, out_dir, single, ka)
+	if ka:
+		raise TypeError("de() got an unexpected keyword argument '{}'".format(next(iter(ka))))
 	import torch
 	from .de import _varying_rows
 	rank, world, group = _world(group)

@@ -23,8 +23,8 @@ SHARDED = ('coex', 'de')
 def check_args(cmd, args):
 	if cmd not in SHARDED:
 		raise ValueError('--gpus applies to the sub-commands {}'.format(', '.join(SHARDED)))
-	if cmd == 'de' and args.get('method', 'ignore') != 'ignore':
-		raise ValueError('--gpus > 1 is provided for `de -m ignore` (gene rows sharded, no exchange); run -m {} on one GPU'.format(args['method']))
+	if cmd == 'de' and args.get('method', 'ignore') not in ('ignore', 'single', 'covariate'):
+		raise ValueError('Unknown method {}'.format(args['method']))
 	if cmd == 'de' and args.get('clfc_out') is not None:
 		raise ValueError('--clfc_out is not provided with --gpus > 1')
 

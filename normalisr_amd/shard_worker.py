@@ -77,7 +77,8 @@ def main(argv):
 			if y.dtype not in (np.float32, np.float64):
 				y = y.astype(np.float64)
 			logging.debug('gene rows %d..%d of %d loaded', lo, hi, rows)
-			res = nd.de(dg, y, dc, dimreduce=dimr)
+			from .run import _de_method
+			res = nd.de(dg, y, dc, dimreduce=dimr, single=_de_method(args.get('method') or 'ignore'))
 			if rank == 0:
 				out = dict(pv_out=res[0], lfc_out=res[1], vard_out=res[3], vart_out=res[4])
 		if rank == 0:
