@@ -13,7 +13,9 @@
 #include "nrm_digits.h"
 #include "nrm_fix.h"
 
+#ifndef RES_R
 #define RES_R 4
+#endif
 #define RES_CB 8
 #define RES_NC_MAX 2048  // OLS tables a = x C^T and b = a dci live in dynamic LDS: 2 * RES_R * nc doubles (128 KiB at 2048)
 
