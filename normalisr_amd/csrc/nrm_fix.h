@@ -83,26 +83,60 @@ __device__ __forceinline__ double nrm_fix_corr(const double* __restrict__ ux, co
 // single-precision square root rounded up, the diagnostic quotient is taken in single precision.
 struct FixAcc {
 	int bad;         // pairs over the budget whose P-value is not 0
-	float worst;     // largest error estimate among the pairs with a non-zero P-value
+	float worst;     // largest error estimate met (among pairs within the budget, or over it with a non-zero P-value)
 	double lo2_min;  // pairs over the budget with P = 0: the smallest (|r| - bound)^2 among them -- P is monotone in R^2, so if P is still
 					 // 0 there, every one of them is exempt (one more P-value evaluation per thread, after its pairs: nrm_fix_close)
+	double r2max, cmax, gmax;  // first level: the largest R^2, c and g among the thread's pairs (one column, several rows)
 };
-__device__ __forceinline__ FixAcc nrm_fix_acc() { return FixAcc{0, 0.f, INFINITY}; }
+__device__ __forceinline__ FixAcc nrm_fix_acc() { return FixAcc{0, 0.f, INFINITY, 0.0, 0.0, 0.0}; }
 
-__device__ __forceinline__ void nrm_fix_guard(const FixArgs& f, double cx, double gx, const FixCol& y, double r2, double p, double sqrt_dof, FixAcc& a) {
-	const double dr = fma(f.kconst * cx, y.c, gx + y.g);
-	const double ar = (double)(sqrtf((float)r2) * 1.0000002f);  // >= |r| (r2 below the float range: |r| < 1e-19 counts as 0)
+// Two levels, because K3 is bound by the fp64 vector ALU.  Per pair only three maxima are kept (nrm_fix_note).  After its pairs a
+// thread evaluates the bound ONCE for the worst combination of them (nrm_fix_screen): within the budget -- the normal case -- every
+// pair of the thread is certified; otherwise the thread goes over its pairs again with the exact per-pair test (nrm_fix_guard).
+__device__ __forceinline__ void nrm_fix_note(FixAcc& a, double cx, double gx, double r2) {
+	a.r2max = fmax(a.r2max, r2);
+	a.cmax = fmax(a.cmax, cx);
+	a.gmax = fmax(a.gmax, gx);
+}
+
+// error estimate num / den of a pair with these c, g and R^2; |d ln p / d r| <= (sqrt(dof) + dof |r|) / (1 - R^2)^2: the hazard rate of the
+// normal limit (<= 1 + t, which the t distribution's stays under) times dt/dr = sqrt(dof) (1 - R^2)^-3/2.  |r| comes from a
+// single-precision square root rounded up (R^2 below the float range: |r| < 1e-19 counts as 0).
+__device__ __forceinline__ void nrm_fix_bound(const FixArgs& f, double cx, double gx, const FixCol& y, double r2, double sqrt_dof, double& dr,
+											  double& ar, double& num, double& den) {
+	dr = fma(f.kconst * cx, y.c, gx + y.g);
+	ar = (double)(sqrtf((float)r2) * 1.0000002f);
 	const double om = fmax(1.0 - r2, 1e-150);
-	const double num = dr * fma(f.dof, ar, sqrt_dof), den = om * om;
+	num = dr * fma(f.dof, ar, sqrt_dof);
+	den = om * om;
+}
+
+// true: the thread has to look at its pairs one by one
+__device__ __forceinline__ bool nrm_fix_screen(const FixArgs& f, FixAcc& a, const FixCol& y, double sqrt_dof) {
+	double dr, ar, num, den;
+	nrm_fix_bound(f, a.cmax, a.gmax, y, a.r2max, sqrt_dof, dr, ar, num, den);
+	if (num > f.budget * den || !(num == num)) return true;
+	a.worst = fmaxf(a.worst, __fdividef((float)num, (float)den));
+	return false;
+}
+
+// the exact test of one pair whose P-value is (p_nonzero) or is not 0 as stored -- a P-value that underflowed in the output type
+// counts as 0 here and goes through the exemption test, which is evaluated in fp64: a P-value that is 0 on the whole interval
+// |r| +- bound is exempt
+__device__ __forceinline__ void nrm_fix_guard(const FixArgs& f, double cx, double gx, const FixCol& y, double r2, double sqrt_dof, bool p_nonzero, FixAcc& a) {
+	double dr, ar, num, den;
+	nrm_fix_bound(f, cx, gx, y, r2, sqrt_dof, dr, ar, num, den);
+	const float err = __fdividef((float)num, (float)den);
 	if (num > f.budget * den) {
-		if (p != 0.0)
+		if (p_nonzero) {
 			a.bad++;
-		else {
+			a.worst = fmaxf(a.worst, err);
+		} else {
 			const double lo = fmax(ar - dr, 0.0);
 			a.lo2_min = fmin(a.lo2_min, lo * lo);
 		}
-	}
-	if (p != 0.0) a.worst = fmaxf(a.worst, __fdividef((float)num, (float)den));
+	} else
+		a.worst = fmaxf(a.worst, err);
 }
 
 template <typename Plan, typename PFn>

@@ -127,9 +127,7 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep(const double* __restrict
 	const double sqrt_dof = sqrt(fix.dof);
 	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, ny);
-	for (int r = ty; r < SW_T; r += 4) {
-		const int64_t gi = (int64_t)bi * SW_T + r;
-		if (gi >= nx || gj >= ny) continue;
+	auto pair_dot = [&](int r) {  // x~_i . y~_j of the pair in row r of this thread's column
 		double d;
 		if (!symmetric)
 			d = tile[r][tx];
@@ -146,6 +144,12 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep(const double* __restrict
 			const bool swap = symmetric && (mirror || (bi == bj && r > tx));
 			d += swap ? nrm_fix_corr(sfc[tx], nrm_fix_col(sfx[r]), fix.top, fix.inv_n) : nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 		}
+		return d;
+	};
+	for (int r = ty; r < SW_T; r += 4) {
+		const int64_t gi = (int64_t)bi * SW_T + r;
+		if (gi >= nx || gj >= ny) continue;
+		const double d = pair_dot(r);
 		const double vx = sx[r], vy = sy[tx];
 		double r2 = (d * d) / (vx * vy);  // = gamma^2 vx / vy  (association.py:235)
 		double p, stat, rr, tt;
@@ -162,13 +166,22 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep(const double* __restrict
 			rr = d / sqrt(vx * vy);
 			double rc = fmin(r2, 1.0);
 			tt = copysign(sqrt(dof * rc / (1.0 - rc)), d);
-			if (fix.fx && fix.budget > 0.0) nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, facc);
+			if (fix.fx && fix.budget > 0.0) nrm_fix_note(facc, sfx[r][5], sfx[r][6], r2);
 		}
 		const int64_t o = gi * ldo + gj;
 		store_out<OutT>(p_out, o, p);
 		store_out<OutT>(stat_out, o, stat);
 		if (r_out) store_out<OutT>(r_out, o, rr);
 		if (t_out) store_out<OutT>(t_out, o, tt);
+	}
+	if (fix.fx && fix.budget > 0.0 && nrm_fix_screen(fix, facc, fy, sqrt_dof)) {  // rare: the exact test, pair by pair
+#pragma unroll 1
+		for (int r = ty; r < SW_T; r += 4) {
+			const int64_t gi = (int64_t)bi * SW_T + r;
+			if (gi >= nx || gj >= ny || (symmetric && gi == gj)) continue;
+			const double d = pair_dot(r), r2 = (d * d) / (sx[r] * sy[tx]);
+			nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, sqrt_dof, nrm_pvalue(r2, pl) != 0.0, facc);
+		}
 	}
 	if (flags) {
 		if (bad_nf) atomicAdd(&flags[0], 1);
@@ -231,13 +244,23 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_sym(const double* __rest
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
-			if (fix.fx && fix.budget > 0.0) nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, facc);
+			if (fix.fx && fix.budget > 0.0) nrm_fix_note(facc, sfx[r][5], sfx[r][6], r2);
 		}
 		pv[i] = (OutT)p;
 		sv[i] = (OutT)st;
 		if (gi < ng && gj < ng && !lower) {
 			p_out[gi * ldo + gj] = (OutT)p;
 			stat_out[gi * ldo + gj] = (OutT)st;
+		}
+	}
+	if (fix.fx && fix.budget > 0.0 && nrm_fix_screen(fix, facc, fy, sqrt_dof)) {  // rare: the exact test, pair by pair
+#pragma unroll
+		for (int i = 0; i < SW_T / 4; i++) {  // (unrolled: pv[i] -- is the pair's P-value 0? -- stays in registers)
+			const int r = ty + 4 * i;
+			const int64_t gi = (int64_t)bi * SW_T + r;
+			if (gi >= ng || gj >= ng || gi == gj || (bi == bj && r > tx)) continue;
+			const double d = tile[r][tx] + nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+			nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, (d * d) / (sx[r] * sy[tx]), sqrt_dof, pv[i] != (OutT)0, facc);
 		}
 	}
 	{
@@ -315,12 +338,22 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_mirror(const double* __r
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			p = nrm_pvalue(r2, pl);
 			st = d / ncells;
-			if (fix.fx && fix.budget > 0.0) nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, r2, p, sqrt_dof, facc);
+			if (fix.fx && fix.budget > 0.0) nrm_fix_note(facc, sfx[r][5], sfx[r][6], r2);
 			p_out[(r0 + gi) * ldo + c0 + gj] = (OutT)p;
 			stat_out[(r0 + gi) * ldo + c0 + gj] = (OutT)st;
 		}
 		pv[i] = (OutT)p;
 		sv[i] = (OutT)st;
+	}
+	if (fix.fx && fix.budget > 0.0 && nrm_fix_screen(fix, facc, fy, sqrt_dof)) {  // rare: the exact test, pair by pair
+#pragma unroll
+		for (int i = 0; i < SW_T / 4; i++) {  // (unrolled: pv[i] -- is the pair's P-value 0? -- stays in registers)
+			const int r = ty + 4 * i;
+			const int64_t gi = (int64_t)bi * SW_T + r;
+			if (gi >= mx || gj >= my) continue;
+			const double d = dot[gi * ldd + gj] + nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+			nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, (d * d) / (sx[r] * sy[tx]), sqrt_dof, pv[i] != (OutT)0, facc);
+		}
 	}
 	const int64_t oj = (int64_t)bi * SW_T + tx;  // mirrored: rows c0 + (block bj), columns r0 + (block bi)
 #pragma unroll
