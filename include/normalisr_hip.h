@@ -139,8 +139,8 @@ int64_t nrm_gram_workspace_bytes(void);
  * (csrc/nrm_gram_i8.hip): every row is scaled by a power of two, rounded once to 8 * nslices - 2 bits (nslices = 6: 46 bits,
  * 1.4e-14 of the row's largest entry; 5: 38 bits) and cut into nslices balanced base-256 digits; the digit products are
  * accumulated in int32 without rounding and combined in fp64.  About 2.5x (6 slices) / 3.4x (5) the rate of the fp64 kernel.
- *   nrm_quantize_rows: d_x (rows_pad, ldx) fp64 rows as written by nrm_residualize (rows_pad % NRM_ROW_TILE == 0, k_pad % 16 == 0,
- *       zero padded) -> d_q (nrm_quant_bytes() bytes: digit planes in the kernel's tiled layout) and d_exp (rows_pad) int32 with
+ *   nrm_quantize_rows: d_x (rows_pad, ldx) fp64 rows as written by nrm_residualize (rows_pad % 32 == 0 -- % NRM_ROW_TILE for
+ *       nrm_gram_i8 operands --, k_pad % 16 == 0, zero padded) -> d_q (nrm_quant_bytes() bytes: digit planes in the kernel's tiled layout) and d_exp (rows_pad) int32 with
  *       x = q * 2^exp.
  *   nrm_gram_i8_band: as nrm_gram_f64_band with quantised operands (d_qb == d_qa, d_eb == d_ea for symmetric problems).
  *       plane_*_bytes: distance between an operand's digit planes, 0 = dense (m_pad / 32 * ceil(k_pad / 32) KB); an operand may be
@@ -256,7 +256,24 @@ int64_t nrm_gram_skinny_workspace_bytes(void);  /* scratch for d_work (determini
 int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
 					   int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,
 					   void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags,
-					   int const_last /* as above: covariate nc-1 in column 31, the design rows from column nc-1 on */, void* stream);
+					   int const_last /* as above: covariate nc-1 in column 31, the design rows from column nc-1 on */,
+					   /* d_g from nrm_skinny_i8 (all NULL / 0 otherwise): its digit sums and shifts, the records and shifts of the Z rows
+					    * (nrm_quantize_rows), the sums of squares the shifts were taken with (or NULL) and the guard's tolerance: every column
+					    * gets the exact mean-product correction, every pair the accuracy guard (d_flags[2], [3] as in nrm_assoc_sweep;
+					    * a row whose sum of squares differs from d_ss_ref counts as uncertified) */
+					   const double* d_dig, const int32_t* d_ysh, const double* d_zfix, const int32_t* d_zsh, const double* d_ss_ref, double guard_tol,
+					   void* stream);
+/*
+ * The streaming pass on the int8 matrix cores (csrc/nrm_skinny_i8.hip): same contract as nrm_gram_skinny, the products exact for
+ * 46-bit fixed-point operands.  d_ysh (rows): shifts of the expression rows from nrm_row_scales -- the rows must be the ones the
+ * shifts were taken from (nrm_row_scales also returns their sums of squares; pass them to nrm_de_small_sweep as d_ss_ref).
+ * d_zq / d_zsh: the 32 Z rows as nrm_quantize_rows(d_z, 32, k_pad, ...) wrote them (6 digit planes); Z row 31 must hold a non-zero
+ * constant (its column returns the digit sums of the expression rows): at most 31 rows of Z carry data.  d_dig (rows_pad, 8).
+ */
+int nrm_row_scales(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, int32_t* d_ysh, double* d_ss, void* stream);
+int nrm_skinny_i8(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const int32_t* d_ysh, const void* d_zq,
+				  const int32_t* d_zsh, int64_t k_pad, double* d_g, double* d_ss, double* d_dig, int64_t rows_pad, void* d_work, void* stream);
+int64_t nrm_skinny_i8_workspace_bytes(void);
 
 /*
  * single=4 sweep (competition-aware DE, association.py:421-576 in closed form).

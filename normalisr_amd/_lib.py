@@ -52,7 +52,11 @@ _SIGNATURES = {
 	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp], _i32),
 	'nrm_gram_skinny': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_gram_skinny_workspace_bytes': ([], _i64),
-	'nrm_de_small_sweep': ([_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp], _i32),
+	'nrm_de_small_sweep': ([_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32,
+							_vp, _vp, _vp, _vp, _vp, _dbl, _vp], _i32),
+	'nrm_row_scales': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp], _i32),
+	'nrm_skinny_i8': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp], _i32),
+	'nrm_skinny_i8_workspace_bytes': ([], _i64),
 	'nrm_single1_sweep': ([_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_binnet': ([_vp, _i32, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_binnet_rows': ([_vp, _i32, _i64, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),

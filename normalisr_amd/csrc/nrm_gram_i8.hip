@@ -331,8 +331,8 @@ extern "C" int64_t nrm_quant_bytes(int64_t rows_pad, int64_t k_pad, int nslices)
 extern "C" int nrm_quantize_rows(const double* d_x, int64_t rows_pad, int64_t k_pad, int64_t ldx, int nslices, void* d_q, int32_t* d_exp,
 								 double* d_fix, int64_t n_cells, void* stream) {
 	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_quantize_rows: 5 or 6 slices");
-	NRM_REQUIRE(rows_pad >= 0 && rows_pad % GM == 0 && k_pad > 0 && k_pad % 16 == 0 && ldx >= k_pad && ldx % 2 == 0,
-				"nrm_quantize_rows: rows must be padded to %d, cells to 16", GM);
+	NRM_REQUIRE(rows_pad >= 0 && rows_pad % 32 == 0 && k_pad > 0 && k_pad % 16 == 0 && ldx >= k_pad && ldx % 2 == 0,
+				"nrm_quantize_rows: rows must be padded to 32 (%d for nrm_gram_i8), cells to 16", GM);
 	if (rows_pad == 0) return NRM_OK;
 	NRM_REQUIRE(d_x && d_q && d_exp && (uintptr_t)d_x % 16 == 0 && (uintptr_t)d_q % 16 == 0, "nrm_quantize_rows: null or misaligned pointer");
 	NRM_REQUIRE(!d_fix || (n_cells > 0 && n_cells <= k_pad && k_pad < (1 << 22)), "nrm_quantize_rows: row records need 0 < n_cells <= k_pad < 2^22");

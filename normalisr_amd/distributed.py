@@ -774,7 +774,9 @@ class DePlan:
 		self.result = None
 		self._ev = []
 		self._graph = StepGraph(self.eng.torch)
-		self._state = {}  # buffers of the streaming path that a captured graph points into: owned by the plan (see association_de_streaming)
+		# buffers of the streaming path that a captured graph points into, and the row scales of the resident expression rows: owned by
+		# the plan (see association_de_streaming); keep=True: the plan is resident, its rows will be streamed again
+		self._state = {'keep': True}
 
 	def _run(self):
 		# resident step: p / gamma / sums of squares stay in HBM; results() brings them to the host and checks the flags
@@ -800,6 +802,9 @@ class DePlan:
 		try:
 			self.eng.check_flags(r['flags'])
 		except GuardHit as g:  # the integer engine could not certify every P-value: this step again, eagerly, on the fp64 Gram kernel
+			self._state.pop('yscale', None)  # (streaming path: no more integer passes for this plan -- stale row scales count as a hit)
+			self._state['keep'] = False
+			self._graph.enabled, self._graph.graph = False, None
 			with self.eng.forced_f64():
 				r = self._run()
 				self.eng.check_flags(r['flags'])

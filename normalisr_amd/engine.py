@@ -890,9 +890,16 @@ class Engine:
 			# A constant covariate row (the intercept) leaves Z: its product with every expression row is a plain sum, taken on the
 			# vector ALU by the streaming kernel (column 31 of G) instead of occupying a matrix-core row group.  The covariates are
 			# reordered so that it comes last; dci is permuted with them (b' = P b: no rank assumption), alpha is put back in order.
+			# Streaming on the int8 matrix cores (csrc/nrm_skinny_i8.hip; opt-in with NRM_DE_I8=1: correct, not yet faster than the fp64
+			# kernel): needs the fixed-point scale of every expression row before the row is streamed, i.e. rows that were seen
+			# before -- a caller that keeps `state` (a DePlan) gets them from nrm_row_scales at the end of its first step and streams on
+			# the integer engine from the second step on
+			ysc = state.get('yscale')
+			use_i8 = (ysc is not None and not isinstance(dy, np.ndarray) and ysc[0] is dy and self.gram_slices(n) == 6 and nc + nx <= 31
+					  and not (want_alpha or want_rt) and os.environ.get('NRM_DE_I8', '0') == '1')
 			ci, cval = self.constant_row(d_c)
-			if os.environ.get('NRM_CONST_ROW', '1') == '0' or nc + nx > 31 + (ci >= 0):
-				ci, cval = -1, 0.0
+			if use_i8 or os.environ.get('NRM_CONST_ROW', '1') == '0' or nc + nx > 31 + (ci >= 0):
+				ci, cval = -1, 0.0  # (the integer kernel takes the intercept like any other row: its 32-row tile has room)
 			perm = None
 			if ci >= 0:
 				perm = [c for c in range(nc) if c != ci] + [ci]
@@ -912,9 +919,10 @@ class Engine:
 			zc = state.get('z')
 			if zc is not None and zc[0] is d_c and d_c is not None and zc[1].shape[1] == k32 and zc[2] == ci:
 				z = zc[1]
-				_lib.check(self.lib.nrm_fill_zero(z[ncz:].data_ptr(), (32 - ncz) * k32 * 8, self._stream()))
+				_lib.check(self.lib.nrm_fill_zero(z[ncz:].data_ptr(), (31 - ncz) * k32 * 8, self._stream()))
 			else:
 				z = self.zeros((32, k32), torch.float64)
+				z[31].fill_(1.0)  # (row 31: a constant; the integer kernel reads the expression rows' digit sums off its column, the fp64 one ignores it)
 				if ncz:
 					self.copy_rows(z, d_cz[:ncz])
 				if nc:
@@ -937,12 +945,37 @@ class Engine:
 													 rw_work.data_ptr(), 1 if ci >= 0 else 0, self._stream()))
 			rx = Residualized(nx, n, xt, ssx, coefx)
 			y = self._rows_padded16(dy)
+			ycode = NRM_F64 if y.dtype == torch.float64 else NRM_F32
 			ny_pad = _round_up(ny, 256)
 			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
 			ssraw = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
-			_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), NRM_F64 if y.dtype == torch.float64 else NRM_F32, ny, n, y.stride(0),
-												z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(), ny_pad, ncz + nx, float(cval), self._skinny_work().data_ptr(),
-												self._stream()))
+			i8 = (0, 0, 0, 0, 0, 0.0)  # the sweep's extra arguments when G comes from the integer kernel
+			use_i8 = use_i8 and y is dy  # (a padded copy of the rows is not what the scales were taken from)
+			if use_i8:
+				with _Span(self, 'gram'):
+					nks = k32 // 32
+					planes = torch.empty((6 * nks * 1024, ), dtype=torch.uint8, device=self.device)
+					zsh = torch.empty((32, ), dtype=torch.int32, device=self.device)
+					zfix = torch.empty((32, FIX_STRIDE), dtype=torch.float64, device=self.device)
+					_lib.check(self.lib.nrm_quantize_rows(z.data_ptr(), 32, k32, k32, 6, planes.data_ptr(), zsh.data_ptr(), zfix.data_ptr(), int(n), self._stream()))
+					dig = torch.empty((ny_pad, 8), dtype=torch.float64, device=self.device)
+					if getattr(self, '_skinny_i8_ws', None) is None:
+						self._skinny_i8_ws = torch.empty((int(self.lib.nrm_skinny_i8_workspace_bytes()) // 8, ), dtype=torch.float64, device=self.device)
+					_lib.check(self.lib.nrm_skinny_i8(y.data_ptr(), ycode, ny, n, y.stride(0), ysc[1].data_ptr(), planes.data_ptr(), zsh.data_ptr(), k32,
+													  g.data_ptr(), ssraw.data_ptr(), dig.data_ptr(), ny_pad, self._skinny_i8_ws.data_ptr(), self._stream()))
+				i8 = (dig.data_ptr(), ysc[1].data_ptr(), zfix.data_ptr(), zsh.data_ptr(), ysc[2].data_ptr(), float(self.guard_tol))
+			else:
+				with _Span(self, 'gram'):
+					_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), ycode, ny, n, y.stride(0), z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(),
+														ny_pad, ncz + nx, float(cval), self._skinny_work().data_ptr(), self._stream()))
+				if (state.get('keep', False) and (ysc is None or ysc[0] is not dy) and y is dy and self.gram_slices(n) == 6 and nc + nx <= 31
+						and not (want_alpha or want_rt) and os.environ.get('NRM_DE_I8', '0') == '1'):
+					# a resident caller: take the row scales now, for the next steps
+					ysh = torch.empty((ny, ), dtype=torch.int32, device=self.device)
+					ss0 = torch.empty((ny, ), dtype=torch.float64, device=self.device)
+					with _Span(self, 'row scales'):
+						_lib.check(self.lib.nrm_row_scales(y.data_ptr(), ycode, ny, n, y.stride(0), ysh.data_ptr(), ss0.data_ptr(), self._stream()))
+					state['yscale'] = (dy, ysh, ss0)
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
@@ -954,7 +987,7 @@ class Engine:
 			_lib.check(self.lib.nrm_de_small_sweep(g.data_ptr(), ssraw.data_ptr(), 0 if d_dciz is None else d_dciz.data_ptr(), nc, int(rank),
 												   rx.ss.data_ptr(), nx, ny, n, float(dof), stat_kind, p.data_ptr(), stat.data_ptr(),
 												   0 if r is None else r.data_ptr(), 0 if t is None else t.data_ptr(), _code(out_dtype),
-												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), 1 if ci >= 0 else 0, self._stream()))
+												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), 1 if ci >= 0 else 0, *i8, self._stream()))
 			alpha = None
 			if want_alpha:
 				if nc > 0:
