@@ -12,12 +12,10 @@
 // resident rows are streamed more than once (a DePlan's second step on; the caller keeps the scales with the plan).
 //
 // STATUS (round 3): correct (tests/test_gpu_round3.py, tools/k2s_i8_check.py: G to 4e-15 of |y||z|, sums of squares and digit sums
-// exact) but NOT the default -- 4.7 ms on configs[2] against 1.87 ms for the fp64 kernel.  The ablation (SQ_EXP, tools/build_exp.sh):
-// conversion + matrix cores fed zeros 0.95 ms; loads + LDS writes alone 2.1 ms; loads + conversion 2.4 ms; all three 4.7 ms.  The
-// expression rows come through REGISTERS here (they must be converted before they reach LDS), and four loader waves with one
-// stage in flight each cannot keep the HBM pipe full (3.3-3.8 TB/s); a third register set does not fit beside the 228 registers
-// of the MFMA waves.  What the formulation needs is the fp64 kernel's DMA ring for the raw rows plus converter waves that read
-// them from LDS -- 128-row tiles so that ring (64 KB) and digit images (48 KB) fit -- which is the next step.  Opt in: NRM_DE_I8=1.
+// exact) but NOT the default -- on configs[2] the form below (rows through registers) takes 4.7 ms, the DMA form further down 2.5 ms,
+// the fp64 kernel 1.87 ms.  The arithmetic is not the problem (conversion + matrix cores fed zeros: 0.95 ms, against a matrix-core
+// floor of 1.56 ms in fp64); feeding it is: see the ablations in DESIGN.md section 4.  Opt in: NRM_DE_I8=1 (NRM_DE_I8_DMA=0: this form
+// for fp32 rows too).
 //
 // Structure: one workgroup per CU owns 256 rows; 4 LOADER waves pull the rows through registers (two stages of 32 cells in
 // flight), cut every value into 6 balanced base-256 digits (nrm_digits.h) and write them to LDS in K2's operand layout (1 KB
@@ -26,6 +24,7 @@
 // fp64 every 512 k-steps.  One barrier per k-step; LDS 2 x (48 + 6) KB.  Sums of squares stay on the vector ALU in fp64 (they
 // must be exact: |y~|^2 = |y|^2 - ...); the digit sums feed K3's exact correction for the dropped digit products (nrm_fix.h).
 // Persistent DP + stream-K schedule and deterministic fix-up as in nrm_gram_skinny.hip.
+#include <cstdlib>
 #include "nrm_common.h"
 #include "nrm_digits.h"
 
@@ -45,6 +44,7 @@ typedef double d2v_t __attribute__((ext_vector_type(2)));
 
 struct SkinnyQSched {
 	int nkt, tiles_dp, tiles_sk, units_per_wg, nwg;
+	int tm;        // rows per workgroup tile (256: rows through registers; 128: rows by DMA)
 	double* work;  // per partial piece: (256 x 32) G, 256 sums of squares, (256 x 8) digit sums; two pieces per workgroup
 };
 #define SQ_SLAB ((int64_t)SQ_TM * (SQN + 1 + SQ_DIG))
@@ -317,6 +317,272 @@ __global__ void __launch_bounds__(512) k_skinny_i8(const T* __restrict__ Y, int6
 	}
 }
 
+// ---- the same with the raw rows brought in by DMA (fp32 rows) ----------------------------------------------------------------------
+// The kernel above pulls the rows through the registers of four loader waves, which cannot keep the HBM pipe full.  Here, as in
+// the fp64 kernel, LOADER waves do nothing but issue global -> LDS DMA into a ring of raw stages (no registers, three stages ahead),
+// CONVERTER waves read a raw stage from LDS, cut it into digits and write the digit images, MFMA waves contract them.  128-row
+// tiles so that the raw ring (4 x 16 KB), two digit stages (2 x 24 KB) and Z (2 x 6 KB) fit in LDS; 12 waves, 3 per SIMD: one
+// loader, one converter (32 rows), one MFMA wave (32 rows x 32 Z rows, 96 accumulators) each.  One barrier per k-step:
+//   after it, raw stage ks + 1 has landed and digit buffer ks % 2 holds stage ks; during k-step ks the MFMA waves contract that
+//   buffer, the converters turn raw stage ks + 1 into the other one, the loaders refill the raw buffer of stage ks (converted during
+//   k-step ks - 1) with stage ks + 4 and wait for stage ks + 2.
+#define SD_TM 128
+#define SD_D 4
+__device__ __forceinline__ void sd_dma16(const void* gsrc, unsigned lds_dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+				 : "=&s"(keep)
+				 : "v"(gsrc), "s"(lds_dst)
+				 : "memory");
+}
+#define SD_PS 6  // DMA instructions per loader wave and stage: 4 of the 16 row groups (8 rows x 128 B each) + 2 of the 8 Z slots (6 planes, 2 spares)
+__device__ __forceinline__ void sd_wait(int younger) {  // all of this wave's DMA done except those of `younger` (0..3) stages
+	if (younger <= 0)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	else if (younger == 1)
+		asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SD_PS) : "memory");
+	else if (younger == 2)
+		asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * SD_PS) : "memory");
+	else
+		asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * SD_PS) : "memory");
+}
+
+#define SD_SLAB ((int64_t)SD_TM * (SQN + 1 + SQ_DIG))
+
+__global__ void __launch_bounds__(768) k_skinny_i8_dma(const float* __restrict__ Y, int64_t rows, int64_t n, int64_t ldy, const int* __restrict__ ysh,
+													   const char* __restrict__ ZQ, int64_t zplane, const int* __restrict__ zsh, double* __restrict__ G,
+													   double* __restrict__ ss, double* __restrict__ dig, SkinnyQSched s) {
+	constexpr int NS = SQ_NS, D = SD_D;
+	constexpr int RSTAGE = SD_TM * 128, ASTAGE = (SD_TM / 32) * NS * 1024, ZSTAGE = NS * 1024, ZD = D + 1;
+	__shared__ __attribute__((aligned(1024))) char rlds[D * RSTAGE];
+	__shared__ __attribute__((aligned(1024))) char alds[2 * ASTAGE];
+	// the Z planes of a stage travel with its rows, D stages ahead, and are read at its k-step: D + 1 buffers (+ 2 KB for the two spare slots)
+	__shared__ __attribute__((aligned(1024))) char zlds[ZD * ZSTAGE + 2048];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0-3 MFMA, 4-7 converters, 8-11 loaders
+	typedef __attribute__((address_space(3))) char* lds_ptr_t;
+	const unsigned rlds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)rlds);
+	const unsigned zlds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)zlds);
+	const int per_xcd = s.nwg >> 3;
+	const int p = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+	int t_dp = p;
+	int64_t u = (int64_t)p * s.units_per_wg;
+	const int64_t total = (int64_t)s.tiles_sk * s.nkt;
+	int64_t uend = u + s.units_per_wg;
+	if (uend > total) uend = total;
+	int sk_piece = 0;
+	const int nks_all = (int)((n + 31) / 32);
+	const int64_t n16 = (n + 15) / 16 * 16;
+	const int mr = lane & 31;
+	const int pos = (2 * mr + ((lane >> 5) ^ ((mr >> 3) & 1))) * 16;
+	for (;;) {
+		int t, c0, c1;
+		double* slab = nullptr;
+		if (t_dp < s.tiles_dp) {
+			t = t_dp;
+			c0 = 0;
+			c1 = s.nkt;
+			t_dp += s.nwg;
+		} else if (u < uend) {
+			const int ts = (int)(u / s.nkt);
+			c0 = (int)(u - (int64_t)ts * s.nkt);
+			int64_t c1l = c0 + (uend - u);
+			c1 = c1l > s.nkt ? s.nkt : (int)c1l;
+			t = s.tiles_dp + ts;
+			u += c1 - c0;
+			if (!(c0 == 0 && c1 == s.nkt)) slab = s.work + ((int64_t)2 * p + sk_piece) * SD_SLAB;
+			sk_piece++;
+		} else {
+			break;
+		}
+		const int st0 = c0 * (SQC / 32);
+		int st1 = c1 * (SQC / 32);
+		if (st1 > nks_all) st1 = nks_all;
+		const int64_t row0 = (int64_t)t * SD_TM;
+		__syncthreads();  // previous piece: everyone is done with LDS
+		if (wid >= 8) {
+			// ---- loader waves: DMA issue, counted waits, the barriers ----
+			const int li = wid - 8;
+			const float* ysrc[4];  // row groups li, li + 4, li + 8, li + 12 (8 rows each): lane -> row lane >> 3, 16-byte chunk lane & 7
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int64_t r = row0 + 8 * (li + 4 * j) + (lane >> 3);
+				ysrc[j] = Y + (r < rows ? r : 0) * ldy + (lane & 7) * 4;
+			}
+			const char* zsrc[2];  // Z slots li and li + 4 (slots 6 and 7 re-fetch plane 0 into spare LDS: every loader issues the same count)
+#pragma unroll
+			for (int q = 0; q < 2; q++) {
+				const int slot = li + 4 * q;
+				zsrc[q] = ZQ + (int64_t)(slot < NS ? slot : 0) * zplane + lane * 16;
+			}
+			auto issue = [&](int buf, int ks) {
+				const int64_t k0 = (int64_t)ks * 32;
+				const bool past = k0 + (lane & 7) * 4 >= n16;  // beyond the readable part of the rows: fetch anything valid, the converter zeroes it
+				if (SQ_EXP & 4) return;
+#pragma unroll
+				for (int j = 0; j < 4; j++) sd_dma16(past ? (const void*)Y : (const void*)(ysrc[j] + k0), rlds0 + buf * RSTAGE + (li + 4 * j) * 1024);
+				const unsigned zb = zlds0 + ((ks - st0) % ZD) * ZSTAGE;
+				sd_dma16(zsrc[0] + (int64_t)ks * 1024, zb + li * 1024);  // planes 0-3
+				sd_dma16(zsrc[1] + (int64_t)ks * 1024, li < 2 ? zb + (li + 4) * 1024 : zlds0 + ZD * ZSTAGE + (li - 2) * 1024);  // planes 4, 5; spares
+			};
+			for (int d = 0; d < D; d++)
+				if (st0 + d < st1) issue(d, st0 + d);
+			{
+				int younger = st1 - 1 - st0;
+				sd_wait(younger > D - 1 ? D - 1 : younger);  // stage st0 has landed
+			}
+			__syncthreads();  // A: the converters may read raw stage st0
+			{
+				int younger = st1 - 2 - st0;
+				if (st0 + 1 < st1) sd_wait(younger > D - 2 ? D - 2 : younger);  // stage st0 + 1 has landed
+			}
+			__syncthreads();  // B: digit buffer 0 holds stage st0
+			for (int ks = st0; ks < st1; ks++) {
+				if (ks + D < st1) issue((ks - st0) % D, ks + D);  // the raw buffer of stage ks was converted during k-step ks - 1
+				if (ks + 2 < st1) {
+					int younger = st1 - 3 - ks;  // stages issued beyond ks + 2
+					sd_wait(younger > D - 2 ? D - 2 : younger);  // stage ks + 2 has landed
+				}
+				__syncthreads();
+			}
+			continue;
+		}
+		if (wid >= 4) {
+			// ---- converter waves: raw stage in LDS -> digit images in LDS; sums of squares of their 32 rows ----
+			const int cw = wid - 4, lr = lane >> 3, c4 = (lane & 7) * 4;
+			int sh[4];
+			double sq[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int64_t r = row0 + cw * 32 + 8 * j + lr;
+				sh[j] = ysh[r < rows ? r : 0];
+				sq[j] = 0.0;
+			}
+			auto convert = [&](int rbuf, int abuf, int ks) {
+				if (SQ_EXP & 2) return;
+				const char* raw = rlds + rbuf * RSTAGE + (cw * 32 + lr) * 128 + (lane & 7) * 16;
+				char* a = alds + abuf * ASTAGE + (cw * NS) * 1024;
+				const bool inside = (int64_t)ks * 32 + c4 < n;  // (cells from n to the end of the k-step count as zeros)
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					float4 v = *reinterpret_cast<const float4*>(raw + j * 8 * 128);
+					if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+					if (inside && (int64_t)ks * 32 + c4 + 4 > n) {  // the row ends inside these four cells
+						const int64_t k = (int64_t)ks * 32 + c4;
+						if (k + 1 >= n) v.y = 0.f;
+						if (k + 2 >= n) v.z = 0.f;
+						if (k + 3 >= n) v.w = 0.f;
+					}
+					double x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+					for (int i = 0; i < 4; i++) sq[j] = fma(x[i], x[i], sq[j]);
+					unsigned w[NS];
+					nrm_digits4<NS>(x, sh[j], w);
+					const int rr = j * 8 + lr;  // row of the 32-row block; halves swapped when (rr >> 3) & 1 = j & 1
+					char* dst = a + (2 * rr) * 16 + (((c4 >> 4) ^ (j & 1)) << 4) + (c4 & 15);
+#pragma unroll
+					for (int q = 0; q < NS; q++) *reinterpret_cast<unsigned*>(dst + q * 1024) = w[q];
+				}
+			};
+			__syncthreads();  // A
+			if (st0 < st1) convert(0, 0, st0);
+			__syncthreads();  // B
+			for (int ks = st0; ks < st1; ks++) {
+				if (ks + 1 < st1) convert((ks + 1 - st0) % D, (ks + 1 - st0) & 1, ks + 1);
+				__syncthreads();
+			}
+			double* sbase = slab ? slab + SD_TM * SQN : ss + row0;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				double v = sq[j];
+				v += __shfl_xor(v, 1, 64);
+				v += __shfl_xor(v, 2, 64);
+				v += __shfl_xor(v, 4, 64);
+				if ((lane & 7) == 0) sbase[cw * 32 + 8 * j + lr] = v;
+			}
+			continue;
+		}
+		// ---- MFMA waves: 32 rows x 32 Z rows each ----
+		i16_t acc[NS];
+		auto clear = [&]() {
+#pragma unroll
+			for (int w = 0; w < NS; w++)
+#pragma unroll
+				for (int j = 0; j < 16; j++) acc[w][j] = 0;
+		};
+		double* gbase = slab ? slab + (wid * 32) * SQN : G + (row0 + wid * 32) * SQN;
+		double* dbase = slab ? slab + SD_TM * (SQN + 1) + (wid * 32) * SQ_DIG : dig + (row0 + wid * 32) * SQ_DIG;
+		const int zsh_l = zsh[lane & 31];
+		auto flush = [&](bool first) {
+#pragma unroll
+			for (int q = 0; q < 16; q++) {
+				const int rr = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+				long long lo = 0, hi = 0;
+#pragma unroll
+				for (int w = 0; w < NS; w++) {
+					if (w < 3)
+						lo += (long long)acc[w][q] << (8 * w);
+					else
+						hi += (long long)acc[w][q] << (8 * (w - 3));
+				}
+				double v = fma((double)hi, 16777216.0, (double)lo);
+				const int64_t r = row0 + wid * 32 + rr;
+				v = ldexp(v, ysh[r < rows ? r : 0] + zsh_l + 8 * (NS - 1));
+				double* o = gbase + (int64_t)rr * SQN + (lane & 31);
+				*o = first ? v : *o + v;
+				if ((lane & 31) == SQN - 1) {
+#pragma unroll
+					for (int w = 0; w < SQ_DIG; w++) {
+						const double dv = w < NS - 1 ? (double)acc[w][q] * 0.03125 : 0.0;
+						double* od = dbase + (int64_t)rr * SQ_DIG + w;
+						*od = first ? dv : *od + dv;
+					}
+				}
+			}
+		};
+		clear();
+		int in_chunk = 0;
+		bool first = true;
+		__syncthreads();  // A
+		__syncthreads();  // B: digit buffer 0 holds stage st0, its Z planes have landed
+		for (int ks = st0; ks < st1; ks++) {
+			const char* a = alds + ((ks - st0) & 1) * ASTAGE + (wid * NS) * 1024 + pos;
+			const char* z = zlds + ((ks - st0) % ZD) * ZSTAGE + pos;
+			i4_t fa[NS], fb[NS];
+			if (SQ_EXP & 1) {
+				__syncthreads();
+				continue;
+			}
+			fa[0] = *reinterpret_cast<const i4_t*>(a);
+			fb[NS - 1] = *reinterpret_cast<const i4_t*>(z + (NS - 1) * 1024);
+			fa[1] = *reinterpret_cast<const i4_t*>(a + 1024);
+			fb[NS - 2] = *reinterpret_cast<const i4_t*>(z + (NS - 2) * 1024);
+#pragma unroll
+			for (int sI = 0; sI < NS; sI++) {
+#pragma unroll
+				for (int tI = NS - 1 - sI; tI < NS; tI++) acc[sI + tI - (NS - 1)] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[sI], fb[tI], acc[sI + tI - (NS - 1)], 0, 0, 0);
+				if (sI + 2 < NS) {
+					fa[sI + 2] = *reinterpret_cast<const i4_t*>(a + (sI + 2) * 1024);
+					fb[NS - 3 - sI] = *reinterpret_cast<const i4_t*>(z + (NS - 3 - sI) * 1024);
+				}
+			}
+			__syncthreads();
+			if (++in_chunk >= SQ_FLUSH && ks + 1 < st1) {
+				flush(first);
+				first = false;
+				clear();
+				in_chunk = 0;
+			}
+		}
+		if (st0 < st1)
+			flush(first);
+		else if (slab) {
+			clear();
+			flush(true);
+		}
+	}
+}
+
 // Sum the slabs of every split row tile in workgroup order (deterministic) into G, ss and dig.
 __global__ void __launch_bounds__(256) k_skinny_i8_fixup(double* __restrict__ G, double* __restrict__ ss, double* __restrict__ dig, SkinnyQSched s) {
 	const int ts = blockIdx.x;
@@ -327,18 +593,19 @@ __global__ void __launch_bounds__(256) k_skinny_i8_fixup(double* __restrict__ G,
 	if (first == last && (int64_t)first * s.units_per_wg <= u0 && (int64_t)(first + 1) * s.units_per_wg >= u1) return;  // written whole
 	const int64_t t = s.tiles_dp + ts;
 	const int e = (blockIdx.y * 256 + threadIdx.x) * 2;
-	if (e >= SQ_SLAB) return;
+	const int64_t slab = (int64_t)s.tm * (SQN + 1 + SQ_DIG);
+	if (e >= slab) return;
 	const int first_local = ((int64_t)first * s.units_per_wg / s.nkt) == ts ? 0 : 1;
-	const double* src = s.work + ((int64_t)2 * first + first_local) * SQ_SLAB + e;
+	const double* src = s.work + ((int64_t)2 * first + first_local) * slab + e;
 	d2v_t acc = *reinterpret_cast<const d2v_t*>(src);
-	src += (int64_t)(2 - first_local) * SQ_SLAB;
-	for (int p = first + 1; p <= last; p++, src += 2 * SQ_SLAB) acc += *reinterpret_cast<const d2v_t*>(src);
-	if (e < SQ_TM * SQN)
-		*reinterpret_cast<d2v_t*>(G + t * SQ_TM * SQN + e) = acc;
-	else if (e < SQ_TM * (SQN + 1))
-		*reinterpret_cast<d2v_t*>(ss + t * SQ_TM + (e - SQ_TM * SQN)) = acc;
+	src += (int64_t)(2 - first_local) * slab;
+	for (int p = first + 1; p <= last; p++, src += 2 * slab) acc += *reinterpret_cast<const d2v_t*>(src);
+	if (e < s.tm * SQN)
+		*reinterpret_cast<d2v_t*>(G + t * s.tm * SQN + e) = acc;
+	else if (e < s.tm * (SQN + 1))
+		*reinterpret_cast<d2v_t*>(ss + t * s.tm + (e - s.tm * SQN)) = acc;
 	else
-		*reinterpret_cast<d2v_t*>(dig + t * SQ_TM * SQ_DIG + (e - SQ_TM * (SQN + 1))) = acc;
+		*reinterpret_cast<d2v_t*>(dig + t * s.tm * SQ_DIG + (e - s.tm * (SQN + 1))) = acc;
 }
 
 // Row scales of a resident matrix for the integer engines: ysh[row] = e - 46 with 2^e > max_k |Y[row,k]| (frexp), and the rows'
@@ -416,7 +683,14 @@ extern "C" int nrm_skinny_i8(const void* d_y, int y_dtype, int64_t rows, int64_t
 	hipStream_t st = (hipStream_t)stream;
 	SkinnyQSched s;
 	s.work = (double*)d_work;
-	const int64_t tiles = rows_pad / SQ_TM;
+	static int variant = -1;  // NRM_DE_I8_DMA=0: fp32 rows through registers too (the first form of this kernel)
+	if (variant < 0) {
+		const char* e = getenv("NRM_DE_I8_DMA");
+		variant = (e && e[0] == '0') ? 0 : 1;
+	}
+	const bool dma = y_dtype == NRM_F32 && variant == 1;
+	s.tm = dma ? SD_TM : SQ_TM;
+	const int64_t tiles = rows_pad / s.tm;
 	s.nkt = (int)(k_pad / SQC);
 	s.nwg = sq_num_cu();
 	s.nwg -= s.nwg % 8;
@@ -428,10 +702,13 @@ extern "C" int nrm_skinny_i8(const void* d_y, int y_dtype, int64_t rows, int64_t
 	if (y_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_skinny_i8<double>, dim3((unsigned)s.nwg), dim3(512), 0, st, (const double*)d_y, rows, n, ldy, d_ysh, (const char*)d_zq, zplane,
 						   d_zsh, d_g, d_ss, d_dig, s);
+	else if (dma)
+		hipLaunchKernelGGL(k_skinny_i8_dma, dim3((unsigned)s.nwg), dim3(768), 0, st, (const float*)d_y, rows, n, ldy, d_ysh, (const char*)d_zq, zplane, d_zsh,
+						   d_g, d_ss, d_dig, s);
 	else
 		hipLaunchKernelGGL(k_skinny_i8<float>, dim3((unsigned)s.nwg), dim3(512), 0, st, (const float*)d_y, rows, n, ldy, d_ysh, (const char*)d_zq, zplane,
 						   d_zsh, d_g, d_ss, d_dig, s);
 	if (s.tiles_sk > 0)
-		hipLaunchKernelGGL(k_skinny_i8_fixup, dim3((unsigned)s.tiles_sk, (unsigned)((SQ_SLAB / 2 + 255) / 256)), dim3(256), 0, st, d_g, d_ss, d_dig, s);
+		hipLaunchKernelGGL(k_skinny_i8_fixup, dim3((unsigned)s.tiles_sk, (unsigned)((s.tm * (SQN + 1 + SQ_DIG) / 2 + 255) / 256)), dim3(256), 0, st, d_g, d_ss, d_dig, s);
 	return nrm_check_launch("k_skinny_i8");
 }
