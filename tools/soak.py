@@ -11,6 +11,13 @@ import oracle
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
 worst = dict(p=0.0, d=0.0)
+from normalisr_amd.engine import get_engine
+guard = dict(calls=0, fallbacks=0, worst=0.0)  # the integer engine's accuracy guard over the soak
+def note_guard():
+	g = get_engine().last_guard
+	guard['calls'] += 1
+	guard['fallbacks'] += bool(g['fallback'])
+	guard['worst'] = max(guard['worst'], g['worst'])
 t0 = time.time()
 for it in range(cases):
 	ng = int(rng.choice([1, 2, 127, 128, 129, 500, 1023, 1025, 1500, 2049, 2600, 3100]))
@@ -28,6 +35,7 @@ for it in range(cases):
 	tol = 2e-6 if f32 else 1e-6
 	if ng > 1:
 		p, d, v = norm.coex(dt, dc)
+		note_guard()
 		po, do, vo = oracle.coex(d64, dc)
 		m = ~np.eye(ng, dtype=bool)
 		ep = float(np.max(np.abs(p[m] - po[m]) / np.maximum(po[m], 1e-30)))
@@ -38,10 +46,11 @@ for it in range(cases):
 	dg = (rng.random((nx, n)) < 0.3).astype(dt.dtype)
 	dg[:, 0], dg[:, 1] = 0, 1  # never constant
 	r = norm.de(dg, dt, dc)
+	note_guard()
 	ro = oracle.de(dg.astype(np.float64), d64, dc)
 	ep = float(np.max(np.abs(r[0] - ro[0]) / np.maximum(ro[0], 1e-30)))
 	eg = float(np.max(np.abs(r[1] - ro[1]) / np.maximum(np.abs(ro[1]), 1e-6)))
 	assert ep < tol and eg < tol, ('de', nx, ng, n, nc, f32, ep, eg)
 	worst['p'], worst['d'] = max(worst['p'], ep), max(worst['d'], eg)
 	print('case %d ok: genes %d cells %d cov %d %s  (%.0f s)' % (it, ng, n, nc, 'fp32' if f32 else 'fp64', time.time() - t0), flush=True)
-print('all ok; worst relative errors', worst)
+print('all ok; worst relative errors', worst, 'guard', guard)
