@@ -78,7 +78,9 @@ __device__ __forceinline__ void fix_finish(const FixArgs& f, int32_t* __restrict
 	}
 	if ((threadIdx.x & 63) == 0) {
 		if (bad) atomicAdd(&flags[2], bad);
-		if (worst > 0.f) atomicMax(&flags[3], __float_as_int(worst));
+		// (a maximum only grows: a wave that cannot raise it stays away -- tens of thousands of atomics on one address cost more than
+		// the guard itself; a stale read merely sends a redundant atomic)
+		if (worst > 0.f && __float_as_int(worst) > __hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[3], __float_as_int(worst));
 	}
 }
 
@@ -192,49 +194,62 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep(const double* __restrict
 
 // Symmetric (coex) sweep over the upper triangle of 64x64 tiles only: every p-value is computed once and
 // written twice (direct and mirrored through an LDS transpose), halving the special-function work.
-template <typename OutT>
+// A workgroup is one straight line: every thread loads its 16 products straight from memory (coalesced along tx) while the row
+// tables are staged, computes, stores its results and leaves a copy in LDS; ONE barrier that waits for LDS only (the stores stay
+// in flight: __syncthreads() would drain them, and at 3 workgroups per CU those drains were a third of this kernel's time)
+// publishes the tile, and the mirrored block is stored from its transpose.
+template <typename OutT, int SR>  // SR: rows of a workgroup's piece of a tile (64, 32 or 16; 32 = two workgroups per tile: a finer tail)
 __global__ void __launch_bounds__(256, 3) k_assoc_sweep_sym(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ss,
 														  int64_t ng, int nb, double ncells, PvalPlan pl, OutT* __restrict__ p_out,
 														  OutT* __restrict__ stat_out, int64_t ldo, int32_t* __restrict__ flags, int bi0, FixArgs fix) {
-	__shared__ double tile[SW_T][SW_T + 1];
-	__shared__ double sx[SW_T], sy[SW_T];
-	__shared__ double sfx[SW_T][SW_FIX];
-	int b = blockIdx.x, bi = bi0, len = nb - bi0;
+	__shared__ OutT tp[SR][SW_T + 1], ts[SR][SW_T + 1];  // results of the piece, read back transposed
+	__shared__ double sx[SR], sy[SW_T];
+	__shared__ double sfx[SR][SW_FIX];
+	constexpr int NI = SR / 4;
+	const int h0 = (int)(blockIdx.x % (SW_T / SR)) * SR;  // first row of the piece within its tile
+	int b = blockIdx.x / (SW_T / SR), bi = bi0, len = nb - bi0;
 	while (b >= len) {
 		b -= len;
 		bi++;
 		len--;
 	}
 	const int bj = bi + b;
-	fix_stage_rows(fix, sfx, (int64_t)bi * SW_T, ng);
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-	for (int r = ty; r < SW_T; r += 4) {
-		int64_t gi = (int64_t)bi * SW_T + r, gj = (int64_t)bj * SW_T + tx;
-		tile[r][tx] = (gi < ng && gj < ng) ? dot[gi * ldd + gj] : 0.0;
+	const int64_t gj = (int64_t)bj * SW_T + tx;
+	double dv[NI];
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		const int64_t gi = (int64_t)bi * SW_T + h0 + ty + 4 * i;
+		dv[i] = (gi < ng && gj < ng) ? dot[gi * ldd + gj] : 0.0;
 	}
-	if (threadIdx.x < SW_T) {
-		int64_t gi = (int64_t)bi * SW_T + threadIdx.x;
+	if (fix.fx)
+		for (int i = threadIdx.x; i < SR * SW_FIX; i += 256) {
+			const int r = i / SW_FIX, c = i - r * SW_FIX;
+			const int64_t gi = (int64_t)bi * SW_T + h0 + r;
+			sfx[r][c] = gi < ng ? fix.fx[gi * NRM_FIX_STRIDE + c] : 0.0;
+		}
+	if (threadIdx.x >= 128 && threadIdx.x < 128 + SR) {
+		const int t = threadIdx.x - 128;
+		int64_t gi = (int64_t)bi * SW_T + h0 + t;
 		double v = gi < ng ? ss[gi] : 1.0;
-		sx[threadIdx.x] = (v == 0.0) ? ncells : v;
-	} else if (threadIdx.x < 2 * SW_T) {
+		sx[t] = (v == 0.0) ? ncells : v;
+	} else if (threadIdx.x >= SW_T && threadIdx.x < 2 * SW_T) {
 		int t = threadIdx.x - SW_T;
-		int64_t gj = (int64_t)bj * SW_T + t;
-		double v = gj < ng ? ss[gj] : 1.0;
+		int64_t gc = (int64_t)bj * SW_T + t;
+		double v = gc < ng ? ss[gc] : 1.0;
 		sy[t] = (v == 0.0) ? ncells : v;
 	}
+	const FixCol fy = fix_column(fix, gj, ng);
 	__syncthreads();
 	int bad_nf = 0, bad_rng = 0;
 	FixAcc facc = nrm_fix_acc();
 	const double sqrt_dof = sqrt(fix.dof);
-	const int64_t gj = (int64_t)bj * SW_T + tx;
-	const FixCol fy = fix_column(fix, gj, ng);
-	OutT pv[SW_T / 4], sv[SW_T / 4];  // (in the output type: half the registers for fp32 results)
 #pragma unroll
-	for (int i = 0; i < SW_T / 4; i++) {
+	for (int i = 0; i < NI; i++) {
 		const int r = ty + 4 * i;
-		const int64_t gi = (int64_t)bi * SW_T + r;
-		const bool lower = bi == bj && r > tx;  // below the diagonal of a diagonal tile: filled in from its mirror image afterwards
-		double d = tile[r][tx];
+		const int64_t gi = (int64_t)bi * SW_T + h0 + r;
+		const bool lower = bi == bj && h0 + r > tx;  // below the diagonal of a diagonal tile: filled in from its mirror image afterwards
+		double d = dv[i];
 		if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 		const double vx = sx[r], vy = sy[tx];
 		const double r2 = (d * d) / (vx * vy);
@@ -246,8 +261,8 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_sym(const double* __rest
 			st = d / ncells;
 			if (fix.fx && fix.budget > 0.0) nrm_fix_note(facc, sfx[r][5], sfx[r][6], r2);
 		}
-		pv[i] = (OutT)p;
-		sv[i] = (OutT)st;
+		tp[r][tx] = (OutT)p;
+		ts[r][tx] = (OutT)st;
 		if (gi < ng && gj < ng && !lower) {
 			p_out[gi * ldo + gj] = (OutT)p;
 			stat_out[gi * ldo + gj] = (OutT)st;
@@ -255,35 +270,27 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_sym(const double* __rest
 	}
 	if (fix.fx && fix.budget > 0.0 && nrm_fix_screen(fix, facc, fy, sqrt_dof)) {  // rare: the exact test, pair by pair
 #pragma unroll
-		for (int i = 0; i < SW_T / 4; i++) {  // (unrolled: pv[i] -- is the pair's P-value 0? -- stays in registers)
+		for (int i = 0; i < NI; i++) {
 			const int r = ty + 4 * i;
-			const int64_t gi = (int64_t)bi * SW_T + r;
-			if (gi >= ng || gj >= ng || gi == gj || (bi == bj && r > tx)) continue;
-			const double d = tile[r][tx] + nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
-			nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, (d * d) / (sx[r] * sy[tx]), sqrt_dof, pv[i] != (OutT)0, facc);
+			const int64_t gi = (int64_t)bi * SW_T + h0 + r;
+			if (gi >= ng || gj >= ng || gi == gj || (bi == bj && h0 + r > tx)) continue;
+			const double d = dv[i] + nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+			nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, (d * d) / (sx[r] * sy[tx]), sqrt_dof, tp[r][tx] != (OutT)0, facc);
 		}
 	}
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tp / ts are complete; the stores above stay in flight
 	{
-		const int64_t oj = (int64_t)bi * SW_T + tx;  // mirrored block: rows of block bj, columns of block bi
-		__syncthreads();
+		// mirrored block: rows of block bj, columns h0 .. h0 + SR of block bi; a wave stores 64 / SR rows of SR results at a time
+		const int mc = threadIdx.x & (SR - 1), mr0 = threadIdx.x / SR;
+		const int64_t oj = (int64_t)bi * SW_T + h0 + mc;
 #pragma unroll
-		for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = pv[i];
-		__syncthreads();
-#pragma unroll
-		for (int i = 0; i < SW_T / 4; i++) {
-			const int r = ty + 4 * i;
+		for (int i = 0; i < NI; i++) {
+			const int r = mr0 + (256 / SR) * i;
 			const int64_t oi = (int64_t)bj * SW_T + r;
-			if (oi < ng && oj < ng && (bi != bj || r > tx)) p_out[oi * ldo + oj] = (OutT)tile[tx][r];
-		}
-		__syncthreads();
-#pragma unroll
-		for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = sv[i];
-		__syncthreads();
-#pragma unroll
-		for (int i = 0; i < SW_T / 4; i++) {
-			const int r = ty + 4 * i;
-			const int64_t oi = (int64_t)bj * SW_T + r;
-			if (oi < ng && oj < ng && (bi != bj || r > tx)) stat_out[oi * ldo + oj] = (OutT)tile[tx][r];
+			if (oi < ng && oj < ng && (bi != bj || r > h0 + mc)) {
+				p_out[oi * ldo + oj] = tp[mc][r];
+				stat_out[oi * ldo + oj] = ts[mc][r];
+			}
 		}
 	}
 	if (flags) {
@@ -301,11 +308,18 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_mirror(const double* __r
 															 const double* __restrict__ ssy, int64_t mx, int64_t my, double ncells, PvalPlan pl,
 															 OutT* __restrict__ p_out, OutT* __restrict__ stat_out, int64_t ldo, int64_t r0,
 															 int64_t c0, int32_t* __restrict__ flags, FixArgs fix) {
-	__shared__ double tile[SW_T][SW_T + 1];
+	__shared__ OutT tp[SW_T][SW_T + 1], ts[SW_T][SW_T + 1];  // results of the tile, read back transposed (as in k_assoc_sweep_sym)
 	__shared__ double sx[SW_T], sy[SW_T];
 	__shared__ double sfx[SW_T][SW_FIX];
 	const int bi = blockIdx.y, bj = blockIdx.x;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	const int64_t gj = (int64_t)bj * SW_T + tx;
+	double dv[SW_T / 4];
+#pragma unroll
+	for (int i = 0; i < SW_T / 4; i++) {
+		const int64_t gi = (int64_t)bi * SW_T + ty + 4 * i;
+		dv[i] = (gi < mx && gj < my) ? dot[gi * ldd + gj] : 0.0;
+	}
 	fix_stage_rows(fix, sfx, (int64_t)bi * SW_T, mx);
 	if (threadIdx.x < SW_T) {
 		const int64_t gi = (int64_t)bi * SW_T + threadIdx.x;
@@ -313,24 +327,22 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_mirror(const double* __r
 		sx[threadIdx.x] = (v == 0.0) ? ncells : v;  // variance 0 -> 1  (association.py:231)
 	} else if (threadIdx.x < 2 * SW_T) {
 		const int t = threadIdx.x - SW_T;
-		const int64_t gj = (int64_t)bj * SW_T + t;
-		const double v = gj < my ? ssy[gj] : 1.0;
+		const int64_t gc = (int64_t)bj * SW_T + t;
+		const double v = gc < my ? ssy[gc] : 1.0;
 		sy[t] = (v == 0.0) ? ncells : v;
 	}
 	__syncthreads();
 	int bad_nf = 0, bad_rng = 0;
 	FixAcc facc = nrm_fix_acc();
 	const double sqrt_dof = sqrt(fix.dof);
-	const int64_t gj = (int64_t)bj * SW_T + tx;
 	const FixCol fy = fix_column(fix, gj, my);
-	OutT pv[SW_T / 4], sv[SW_T / 4];  // (in the output type: half the registers for fp32 results)
 #pragma unroll
 	for (int i = 0; i < SW_T / 4; i++) {
 		const int r = ty + 4 * i;
 		const int64_t gi = (int64_t)bi * SW_T + r;
 		double p = 0.0, st = 0.0;
 		if (gi < mx && gj < my) {
-			double d = dot[gi * ldd + gj];
+			double d = dv[i];
 			if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 			const double vx = sx[r], vy = sy[tx];
 			const double r2 = (d * d) / (vx * vy);
@@ -342,38 +354,29 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_mirror(const double* __r
 			p_out[(r0 + gi) * ldo + c0 + gj] = (OutT)p;
 			stat_out[(r0 + gi) * ldo + c0 + gj] = (OutT)st;
 		}
-		pv[i] = (OutT)p;
-		sv[i] = (OutT)st;
+		tp[r][tx] = (OutT)p;
+		ts[r][tx] = (OutT)st;
 	}
 	if (fix.fx && fix.budget > 0.0 && nrm_fix_screen(fix, facc, fy, sqrt_dof)) {  // rare: the exact test, pair by pair
 #pragma unroll
-		for (int i = 0; i < SW_T / 4; i++) {  // (unrolled: pv[i] -- is the pair's P-value 0? -- stays in registers)
+		for (int i = 0; i < SW_T / 4; i++) {
 			const int r = ty + 4 * i;
 			const int64_t gi = (int64_t)bi * SW_T + r;
 			if (gi >= mx || gj >= my) continue;
-			const double d = dot[gi * ldd + gj] + nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
-			nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, (d * d) / (sx[r] * sy[tx]), sqrt_dof, pv[i] != (OutT)0, facc);
+			const double d = dv[i] + nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+			nrm_fix_guard(fix, sfx[r][5], sfx[r][6], fy, (d * d) / (sx[r] * sy[tx]), sqrt_dof, tp[r][tx] != (OutT)0, facc);
 		}
 	}
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tp / ts are complete; the stores above stay in flight
 	const int64_t oj = (int64_t)bi * SW_T + tx;  // mirrored: rows c0 + (block bj), columns r0 + (block bi)
 #pragma unroll
-	for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = pv[i];
-	__syncthreads();
-#pragma unroll
 	for (int i = 0; i < SW_T / 4; i++) {
 		const int r = ty + 4 * i;
 		const int64_t oi = (int64_t)bj * SW_T + r;
-		if (oi < my && oj < mx) p_out[(c0 + oi) * ldo + r0 + oj] = (OutT)tile[tx][r];
-	}
-	__syncthreads();
-#pragma unroll
-	for (int i = 0; i < SW_T / 4; i++) tile[ty + 4 * i][tx] = sv[i];
-	__syncthreads();
-#pragma unroll
-	for (int i = 0; i < SW_T / 4; i++) {
-		const int r = ty + 4 * i;
-		const int64_t oi = (int64_t)bj * SW_T + r;
-		if (oi < my && oj < mx) stat_out[(c0 + oi) * ldo + r0 + oj] = (OutT)tile[tx][r];
+		if (oi < my && oj < mx) {
+			p_out[(c0 + oi) * ldo + r0 + oj] = tp[tx][r];
+			stat_out[(c0 + oi) * ldo + r0 + oj] = ts[tx][r];
+		}
 	}
 	if (flags) {
 		if (bad_nf) atomicAdd(&flags[0], 1);
@@ -518,7 +521,7 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 		if (bad_rng) atomicAdd(&flags[1], 1);
 		if (sf.zfix) {
 			if (bad_fix) atomicAdd(&flags[2], bad_fix);
-			if (worst > 0.f) atomicMax(&flags[3], __float_as_int(worst));
+			if (worst > 0.f && __float_as_int(worst) > __hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[3], __float_as_int(worst));
 		}
 	}
 }
@@ -578,12 +581,13 @@ extern "C" int nrm_assoc_sweep_band(const double* d_dot, int64_t ldd, const doub
 	if (symmetric && !d_r && !d_t && stat_kind == 0) {
 		// upper-triangle blocks of block rows [b0, b1); their mirrored writes land in rows >= row0, columns [row0, row1)
 		const int64_t nb = (nx + SW_T - 1) / SW_T;
-		dim3 g((unsigned)((b1 - b0) * nb - (b1 * (b1 - 1) - b0 * (b0 - 1)) / 2));
+		const unsigned tiles = (unsigned)((b1 - b0) * nb - (b1 * (b1 - 1) - b0 * (b0 - 1)) / 2);
+		// pieces of 32 rows: 0.185 ms on BASELINE configs[1] against 0.196 with whole tiles (tools/k3_time.py), 16 rows gain nothing more
 		if (out_dtype == NRM_F64)
-			hipLaunchKernelGGL(k_assoc_sweep_sym<double>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
+			hipLaunchKernelGGL((k_assoc_sweep_sym<double, 32>), dim3(tiles * 2), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
 							   (double)n_cells, to_dev(plan), (double*)d_p, (double*)d_stat, ldo, d_flags, (int)b0, fix);
 		else
-			hipLaunchKernelGGL(k_assoc_sweep_sym<float>, g, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
+			hipLaunchKernelGGL((k_assoc_sweep_sym<float, 32>), dim3(tiles * 2), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_ssx, nx, (int)nb,
 							   (double)n_cells, to_dev(plan), (float*)d_p, (float*)d_stat, ldo, d_flags, (int)b0, fix);
 		return nrm_check_launch("k_assoc_sweep_sym");
 	}

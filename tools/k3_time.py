@@ -1,5 +1,5 @@
 """Time nrm_assoc_sweep alone (symmetric, C2 shape, fp32 outputs) from a given build: without row records (fp64 Gram kernels), with
-the integer engine's correction only (guard tolerance 0), and with correction + guard.  Usage: k3_time.py [lib.so]"""
+the integer engine's correction only (guard tolerance 0), and with correction + guard.  Usage: k3_time.py [lib.so|-] [genes]"""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -7,8 +7,9 @@ from normalisr_amd import _lib
 if len(sys.argv) > 1 and sys.argv[1] != '-':
 	_lib.LIB_PATH = sys.argv[1]
 lib = _lib.load()
-ng, n = 5000, 10000
-mp = 5120
+ng = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+n = 10000
+mp = (ng + 255) // 256 * 256
 g = torch.Generator(device='cuda').manual_seed(3)
 x = torch.randn((ng, n), dtype=torch.float64, device='cuda', generator=g)
 dot = torch.zeros((mp, mp), dtype=torch.float64, device='cuda')
