@@ -244,28 +244,47 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_sym(const double* __rest
 	int bad_nf = 0, bad_rng = 0;
 	FixAcc facc = nrm_fix_acc();
 	const double sqrt_dof = sqrt(fix.dof);
+	unsigned slow = 0;  // pairs the straight-line P-value does not cover (R^2 >= 1/4, small dof, non-finite): redone below
 #pragma unroll
 	for (int i = 0; i < NI; i++) {
 		const int r = ty + 4 * i;
 		const int64_t gi = (int64_t)bi * SW_T + h0 + r;
 		const bool lower = bi == bj && h0 + r > tx;  // below the diagonal of a diagonal tile: filled in from its mirror image afterwards
+		const bool pair = gi < ng && gj < ng && gi != gj && !lower;
 		double d = dv[i];
 		if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
 		const double vx = sx[r], vy = sy[tx];
 		const double r2 = (d * d) / (vx * vy);
-		double p = 0.0, st = 0.0;
-		if (gi < ng && gj < ng && gi != gj && !lower) {
+		bool ok;
+		double p = nrm_pvalue_fast(r2, pl, ok);  // no branch around it: the NI evaluations of a thread interleave
+		double st = d / ncells;
+		if (pair) {
 			if (!isfinite(r2) || !isfinite(vx) || !isfinite(vy)) bad_nf = 1;
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
-			p = nrm_pvalue(r2, pl);
-			st = d / ncells;
+			if (!ok) slow |= 1u << i;
 			if (fix.fx && fix.budget > 0.0) nrm_fix_note(facc, sfx[r][5], sfx[r][6], r2);
+		} else {
+			p = 0.0;
+			st = 0.0;
 		}
 		tp[r][tx] = (OutT)p;
 		ts[r][tx] = (OutT)st;
 		if (gi < ng && gj < ng && !lower) {
 			p_out[gi * ldo + gj] = (OutT)p;
 			stat_out[gi * ldo + gj] = (OutT)st;
+		}
+	}
+	if (slow) {
+#pragma unroll 1
+		for (int i = 0; i < NI; i++) {  // (one copy of the general P-value code: the product comes from memory again)
+			if (!(slow >> i & 1)) continue;
+			const int r = ty + 4 * i;
+			const int64_t gi = (int64_t)bi * SW_T + h0 + r;
+			double d = dot[gi * ldd + gj];
+			if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+			const OutT p = (OutT)nrm_pvalue((d * d) / (sx[r] * sy[tx]), pl);
+			tp[r][tx] = p;
+			p_out[gi * ldo + gj] = p;  // (after the store above, from the same thread: this one stays)
 		}
 	}
 	if (fix.fx && fix.budget > 0.0 && nrm_fix_screen(fix, facc, fy, sqrt_dof)) {  // rare: the exact test, pair by pair
@@ -336,26 +355,45 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_mirror(const double* __r
 	FixAcc facc = nrm_fix_acc();
 	const double sqrt_dof = sqrt(fix.dof);
 	const FixCol fy = fix_column(fix, gj, my);
+	unsigned slow = 0;  // (as in k_assoc_sweep_sym)
 #pragma unroll
 	for (int i = 0; i < SW_T / 4; i++) {
 		const int r = ty + 4 * i;
 		const int64_t gi = (int64_t)bi * SW_T + r;
-		double p = 0.0, st = 0.0;
-		if (gi < mx && gj < my) {
-			double d = dv[i];
-			if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
-			const double vx = sx[r], vy = sy[tx];
-			const double r2 = (d * d) / (vx * vy);
+		const bool pair = gi < mx && gj < my;
+		double d = dv[i];
+		if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+		const double vx = sx[r], vy = sy[tx];
+		const double r2 = (d * d) / (vx * vy);
+		bool ok;
+		double p = nrm_pvalue_fast(r2, pl, ok);
+		double st = d / ncells;
+		if (pair) {
 			if (!isfinite(r2) || !isfinite(vx) || !isfinite(vy)) bad_nf = 1;
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
-			p = nrm_pvalue(r2, pl);
-			st = d / ncells;
+			if (!ok) slow |= 1u << i;
 			if (fix.fx && fix.budget > 0.0) nrm_fix_note(facc, sfx[r][5], sfx[r][6], r2);
 			p_out[(r0 + gi) * ldo + c0 + gj] = (OutT)p;
 			stat_out[(r0 + gi) * ldo + c0 + gj] = (OutT)st;
+		} else {
+			p = 0.0;
+			st = 0.0;
 		}
 		tp[r][tx] = (OutT)p;
 		ts[r][tx] = (OutT)st;
+	}
+	if (slow) {
+#pragma unroll 1
+		for (int i = 0; i < SW_T / 4; i++) {
+			if (!(slow >> i & 1)) continue;
+			const int r = ty + 4 * i;
+			const int64_t gi = (int64_t)bi * SW_T + r;
+			double d = dot[gi * ldd + gj];
+			if (fix.fx) d += nrm_fix_corr(sfx[r], fy, fix.top, fix.inv_n);
+			const OutT p = (OutT)nrm_pvalue((d * d) / (sx[r] * sy[tx]), pl);
+			tp[r][tx] = p;
+			p_out[(r0 + gi) * ldo + c0 + gj] = p;
+		}
 	}
 	if (fix.fx && fix.budget > 0.0 && nrm_fix_screen(fix, facc, fy, sqrt_dof)) {  // rare: the exact test, pair by pair
 #pragma unroll

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 SRC=$1; MACRO=$2; shift 2
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -mllvm -amdgpu-mfma-vgpr-form=1"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -mllvm -amdgpu-mfma-vgpr-form=1 $EXTRA"
 mkdir -p tools/exp/obj tools/exp/var
 stem=$(basename $SRC .hip)
 for f in normalisr_amd/csrc/*.hip; do

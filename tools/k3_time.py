@@ -1,5 +1,5 @@
 """Time nrm_assoc_sweep alone (symmetric, C2 shape, fp32 outputs) from a given build: without row records (fp64 Gram kernels), with
-the integer engine's correction only (guard tolerance 0), and with correction + guard.  Usage: k3_time.py [lib.so|-] [genes]"""
+the integer engine's correction only (guard tolerance 0), and with correction + guard.  Usage: k3_time.py [lib.so|-] [genes] [common factor weight]"""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -12,6 +12,8 @@ n = 10000
 mp = (ng + 255) // 256 * 256
 g = torch.Generator(device='cuda').manual_seed(3)
 x = torch.randn((ng, n), dtype=torch.float64, device='cuda', generator=g)
+if len(sys.argv) > 3:  # a common factor of this weight in every row: R^2 = (w^2 / (1 + w^2))^2 for every pair
+	x += float(sys.argv[3]) * torch.randn((1, n), dtype=torch.float64, device='cuda', generator=g)
 dot = torch.zeros((mp, mp), dtype=torch.float64, device='cuda')
 dot[:ng, :ng] = x @ x.T
 ss = torch.zeros(mp, dtype=torch.float64, device='cuda')
