@@ -17,6 +17,12 @@
 #define RES_R 4
 #endif
 #define RES_CB 8
+#ifndef K1_U1
+#define K1_U1 2
+#endif
+#ifndef K1_U3
+#define K1_U3 1
+#endif
 #define RES_NC_MAX 2048  // OLS tables a = x C^T and b = a dci live in dynamic LDS: 2 * RES_R * nc doubles (128 KiB at 2048)
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -196,6 +202,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			for (int r = 0; r < RES_R; r++)
 #pragma unroll
 				for (int q = 0; q < CB; q++) acc[r][q] = 0.0;
+#pragma unroll K1_U1
 			for (int64_t k = (int64_t)tid * 4; k < n4; k += 1024) {
 				double xv[RES_R][4];
 #pragma unroll
@@ -390,6 +397,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			dsq[r][s] = 0u;
 		}
 	const int64_t kres = out ? ldo : ((n + 3) & ~(int64_t)3), kq = NS ? qo.nks * 32 : 0;
+#pragma unroll K1_U3
 	for (int64_t k = (int64_t)tid * 4; k < (kres > kq ? kres : kq); k += 1024) {
 		double v[RES_R][4];
 		if (k < n)
