@@ -209,6 +209,6 @@ extern "C" int nrm_gram_f64_band(const double* d_a, const double* d_b, int64_t m
 	NRM_TRY_RC(gram_plan(s, m_pad, n_pad, k_pad / GK, symmetric, m_rows, n_rows, row0, row1, 2 * g_num_cu, (double*)d_work));
 	hipLaunchKernelGGL(k_gram_f64, dim3((unsigned)s.nwg), dim3(256), 0, (hipStream_t)stream, d_a, d_b, lda, ldb, d_dot, ldd, symmetric, s);
 	if (s.tiles_al + s.tiles_sk > 0)
-		hipLaunchKernelGGL(k_gram_fixup<0>, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
+		hipLaunchKernelGGL(k_gram_fixup<0>, dim3((unsigned)(s.tiles_al + s.tiles_sk), GM / GFIX_ROWS), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_f64");
 }

@@ -379,7 +379,7 @@ static int gram_i8_impl(const void* d_qa, const int32_t* d_ea, int64_t plane_a_b
 		hipLaunchKernelGGL(k_gram_i8<6>, dim3((unsigned)s.nwg), dim3(512), 0, (hipStream_t)stream, (const char*)d_qa, (const char*)d_qb, plane_a,
 						   plane_b, nks, d_ea, d_eb, d_dot, ldd, symmetric, s, bb);
 	if (s.tiles_al + s.tiles_sk > 0)
-		hipLaunchKernelGGL(k_gram_fixup<1>, dim3((unsigned)(s.tiles_al + s.tiles_sk), 8), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
+		hipLaunchKernelGGL(k_gram_fixup<1>, dim3((unsigned)(s.tiles_al + s.tiles_sk), GM / GFIX_ROWS), dim3(256), 0, (hipStream_t)stream, d_dot, ldd, symmetric, s);
 	return nrm_check_launch("k_gram_i8");
 }
 

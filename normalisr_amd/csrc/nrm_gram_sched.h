@@ -7,6 +7,9 @@
 #include "nrm_host_logic.h"
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
+#ifndef GFIX_ROWS
+#define GFIX_ROWS 4  // rows of a split tile per fix-up workgroup (C2: 32 us at 16, 22 at 8, 18 at 4 -- one pass per thread)
+#endif
 
 // the persistent loop of this workgroup (see gram_pieces_of)
 template <typename F>
@@ -39,10 +42,10 @@ __global__ void __launch_bounds__(256) k_gram_fixup(double* __restrict__ C, int6
 		base = s.work + (int64_t)s.tiles_al * s.parts * (GM * GN);
 		sk_first_local = ((int64_t)first * s.units_per_wg / s.nkt) == ts ? 0 : 1;
 	}
-	// blockIdx.y selects 16 of the tile's 128 rows: 8 workgroups per tile keep enough loads in flight
+	// blockIdx.y selects GFIX_ROWS of the tile's 128 rows: enough workgroups to keep loads in flight (a thread's additions are a chain)
 	double* ct = C + (int64_t)ti * GM * ldc + (int64_t)tj * GN;
-	const int e0 = blockIdx.y * (16 * GN);
-	for (int e = e0 + threadIdx.x * 2; e < e0 + 16 * GN; e += 512) {
+	const int e0 = blockIdx.y * (GFIX_ROWS * GN);
+	for (int e = e0 + threadIdx.x * 2; e < e0 + GFIX_ROWS * GN; e += 512) {
 		d2_t acc = (d2_t){0.0, 0.0};
 		if (b < s.tiles_al) {
 			for (int q = 0; q < count; q++) acc += *reinterpret_cast<const d2_t*>(base + (int64_t)q * (GM * GN) + e);
