@@ -240,6 +240,16 @@ int nrm_alpha(const void* d_stat, int stat_dtype, int64_t ldg, int stat_kind, co
  *   nrm_de_small_sweep: |y~|^2 = ss - (y C^T) dci (C y^T), y~.x~ = y.x~  ->  R^2, p, gamma|cov (association.py:226-235,249);
  *       d_ssy (ny) receives |y~|^2; d_by (ny, nc) or NULL receives the OLS coefficients ccy (for alpha).
  */
+/*
+ * The OLS products a = x C^T of the design rows of the streaming de path (first half of association.py:224-227 for dx): rows <= 32
+ * design rows against nc <= 32 covariate rows, spread along the cells, partial sums added in a fixed order.
+ *   d_ga (rows, 32): a[r][c] at d_ga[r * 32 + c]; the last covariate in column 31 when const_last != 0 (the layout
+ *   nrm_residualize_wide reads).  d_work: nrm_design_products_workspace_doubles(rows, n_cells) doubles.
+ */
+int64_t nrm_design_products_workspace_doubles(int64_t rows, int64_t n_cells);
+int nrm_design_products(const void* d_x, int x_dtype, int64_t rows, int64_t n_cells, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
+						double* d_ga, double* d_work, int const_last, void* stream);
+
 /* Residualise <= 32 rows with the work spread along the cells (used for the design rows of the streaming path):
  * d_ga (rows, 32) holds x C^T in its first nc columns (from nrm_gram_skinny against Z = [C; 0]); out (rows, ldo) fp64,
  * zero padded up to ldo; d_ss (rows) sums of squares; d_coef (rows, nc) or NULL the OLS coefficients. */

@@ -625,6 +625,74 @@ __global__ void __launch_bounds__(256) k_rw_sum(const double* __restrict__ part,
 	if (threadIdx.x == 0) ss[r] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
+// The OLS products a = x C^T of a few design rows, spread along the cells like k_residualize_wide: every workgroup takes 1024 cells of
+// all rows and covariates, k_xc_sum adds the per-block partial sums in a fixed order (bitwise reproducible, no atomics).  Output in the
+// layout k_residualize_wide reads: ga[r * 32 + c], the last covariate in column 31 when const_last.  (Until late in round 3 these
+// came from nrm_gram_skinny on a 256-row tile holding the 1 - 31 design rows: one tile cut into 256 stream-K pieces, whose fix-up
+// then added 256 slabs in a chain -- 36 + 48 us per step of configs[2], against 8 + 4 here.)
+template <typename T>
+__global__ void __launch_bounds__(256) k_xc_partial(const T* __restrict__ x, int rows, int64_t n, int64_t ldx, const double* __restrict__ c, int nc,
+													 int64_t ldc, double* __restrict__ part) {
+	__shared__ double s_w[4][RW_ROWS];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int64_t k0 = (int64_t)blockIdx.x * 1024;
+	for (int r = 0; r < rows; r++) {
+		double xv[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int64_t k = k0 + tid + 256 * j;
+			xv[j] = k < n ? (double)x[(int64_t)r * ldx + k] : 0.0;
+		}
+		for (int q = 0; q < nc; q++) {
+			double acc = 0.0;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int64_t k = k0 + tid + 256 * j;
+				if (k < n) acc = fma(xv[j], c[(int64_t)q * ldc + k], acc);
+			}
+			acc = wave_sum(acc);
+			if (lane == 0) s_w[wid][q] = acc;
+		}
+		__syncthreads();
+		if (tid < nc) part[((int64_t)blockIdx.x * rows + r) * RW_ROWS + tid] = (s_w[0][tid] + s_w[1][tid]) + (s_w[2][tid] + s_w[3][tid]);
+		__syncthreads();
+	}
+}
+
+// one workgroup per design row: thread (g, q) adds the partial sums of blocks g, g + 8, ... of covariate q, the 8 groups are added in order
+__global__ void __launch_bounds__(256) k_xc_sum(const double* __restrict__ part, int nblocks, int rows, int nc, double* __restrict__ ga, int const_last) {
+	__shared__ double s_g[8][RW_ROWS];
+	const int r = blockIdx.x, q = threadIdx.x & 31, g = threadIdx.x >> 5;
+	double acc = 0.0;
+	if (q < nc)
+		for (int b = g; b < nblocks; b += 8) acc += part[((int64_t)b * rows + r) * RW_ROWS + q];
+	s_g[g][q] = acc;
+	__syncthreads();
+	if (threadIdx.x < nc) {
+		double v = s_g[0][q];
+#pragma unroll
+		for (int i = 1; i < 8; i++) v += s_g[i][q];
+		ga[r * 32 + ((const_last && q == nc - 1) ? 31 : q)] = v;
+	}
+}
+
+extern "C" int64_t nrm_design_products_workspace_doubles(int64_t rows, int64_t n) { return rows * RW_ROWS * ((n + 1023) / 1024); }
+
+extern "C" int nrm_design_products(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
+								   double* d_ga, double* d_work, int const_last, void* stream) {
+	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_design_products: bad dtype");
+	NRM_REQUIRE(rows > 0 && rows <= RW_ROWS && nc > 0 && nc <= RW_ROWS, "nrm_design_products: 1 to %d rows and covariates", RW_ROWS);
+	NRM_REQUIRE(n > 0 && ldx >= n && ldc >= n && d_x && d_c && d_ga && d_work, "Incorrect dx/dy/dc size.");
+	hipStream_t st = (hipStream_t)stream;
+	const dim3 grid((unsigned)((n + 1023) / 1024));
+	if (x_dtype == NRM_F64)
+		hipLaunchKernelGGL(k_xc_partial<double>, grid, dim3(256), 0, st, (const double*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_work);
+	else
+		hipLaunchKernelGGL(k_xc_partial<float>, grid, dim3(256), 0, st, (const float*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_work);
+	hipLaunchKernelGGL(k_xc_sum, dim3((unsigned)rows), dim3(256), 0, st, d_work, (int)grid.x, (int)rows, (int)nc, d_ga, const_last);
+	return nrm_check_launch("k_xc_partial");
+}
+
 extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 									int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
 									double* d_ss, double* d_coef, double* d_work, int const_last, void* stream) {

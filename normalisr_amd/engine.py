@@ -930,11 +930,11 @@ class Engine:
 			xd = self._rows_padded16(as_input(dx) if isinstance(dx, np.ndarray) else dx)
 			xcode = NRM_F64 if xd.dtype == torch.float64 else NRM_F32
 			gx = torch.empty((256, 32), dtype=torch.float64, device=self.device)
-			ssx_raw = torch.empty((256, ), dtype=torch.float64, device=self.device)
 			active = rank > 0 and nc > 0
-			if active:
-				_lib.check(self.lib.nrm_gram_skinny(xd.data_ptr(), xcode, nx, n, xd.stride(0), z.data_ptr(), k32, k32, gx.data_ptr(),
-													ssx_raw.data_ptr(), 256, max(ncz, 1), float(cval), self._skinny_work().data_ptr(), self._stream()))
+			if active:  # a = x C^T (against the covariates in Z's order, the constant one last: column 31)
+				xc_work = torch.empty((int(self.lib.nrm_design_products_workspace_doubles(nx, n)), ), dtype=torch.float64, device=self.device)
+				_lib.check(self.lib.nrm_design_products(xd.data_ptr(), xcode, nx, n, xd.stride(0), d_cz.data_ptr(), nc, d_cz.stride(0), gx.data_ptr(),
+														xc_work.data_ptr(), 1 if ci >= 0 else 0, self._stream()))
 			xt = z[ncz:ncz + nx]  # the residualised design rows are written straight into their rows of Z (zero padded up to k32)
 			rw_work = torch.empty((32 * ((k32 + 1023) // 1024), ), dtype=torch.float64, device=self.device)
 			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
