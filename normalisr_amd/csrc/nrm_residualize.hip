@@ -643,15 +643,23 @@ __global__ void __launch_bounds__(256) k_xc_partial(const T* __restrict__ x, int
 			const int64_t k = k0 + tid + 256 * j;
 			xv[j] = k < n ? (double)x[(int64_t)r * ldx + k] : 0.0;
 		}
-		for (int q = 0; q < nc; q++) {
-			double acc = 0.0;
+		for (int q0 = 0; q0 < nc; q0 += 8) {  // 8 covariates at a time: 32 independent loads in flight per thread
+			double cv[8][4];
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const int64_t k = k0 + tid + 256 * j;
-				if (k < n) acc = fma(xv[j], c[(int64_t)q * ldc + k], acc);
+			for (int i = 0; i < 8; i++)
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const int64_t k = k0 + tid + 256 * j;
+					cv[i][j] = (q0 + i < nc && k < n) ? c[(int64_t)(q0 + i) * ldc + k] : 0.0;
+				}
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				double acc = 0.0;
+#pragma unroll
+				for (int j = 0; j < 4; j++) acc = fma(xv[j], cv[i][j], acc);
+				acc = wave_sum(acc);
+				if (lane == 0 && q0 + i < nc) s_w[wid][q0 + i] = acc;
 			}
-			acc = wave_sum(acc);
-			if (lane == 0) s_w[wid][q] = acc;
 		}
 		__syncthreads();
 		if (tid < nc) part[((int64_t)blockIdx.x * rows + r) * RW_ROWS + tid] = (s_w[0][tid] + s_w[1][tid]) + (s_w[2][tid] + s_w[3][tid]);
