@@ -7,7 +7,7 @@ Run in the dev container only (the reference lives at /root/reference and never 
 
 Each fixture is data only: seeded synthetic inputs plus the outputs the reference
 (normalisr v1.0.0, numpy/scipy versions recorded in meta.json) produced for them.
-Fixture names follow SURVEY.md section 8(c): G1..G7; G8..G11 were added with the components they pin.
+Fixture names follow SURVEY.md section 8(c): G1..G7; G8..G11 and G13 were added with the components they pin (G12: make_pvalue_grid.py).
 """
 import gzip
 import io
@@ -378,6 +378,19 @@ def g11():
 	save('G11_i8hard', **out)
 
 
+def g13():
+	"""Reference outputs at 100 000 cells (BASELINE configs[2]'s cell count), fp64 and fp32 inputs; the inputs are rebuilt from the
+	seed by g13_inputs on either side, only the outputs are stored."""
+	from g13_inputs import g13_inputs
+	dt, dc, dg = g13_inputs()
+	out = dict(seed=13, n=dt.shape[1], ng=dt.shape[0], check=np.array([dt.sum(), dc.sum(), dg.sum()]))
+	p, d, v = norm.coex(dt, dc)
+	out.update(coex_p=p, coex_dot=d, coex_var=v)
+	pd_, g, a, vg, vt = norm.de(dg, dt, dc, lowmem=False)  # (lowmem=False: alpha is returned)
+	out.update(de_p=pd_, de_gamma=g, de_alpha=a, de_varg=vg, de_vart=vt)
+	save('G13_100k', **out)
+
+
 def main():
 	if len(sys.argv) > 1:  # selected fixtures only, e.g. `make_golden.py g11`
 		for name in sys.argv[1:]:
@@ -394,6 +407,7 @@ def main():
 	g9()
 	skl = g10()
 	g11()
+	g13()
 	meta = dict(sklearn=skl, reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:

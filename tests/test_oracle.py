@@ -1,4 +1,6 @@
 """CPU: pin the oracle (oracle/) against the golden vectors generated from the reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -200,3 +202,31 @@ def test_g11_rows_that_are_hard_for_fixed_point(golden):
 		pr = g['de_%s_p' % name]
 		ok = pr >= 2.3e-308
 		assert relerr(pd_[ok], pr[ok]) < rt, name
+
+
+def g13_problem(golden):
+	"""G13's inputs, rebuilt from the seed (tests/golden/g13_inputs.py), checked against the sums the reference run recorded."""
+	import importlib.util
+	spec = importlib.util.spec_from_file_location('g13_inputs', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g13_inputs.py'))
+	mod = importlib.util.module_from_spec(spec)
+	spec.loader.exec_module(mod)
+	g = golden('G13_100k')
+	dt, dc, dg = mod.g13_inputs(int(g['seed']), int(g['n']), int(g['ng']))
+	assert np.array_equal(np.array([dt.sum(), dc.sum(), dg.sum()]), g['check'])  # the same numbers the reference saw
+	return g, dt, dc, dg
+
+
+def test_g13_reference_outputs_at_100k_cells(golden):
+	"""G13: the reference's coex and de outputs for 40 genes x 100 000 cells (the cell count of BASELINE configs[2]); only the outputs
+	are stored, the inputs come from the seed.  The oracle must sit on them; the GPU tests hold the device paths to the same vectors."""
+	g, dt, dc, dg = g13_problem(golden)
+	p, d, v = oracle.coex(dt, dc)
+	off = ~np.eye(dt.shape[0], dtype=bool)
+	pr = g['coex_p']
+	ok = off & (pr >= 2.3e-308)
+	assert relerr(p[ok], pr[ok]) < 1e-7 and relerr(v, g['coex_var']) < 1e-10
+	assert np.max(np.abs(d - g['coex_dot']) / np.sqrt(np.outer(v, v))) < 1e-11
+	pd_, gam, a, vg, vt = oracle.de(dg, dt, dc)
+	ok = g['de_p'] >= 2.3e-308
+	assert relerr(pd_[ok], g['de_p'][ok]) < 1e-7 and relerr(gam, g['de_gamma'], 1e-12) < 1e-7
+	assert relerr(vg, g['de_varg']) < 1e-10 and relerr(vt, g['de_vart']) < 1e-10
