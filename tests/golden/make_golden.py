@@ -7,7 +7,7 @@ Run in the dev container only (the reference lives at /root/reference and never 
 
 Each fixture is data only: seeded synthetic inputs plus the outputs the reference
 (normalisr v1.0.0, numpy/scipy versions recorded in meta.json) produced for them.
-Fixture names follow SURVEY.md section 8(c): G1..G7; G8..G11 and G13 were added with the components they pin (G12: make_pvalue_grid.py).
+Fixture names follow SURVEY.md section 8(c): G1..G7; G8..G11, G13 and G14 were added with the components they pin (G12: make_pvalue_grid.py).
 """
 import gzip
 import io
@@ -391,6 +391,15 @@ def g13():
 	save('G13_100k', **out)
 
 
+def g14():
+	"""BASELINE configs[1] at full size through the reference (nth=8; ~1 minute): outputs of 12 gene rows against all 5000."""
+	from g14_inputs import g14_inputs
+	dt, dc, rows = g14_inputs()
+	p, d, v = norm.coex(dt.astype(np.float64), dc, nth=8)
+	rows = rows[:12]  # (1 MB of outputs)
+	save('G14_c2', seed=14, rows=rows, check=np.array([float(dt.astype(np.float64).sum()), dc.sum()]), p=p[rows], dot=d[rows], var=v)
+
+
 def main():
 	if len(sys.argv) > 1:  # selected fixtures only, e.g. `make_golden.py g11`
 		for name in sys.argv[1:]:
@@ -408,6 +417,7 @@ def main():
 	skl = g10()
 	g11()
 	g13()
+	g14()
 	meta = dict(sklearn=skl, reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:

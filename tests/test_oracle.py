@@ -230,3 +230,29 @@ def test_g13_reference_outputs_at_100k_cells(golden):
 	ok = g['de_p'] >= 2.3e-308
 	assert relerr(pd_[ok], g['de_p'][ok]) < 1e-7 and relerr(gam, g['de_gamma'], 1e-12) < 1e-7
 	assert relerr(vg, g['de_varg']) < 1e-10 and relerr(vt, g['de_vart']) < 1e-10
+
+
+def g14_problem(golden):
+	"""G14's inputs (BASELINE configs[1] at full size), rebuilt from the seed (tests/golden/g14_inputs.py)."""
+	import importlib.util
+	spec = importlib.util.spec_from_file_location('g14_inputs', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g14_inputs.py'))
+	mod = importlib.util.module_from_spec(spec)
+	spec.loader.exec_module(mod)
+	g = golden('G14_c2')
+	dt, dc, _ = mod.g14_inputs(int(g['seed']))
+	assert np.array_equal(np.array([float(dt.astype(np.float64).sum()), dc.sum()]), g['check'])  # the same numbers the reference saw
+	return g, dt, dc
+
+
+def test_g14_config1_rows_against_the_reference(golden):
+	"""G14: the reference's outputs for 12 gene rows of BASELINE configs[1] at full size (5000 genes x 10 000 cells; the fp32 values
+	upcast to fp64).  Here the oracle computes those rows against all genes (a rectangle of the same problem)."""
+	g, dt, dc = g14_problem(golden)
+	rows = g['rows']
+	d64 = dt.astype(np.float64)
+	p, gam, a, vx, vy = oracle.association_tests(d64[rows], d64, dc, return_dot=True)
+	pr = g['p']
+	ok = pr >= 2.3e-308
+	ok[np.arange(len(rows)), rows] = False  # (the coex diagonal is 0 by definition)
+	assert relerr(p[ok], pr[ok]) < 1e-7
+	assert relerr(vy, g['var']) < 1e-10 and np.max(np.abs(gam - g['dot'])[ok]) < 1e-11 * np.sqrt(g['var'].max() * g['var'][rows].max())
