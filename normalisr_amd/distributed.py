@@ -208,13 +208,14 @@ class HipBackend:
 		"""The digit planes of these rows can be written (and sent) in cell chunks: integer engine and 16-byte aligned rows."""
 		return bool(self.eng.gram_slices(x.shape[1])) and self.eng.k1_quantises(x, cov[0])
 
-	def residualize(self, x, cov, rows_pad, chunks=0):
+	def residualize(self, x, cov, rows_pad, chunks=0, into=None):
+		"""into: the block a previous step of the same plan got from here, to be overwritten (engine.residualize)."""
 		d_c, d_dci, dcr = cov
 		ns = self.eng.gram_slices(x.shape[1])
 		if chunks:
-			r = self.eng.residualize_chunked(x, d_c, d_dci, dcr, rows_pad, ns, chunks)
+			r = self.eng.residualize_chunked(x, d_c, d_dci, dcr, rows_pad, ns, chunks, into=into)
 			return r, r.ss
-		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad, nslices=ns, keep_fp64=not ns)
+		r = self.eng.residualize(x, d_c, d_dci, dcr, rows_pad=rows_pad, nslices=ns, keep_fp64=not ns, into=into)
 		if ns and getattr(r, '_quant', None) is None:  # rows K1 could not quantise itself (unaligned): separate pass
 			self.eng.quantized(r, ns)
 		return r, r.ss
@@ -394,6 +395,11 @@ class CoexPlan:
 			self.n_partners = (world - 1) // 2
 			self.all_x = self.be.torch.empty(((world + self.n_partners) * self.rows, self.n), dtype=dt_local.dtype, device=dt_local.device)
 
+	def _into(self):
+		"""The previous step's own block, for K1 to overwrite (nothing reads it once the step's outputs exist) -- device backend only."""
+		prev = getattr(self, '_blk', None)
+		return dict(into=prev) if prev is not None and isinstance(self.be, HipBackend) else {}
+
 	def _timed(self, name, timed, fn):
 		if not timed:
 			return fn()
@@ -483,7 +489,7 @@ class CoexPlan:
 		chunk travels, then every other pair of this rank chunk by chunk as the pieces land."""
 		import torch.distributed as dist
 		be = self.be
-		blk, ss = self._timed('residualize', timed, lambda: be.residualize(self.x, self.cov, self.rows_pad, chunks=self.chunks))
+		blk, ss = self._timed('residualize', timed, lambda: be.residualize(self.x, self.cov, self.rows_pad, chunks=self.chunks, **self._into()))
 		self._blk, self._ss = blk, ss
 		S = be.n_chunks(blk)
 		chunks, once = be.chunk_payload(blk)
@@ -565,7 +571,7 @@ class CoexPlan:
 			return self._step_chunked(timed)
 		if self.multi and self.exchange_raw:
 			self._pending = self._exchange(None, None)  # raw rows travel: nothing to wait for, start before K1
-		blk, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad))
+		blk, ss = self._timed('residualize', timed, lambda: self.be.residualize(self.x, self.cov, self.rows_pad, **self._into()))
 		self._blk, self._ss = blk, ss
 		if self.multi and not self.exchange_raw:
 			self._pending = self._exchange(blk, ss)

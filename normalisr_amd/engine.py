@@ -265,15 +265,30 @@ class Engine:
 		e = None if d_c is None else self._cmax.get(d_c.data_ptr())
 		return e[1].data_ptr() if e is not None and e[0]() is d_c else 0
 
-	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True):
+	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True, into=None):
 		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n).  nslices = 5 / 6: also (keep_fp64=False: only) the
-		fixed-point digit planes of the integer Gram engine, written by K1 itself."""
+		fixed-point digit planes of the integer Gram engine, written by K1 itself.
+		into: a Residualized of an earlier call with the same arguments whose buffers may be overwritten (a resident plan's previous
+		step): no GB-sized allocation per step -- the caching allocator serves those from its free blocks most of the time, but a
+		free 11 GB block that was split for a 100 MB request in between costs the next step a 50 ms hipMalloc (seen as an
+		intermittent 5 - 40x slower "K1" of the configs[4] slice in bench.py)."""
 		if isinstance(x, np.ndarray):
 			x = self.upload(as_input(x))
 		with _Span(self, 'residualize'):
-			return self._residualize(x, d_c, d_dci, rank, want_coef, rows_pad, nslices, keep_fp64)
+			return self._residualize(x, d_c, d_dci, rank, want_coef, rows_pad, nslices, keep_fp64, into)
 
-	def _residualize(self, x, d_c, d_dci, rank, want_coef, rows_pad, nslices, keep_fp64):
+	@staticmethod
+	def _reusable(into, rows, n, rp, kp, nslices, plane_bytes, chunked):
+		q = getattr(into, '_quant', None)
+		if into is None or q is None or into.data is not None or into.coef is not None or into.fix is None:
+			return False
+		planes = q[0]
+		if chunked != isinstance(planes, list):
+			return False
+		have = sum(int(t.numel()) for t in planes) if chunked else int(planes.numel())
+		return (into.rows, into.n, into.rows_pad, into.k_pad, q[2]) == (rows, n, rp, kp, nslices) and have == plane_bytes
+
+	def _residualize(self, x, d_c, d_dci, rank, want_coef, rows_pad, nslices, keep_fp64, into=None):
 		torch = self.torch
 		with torch.cuda.device(self.device):
 			if isinstance(x, np.ndarray):
@@ -285,12 +300,16 @@ class Engine:
 			esz = x.element_size()
 			fused = bool(nslices) and rp % ROW_TILE == 0 and self.k1_quantises(x, d_c)
 			if fused:
-				ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
 				coef = self.zeros((rows, nc), torch.float64) if want_coef else None
 				out = torch.empty((rp, kp), dtype=torch.float64, device=self.device) if keep_fp64 else None
-				planes = torch.empty((int(self.lib.nrm_quant_bytes(rp, kp, nslices)), ), dtype=torch.uint8, device=self.device)
-				exps = torch.empty((rp, ), dtype=torch.int32, device=self.device)
-				fix = torch.empty((rp, FIX_STRIDE), dtype=torch.float64, device=self.device)
+				pb = int(self.lib.nrm_quant_bytes(rp, kp, nslices))
+				if not keep_fp64 and not want_coef and self._reusable(into, rows, n, rp, kp, nslices, pb, False):
+					ss, planes, exps, fix = into.ss, into._quant[0], into._quant[1], into.fix
+				else:
+					ss = torch.empty((rp, ), dtype=torch.float64, device=self.device)
+					planes = torch.empty((pb, ), dtype=torch.uint8, device=self.device)
+					exps = torch.empty((rp, ), dtype=torch.int32, device=self.device)
+					fix = torch.empty((rp, FIX_STRIDE), dtype=torch.float64, device=self.device)
 				_lib.check(self.lib.nrm_residualize_q(
 					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
@@ -317,9 +336,10 @@ class Engine:
 		return x.stride(1) == 1 and (x.stride(0) * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0 and (
 			d_c is None or ((d_c.stride(0) * 8) % 16 == 0 and d_c.data_ptr() % 16 == 0))
 
-	def residualize_chunked(self, x, d_c, d_dci, rank, rows_pad, nslices, chunks):
+	def residualize_chunked(self, x, d_c, d_dci, rank, rows_pad, nslices, chunks, into=None):
 		"""K1 with the digit planes cut along the cells into (at most) `chunks` operands of equal size that share the row
-		exponents (nrm_residualize_q_chunked): what the sharded coex path sends to the other GPUs piece by piece."""
+		exponents (nrm_residualize_q_chunked): what the sharded coex path sends to the other GPUs piece by piece.
+		into: see residualize."""
 		torch = self.torch
 		with torch.cuda.device(self.device):
 			rows, n = x.shape
@@ -329,10 +349,13 @@ class Engine:
 			cks = (nks + max(1, chunks) - 1) // max(1, chunks)
 			nchunks = (nks + cks - 1) // cks
 			cb = int(self.lib.nrm_quant_bytes(rows_pad, 32 * cks, nslices))
-			planes = torch.empty((nchunks * cb, ), dtype=torch.uint8, device=self.device)
-			exps = torch.empty((rows_pad, ), dtype=torch.int32, device=self.device)
-			ss = torch.empty((rows_pad, ), dtype=torch.float64, device=self.device)
-			fix = torch.empty((rows_pad, FIX_STRIDE), dtype=torch.float64, device=self.device)
+			if self._reusable(into, rows, n, rows_pad, kp, nslices, nchunks * cb, True) and into.cks == cks and getattr(into, '_planes', None) is not None:
+				planes, exps, ss, fix = into._planes, into._quant[1], into.ss, into.fix
+			else:
+				planes = torch.empty((nchunks * cb, ), dtype=torch.uint8, device=self.device)
+				exps = torch.empty((rows_pad, ), dtype=torch.int32, device=self.device)
+				ss = torch.empty((rows_pad, ), dtype=torch.float64, device=self.device)
+				fix = torch.empty((rows_pad, FIX_STRIDE), dtype=torch.float64, device=self.device)
 			_lib.check(self.lib.nrm_residualize_q_chunked(
 				x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 				0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
@@ -340,6 +363,7 @@ class Engine:
 				cks, self.cmax_ptr(d_c), fix.data_ptr(), self._stream()))
 		r = Residualized(rows, n, None, ss, None, shape=(rows_pad, kp))
 		r._quant = ([planes[c * cb:(c + 1) * cb] for c in range(nchunks)], exps, nslices)
+		r._planes = planes  # (the one buffer the chunk operands are views of)
 		r.cks = cks
 		r.fix = fix
 		return r
@@ -1053,8 +1077,12 @@ class Engine:
 			return self.association_de_chunked(dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov)
 		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
 		ns = self.gram_slices(n)  # integer engine: K1 writes the digit planes itself and the fp64 residuals are never stored
-		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha, nslices=ns, keep_fp64=not ns)
-		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha, nslices=ns, keep_fp64=not ns)
+		# a resident caller's state (a DePlan) lends the previous step's K1 outputs to be overwritten: no GB-sized allocation per step
+		keep = resident and state is not None and state.get('keep', False)
+		rx = self.residualize(dx, d_c, d_dci, rank, want_coef=want_alpha, nslices=ns, keep_fp64=not ns, into=state.get('rx') if keep else None)
+		ry = rx if samexy else self.residualize(dy, d_c, d_dci, rank, want_coef=want_alpha, nslices=ns, keep_fp64=not ns, into=state.get('ry') if keep else None)
+		if keep:
+			state['rx'], state['ry'] = rx, ry
 		host = None
 		if not (device_out or resident or want_rt or want_alpha) and self.banded_ok(nx, ny, out_dtype):
 			# the result arrays are page-locked by a helper thread while K1/K2 run.  Started only now, after the uploads: a
