@@ -21,7 +21,8 @@ not already running under one; under `python -m torch.distributed.run ... bench.
 ranks it was given.  Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_gram_i8),
 timed live with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the
 reference's algorithm, test infrastructure) on a bounded sample on this box's host cores (N=1 only); the extra
-workloads carry their own, extrapolated from sampled rows.  `guard` is the verdict of the integer engine's accuracy
+workloads carry their own, extrapolated from sampled rows.  `kernels_roofline` prices the two kernels beside K2 against the rooflines that
+bound them (K1: HBM; K3: fp64 vector ALU).  `guard` is the verdict of the integer engine's accuracy
 guard over the timed steps (pairs it could not certify: must be 0 here).
 """
 import argparse
@@ -88,6 +89,29 @@ def gram_roofline(n_cells, flops, gram_ms, rows_pad, k_pad):
 				algorithmic_bytes=abytes, kernel_ms=gram_ms, arithmetic=note, int8_tops_executed=(achieved * (ns * (ns + 1) // 2) if ns else None),
 				frac_of_fp64_mfma_peak=achieved / F64_MFMA_PEAK_TFLOPS, frac_of_fp32_mfma_peak=achieved / F32_MFMA_PEAK_TFLOPS)
 HBM_PEAK_GBS = 8000.0
+F64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+
+
+def side_rooflines(kernels_ms, rows, n, esz, ns, tests, out_esz):
+	"""The two kernels beside K2, each against the roofline that bounds it, from ALGORITHMIC work over the measured
+	time.  K1 is HBM-bound: it reads every row once (its second sweep is served from L2 / MALL for rows that fit there) and writes
+	ns digit bytes per value (or the fp64 residual).  K3 is bound by the fp64 vector ALU (about 250 fp64 instructions per test out of
+	~500 in all: P-value function, correction, guard); its traffic -- 8 bytes read, 2 results written per test -- is reported beside it."""
+	out = {}
+	k1, k3 = kernels_ms.get('residualize'), kernels_ms.get('sweep')
+	if k1:
+		b = float(rows) * n * (esz + (ns if ns else 8))
+		out['k_residualize'] = dict(bound='hbm', algorithmic_bytes=b, achieved=b / (k1 * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+									frac=b / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, kernel_ms=k1)
+	if k3:
+		b = float(tests) * (8 + 2 * out_esz)
+		out['k_assoc_sweep'] = dict(bound='fp64 valu', tests_per_s=tests / (k3 * 1e-3), fp64_instructions_per_test_estimate=250,
+									achieved=250 * tests / (k3 * 1e-3) / 1e12, peak=F64_VALU_PEAK_TFLOPS / 2, unit='T fp64 instructions/s',
+									frac=250 * tests / (k3 * 1e-3) / 1e12 / (F64_VALU_PEAK_TFLOPS / 2), algorithmic_bytes=b,
+									hbm_gbs=b / (k3 * 1e-3) / 1e9, kernel_ms=k3)
+	return out
+
+
 C5_ROWS_PER_RANK = 3750  # configs[4]: 30 000 genes over 8 GPUs
 C5_CELLS = 500000
 
@@ -313,6 +337,7 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 			   roofline=gram_roofline(n, flops, gram_ms, plan.rows_pad, plan.k_pad),
 			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region',
 			   guard=guard_verdict(plan.flags, plan.be.eng))
+	out['kernels_roofline'] = side_rooflines(out['kernels_ms'], rows_local, n, esz, SLICES(n), plan.local_pair_count(), esz)
 	return out, plan
 
 
