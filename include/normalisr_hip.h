@@ -313,6 +313,20 @@ int nrm_single1_sweep(const double* d_g, int64_t ldg, const double* d_g2, int64_
 					  int out_dtype, int64_t ldo, int32_t* d_flags, void* stream);
 
 /*
+ * The same single=1 statistics for designs with entries >= 0 (gRNA incidence), without the masked Gram contractions: the cells are
+ * permuted -- first the n_common cells where every grouping is 0, then, grouping by grouping, the cells where only that grouping is
+ * not 0 (d_seg[i] .. d_seg[i+1], positions in the permuted order; cells carrying several groupings are left out) -- and handed over as
+ *   d_yt (cells, ldy): the expression matrix TRANSPOSED in that order (y_dtype), d_ct (cells, nc) fp64 the covariates likewise,
+ *   d_xp (cells) fp64 the grouping's own value at each cell (0 on the common cells).
+ * d_info, outputs and flags as nrm_single1_sweep.  d_work: nrm_single1_sparse_workspace_doubles(ny, nc, n_common) doubles.  nc <= 32.
+ */
+int64_t nrm_single1_sparse_workspace_doubles(int64_t ny, int64_t nc, int64_t n_common);
+int nrm_single1_sparse(const void* d_yt, int y_dtype, int64_t ldy, const double* d_ct, const double* d_xp, const int64_t* d_seg,
+					   int64_t n_common, const double* d_info, int64_t info_pitch, int64_t nc, int64_t nx, int64_t ny, int return_dot,
+					   void* d_p, void* d_stat, void* d_vary, void* d_alpha, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags,
+					   void* stream);
+
+/*
  * binnet -- binarise a (ng, ng) co-expression P-value matrix at a per-row Benjamini-Hochberg q-value cutoff
  * (reference binnet.py:134-173 with bh :77-131; the consumer of coex's p-matrix).  d_out (ng, ldo) bytes 0/1, diagonal 0;
  * *d_total receives the number of selected entries (0 -> the reference raises "Empty binary network");

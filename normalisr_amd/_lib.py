@@ -60,6 +60,8 @@ _SIGNATURES = {
 	'nrm_skinny_i8': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp], _i32),
 	'nrm_skinny_i8_workspace_bytes': ([], _i64),
 	'nrm_single1_sweep': ([_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+	'nrm_single1_sparse_workspace_doubles': ([_i64, _i64, _i64], _i64),
+	'nrm_single1_sparse': ([_vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
 	'nrm_binnet': ([_vp, _i32, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_binnet_rows': ([_vp, _i32, _i64, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_normvar_weights': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp], _i32),

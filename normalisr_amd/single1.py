@@ -13,6 +13,7 @@ a tiny host step per grouping (inv_rank of C_S C_S^T: the rank is an integer and
 sweep kernel (csrc/nrm_single1.hip).  Groupings are processed in chunks to bound the size of W.
 """
 import logging
+import os
 
 import numpy as np
 
@@ -65,6 +66,8 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		assert bool((hi > lo).all())  # >1 distinct value among the selected cells (:917-918)
 		del lo, hi
 		ns = sel.sum(dim=1).cpu().numpy().astype(np.float64)
+		if nc <= 32 and not bool((d_dx < 0).any()) and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
+			return _sparse(eng, d_dx, dx.dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt)
 		ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
 		y2 = Residualized_sq(ry, eng)
 		d_c = eng.upload(c64) if nc else None
@@ -124,6 +127,82 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		eng.check_flags(flags)
 		return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), varx.astype(out_dtype),
 				eng.download(vary))
+
+
+def _segment_sums(v, starts, counts):
+	"""Sums of v (..., cells) over consecutive segments of the last axis; empty segments give 0 (np.add.reduceat would not)."""
+	out = np.zeros(v.shape[:-1] + (len(counts), ))
+	nz = counts > 0
+	if nz.any():
+		out[..., nz] = np.add.reduceat(v, starts[nz], axis=-1)
+	return out
+
+
+def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt):
+	"""single=1 for a design with entries >= 0 (csrc/nrm_single1.hip, second half): the cells every grouping shares (all of dx is 0)
+	are summed once per gene, each grouping adds its own few cells inside the sweep; no masked Gram contraction, no loop over chunks
+	of groupings.  The statistics of the groupings themselves (M_i = C_S C_S^T, C_S x_S, |x_S|^2: association.py:350-364) are taken on
+	the host from the same decomposition, in a fixed order."""
+	torch = eng.torch
+	nzm = d_dx != 0
+	cnt = nzm.sum(dim=0)
+	idx_n = torch.nonzero(cnt == 0).flatten()
+	idx_e = torch.nonzero(cnt == 1).flatten()
+	owner = torch.argmax(nzm[:, idx_e].to(torch.int8), dim=0)
+	order = torch.argsort(owner, stable=True)
+	idx_e, owner = idx_e[order], owner[order]
+	n_common = int(idx_n.numel())
+	perm = torch.cat([idx_n, idx_e])
+	counts = torch.bincount(owner, minlength=nx).cpu().numpy()
+	seg = np.concatenate([[0], np.cumsum(counts)]) + n_common
+	xp = torch.cat([torch.zeros(n_common, dtype=torch.float64, device=eng.device), d_dx[owner, idx_e].to(torch.float64)])
+	# grouping-side statistics on the host
+	perm_h = perm.cpu().numpy()
+	xe = xp[n_common:].cpu().numpy()
+	cp = c64[:, perm_h]  # (nc, cells in the permuted order)
+	starts = (seg[:-1] - n_common).astype(np.int64)
+	pitch = 26 + nc + nc * nc
+	info = np.zeros((nx, pitch))
+	xx = _segment_sums(xe * xe, starts, counts)
+	rk = np.zeros(nx, dtype=np.int64)
+	if nc:
+		ce = cp[:, n_common:]
+		mc = (cp[:, :n_common] @ cp[:, :n_common].T)[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
+		xc = _segment_sums(ce * xe, starts, counts).T  # (nx, nc)
+		mi, rk = inv_rank(mc)  # association.py:350-351
+		mi[rk == 0] = 0
+		ccx = np.einsum('icd,id->ic', mi, xc)
+		info[:, 26:26 + nc] = ccx
+		info[:, 26 + nc:] = mi.reshape(nx, nc * nc)
+		xx = xx - np.einsum('ic,ic->i', xc, ccx)
+	vxx = xx / ns
+	vxx[vxx == 0] = 1  # association.py:362-364
+	dof = ns - 1 - rk - dimreduce
+	if (dof <= 0).any():
+		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+	info[:, 0], info[:, 1] = ns, vxx
+	dof = np.ascontiguousarray(dof, dtype=np.float64)
+	_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, nx, info.ctypes.data + 16, pitch))
+	# the expression matrix: uploaded in its own dtype, the cells that matter gathered in the permuted order, transposed
+	d_y = eng.upload(_engine.as_input(dy))
+	yt = d_y.index_select(1, perm).t().contiguous()  # (cells, ny)
+	del d_y
+	ct = eng.upload(np.ascontiguousarray(cp.T)) if nc else None
+	p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+	stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+	vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+	alpha = None if lowmem else torch.zeros((nx, ny, nc), dtype=tdt, device=eng.device)
+	flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
+	work = torch.empty((int(eng.lib.nrm_single1_sparse_workspace_doubles(ny, nc, n_common)), ), dtype=torch.float64, device=eng.device)
+	d_seg = eng.upload(np.ascontiguousarray(seg, dtype=np.int64))
+	d_info = eng.upload(info)
+	code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
+	_lib.check(eng.lib.nrm_single1_sparse(yt.data_ptr(), _lib.NRM_F64 if yt.dtype == torch.float64 else _lib.NRM_F32, yt.stride(0),
+										  0 if ct is None else ct.data_ptr(), xp.data_ptr(), d_seg.data_ptr(), n_common, d_info.data_ptr(), pitch, nc, nx, ny,
+										  1 if return_dot else 0, p.data_ptr(), stat.data_ptr(), vary.data_ptr(), 0 if alpha is None else alpha.data_ptr(),
+										  code, ny, work.data_ptr(), flags.data_ptr(), eng._stream()))
+	eng.check_flags(flags)
+	return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), vxx.astype(out_dtype), eng.download(vary))
 
 
 def Residualized_sq(ry, eng):
