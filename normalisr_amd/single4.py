@@ -250,8 +250,24 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	with torch.cuda.device(eng.device):
 		prodyT_d = eng.zeros((ry.rows_pad, mp), torch.float64)
 	eng.gram(ry, ra, False, dot=prodyT_d)
+	# the spectrum decides whether the closed form applies; the inverse it needs is taken beside it on a second host thread (LAPACK
+	# releases the GIL; both take ~20 ms at 1000 groupings) and thrown away when it does not
+	spec = None
 	with _engine.host_blas():
-		ev = np.linalg.eigvalsh(prod)
+		if mpc == 0 and method in ('auto', 'scipy'):
+			from concurrent.futures import ThreadPoolExecutor
+
+			def _try_inverse():
+				try:
+					return _spd_inverse(prod)
+				except Exception:  # not positive definite: the spectrum will say so
+					return None
+			with ThreadPoolExecutor(1) as ex:
+				fut = ex.submit(_try_inverse)
+				ev = np.linalg.eigvalsh(prod)
+				spec = fut.result()
+		else:
+			ev = np.linalg.eigvalsh(prod)
 	closed = mpc == 0 and method in ('auto', 'scipy') and ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)
 	if not closed:
 		logging.info('single=4: no closed form (rank-deficient A A^T or truncated inverse); following the per-grouping algorithm on the host.')
@@ -264,8 +280,11 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	if n <= m + np.max(dimreduce):
 		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
 	dr_groups = [int(dimreduce)] if np.ndim(dimreduce) == 0 else [int(v) for v in np.unique(dimreduce)]
-	with _engine.host_blas():
-		ninv = _spd_inverse(prod)  # N = M^-1 (symmetric)
+	if spec is not None:
+		ninv = spec
+	else:
+		with _engine.host_blas():
+			ninv = _spd_inverse(prod)  # N = M^-1 (symmetric)
 	dxx = 1.0 / (n * np.diag(ninv)[:nx])
 	n_pad = np.zeros((mp, mp))
 	n_pad[:m, :m] = ninv
