@@ -24,9 +24,10 @@ for rep in range(3):
 	dci, rank = inv_rank(dc @ dc.T)
 	cov = eng.covariates(dc, dci)
 	x, t_up = T(lambda: eng.upload(dt))
-	rx, t_k1 = T(lambda: eng.residualize(x, cov[0], cov[1], rank))
-	dot, t_k2 = T(lambda: eng.gram(rx, rx, True))
-	sw, t_k3 = T(lambda: eng.sweep(dot, rx.ss, rx.ss, ng, ng, n, n - 1 - rank, True, 0, np.float32))
+	ns = eng.gram_slices(n)  # 6: the integer engine (from 2048 cells on)
+	rx, t_k1 = T(lambda: eng.residualize(x, cov[0], cov[1], rank, nslices=ns, keep_fp64=not ns))
+	dot, t_k2 = T(lambda: eng.gram(rx, rx, True, nslices=ns))
+	sw, t_k3 = T(lambda: eng.sweep(dot, rx.ss, rx.ss, ng, ng, n, n - 1 - rank, True, 0, np.float32, fix=eng.fix_args(rx, rx)))
 	p, t_dp = T(lambda: eng.download(sw[0]))
 	s, t_ds = T(lambda: eng.download(sw[1]))
 	print(f'{ng}x{n}: coex() {t_all:.1f} ms | upload {t_up:.1f}  K1 {t_k1:.1f}  K2 {t_k2:.1f}  K3 {t_k3:.1f}  D2H p {t_dp:.1f}  D2H dot {t_ds:.1f}', flush=True)
