@@ -2,7 +2,7 @@
 error of gamma / covariance against the CPU oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')  # run from the repository root
 import oracle
 from normalisr_amd.association import association_tests
 def rel(a, b, floor):

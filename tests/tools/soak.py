@@ -4,7 +4,7 @@ tests/test_gpu_parity.py::test_randomised_shapes_vs_oracle: gene counts that exe
 band cut, odd cell counts, both dtypes, 0-10 covariates.  Usage: soak.py [cases [seed]]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import normalisr_amd.normalisr as norm
 import oracle
 

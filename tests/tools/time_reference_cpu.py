@@ -4,7 +4,7 @@ the oracle port on the same synthetic C2-shaped input (SURVEY 8d 'CPU baseline')
 Usage: OPENBLAS_NUM_THREADS=1 python tools/time_reference_cpu.py [genes cells]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 ng, n = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5000, 10000)
 rng = np.random.default_rng(2)
