@@ -416,7 +416,7 @@ class CoexPlan:
 		import torch.distributed as dist
 		torch = self.be.torch
 		nccl = dist.get_backend(self.group) == 'nccl'
-		self._partner = {}
+		self._partner_prev, self._partner = getattr(self, '_partner', {}), {}
 		if self.exchange_raw:
 			if nccl:
 				return [dist.all_gather_into_tensor(self.all_x[:self.world * self.rows], self.x, group=self.group, async_op=True)]
@@ -439,7 +439,9 @@ class CoexPlan:
 				ss = self._g_once[-1][b]
 				self._partner[b] = (self.be.from_chunks([g[b] for g in self._g_chunks], [g[b] for g in self._g_once[:-1]], self._blk, ss), ss)
 			elif self.exchange_raw:  # partner block arrived raw: residualise it here (once per step)
-				self._partner[b] = self.be.residualize(self.all_x[b * self.rows:(b + 1) * self.rows], self.cov, self.rows_pad)
+				prev = getattr(self, '_partner_prev', {}).get(b)
+				self._partner[b] = self.be.residualize(self.all_x[b * self.rows:(b + 1) * self.rows], self.cov, self.rows_pad,
+													   **(dict(into=prev[0]) if prev is not None and isinstance(self.be, HipBackend) else {}))
 			else:
 				ss = self._gathered[-1][b]
 				self._partner[b] = (self.be.from_payload([g[b] for g in self._gathered[:-1]], self.rows, self.rows_pad, self.n, self.k_pad, ss), ss)
@@ -467,7 +469,10 @@ class CoexPlan:
 		if wrap > 0:
 			self.all_x[W * R:(W + wrap) * R].copy_(self.all_x[:wrap * R])
 		xs = self.all_x[(self.rank + 1) * R:(self.rank + 1 + K) * R]
-		pd, pss = self._timed('residualize', timed, lambda: self.be.residualize(xs, self.cov, _round_up(K * R, ROW_TILE)))
+		prev = getattr(self, '_pd', None)  # (the previous step's partner block: overwritten, see _into)
+		pd, pss = self._timed('residualize', timed, lambda: self.be.residualize(xs, self.cov, _round_up(K * R, ROW_TILE),
+																			   **(dict(into=prev) if prev is not None and isinstance(self.be, HipBackend) else {})))
+		self._pd = pd
 		dot = self._timed('gram', timed, lambda: self.be.gram(self._blk, pd, False, R, K * R))
 		p, stat, self.flags = self._timed('sweep', timed, lambda: self.be.sweep(dot, self._ss, pss, R, K * R, self.n, self.dof, False, self.out_dtype, self.flags,
 																				a=self._blk, b=pd))
