@@ -55,13 +55,13 @@ class PinnedPool:
 	"""Page-locked host blocks behind the numpy result arrays of the numpy-in / numpy-out calls.  A fresh 200 MB result needs its
 	pages faulted in and registered before a device-to-host copy can run at the PCIe rate (4-9 ms: longer than the whole C2
 	computation); a block handed back when its array is garbage-collected is reused by the next call of the same size at no cost.
-	The pool is bounded (NRM_PINNED_POOL_MB, default 2048; 0 disables it): beyond the bound results fall back to ordinary numpy
+	The pool is bounded (NRM_PINNED_POOL_MB, default 4096; 0 disables it): beyond the bound results fall back to ordinary numpy
 	memory that is page-locked in place for the duration of the call.  Arrays handed to the caller keep their block page-locked
 	for as long as the caller holds them (up to the bound in total)."""
 
 	def __init__(self, lib):
 		self.lib = lib
-		self.limit = int(float(os.environ.get('NRM_PINNED_POOL_MB', '2048')) * (1 << 20))
+		self.limit = int(float(os.environ.get('NRM_PINNED_POOL_MB', '4096')) * (1 << 20))
 		self.free = {}   # capacity -> [pointers]
 		self.total = 0   # bytes allocated (handed out or free)
 		self.lock = threading.RLock()  # re-entrant: _give runs from weakref.finalize, possibly inside a GC pass triggered under the lock
