@@ -8,9 +8,11 @@ every row once, and the device schedules 128x128 tiles itself, so bsx/bsy/nth ar
 compatibility but do not change the result (the reference's own results vary ~4e-14 with tile size).
 """
 import logging
+import os
 
 import numpy as np
 
+from . import _lib
 from . import engine as _engine
 
 
@@ -189,6 +191,41 @@ def _prepare_covariates(dc):
 	return dc64, dci, dcr
 
 
+def _have_torch():
+	try:
+		import torch  # noqa: F401
+		return True
+	except ImportError:
+		return False
+
+
+def _single0_host_entry(dx, dy, dc64, dci, dcr, dimreduce, return_dot, want_alpha, out_dtype, want_rt):
+	"""single=0 through nrm_association_tests_host (include/normalisr_hip.h): the C entry a maintainer of the reference would bind --
+	host buffers in, host buffers out, uploads, kernels, the integer engine's guard and its fp64 rerun inside the library.  Used
+	when torch cannot be imported: the package then needs numpy and the library only."""
+	import ctypes
+	lib = _lib.load()
+	samexy = dy is None
+	nx, n = dx.shape
+	ny = nx if samexy else dy.shape[0]
+	nc = dc64.shape[0]
+	odt = np.dtype(out_dtype)
+	code = lambda a: _lib.NRM_F64 if a.dtype == np.float64 else _lib.NRM_F32
+	vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+	p, stat = np.empty((nx, ny), dtype=odt), np.empty((nx, ny), dtype=odt)
+	alpha = np.empty((nx, ny, nc), dtype=odt) if (want_alpha and not samexy) else None
+	varx = None if samexy else np.empty(nx, dtype=odt)
+	vary = np.empty(ny, dtype=odt)
+	r = np.empty((nx, ny), dtype=odt) if want_rt else None
+	t = np.empty((nx, ny), dtype=odt) if want_rt else None
+	dc64 = np.ascontiguousarray(dc64)
+	dci = np.ascontiguousarray(dci, dtype=np.float64)
+	_lib.check(lib.nrm_association_tests_host(vp(dx), code(dx), nx, vp(dy), 0 if samexy else code(dy), 0 if samexy else ny, vp(dc64), _lib.NRM_F64, nc, n,
+											  vp(dci), int(dcr), int(dimreduce), 1 if (samexy or return_dot) else 0, vp(p), vp(stat), vp(alpha), vp(varx), vp(vary),
+											  vp(r), vp(t), _lib.NRM_F64 if odt == np.float64 else _lib.NRM_F32))
+	return dict(p=p, stat=stat, alpha=alpha, varx=varx, vary=vary, r=r, t=t, dof=n - 1 - dcr - dimreduce)
+
+
 def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, bs4=500,
 					  return_stats=False, device_out=False, **ka):
 	"""All-pairs association tests between rows of dx and dy (or dx with itself when dy is None).
@@ -249,8 +286,14 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		raise ValueError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
 	if samexy and not lowmem:
 		raise NotImplementedError('alpha for dy=None is not meaningful in the reference (symmetrised) and is not provided.')
-	eng = _engine.get_engine()
-	res = eng.association_single0(_engine.as_input(dx), None if samexy else _engine.as_input(dy), dc64, dci, dcr,
+	if os.environ.get('NRM_HOST_ENTRY', '') == '1' or not _have_torch():
+		# no torch in this process (or asked for): the library's own whole-problem entry, numpy buffers in and out
+		if device_out:
+			raise RuntimeError('device_out=True returns torch tensors: torch is needed for it.')
+		res = _single0_host_entry(_engine.as_input(dx), None if samexy else _engine.as_input(dy), dc64, dci, dcr, dimreduce, return_dot,
+								  not lowmem, out_dtype, return_stats)
+	else:
+		res = _engine.get_engine().association_single0(_engine.as_input(dx), None if samexy else _engine.as_input(dy), dc64, dci, dcr,
 								  dimreduce, return_dot=return_dot, want_alpha=not lowmem, out_dtype=out_dtype,
 								  want_rt=return_stats, device_out=device_out and not return_stats)
 	stat = res['stat']
