@@ -32,8 +32,9 @@ _SIGNATURES = {
 	'nrm_fill_zero': ([_vp, _i64, _vp], _i32),
 	'nrm_copy_rows': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
-	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp], _i32),
-	'nrm_residualize_q_chunked': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp], _i32),
+	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
+	'nrm_residualize_workspace_bytes': ([_i32, _i64, _i64, _i64, _i64], _i64),
+	'nrm_residualize_q_chunked': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
 	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_f64_band': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_workspace_bytes': ([], _i64),

@@ -25,17 +25,42 @@ def is_stale():
 	return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
 
 
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-pthread', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
+OBJ = os.path.join(HERE, 'csrc', '_obj')
+
+
 def build(force=False, verbose=False):
-	"""Compile every HIP source for gfx950 into one shared library next to the package."""
+	"""Compile every HIP source for gfx950 (one object per source, stale ones only, in parallel) and link them into one shared
+	library next to the package."""
 	if not force and not is_stale():
 		return LIB
 	# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (with AGPR accumulators v_mfma_f64_16x16x4_f64 runs at half rate on MI355X)
-	cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-pthread', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-o', LIB] + SOURCES
+	from concurrent.futures import ThreadPoolExecutor
+	hipcc = hipcc_path()
+	os.makedirs(OBJ, exist_ok=True)
+	newest_header = max(os.path.getmtime(f) for f in HEADERS)
+
+	def compile_one(src):
+		obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+		if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+			return obj, None
+		cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+		if verbose:
+			print(' '.join(cmd), flush=True)
+		r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+		return obj, (r.stdout if r.returncode != 0 else None)
+
+	with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4, 8)) as pool:
+		done = list(pool.map(compile_one, SOURCES))
+	for obj, err in done:
+		if err is not None:
+			raise RuntimeError('hipcc failed:\n' + err)
+	cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB] + [o for o, _ in done]
 	if verbose:
-		print(' '.join(cmd))
+		print(' '.join(cmd), flush=True)
 	r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 	if r.returncode != 0:
-		raise RuntimeError('hipcc failed:\n' + r.stdout)
+		raise RuntimeError('hipcc (link) failed:\n' + r.stdout)
 	return LIB
 
 

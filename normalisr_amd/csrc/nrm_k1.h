@@ -1,0 +1,65 @@
+// Pieces shared by the K1 kernels (nrm_residualize.hip: k_residualize, k_residualize_v4; nrm_residualize_res.hip: k_residualize_res).
+#pragma once
+#include "nrm_common.h"
+#include "nrm_digits.h"
+#include "nrm_fix.h"
+
+#define RES_NC_MAX 2048  // OLS tables a = x C^T and b = a dci live in dynamic LDS: 2 * RES_R * nc doubles (128 KiB at 2048)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+
+// Vectorised variant: every lane moves 4 consecutive cells per step (16-byte loads of fp32 input, 32-byte
+// loads/stores of fp64 covariates and residuals), so one wave-instruction covers 1-2 KiB of a row.
+// Needs 16-byte aligned rows: ldx % (16/sizeof(T)) == 0, ldc % 2 == 0, ldo % 4 == 0.
+template <typename T>
+struct Vec4Load;
+template <>
+struct Vec4Load<float> {
+	static __device__ __forceinline__ void ld(const float* p, double (&v)[4]) {
+		float4 t = *reinterpret_cast<const float4*>(p);
+		v[0] = t.x;
+		v[1] = t.y;
+		v[2] = t.z;
+		v[3] = t.w;
+	}
+};
+template <>
+struct Vec4Load<double> {
+	static __device__ __forceinline__ void ld(const double* p, double (&v)[4]) {
+		double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+		v[0] = a.x;
+		v[1] = a.y;
+		v[2] = b.x;
+		v[3] = b.y;
+	}
+};
+
+// Fixed-point output for the integer Gram engine (csrc/nrm_gram_i8.hip): digit planes in its tiled layout and one exponent per
+// row, written straight from K1 so that the fp64 residuals never make the round trip through HBM (NS = 0: none).
+struct QuantOut {
+	char* q;              // NS planes of plane_bytes each
+	int64_t plane_bytes;
+	int64_t nks;          // k-steps of 32 cells
+	int64_t cks;          // k-steps per cell chunk (== nks: one chunk); chunk c is an operand of its own at q + c * chunk_bytes
+	int64_t chunk_bytes;
+	int* exps;            // x = digits * 2^exps[row]
+	const double* cmax;   // (nc) largest |C_c| of every covariate row: bounds the residuals without a sweep of their own
+	double* fix;          // (rows_pad, NRM_FIX_STRIDE) row records for K3's correction and guard (nrm_fix.h), or nullptr
+};
+
+// Loosest fixed-point scale K1 accepts from the bound max|x| + sum_c |b_c| max|C_c| without looking: bound / rms of the residuals
+// (the rms estimated from the first sweep as |x|^2 - a.b).  Beyond it -- rows whose mean dwarfs their spread, near-collinear
+// covariates with large opposite coefficients -- the residuals are swept for their true maximum, so that no more than log2 of
+// this / (true max / rms) of the 8 NS - 2 bits are lost to the overestimate.
+#define RES_LOOSE 12.0
+
+
+// nrm_residualize_res.hip: K1 with the rows resident on chip (one HBM read per row)
+bool nrm_k1_res_applies(int x_dtype, int64_t n, int64_t nc, int64_t chunk_ksteps);
+int nrm_k1_res_launch(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int nc, int64_t ldc, const double* d_dci,
+					  int active, int64_t rows_pad, double* d_ss, double* d_coef, int nslices, const QuantOut& qo, void* d_work, int64_t work_bytes,
+					  int64_t chunk_ksteps, hipStream_t st);

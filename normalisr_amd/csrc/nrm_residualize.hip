@@ -9,9 +9,9 @@
 //
 // One workgroup (256 threads) owns RES_R consecutive rows so that every covariate element fetched
 // from L2 is used RES_R times; covariates are swept in chunks of RES_CB to bound registers.
-#include "nrm_common.h"
-#include "nrm_digits.h"
-#include "nrm_fix.h"
+#include "nrm_k1.h"
+#include <cstdlib>
+#include <cstring>
 
 #ifndef RES_R
 #define RES_R 4
@@ -23,13 +23,6 @@
 #ifndef K1_U3
 #define K1_U3 1
 #endif
-#define RES_NC_MAX 2048  // OLS tables a = x C^T and b = a dci live in dynamic LDS: 2 * RES_R * nc doubles (128 KiB at 2048)
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-	return v;
-}
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
@@ -126,51 +119,6 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 	__syncthreads();
 	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
 }
-
-// Vectorised variant: every lane moves 4 consecutive cells per step (16-byte loads of fp32 input, 32-byte
-// loads/stores of fp64 covariates and residuals), so one wave-instruction covers 1-2 KiB of a row.
-// Needs 16-byte aligned rows: ldx % (16/sizeof(T)) == 0, ldc % 2 == 0, ldo % 4 == 0.
-template <typename T>
-struct Vec4Load;
-template <>
-struct Vec4Load<float> {
-	static __device__ __forceinline__ void ld(const float* p, double (&v)[4]) {
-		float4 t = *reinterpret_cast<const float4*>(p);
-		v[0] = t.x;
-		v[1] = t.y;
-		v[2] = t.z;
-		v[3] = t.w;
-	}
-};
-template <>
-struct Vec4Load<double> {
-	static __device__ __forceinline__ void ld(const double* p, double (&v)[4]) {
-		double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
-		v[0] = a.x;
-		v[1] = a.y;
-		v[2] = b.x;
-		v[3] = b.y;
-	}
-};
-
-// Fixed-point output for the integer Gram engine (csrc/nrm_gram_i8.hip): digit planes in its tiled layout and one exponent per
-// row, written straight from K1 so that the fp64 residuals never make the round trip through HBM (NS = 0: none).
-struct QuantOut {
-	char* q;              // NS planes of plane_bytes each
-	int64_t plane_bytes;
-	int64_t nks;          // k-steps of 32 cells
-	int64_t cks;          // k-steps per cell chunk (== nks: one chunk); chunk c is an operand of its own at q + c * chunk_bytes
-	int64_t chunk_bytes;
-	int* exps;            // x = digits * 2^exps[row]
-	const double* cmax;   // (nc) largest |C_c| of every covariate row: bounds the residuals without a sweep of their own
-	double* fix;          // (rows_pad, NRM_FIX_STRIDE) row records for K3's correction and guard (nrm_fix.h), or nullptr
-};
-
-// Loosest fixed-point scale K1 accepts from the bound max|x| + sum_c |b_c| max|C_c| without looking: bound / rms of the residuals
-// (the rms estimated from the first sweep as |x|^2 - a.b).  Beyond it -- rows whose mean dwarfs their spread, near-collinear
-// covariates with large opposite coefficients -- the residuals are swept for their true maximum, so that no more than log2 of
-// this / (true max / rms) of the 8 NS - 2 bits are lost to the overestimate.
-#define RES_LOOSE 12.0
 
 template <typename T, int CB, int NS>
 __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
@@ -493,7 +441,7 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
 							const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
 							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, int64_t chunk_ksteps, const double* d_cmax, double* d_fix,
-							void* stream) {
+							void* d_work, int64_t work_bytes, void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
 	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
 	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
@@ -530,6 +478,12 @@ static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t 
 		}
 		qo.q = (char*)d_q;
 		qo.exps = d_exp;
+		// rows resident on chip between the two phases (nrm_residualize_res.hip) whenever the caller lends a workspace and only the
+		// digit planes are wanted; NRM_K1=v4 keeps the two-sweep kernel (ablation)
+		static const bool two_sweeps = getenv("NRM_K1") && !strcmp(getenv("NRM_K1"), "v4");
+		if (d_work && !d_out && !two_sweeps && (!active || n % 4 == 0 || ldc >= ((n + 3) & ~(int64_t)3)) && nrm_k1_res_applies(x_dtype, n, nc, chunk_ksteps))
+			return nrm_k1_res_launch(d_x, x_dtype, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, rows_pad, d_ss, d_coef, nslices, qo, d_work, work_bytes,
+									 chunk_ksteps, (hipStream_t)stream);
 	}
 	if (x_dtype == NRM_F64)
 		launch_residualize<double>(vec, (const double*)d_x, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, d_out, ldo, rows_pad, d_ss, d_coef,
@@ -545,15 +499,15 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
 	NRM_REQUIRE(d_out != nullptr, "nrm_residualize: null output");
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, 0, nullptr,
-							nullptr, stream);
+							nullptr, nullptr, 0, stream);
 }
 
 extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 								 int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss,
 								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax,
-								 double* d_fix, void* stream) {
+								 double* d_fix, void* d_work, int64_t work_bytes, void* stream) {
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp,
-							plane_pitch_bytes, 0, d_cmax, d_fix, stream);
+							plane_pitch_bytes, 0, d_cmax, d_fix, d_work, work_bytes, stream);
 }
 
 // The same with the digit planes cut along the cells into chunks of chunk_ksteps * 32 cells: chunk c is a dense quantised
@@ -562,10 +516,11 @@ extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int
 // (nrm_gram_i8_chunk).  d_q: ceil(ceil(k_pad / 32) / chunk_ksteps) * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices) bytes.
 extern "C" int nrm_residualize_q_chunked(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 										 int64_t ldc, const double* d_dci, int rank, int64_t rows_pad, double* d_ss, int nslices, void* d_q,
-										 int32_t* d_exp, int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* stream) {
+										 int32_t* d_exp, int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* d_work, int64_t work_bytes,
+										 void* stream) {
 	NRM_REQUIRE(chunk_ksteps > 0 && chunk_ksteps < (1 << 24), "nrm_residualize_q_chunked: bad chunk size");
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, nullptr, 0, rows_pad, d_ss, nullptr, nslices, d_q, d_exp, 0,
-							chunk_ksteps, d_cmax, d_fix, stream);
+							chunk_ksteps, d_cmax, d_fix, d_work, work_bytes, stream);
 }
 
 // Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS

@@ -150,6 +150,7 @@ class Engine:
 		self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
 		self._gram_work = None
 		self._skinny_ws = None
+		self._k1_ws = {}
 		self._copy = None
 		self.pool = PinnedPool(self.lib)
 		self._cmax = {}
@@ -265,6 +266,19 @@ class Engine:
 		e = None if d_c is None else self._cmax.get(d_c.data_ptr())
 		return e[1].data_ptr() if e is not None and e[0]() is d_c else 0
 
+	def k1_work(self, dtype_code, rows_pad, n, nc, chunk_ksteps=0):
+		"""(pointer, bytes) of the scratch through which K1 keeps its rows on chip (csrc/nrm_residualize_res.hip): one buffer per
+		launch stream, zeroed when it is allocated (the kernel leaves its counters at zero), grown on demand.  (0, 0): the shape is
+		outside that kernel, or NRM_K1=v4 asks for the two-sweep kernel."""
+		need = int(self.lib.nrm_residualize_workspace_bytes(dtype_code, rows_pad, n, nc, chunk_ksteps))
+		if need == 0 or os.environ.get('NRM_K1', '') == 'v4':
+			return 0, 0
+		key = self._stream()
+		w = self._k1_ws.get(key)
+		if w is None or w.numel() < need:
+			w = self._k1_ws[key] = self.zeros((need + (need >> 2), ), self.torch.uint8)
+		return w.data_ptr(), int(w.numel())
+
 	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True, into=None):
 		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n).  nslices = 5 / 6: also (keep_fp64=False: only) the
 		fixed-point digit planes of the integer Gram engine, written by K1 itself.
@@ -315,7 +329,7 @@ class Engine:
 					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 					0 if d_dci is None else d_dci.data_ptr(), int(rank), 0 if out is None else out.data_ptr(), kp, rp, ss.data_ptr(),
 					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self.cmax_ptr(d_c), fix.data_ptr(),
-					self._stream()))
+					*self.k1_work(NRM_F64 if x.dtype == torch.float64 else NRM_F32, rp, n, nc), self._stream()))
 				r = Residualized(rows, n, out, ss, coef, shape=(rp, kp))
 				r._quant = (planes, exps, nslices)
 				r.fix = fix
@@ -360,7 +374,8 @@ class Engine:
 				x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 				0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 				0 if d_dci is None else d_dci.data_ptr(), int(rank), rows_pad, ss.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(),
-				cks, self.cmax_ptr(d_c), fix.data_ptr(), self._stream()))
+				cks, self.cmax_ptr(d_c), fix.data_ptr(), *self.k1_work(NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows_pad, n, nc, cks),
+				self._stream()))
 		r = Residualized(rows, n, None, ss, None, shape=(rows_pad, kp))
 		r._quant = ([planes[c * cb:(c + 1) * cb] for c in range(nchunks)], exps, nslices)
 		r._planes = planes  # (the one buffer the chunk operands are views of)
@@ -712,7 +727,7 @@ class Engine:
 						xc.data_ptr(), NRM_F64 if xc.dtype == torch.float64 else NRM_F32, b - a, n, xc.stride(0),
 						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
 						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
-						fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
+						fixt.data_ptr() + a * FIX_STRIDE * 8, *self.k1_work(NRM_F64 if xc.dtype == torch.float64 else NRM_F32, rpc, n, nc), self._stream()))
 					blk = self.row_block(whole, a, a + rpc, rows=b - a)
 					dot = self.gram(blk, blk, True, nslices=ns)
 					_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), blk.ss.data_ptr(), blk.ss.data_ptr(), b - a, b - a, int(n), float(dof), 1, 0,
@@ -789,7 +804,7 @@ class Engine:
 						x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, b - a, n, x.stride(0),
 						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
 						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
-						fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
+						fixt.data_ptr() + a * FIX_STRIDE * 8, *self.k1_work(NRM_F64 if x.dtype == torch.float64 else NRM_F32, rpc, n, nc), self._stream()))
 				torch.cuda.current_stream(self.device).synchronize()  # the block is released before the next one is made
 				del x
 			mark('residualised')
