@@ -103,13 +103,15 @@ int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int
 					  void* d_work, int64_t work_bytes, void* stream);
 /* d_work / work_bytes (nrm_residualize_q, nrm_residualize_q_chunked): a device scratch of at least nrm_residualize_workspace_bytes()
  * bytes, 16-byte aligned, ZEROED ONCE by the caller when it is allocated (the kernel leaves its counters at zero again) and not
- * shared by launches that may run at the same time.  With it -- and d_out == NULL, at most 48 covariates, n % 4 == 0 or covariate
- * rows padded with finite values to a multiple of 4 cells (ldc >= round_up(n, 4)) -- K1 keeps every row ON CHIP between its two
+ * shared by launches that may run at the same time.  With it -- and d_out == NULL, at most 48 covariates, n % 4 == 0 -- K1 keeps every row ON CHIP between its two
  * phases (csrc/nrm_residualize_res.hip): one HBM read per input row instead of two; a row longer than 6144 fp32 / 3072 fp64 cells
  * is shared by the workgroups that hold its segments, which exchange their partial products through the scratch (summed in a
  * fixed order: results are bitwise reproducible).  NULL: the two-sweep kernel.  Returns 0 for shapes the resident kernel does not
  * take. */
 int64_t nrm_residualize_workspace_bytes(int x_dtype, int64_t rows_pad, int64_t n, int64_t nc, int64_t chunk_ksteps);
+/* Profiling aid, not part of the product path: d_stamps = a device buffer of 8 int64 per work item of the resident kernel (see
+ * csrc/nrm_residualize_res.hip) that later launches fill with time stamps of its phases; NULL switches it off (tools/k1_phases.py). */
+int nrm_k1_debug_buffer(void* d_stamps);
 /* The same with the digit planes cut along the cells into chunks of 32 * chunk_ksteps cells: chunk c is a dense quantised operand
  * of its own (nslices planes of rows_pad / 32 * chunk_ksteps KB) at d_q + c * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices);
  * all chunks share d_exp; the last chunk is zero padded.  The sharded coex path (normalisr_amd/distributed.py; the N > 1 form of

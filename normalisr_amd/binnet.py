@@ -72,21 +72,22 @@ def binnet(net, qcut):
 	if qcut <= 0 or qcut >= 1:
 		raise ValueError('Q-value cutoff must be between 0 and 1.')
 	eng = _engine.get_engine()
-	torch = eng.torch
-	with torch.cuda.device(eng.device):
-		d_p = net.contiguous() if on_device else eng.upload(_engine.as_input(net))
-		if d_p.dtype not in (torch.float32, torch.float64):
-			d_p = d_p.to(torch.float64)
-		out = torch.empty((nt, nt), dtype=torch.uint8, device=eng.device)
-		total = torch.zeros(1, dtype=torch.int64, device=eng.device)
-		flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
-		_lib.check(eng.lib.nrm_binnet(d_p.data_ptr(), _lib.NRM_F64 if d_p.dtype == torch.float64 else _lib.NRM_F32, nt, d_p.stride(0),
-									  float(qcut), out.data_ptr(), out.stride(0), total.data_ptr(), flags.data_ptr(), eng._stream()))
-		if int(flags[0].item()):
-			raise AssertionError('P-values must be finite and within [0,1] (binnet.py:151-152).')
-		if int(total.item()) == 0:
-			raise RuntimeError('Empty binary network.')
-		return out.to(torch.bool) if on_device else eng.download(out).view(np.bool_)  # the kernel writes exact 0/1 bytes
+	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
+		torch = eng.torch
+		with torch.cuda.device(eng.device):
+			d_p = net.contiguous() if on_device else eng.upload(_engine.as_input(net))
+			if d_p.dtype not in (torch.float32, torch.float64):
+				d_p = d_p.to(torch.float64)
+			out = torch.empty((nt, nt), dtype=torch.uint8, device=eng.device)
+			total = torch.zeros(1, dtype=torch.int64, device=eng.device)
+			flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
+			_lib.check(eng.lib.nrm_binnet(d_p.data_ptr(), _lib.NRM_F64 if d_p.dtype == torch.float64 else _lib.NRM_F32, nt, d_p.stride(0),
+										  float(qcut), out.data_ptr(), out.stride(0), total.data_ptr(), flags.data_ptr(), eng._stream()))
+			if int(flags[0].item()):
+				raise AssertionError('P-values must be finite and within [0,1] (binnet.py:151-152).')
+			if int(total.item()) == 0:
+				raise RuntimeError('Empty binary network.')
+			return out.to(torch.bool) if on_device else eng.download(out).view(np.bool_)  # the kernel writes exact 0/1 bytes
 
 
 assert __name__ != "__main__"

@@ -306,7 +306,8 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 	NRM_REQUIRE(!(want_alpha && samexy), "alpha is not provided for dy == NULL (meaningless in the reference, association.py:1066-1068)");
 	DevBuf qx, qy, ex, ey, fx, fy, k1w;
 	int64_t k1_bytes = 0;  // K1's scratch (rows resident on chip, nrm_residualize_res.hip): the larger of the two operands' needs, zeroed once
-	if (nslices) {
+	const char* k1_mode = getenv("NRM_K1");
+	if (nslices && k1_mode && !strcmp(k1_mode, "res")) {
 		k1_bytes = nrm_residualize_workspace_bytes(x_dtype, mp, n, nc, 0);
 		if (!samexy) {
 			const int64_t b = nrm_residualize_workspace_bytes(y_dtype, np_, n, nc, 0);

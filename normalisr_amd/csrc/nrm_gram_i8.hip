@@ -93,10 +93,13 @@ __global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict_
 	const int flip = (r >> 3) & 1;
 	int dsum[NS - 1];
 	unsigned dsq[NS - 1];
+	unsigned long long dsq64[NS - 1];
+	unsigned steps = 0;
 #pragma unroll
 	for (int s = 0; s < NS - 1; s++) {
 		dsum[s] = 0;
 		dsq[s] = 0u;
+		dsq64[s] = 0ull;
 	}
 	for (int64_t k = (int64_t)lane * 4; k < nks * QK; k += 256) {
 		double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -119,13 +122,25 @@ __global__ void __launch_bounds__(256) k_quantize_rows(const double* __restrict_
 			dsum[s] = __builtin_amdgcn_sdot4((int)w[s], 0x01010101, dsum[s], false);
 			dsq[s] = (unsigned)__builtin_amdgcn_sdot4((int)w[s], (int)w[s], (int)dsq[s], false);
 		}
+		// one wave per row: a lane covers cells / 64, so its 32-bit sum of squares (<= 4 * 2^14 per step) is folded into 64 bits
+		// every 2^15 steps (2^31 at most), and the 16-lane sums below are taken in 64 bits -- rows of up to 2^22 cells and beyond
+		if ((++steps & 0x7fff) == 0) {
+#pragma unroll
+			for (int s = 0; s < NS - 1; s++) {
+				dsq64[s] += dsq[s];
+				dsq[s] = 0u;
+			}
+		}
 	}
 	if (fix) {  // the row's record for K3's correction and guard (nrm_fix.h)
 		double S[5] = {0, 0, 0, 0, 0}, Q2[5] = {0, 0, 0, 0, 0};
 #pragma unroll
 		for (int s = 0; s < NS - 1; s++) {
 			S[s] = (double)wave_sum_i32(dsum[s]);
-			Q2[s] = (double)wave_sum_u32(dsq[s]);
+			unsigned long long q = dsq64[s] + dsq[s];
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+			Q2[s] = (double)q;
 		}
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o, 64);

@@ -478,10 +478,11 @@ static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t 
 		}
 		qo.q = (char*)d_q;
 		qo.exps = d_exp;
-		// rows resident on chip between the two phases (nrm_residualize_res.hip) whenever the caller lends a workspace and only the
-		// digit planes are wanted; NRM_K1=v4 keeps the two-sweep kernel (ablation)
-		static const bool two_sweeps = getenv("NRM_K1") && !strcmp(getenv("NRM_K1"), "v4");
-		if (d_work && !d_out && !two_sweeps && (!active || n % 4 == 0 || ldc >= ((n + 3) & ~(int64_t)3)) && nrm_k1_res_applies(x_dtype, n, nc, chunk_ksteps))
+		// rows resident on chip between the two phases (nrm_residualize_res.hip) when the caller lends a workspace.  The callers in this
+		// tree do so only under NRM_K1=res: the kernel reads every row from HBM once, but an item's chain of phases (load, products,
+		// meeting, digits, records: tools/k1_phases.py) keeps its registers for 45 - 90 us at two workgroups per CU, so the two-sweep
+		// kernel below is still faster on every BASELINE shape
+		if (d_work && !d_out && nrm_k1_res_applies(x_dtype, n, nc, chunk_ksteps))
 			return nrm_k1_res_launch(d_x, x_dtype, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, rows_pad, d_ss, d_coef, nslices, qo, d_work, work_bytes,
 									 chunk_ksteps, (hipStream_t)stream);
 	}

@@ -17,12 +17,14 @@
 //
 // Reference: association.py:224-233 (ccx = dci @ (dc @ dx.T); dx1 = dx - ccx @ dc; mean of squares).
 #include "nrm_k1.h"
+#include <cstdlib>
 
 #define RR_R 4         // rows per work item
 #define RR_NC_MAX 48   // covariates (partials of 4 (nc + 14) doubles per item); beyond: k_residualize_v4
 #define RR_STAGE 3072   // doubles of LDS through which the members' partials are gathered (>= 4 (RR_NC_MAX + 2))
 #define RR_SEG_MAX 256 // segments per row (cluster size; far below the 512 workgroup slots of the chip)
 #define RR_CB 2        // covariates per pass over the registers
+#define RR_SLOT 48     // doubles per (wave, row-of-16-lanes) slot of the workgroup reductions (>= 4 rows x 11 record entries)
 
 template <typename T>
 struct RRGeom {
@@ -56,6 +58,42 @@ __device__ __forceinline__ double rr_val(T v) {
 	return (double)v;
 }
 
+// Sum / maximum of a double over the 64 lanes without LDS round trips: four DPP steps inside every row of 16 lanes (two 32-bit moves
+// and one fp64 operation each), then the four row results through scalar registers.  Every lane gets the result.
+template <int CTRL>
+__device__ __forceinline__ double rr_dpp(double v) {
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rr_row_sum(double v) {  // over the 16 lanes of a DPP row; every lane of the row gets it
+	v += rr_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+	v += rr_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+	v += rr_dpp<0x141>(v);  // row_half_mirror
+	v += rr_dpp<0x140>(v);  // row_mirror
+	return v;
+}
+__device__ __forceinline__ double rr_row_max(double v) {
+	v = fmax(v, rr_dpp<0xB1>(v));
+	v = fmax(v, rr_dpp<0x4E>(v));
+	v = fmax(v, rr_dpp<0x141>(v));
+	v = fmax(v, rr_dpp<0x140>(v));
+	return v;
+}
+// fold the 16 (wave, row) partials of a workgroup in a fixed order
+__device__ __forceinline__ double rr_sum16(const double (*p)[RR_SLOT], int o) {
+	double v[4];
+#pragma unroll
+	for (int w = 0; w < 4; w++) v[w] = (p[4 * w][o] + p[4 * w + 1][o]) + (p[4 * w + 2][o] + p[4 * w + 3][o]);
+	return (v[0] + v[1]) + (v[2] + v[3]);
+}
+__device__ __forceinline__ double rr_max16(const double (*p)[RR_SLOT], int o) {
+	double v = p[0][o];
+#pragma unroll
+	for (int w = 1; w < 16; w++) v = fmax(v, p[w][o]);
+	return v;
+}
+
 // slab traffic between the members of a cluster: agent-scope (sc1) stores and loads, which no L1 and no other XCD's L2 keeps
 __device__ __forceinline__ void rr_post(double* p, double v) {
 	__hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -80,17 +118,24 @@ template <typename T, int NS>
 __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx, const double* __restrict__ c, int nc,
 															 int64_t ldc, const double* __restrict__ dci, int active, double* __restrict__ ss,
 															 double* __restrict__ coef, QuantOut qo, int* __restrict__ ctr, double* __restrict__ part, int stride,
-															 int nseg, int gseg, int ngroups) {
+															 int nseg, int gseg, int ngroups, long long* __restrict__ dbg, int ablate) {
 	constexpr int R = RR_R, G = RRGeom<T>::G, CB = RR_CB, NP = NS - 1, NREC = 2 * NP + 1, B = 8 * NS - 2;
 	extern __shared__ double s_dyn[];
-	__shared__ double s_w[4][R * (CB + 2)];
-	__shared__ double s_rec[4][R * NREC];
+	__shared__ double s_w[16][RR_SLOT];  // one slot per (wave, row of 16 lanes)
 	__shared__ double s_fin[R * NREC];
 	__shared__ double s_stage[RR_STAGE];
 	__shared__ double s_xm[R], s_xq[R], s_mx[R];
 	__shared__ int s_sh[R], s_loose, s_item, s_last;
-	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63, slot = tid >> 4;
+	const bool first = (lane & 15) == 0;  // the lane that writes its row's partial
 	const int64_t items = (int64_t)ngroups * nseg;
+	// pseudo-inverse and covariate maxima: once per workgroup into LDS behind the OLS tables
+	double* const s_dci = s_dyn + (size_t)2 * R * ((nc + CB - 1) / CB * CB > 0 ? (nc + CB - 1) / CB * CB : CB);
+	double* const s_cmax = s_dci + (size_t)nc * nc;
+	if (active) {
+		for (int i = tid; i < nc * nc; i += 256) s_dci[i] = dci[i];
+		for (int i = tid; i < nc; i += 256) s_cmax[i] = qo.cmax ? qo.cmax[i] : 0.0;
+	}
 
 	if (tid == 0) s_item = atomicAdd(ctr, 1);
 	__syncthreads();
@@ -99,10 +144,9 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 		// (the arguments pass through an empty asm at the top of every item: what is derived from them is recomputed per item on the
 		// scalar unit instead of being hoisted out of the loop and kept -- spilled -- in vector registers across it)
 		asm volatile("" : "+s"(n), "+s"(nc), "+s"(ldc), "+s"(ldx), "+s"(rows), "+s"(nseg), "+s"(gseg), "+s"(active), "+s"(stride));
-		asm volatile("" : "+s"(qo.nks), "+s"(qo.cks), "+s"(qo.chunk_bytes), "+s"(qo.plane_bytes), "+s"(qo.q), "+s"(qo.fix), "+s"(qo.cmax), "+s"(qo.exps));
-		asm volatile("" : "+s"(x), "+s"(c), "+s"(dci), "+s"(ss), "+s"(coef), "+s"(part), "+s"(ctr));
-		const int64_t n4 = n & ~(int64_t)3, kq = qo.nks * 32;
-		const int64_t klast = ((n + 3) & ~(int64_t)3) - 4;  // last group of 4 cells that has covariate values (pitch >= round_up(n, 4), finite padding)
+		asm volatile("" : "+s"(qo.nks), "+s"(qo.cks), "+s"(qo.chunk_bytes), "+s"(qo.plane_bytes));  // (not the pointers: they would turn into flat ones)
+		const int64_t kq = qo.nks * 32;
+		const int64_t klast = n - 4;  // (n % 4 == 0: the launcher sends other rows to k_residualize_v4)
 		const int gtotal = (int)((kq + 1023) / 1024);
 		const int na = nc + 2;  // a slab row: nc products, max|x|, |x|^2
 		const int ncp = (nc + CB - 1) / CB * CB;  // covariates padded to whole passes (b of a padding covariate is 0)
@@ -112,6 +156,11 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 		const int group = (int)(item / nseg), seg = (int)(item - (int64_t)group * nseg);
 		const int64_t row0 = (int64_t)group * R, k0 = (int64_t)seg * gseg * 1024 + tid * 4;
 		const int gcount = gtotal - seg * gseg < gseg ? gtotal - seg * gseg : gseg;  // groups of 1024 cells in this segment
+		// profiling aid (nrm_k1_debug_buffer): 8 time stamps of the 100 MHz clock per item
+		auto stamp = [&](int i) {
+			if (dbg && tid == 0) dbg[item * 8 + i] = wall_clock64();
+		};
+		stamp(0);
 		int* const gc = ctr + 4 + 4 * group;  // the cluster's counters: first meeting, meeting of the true maxima, row records
 		double* const mine = part + item * stride;
 		const double* const slab = part + (int64_t)group * nseg * stride;
@@ -124,12 +173,10 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 			for (int r = 0; r < R; r++) {
 				const bool live = row0 + r < rows;
 				const T* xr = x + (live ? (row0 + r) : 0) * ldx;
-				if (g < gcount && live && k < n4)
+				if (g < gcount && live && k < n)
 					rr_ld4<T>(xr + k, d[r][g]);
-				else {
-#pragma unroll
-					for (int i = 0; i < 4; i++) d[r][g][i] = (g < gcount && live && k + i < n) ? xr[k + i] : (T)0;
-				}
+				else
+					d[r][g][0] = d[r][g][1] = d[r][g][2] = d[r][g][3] = (T)0;
 			}
 		}
 		// covariates c0 .. c0 + CB - 1 (clamped to the last one: a padding covariate's b is 0, its product unused) at the 4 cells of
@@ -137,6 +184,7 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 		auto cov = [&](int c0, int g, double (&cv)[CB][4]) {
 			int64_t k = k0 + (int64_t)g * 1024;
 			k = k < klast ? k : klast;
+			if (ablate & 2) k = tid * 4;  // (ablation: every covariate load from the same 8 KB -- L1 / L2 hits)
 #pragma unroll
 			for (int q = 0; q < CB; q++) {
 				const int qq = c0 + q < nc ? c0 + q : nc - 1;
@@ -182,20 +230,19 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 			}
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				double m = xmax[r];
-#pragma unroll
-				for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-				const double q = wave_sum(xsq[r]);
-				if (lane == 0) {
-					s_w[wid][r * (CB + 2) + CB] = m;
-					s_w[wid][r * (CB + 2) + CB + 1] = q;
+				const double m = rr_row_max(xmax[r]);
+				const double q = rr_row_sum(xsq[r]);
+				if (first) {
+					s_w[slot][r * (CB + 2) + CB] = m;
+					s_w[slot][r * (CB + 2) + CB + 1] = q;
 				}
 			}
 			__syncthreads();
+			stamp(1);
 			if (tid < R) {
 				const int o = tid * (CB + 2) + CB;
-				const double m = fmax(fmax(s_w[0][o], s_w[1][o]), fmax(s_w[2][o], s_w[3][o]));
-				const double q = (s_w[0][o + 1] + s_w[1][o + 1]) + (s_w[2][o + 1] + s_w[3][o + 1]);
+				const double m = rr_max16(s_w, o);
+				const double q = rr_sum16(s_w, o + 1);
 				if (nseg == 1) {
 					s_xm[tid] = m;
 					s_xq[tid] = q;
@@ -242,15 +289,15 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 					for (int r = 0; r < R; r++)
 #pragma unroll
 						for (int q = 0; q < CB; q++) {
-							const double v = wave_sum(acc[r][q]);
-							if (lane == 0) s_w[wid][r * (CB + 2) + q] = v;
+							const double v = rr_row_sum(acc[r][q]);
+							if (first) s_w[slot][r * (CB + 2) + q] = v;
 						}
 					__syncthreads();
 					if (tid < R * CB) {
 						const int r = tid / CB, q = tid % CB;
 						if (c0 + q < nc) {
 							const int o = r * (CB + 2) + q;
-							const double v = (s_w[0][o] + s_w[1][o]) + (s_w[2][o] + s_w[3][o]);
+							const double v = rr_sum16(s_w, o);
 							if (nseg == 1)
 								ta[r * ncp + c0 + q] = v;
 							else
@@ -261,10 +308,12 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 			}
 		}
 		// ---- the cluster meets: every member adds up the nseg partials in segment order ----
+		stamp(2);
 		if (nseg > 1) {
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__syncthreads();
 			if (tid == 0) rr_meet(gc, nseg);
+			stamp(3);
 			__syncthreads();
 			gather(0, R * na, [&](int i) { return i % na == nc; },
 				   [&](int i, double v) {
@@ -278,13 +327,14 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 				   });
 		}
 		__syncthreads();
+		stamp(4);
 		if (tid == 0) s_item = atomicAdd(ctr, 1);  // the next ticket, drawn only now: it cannot lie in this cluster (see the header)
 		if (active) {
 			for (int i = tid; i < R * ncp; i += 256) {
 				const int r = i / ncp, q = i - r * ncp;
 				double v = 0.0;
 				if (q < nc) {
-					for (int e = 0; e < nc; e++) v = fma(dci[(int64_t)q * nc + e], ta[r * ncp + e], v);
+					for (int e = 0; e < nc; e++) v = fma(s_dci[q * nc + e], ta[r * ncp + e], v);
 					if (coef && seg == 0 && row0 + r < rows) coef[(row0 + r) * nc + q] = v;
 				}
 				tb[i] = v;
@@ -299,7 +349,7 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 				const double sq = s_xq[tid];
 				double proj = 0.0;
 				for (int q = 0; q < nc; q++) {
-					m = fma(fabs(tb[tid * ncp + q]), qo.cmax[q], m);
+					m = fma(fabs(tb[tid * ncp + q]), s_cmax[q], m);
 					proj = fma(ta[tid * ncp + q], tb[tid * ncp + q], proj);
 				}
 				const double est = sq - proj;  // |x~|^2 up to cancellation: trusted only while it is a fair share of |x|^2
@@ -352,19 +402,17 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 #pragma unroll
 					for (int r = 0; r < R; r++)
 #pragma unroll
-						for (int i = 0; i < 4; i++) rmax[r] = fmax(rmax[r], k0 + (int64_t)g * 1024 + i < n ? fabs(v[r][i]) : 0.0);
+						for (int i = 0; i < 4; i++) rmax[r] = fmax(rmax[r], k0 + (int64_t)g * 1024 < n ? fabs(v[r][i]) : 0.0);
 				}
 			}
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				double m = rmax[r];
-#pragma unroll
-				for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-				if (lane == 0) s_w[wid][r] = m;
+				const double m = rr_row_max(rmax[r]);
+				if (first) s_w[slot][r] = m;
 			}
 			__syncthreads();
 			if (tid < R) {
-				const double m = fmax(fmax(s_w[0][tid], s_w[1][tid]), fmax(s_w[2][tid], s_w[3][tid]));
+				const double m = rr_max16(s_w, tid);
 				if (nseg == 1)
 					s_mx[tid] = m;
 				else
@@ -387,6 +435,7 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 			if (seg == 0) qo.exps[row0 + tid] = e - B;
 		}
 		__syncthreads();
+		stamp(5);
 		// ---- phase B: residual from the registers -> sum of squares, digits (layout: nrm_gram_i8.hip), digit statistics ----
 		double sq[R];
 		int dsum[R][NP];
@@ -424,14 +473,16 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 						for (int r = 0; r < R; r++) {
 #pragma unroll
 							for (int i = 0; i < 4; i++) {
-								if (k + i >= n) v[r][i] = 0.0;  // (cells past the row: zero digits)
+								if (k >= n) v[r][i] = 0.0;  // (cells past the row: zero digits)
 								sq[r] = fma(v[r][i], v[r][i], sq[r]);
 							}
 							unsigned w[NS];
 							nrm_digits4<NS>(v[r], sh[r], w);
 							char* dst = qrow[r] + ks * 1024 + (((kk >> 4) ^ flip[r]) << 4) + (kk & 15);
+							if (!(ablate & 1)) {
 #pragma unroll
-							for (int s = 0; s < NS; s++) *reinterpret_cast<unsigned*>(dst + s * qo.plane_bytes) = w[s];
+								for (int s = 0; s < NS; s++) *reinterpret_cast<unsigned*>(dst + s * qo.plane_bytes) = w[s];
+							}
 #pragma unroll
 							for (int s = 0; s < NP; s++) {
 								dsum[r][s] = __builtin_amdgcn_sdot4((int)w[s], 0x01010101, dsum[r][s], false);
@@ -442,23 +493,25 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 				}
 			}
 		}
+		stamp(6);
 		// ---- row records: sum of squares and digit statistics of this segment -> the row's ----
 #pragma unroll
 		for (int r = 0; r < R; r++) {
-			const double v = wave_sum(sq[r]);
-			if (lane == 0) s_rec[wid][r * NREC] = v;
+			const double v = rr_row_sum(sq[r]);
+			if (first) s_w[slot][r * NREC] = v;
 #pragma unroll
 			for (int s = 0; s < NP; s++) {
-				const long long a = wave_sum_i32(dsum[r][s]), b = wave_sum_u32(dsq[r][s]);
-				if (lane == 0) {
-					s_rec[wid][r * NREC + 1 + s] = (double)a;  // (integers far below 2^53: exact)
-					s_rec[wid][r * NREC + 1 + NP + s] = (double)b;
+				const int a = row16_sum(dsum[r][s]);
+				const unsigned b = (unsigned)row16_sum((int)dsq[r][s]);
+				if (first) {
+					s_w[slot][r * NREC + 1 + s] = (double)a;  // (integers far below 2^53: exact)
+					s_w[slot][r * NREC + 1 + NP + s] = (double)b;
 				}
 			}
 		}
 		__syncthreads();
 		if (tid < R * NREC) {
-			const double v = (s_rec[0][tid] + s_rec[1][tid]) + (s_rec[2][tid] + s_rec[3][tid]);
+			const double v = rr_sum16(s_w, tid);
 			if (nseg == 1)
 				s_fin[tid] = v;
 			else
@@ -501,6 +554,7 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 			}
 		}
 		__syncthreads();
+		stamp(7);
 		item = s_item;
 	}
 	// every workgroup draws exactly one ticket past the end; the one that draws the last of them resets the ticket counter
@@ -532,7 +586,7 @@ static int64_t rr_k_ext(int64_t n, int64_t chunk_ksteps) {
 
 // true: the resident kernel takes this shape
 bool nrm_k1_res_applies(int x_dtype, int64_t n, int64_t nc, int64_t chunk_ksteps) {
-	if (nc > RR_NC_MAX) return false;
+	if (nc > RR_NC_MAX || n % 4 != 0 || n < 4) return false;
 	int nseg, gseg;
 	rr_geometry(x_dtype, rr_k_ext(n, chunk_ksteps), &nseg, &gseg);
 	return nseg <= RR_SEG_MAX;
@@ -545,6 +599,18 @@ extern "C" int64_t nrm_residualize_workspace_bytes(int x_dtype, int64_t rows_pad
 	const int64_t groups = (rows_pad + RR_R - 1) / RR_R;
 	const int64_t ints = (4 + 4 * groups + 3) / 4 * 4;  // 16-byte aligned slabs behind the counters
 	return ints * 4 + (nseg > 1 ? groups * nseg * (int64_t)RR_R * (nc + 14) * 8 : 0);
+}
+
+// Profiling aid: a device buffer of 8 int64 per work item (rows_pad / 4 x segments) that the next launches fill with time stamps of
+// the 100 MHz clock (start, rows loaded, products posted, cluster met, partials gathered, scale decided, digits written, done);
+// nullptr switches it off.  Not part of the product path.
+static long long* g_rr_dbg = nullptr;
+static int g_rr_ablate = 0;  // bit 0: no digit stores, bit 1: covariate loads from one 8 KB window (timing experiments only: wrong results)
+extern "C" int nrm_k1_debug_buffer(void* d_stamps) {
+	g_rr_dbg = (long long*)d_stamps;
+	const char* a = getenv("NRM_K1_ABLATE");
+	g_rr_ablate = a ? atoi(a) : 0;
+	return NRM_OK;
 }
 
 static int rr_slots() {  // workgroup slots of the device at two per CU (256 VGPRs per thread)
@@ -576,10 +642,10 @@ int nrm_k1_res_launch(const void* d_x, int x_dtype, int64_t rows, int64_t n, int
 	const int slots = rr_slots();
 	const dim3 grid((unsigned)(items < slots ? items : slots));
 	const int ncp = (nc + RR_CB - 1) / RR_CB * RR_CB;
-	const size_t lds = (size_t)2 * RR_R * (ncp > 0 ? ncp : RR_CB) * sizeof(double);
+	const size_t lds = ((size_t)2 * RR_R * (ncp > 0 ? ncp : RR_CB) + (size_t)nc * nc + nc) * sizeof(double);
 #define RR_GO(T, NS)                                                                                                                            \
 	hipLaunchKernelGGL((k_residualize_res<T, NS>), grid, dim3(256), lds, st, (const T*)d_x, rows, n, ldx, d_c, nc, ldc, d_dci, active, d_ss, d_coef, qo, \
-					   ctr, part, stride, nseg, gseg, (int)groups)
+					   ctr, part, stride, nseg, gseg, (int)groups, g_rr_dbg, g_rr_dbg ? g_rr_ablate : 0)
 	if (x_dtype == NRM_F32) {
 		if (nslices == 6)
 			RR_GO(float, 6);

@@ -50,6 +50,14 @@ __device__ __forceinline__ void store_out(void* base, int64_t idx, double v) {
 }
 
 // Integer-engine row records (nrm_fix.h) inside a sweep: the x rows of the workgroup's tile staged in LDS, the thread's column
+// The guard's counter saturates instead of wrapping: a wave adds its hits only while the counter is below 2^30 (a plain read first:
+// the overshoot is bounded by the waves in flight times the pairs of a wave, far below 2^31), so that "hits > 0" stays true
+// however many of a large problem's pairs fail (46 000 sparse genes on the non-symmetric path would pass 2^31), also after the
+// ranks' counters have been added up.
+__device__ __forceinline__ void nrm_guard_count(int* flags, int bad) {
+	if (bad > 0 && __hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (1 << 30)) atomicAdd(flags + 2, bad);
+}
+
 // record in registers; fix_finish publishes the guard's verdict: flags[2] += uncertified pairs, flags[3] = max error estimate
 // (float bits; positive floats order like their bit patterns).
 #define SW_FIX 7  // doubles of a record the sweeps use: u0..u4, c, g
@@ -77,7 +85,7 @@ __device__ __forceinline__ void fix_finish(const FixArgs& f, int32_t* __restrict
 		worst = fmaxf(worst, __shfl_xor(worst, o, 64));
 	}
 	if ((threadIdx.x & 63) == 0) {
-		if (bad) atomicAdd(&flags[2], bad);
+		nrm_guard_count(flags, bad);
 		// (a maximum only grows: a wave that cannot raise it stays away -- tens of thousands of atomics on one address cost more than
 		// the guard itself; a stale read merely sends a redundant atomic)
 		if (worst > 0.f && __float_as_int(worst) > __hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[3], __float_as_int(worst));
@@ -487,7 +495,7 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 		epsy_g = 0.5 * unit;
 		// not the rows the scales were taken from (the two sums are taken in different orders: equal to rounding when the rows are
 		// the same): counted as uncertified, the caller redoes the step on the fp64 kernel
-		if (sf.ss_ref && !(fabs(sf.ss_ref[y] - ssraw[y]) <= 1e-9 * ssraw[y])) atomicAdd(&flags[2], 1);
+		if (sf.ss_ref && !(fabs(sf.ss_ref[y] - ssraw[y]) <= 1e-9 * ssraw[y])) nrm_guard_count(flags, 1);
 	}
 	double q = 0.0, ty = 0.0;  // ty: sum_c |b_c| |C_c| eps(y, c), the covariates' share of the error of |y~|^2
 	if (rank_pos) {
@@ -558,7 +566,7 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
 		if (sf.zfix) {
-			if (bad_fix) atomicAdd(&flags[2], bad_fix);
+			nrm_guard_count(flags, bad_fix);
 			if (worst > 0.f && __float_as_int(worst) > __hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[3], __float_as_int(worst));
 		}
 	}

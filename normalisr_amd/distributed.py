@@ -84,11 +84,29 @@ def _reduce_flags(flags, group):
 	import torch.distributed as dist
 	f = flags.clone() if dist.get_backend(group) == 'nccl' else flags.cpu()
 	worst = f[3:4].clone() if f.shape[0] >= 4 else None
+	f[:3].clamp_(max=1 << 24)  # counters say "how many" only as a diagnostic: bounded per rank, their int32 sum cannot wrap
 	dist.all_reduce(f, group=group)
 	if worst is not None:
 		dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
 		f[3:4] = worst
 	return f
+
+
+def _on_engine(method):
+	"""Plan method that holds its engine's lock (engine.serialised): a resident plan's step is a sequence of launches on shared
+	scratch buffers, so two threads stepping plans on one device take turns.  Backends without an engine (the numpy backend of the
+	CPU tests) need no lock."""
+	import functools
+
+	@functools.wraps(method)
+	def locked(self, *a, **ka):
+		eng = getattr(self, 'eng', None) or getattr(getattr(self, 'be', None), 'eng', None)
+		if eng is None:
+			return method(self, *a, **ka)
+		with eng.lock:
+			return method(self, *a, **ka)
+
+	return locked
 
 
 class SharedArrays:
@@ -567,6 +585,7 @@ class CoexPlan:
 		self.outputs = outs
 		return outs
 
+	@_on_engine
 	def step(self, timed=False):
 		if timed:
 			self._timed_steps += 1
@@ -648,6 +667,7 @@ class CoexPlan:
 						recvs.append((s_rank, e, transposed))
 		return local, sends, recvs
 
+	@_on_engine
 	def complete_rows(self):
 		"""After step(): the complete rows of this rank's gene block, (rows, world * rows) for p and for the covariance, on
 		this rank's device.  The blocks this rank did not compute itself arrive from the ranks that did (mirrored blocks
@@ -709,6 +729,7 @@ class CoexPlan:
 			f = _reduce_flags(f, self.group)
 		self.be.eng.check_flags(f)
 
+	@_on_engine
 	def binnet_rows(self, p_rows, qcut):
 		"""binnet (binnet.py:134-173) of this rank's complete row block, in HBM: per-row BH q-values need nothing but the
 		row.  Returns the (rows, n_gene) uint8 block; the "Empty binary network" test is made on the sum over ranks."""
@@ -742,6 +763,7 @@ class CoexPlan:
 		else:
 			dst[...] = t.numpy() if hasattr(t, 'numpy') else np.asarray(t)
 
+	@_on_engine
 	def assemble(self, to_numpy=None, out_dir=None):
 		"""(p, dot, var) of the whole problem on rank 0 (None elsewhere) with the reference's contract (symmetric, zero
 		diagonals, coex.py:4-48): every rank completes its row block on its device and copies it into ITS rows of result
@@ -795,6 +817,7 @@ class DePlan:
 											return_dot=self.return_dot, want_alpha=False, out_dtype=self.out_dtype, cov=self.cov,
 											resident=True, state=self._state)
 
+	@_on_engine
 	def step(self, timed=False):
 		torch = self.eng.torch
 		if timed:
@@ -806,6 +829,7 @@ class DePlan:
 			self._ev.append((e0, e1))
 		return self.result
 
+	@_on_engine
 	def results(self):
 		"""(p, gamma, varx, vary) of the last step as numpy arrays, after the reference's assertions (association.py:248,252)."""
 		from .engine import GuardHit

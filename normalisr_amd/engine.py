@@ -8,6 +8,7 @@ Data layout in HBM:
   dot                 fp64 [m_pad][n_pad]
   outputs p / stat    out dtype [nx][ny]
 """
+import functools
 import os
 import threading
 
@@ -120,6 +121,20 @@ class _Span:
 		return False
 
 
+def serialised(method):
+	"""Engine method that runs with the engine's lock held.  One Engine per device is shared by every thread of the process --
+	its Gram / skinny / K1 scratch buffers, copy streams and pinned pool are shared state -- so calls from several Python threads
+	(the reference calls its block kernel from a thread pool: association.py:895,997, parallel.py:47-52; ctypes releases the GIL
+	inside every launch) take turns per device; the lock is re-entrant because the composite methods call the simple ones."""
+
+	@functools.wraps(method)
+	def locked(self, *a, **ka):
+		with self.lock:
+			return method(self, *a, **ka)
+
+	return locked
+
+
 class GuardHit(Exception):
 	"""The integer Gram engine's accuracy guard (csrc/nrm_fix.h) could not certify every P-value of a call: the caller redoes it on
 	the fp64 Gram kernel.  Internal: never reaches the user."""
@@ -148,6 +163,8 @@ class Engine:
 		self.torch = torch
 		self.lib = _lib.load()
 		self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+		self.lock = threading.RLock()
+		self._tls = threading.local()
 		self._gram_work = None
 		self._skinny_ws = None
 		self._k1_ws = {}
@@ -160,9 +177,19 @@ class Engine:
 		self.guard_tol = float(os.environ.get('NRM_I8_GUARD_TOL', '2.5e-7'))
 		self.last_guard = dict(hits=0, worst=0.0, fallback=False)
 
+	@property
+	def last_guard(self):
+		"""Verdict of the accuracy guard for the calling thread's last call on this engine."""
+		return getattr(self._tls, 'guard', None) or dict(hits=0, worst=0.0, fallback=False)
+
+	@last_guard.setter
+	def last_guard(self, v):
+		self._tls.guard = v
+
 	def _stream(self):
 		return self.torch.cuda.current_stream(self.device).cuda_stream
 
+	@serialised
 	def upload(self, a, dtype=None):
 		t = self.torch.from_numpy(np.ascontiguousarray(a))
 		if dtype is not None:
@@ -178,6 +205,7 @@ class Engine:
 	def host_unpin(self, a):
 		_lib.check(self.lib.nrm_host_unpin(a.ctypes.data))
 
+	@serialised
 	def download(self, t):
 		"""Device tensor -> a fresh numpy array.  Large results are copied into the array while it is page-locked (a
 		pageable D2H copy runs at a tenth of the PCIe rate); the lock is dropped before returning."""
@@ -204,12 +232,14 @@ class Engine:
 			self.host_unpin(out)
 		return out
 
+	@serialised
 	def zeros(self, shape, dtype):
 		"""Zero-filled device buffer (allocation by torch, the fill through the C ABI on the launch stream)."""
 		t = self.torch.empty(shape, dtype=dtype, device=self.device)
 		_lib.check(self.lib.nrm_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._stream()))
 		return t
 
+	@serialised
 	def copy_rows(self, dst, src):
 		"""dst[:rows, :cols] = src for 2-D device tensors of one dtype with unit column stride (strided rows allowed)."""
 		rows, cols = src.shape
@@ -217,6 +247,7 @@ class Engine:
 		es = src.element_size()
 		_lib.check(self.lib.nrm_copy_rows(dst.data_ptr(), dst.stride(0) * es, src.data_ptr(), src.stride(0) * es, cols * es, rows, self._stream()))
 
+	@serialised
 	def download_into(self, t, out):
 		"""Device tensor -> an existing C-contiguous numpy array (e.g. this rank's rows of a result matrix shared between the
 		ranks of a node): page-locked in place for the copy when possible, plain pageable copy otherwise."""
@@ -241,6 +272,7 @@ class Engine:
 				self.host_unpin(out)
 		return out
 
+	@serialised
 	def covariates(self, dc, dci):
 		"""fp64 covariates and pseudo-inverse on the device (replicated; tiny)."""
 		torch = self.torch
@@ -269,9 +301,11 @@ class Engine:
 	def k1_work(self, dtype_code, rows_pad, n, nc, chunk_ksteps=0):
 		"""(pointer, bytes) of the scratch through which K1 keeps its rows on chip (csrc/nrm_residualize_res.hip): one buffer per
 		launch stream, zeroed when it is allocated (the kernel leaves its counters at zero), grown on demand.  (0, 0): the shape is
-		outside that kernel, or NRM_K1=v4 asks for the two-sweep kernel."""
+		outside that kernel, or it was not asked for (NRM_K1=res: opt-in, the two-sweep kernel is faster on the BASELINE shapes)."""
+		if os.environ.get('NRM_K1', '') != 'res':
+			return 0, 0
 		need = int(self.lib.nrm_residualize_workspace_bytes(dtype_code, rows_pad, n, nc, chunk_ksteps))
-		if need == 0 or os.environ.get('NRM_K1', '') == 'v4':
+		if need == 0:
 			return 0, 0
 		key = self._stream()
 		w = self._k1_ws.get(key)
@@ -279,6 +313,7 @@ class Engine:
 			w = self._k1_ws[key] = self.zeros((need + (need >> 2), ), self.torch.uint8)
 		return w.data_ptr(), int(w.numel())
 
+	@serialised
 	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True, into=None):
 		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n).  nslices = 5 / 6: also (keep_fp64=False: only) the
 		fixed-point digit planes of the integer Gram engine, written by K1 itself.
@@ -350,6 +385,7 @@ class Engine:
 		return x.stride(1) == 1 and (x.stride(0) * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0 and (
 			d_c is None or ((d_c.stride(0) * 8) % 16 == 0 and d_c.data_ptr() % 16 == 0))
 
+	@serialised
 	def residualize_chunked(self, x, d_c, d_dci, rank, rows_pad, nslices, chunks, into=None):
 		"""K1 with the digit planes cut along the cells into (at most) `chunks` operands of equal size that share the row
 		exponents (nrm_residualize_q_chunked): what the sharded coex path sends to the other GPUs piece by piece.
@@ -383,6 +419,7 @@ class Engine:
 		r.fix = fix
 		return r
 
+	@serialised
 	def gram_chunk(self, a, b, symmetric, chunk, dot, accumulate):
 		"""K2 over one cell chunk of chunked operands (residualize_chunked): dot (+)= a_chunk @ b_chunk.T, exact per chunk."""
 		torch = self.torch
@@ -399,6 +436,7 @@ class Engine:
 												  int(a.rows), int(b.rows), 1 if accumulate else 0, 0, 0, 0, 1, self._gram_work.data_ptr(), self._stream()))
 		return dot
 
+	@serialised
 	def gram_chunk_blocks(self, a, g_chunk, g_exps, first, count, chunk, dot, accumulate):
 		"""The same against `count` consecutive blocks (cyclically from block `first`) of a gathered buffer in ONE launch:
 		g_chunk (world, chunk bytes) holds every rank's digit planes of this cell chunk, g_exps (world, rows_pad) their row
@@ -445,6 +483,7 @@ class Engine:
 		"""int32[4] device counters of a call: non-finite, R^2 > 1 + 1e-8 (association.py:248,252), guard hits, largest guard estimate."""
 		return self.zeros((4, ), self.torch.int32)
 
+	@serialised
 	def quantized(self, r, nslices):
 		"""Fixed-point digit planes and row exponents of residualised rows (cached on the Residualized object; written by K1
 		itself when it could, see residualize)."""
@@ -478,6 +517,7 @@ class Engine:
 			sub.fix = None if r.fix is None else r.fix[lo:hi]
 		return sub
 
+	@serialised
 	def gram(self, a, b, symmetric, dot=None, rows=None, nslices=0):
 		"""K2: dot[m_pad, n_pad] = a.data @ b.data.T.  nslices = 0: fp64 matrix cores (nrm_gram.hip); 5 / 6: the exact
 		fixed-point engine on the int8 matrix cores (nrm_gram_i8.hip), used by the association path for expression-like rows.
@@ -523,6 +563,7 @@ class Engine:
 		so that K1/K2/K3 of chunk c run while chunk c+1 crosses PCIe (NRM_PIPELINE=0 switches it off)."""
 		return (isinstance(dy, np.ndarray) and dy.nbytes >= 2 * self.CHUNK_BYTES and os.environ.get('NRM_PIPELINE', '1') != '0')
 
+	@serialised
 	def association_de_chunked(self, dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov=None):
 		"""General de path with the expression rows streamed from the host: every chunk of genes is an independent
 		problem against the same residualised design rows (association.py:890-909: the reference's tiles are independent
@@ -562,6 +603,7 @@ class Engine:
 			return dict(p=self.download(p), stat=self.download(stat), alpha=None, varx=self.variances(rx.ss, nx, n, out_dtype),
 						vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
 
+	@serialised
 	def start_host_results(self, nx, ny, out_dtype, bands=None):
 		"""Result arrays p and stat on the host, being page-locked by a helper thread (overlaps K1 and the first band of K2).
 		bands: row cuts [0, ..., nx] -- the rows are then locked band by band in that order and host['ready'] counts the bands
@@ -590,6 +632,7 @@ class Engine:
 		res['thread'].start()
 		return res
 
+	@serialised
 	def finish_host_results(self, host):
 		host['thread'].join()
 		self.torch.cuda.synchronize(self.device)
@@ -597,6 +640,7 @@ class Engine:
 			self.host_unpin(a)
 		host['pinned'] = []
 
+	@serialised
 	def association_banded(self, rx, ry, samexy, nx, ny, n, dof, stat_kind, out_dtype, host):
 		"""K2 + K3 band by band on the compute stream while finished bands of p and stat travel to the page-locked result
 		arrays on a copy stream.  Same kernels as the one-launch path; K2's split of the cells between workgroups depends
@@ -645,6 +689,7 @@ class Engine:
 		return (isinstance(dx, np.ndarray) and os.environ.get('NRM_PIPELINE', '1') != '0' and self.gram_slices(n) > 0 and dx.shape[0] > self.BAND
 				and dx.nbytes >= (32 << 20) and (dx.shape[1] * dx.itemsize) % 16 == 0 and (dc.shape[0] == 0 or (dc.shape[1] * 8) % 16 == 0))
 
+	@serialised
 	def association_coex_pipelined(self, dx, dc, dci, rank, dimreduce, out_dtype, cov=None):
 		"""norm.coex, numpy in -> numpy out, with the three PCIe / compute legs overlapped.  The gene rows travel to the GPU in
 		chunks of BAND rows on a copy stream; as soon as chunk c = rows [a, b) has landed, K1 residualises and quantises it, K2
@@ -759,6 +804,7 @@ class Engine:
 				print('coex pipeline trace (ms): ' + ', '.join('%s %.2f' % (w, (t - t0) * 1e3) for w, t in trace))
 			return res
 
+	@serialised
 	def coex_blocks_resident(self, block_fn, n_genes, n, dc, dci, rank, dimreduce, out_dtype, block_rows=3840, timings=None):
 		"""coex of a matrix that is too large to sit in HBM next to its own digit planes (BASELINE configs[4]: 30 000 genes x 500 000
 		cells fp64 = 120 GB in, 90 GB of planes) on ONE GPU: the gene rows arrive block by block -- block_fn(lo, hi) returns rows
@@ -826,6 +872,7 @@ class Engine:
 					timings[n1] = e0.elapsed_time(e1)
 			return dict(p=p, stat=stat, ss=ss, flags=flags, dof=dof, dot=dot)
 
+	@serialised
 	def sweep(self, dot, ssx, ssy, nx, ny, n_cells, dof, symmetric, stat_kind, out_dtype, want_rt=False, flags=None, fix=None):
 		"""K3: p, stat (covariance or gamma) and optionally Pearson r and t for every pair.  fix = fix_args(rx, ry) when dot came
 		from the integer engine."""
@@ -845,6 +892,7 @@ class Engine:
 												flags.data_ptr(), *(fix if fix is not None else (0, 0, 0, 0.0)), self._stream()))
 		return p, stat, r, t, flags
 
+	@serialised
 	def alpha(self, stat, stat_kind, ssx, n_cells, bx, by, nc):
 		"""alpha = by - gamma bx (association.py:238-243) from K3's statistic: gamma (stat_kind 1) or the covariance
 		(stat_kind 0, return_dot) -- the reference derives alpha from gamma either way (:1044-1048 only rescales)."""
@@ -857,6 +905,7 @@ class Engine:
 										  bx.data_ptr(), by.data_ptr(), nx, ny, nc, out.data_ptr(), code, self._stream()))
 		return out
 
+	@serialised
 	def check_flags(self, flags):
 		"""The reference's assertions (association.py:248,252) on a call's device counters, then the verdict of the integer engine's
 		accuracy guard: pairs it could not certify raise GuardHit, which association_single0 (and the sharded drivers) answer by
@@ -871,6 +920,7 @@ class Engine:
 			if f[2] > 0:
 				raise GuardHit(int(f[2]), worst)
 
+	@serialised
 	def variances(self, ss, count, n_cells, out_dtype):
 		"""ss/n with the variance 0 -> 1 substitution (association.py:230-233)."""
 		v = ss[:count].cpu().numpy() / float(n_cells)
@@ -911,6 +961,7 @@ class Engine:
 			raise ValueError('NRM_DE_PATH=streaming needs nx + nc <= 32')
 		return ok
 
+	@serialised
 	def association_de_streaming(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
 								 resident=False, state=None):
 		"""de with nx + nc <= 32: stream the raw expression rows once (HBM-bound), see csrc/nrm_gram_skinny.hip.
@@ -1047,6 +1098,7 @@ class Engine:
 				res['t'] = t.cpu().numpy()
 		return res
 
+	@serialised
 	def association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt=False, cov=None,
 							device_out=False, resident=False, state=None):
 		"""Whole-problem single=0 path on one device.  dy None -> coex (symmetric).

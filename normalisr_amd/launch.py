@@ -48,6 +48,10 @@ def run_sharded(cmd, args):
 		procs.append(subprocess.Popen([sys.executable, '-m', 'normalisr_amd.shard_worker', payload], env=env))
 	status = 0
 	live = list(procs)
+	grace = float(os.environ.get('NRM_RANK_GRACE_S', '20'))  # what the survivors get to exit by themselves after the first failure
+	limit = float(os.environ.get('NRM_JOB_TIMEOUT_S', '0'))  # overall watchdog, 0 = none
+	t0 = time.time()
+	failed_at = None
 	while live:
 		time.sleep(0.05)
 		for p in list(live):
@@ -57,6 +61,15 @@ def run_sharded(cmd, args):
 			live.remove(p)
 			if rc != 0 and status == 0:
 				status = rc if rc > 0 else 1
+				failed_at = time.time()
 				for q in live:  # a dead peer leaves the others waiting in their next collective
 					q.terminate()
+		now = time.time()
+		if limit > 0 and now - t0 > limit and status == 0:
+			status, failed_at = 124, now
+			for q in live:
+				q.terminate()
+		if failed_at is not None and now - failed_at > grace:
+			for q in live:  # SIGTERM was not enough (a rank blocked inside a collective): kill
+				q.kill()
 	return status

@@ -29,11 +29,12 @@ def normvar1(dt, dc, w2=None):
 	if r <= 0:
 		raise RuntimeError('Zero-rank covariates found.')
 	eng = _engine.get_engine()
-	d_c, d_mi = eng.covariates(dc64, mi)
-	res = eng.residualize(_engine.as_input(dt), d_c, d_mi, r)
-	out = eng.download(res.data[:dt.shape[0], :dt.shape[1]].contiguous())
-	assert np.isfinite(out).all()
-	return out.astype(np.result_type(dt.dtype, dc.dtype, np.float32), copy=False)
+	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
+		d_c, d_mi = eng.covariates(dc64, mi)
+		res = eng.residualize(_engine.as_input(dt), d_c, d_mi, r)
+		out = eng.download(res.data[:dt.shape[0], :dt.shape[1]].contiguous())
+		assert np.isfinite(out).all()
+		return out.astype(np.result_type(dt.dtype, dc.dtype, np.float32), copy=False)
 
 
 def _normvar1_weighted(dt, dc, w2, tol=1E-8):
@@ -48,44 +49,45 @@ def _normvar1_weighted(dt, dc, w2, tol=1E-8):
 		raise NotImplementedError('normvar1 on the device takes 1 to 63 covariates.')
 	out_dtype = np.dtype(np.float32) if np.result_type(dt.dtype, dc.dtype, w2.dtype, np.float32) == np.float32 else np.dtype(np.float64)
 	eng = _engine.get_engine()
-	torch = eng.torch
-	iu = np.triu_indices(nc)
-	npair = len(iu[0])
-	with torch.cuda.device(eng.device):
-		y = eng.upload(_engine.as_input(dt))
-		d_w = eng.upload(np.asarray(w2, dtype=np.float64))
-		d_c = eng.upload(np.asarray(dc, dtype=np.float64))
-		rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
-		u = torch.zeros((rp, kp), dtype=torch.float64, device=eng.device)
-		v = torch.zeros((rp, kp), dtype=torch.float64, device=eng.device)
-		u[:nt, :ns] = d_w * d_w
-		v[:nt, :ns] = d_w * y.to(torch.float64)
-		pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
-		pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
-		cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
-		cp[:nc, :ns] = d_c
-		R = _engine.Residualized
-		gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
-		ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
-		m = np.zeros((nt, nc, nc))
-		m[:, iu[0], iu[1]] = gm
-		m[:, iu[1], iu[0]] = gm
-		_, sv, vh = np.linalg.svd(m)
-		keep = sv >= tol * sv[:, :1]
-		if (keep.sum(axis=1) <= 0).any():
-			raise RuntimeError('Zero-rank covariates found.')
-		with np.errstate(divide='ignore'):
-			inv_s = np.where(keep, 1.0 / sv, 0.0)
-		b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)
-		tdt = torch.float64 if out_dtype == np.float64 else torch.float32
-		out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
-		d_b = eng.upload(b)
-		_lib.check(eng.lib.nrm_normvar_apply_w2(y.data_ptr(), _lib.NRM_F64 if y.dtype == torch.float64 else _lib.NRM_F32, nt, ns, y.stride(0), d_w.data_ptr(),
-												d_w.stride(0), d_c.data_ptr(), nc, d_c.stride(0), d_b.data_ptr(), out.data_ptr(),
-												_lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, eng._stream()))
-		dtn = eng.download(out)
-	assert np.isfinite(dtn).all()
-	return dtn
+	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
+		torch = eng.torch
+		iu = np.triu_indices(nc)
+		npair = len(iu[0])
+		with torch.cuda.device(eng.device):
+			y = eng.upload(_engine.as_input(dt))
+			d_w = eng.upload(np.asarray(w2, dtype=np.float64))
+			d_c = eng.upload(np.asarray(dc, dtype=np.float64))
+			rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
+			u = torch.zeros((rp, kp), dtype=torch.float64, device=eng.device)
+			v = torch.zeros((rp, kp), dtype=torch.float64, device=eng.device)
+			u[:nt, :ns] = d_w * d_w
+			v[:nt, :ns] = d_w * y.to(torch.float64)
+			pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+			pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
+			cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+			cp[:nc, :ns] = d_c
+			R = _engine.Residualized
+			gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
+			ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
+			m = np.zeros((nt, nc, nc))
+			m[:, iu[0], iu[1]] = gm
+			m[:, iu[1], iu[0]] = gm
+			_, sv, vh = np.linalg.svd(m)
+			keep = sv >= tol * sv[:, :1]
+			if (keep.sum(axis=1) <= 0).any():
+				raise RuntimeError('Zero-rank covariates found.')
+			with np.errstate(divide='ignore'):
+				inv_s = np.where(keep, 1.0 / sv, 0.0)
+			b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)
+			tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+			out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
+			d_b = eng.upload(b)
+			_lib.check(eng.lib.nrm_normvar_apply_w2(y.data_ptr(), _lib.NRM_F64 if y.dtype == torch.float64 else _lib.NRM_F32, nt, ns, y.stride(0), d_w.data_ptr(),
+													d_w.stride(0), d_c.data_ptr(), nc, d_c.stride(0), d_b.data_ptr(), out.data_ptr(),
+													_lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, eng._stream()))
+			dtn = eng.download(out)
+		assert np.isfinite(dtn).all()
+		return dtn
 
 
 def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, normmean=False, tol=1E-8):
@@ -117,83 +119,84 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 	out_dtype = np.result_type(dt.dtype, dc.dtype, w.dtype, wt.dtype, np.float32)
 	out_dtype = np.dtype(np.float32) if out_dtype == np.float32 else np.dtype(np.float64)
 	eng = _engine.get_engine()
-	torch = eng.torch
-	c64 = np.asarray(dc, dtype=np.float64)
-	npair = nc * (nc + 1) // 2
-	iu = np.triu_indices(nc)
-	with torch.cuda.device(eng.device):
-		y = eng.upload(_engine.as_input(dt))
-		ycode = _lib.NRM_F64 if y.dtype == torch.float64 else _lib.NRM_F32
-		d_lnw = eng.upload(np.log(np.asarray(w, dtype=np.float64)))
-		d_wt = eng.upload(np.asarray(wt, dtype=np.float64))
-		d_c = eng.upload(c64)
-		rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
-		u = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
-		v = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
-		s1 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
-		s2 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
-		_lib.check(eng.lib.nrm_normvar_weights(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), u.data_ptr(),
-											   v.data_ptr(), kp, rp, s1.data_ptr(), s2.data_ptr(), eng._stream()))
-		# operands of the two Gram contractions: P = pairwise products of covariate rows, C itself
-		pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
-		pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
-		cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
-		cp[:nc, :ns] = d_c
-		R = _engine.Residualized
-		gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
-		ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
-		# per-gene pseudo-inverse on the host: batched SVD, rank rule of inv_rank (association.py:77)
-		m = np.zeros((nt, nc, nc))
-		m[:, iu[0], iu[1]] = gm
-		m[:, iu[1], iu[0]] = gm
-		_, sv, vh = np.linalg.svd(m)
-		keep = sv >= tol * sv[:, :1]
-		if (keep.sum(axis=1) <= 0).any():
-			raise RuntimeError('Zero-rank covariates found.')
-		with np.errstate(divide='ignore'):
-			inv_s = np.where(keep, 1.0 / sv, 0.0)
-		b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)  # b_g = M_g^+ a_g
-		scale = np.ones(nt)
-		if keepvar:
-			mean = s1[:nt].cpu().numpy() / ns
-			dv = np.sqrt(np.maximum(s2[:nt].cpu().numpy() / ns - mean * mean, 0.0))  # norm.py:248-249
-			dv2 = np.sqrt(np.maximum(s2[:nt].cpu().numpy() - np.einsum('gc,gc->g', ga, b), 0.0) / ns)  # |y' - P y'|^2 = |y'|^2 - a.b
-			with np.errstate(divide='ignore', invalid='ignore'):
-				scale = (dv / dv2)**np.asarray(wt, dtype=np.float64)  # norm.py:259
-		tdt = torch.float64 if out_dtype == np.float64 else torch.float32
-		out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
-		d_b, d_scale = eng.upload(b), eng.upload(scale)
-		_lib.check(eng.lib.nrm_normvar_apply(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), d_c.data_ptr(), nc,
-											 d_c.stride(0), d_b.data_ptr(), d_scale.data_ptr(), out.data_ptr(),
-											 _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, eng._stream()))
-		# covariates: continuous rows (and the intercept for cat=1) are scaled by w (norm.py:261-273)
-		w64 = np.asarray(w, dtype=np.float64)
-		if cat == 2:
-			dcn = dc * w
-		else:
-			dcn = dc.copy()
-			t0 = ((dc != 0) & (dc != 1)).any(axis=1)
-			if cat == 1:
-				t0 |= (dc == 1).all(axis=1)
-			dcn = dcn.astype(np.result_type(dc.dtype, w.dtype), copy=False)
-			dcn[t0] = dc[t0] * w
-		if normmean:
-			dcn64 = np.asarray(dcn, dtype=np.float64)
-			mi, r = inv_rank(np.matmul(dcn64, dcn64.T))
-			if r <= 0:
+	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
+		torch = eng.torch
+		c64 = np.asarray(dc, dtype=np.float64)
+		npair = nc * (nc + 1) // 2
+		iu = np.triu_indices(nc)
+		with torch.cuda.device(eng.device):
+			y = eng.upload(_engine.as_input(dt))
+			ycode = _lib.NRM_F64 if y.dtype == torch.float64 else _lib.NRM_F32
+			d_lnw = eng.upload(np.log(np.asarray(w, dtype=np.float64)))
+			d_wt = eng.upload(np.asarray(wt, dtype=np.float64))
+			d_c = eng.upload(c64)
+			rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
+			u = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
+			v = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
+			s1 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
+			s2 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
+			_lib.check(eng.lib.nrm_normvar_weights(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), u.data_ptr(),
+												   v.data_ptr(), kp, rp, s1.data_ptr(), s2.data_ptr(), eng._stream()))
+			# operands of the two Gram contractions: P = pairwise products of covariate rows, C itself
+			pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+			pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
+			cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+			cp[:nc, :ns] = d_c
+			R = _engine.Residualized
+			gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
+			ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
+			# per-gene pseudo-inverse on the host: batched SVD, rank rule of inv_rank (association.py:77)
+			m = np.zeros((nt, nc, nc))
+			m[:, iu[0], iu[1]] = gm
+			m[:, iu[1], iu[0]] = gm
+			_, sv, vh = np.linalg.svd(m)
+			keep = sv >= tol * sv[:, :1]
+			if (keep.sum(axis=1) <= 0).any():
 				raise RuntimeError('Zero-rank covariates found.')
-			cov = eng.covariates(dcn64, mi)
-			res = eng.residualize(out, cov[0], cov[1], r)
-			out = res.data[:nt, :ns].to(tdt).contiguous()
-		dtn = eng.download(out)
-	assert np.isfinite(dtn).all() and np.isfinite(dcn).all()
-	ans = [dtn, dcn]
-	if dextra is not None:
-		dextran = dextra * w
-		assert np.isfinite(dextran).all()
-		ans.append(dextran)
-	del w64
-	return ans
+			with np.errstate(divide='ignore'):
+				inv_s = np.where(keep, 1.0 / sv, 0.0)
+			b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)  # b_g = M_g^+ a_g
+			scale = np.ones(nt)
+			if keepvar:
+				mean = s1[:nt].cpu().numpy() / ns
+				dv = np.sqrt(np.maximum(s2[:nt].cpu().numpy() / ns - mean * mean, 0.0))  # norm.py:248-249
+				dv2 = np.sqrt(np.maximum(s2[:nt].cpu().numpy() - np.einsum('gc,gc->g', ga, b), 0.0) / ns)  # |y' - P y'|^2 = |y'|^2 - a.b
+				with np.errstate(divide='ignore', invalid='ignore'):
+					scale = (dv / dv2)**np.asarray(wt, dtype=np.float64)  # norm.py:259
+			tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+			out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
+			d_b, d_scale = eng.upload(b), eng.upload(scale)
+			_lib.check(eng.lib.nrm_normvar_apply(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), d_c.data_ptr(), nc,
+												 d_c.stride(0), d_b.data_ptr(), d_scale.data_ptr(), out.data_ptr(),
+												 _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, eng._stream()))
+			# covariates: continuous rows (and the intercept for cat=1) are scaled by w (norm.py:261-273)
+			w64 = np.asarray(w, dtype=np.float64)
+			if cat == 2:
+				dcn = dc * w
+			else:
+				dcn = dc.copy()
+				t0 = ((dc != 0) & (dc != 1)).any(axis=1)
+				if cat == 1:
+					t0 |= (dc == 1).all(axis=1)
+				dcn = dcn.astype(np.result_type(dc.dtype, w.dtype), copy=False)
+				dcn[t0] = dc[t0] * w
+			if normmean:
+				dcn64 = np.asarray(dcn, dtype=np.float64)
+				mi, r = inv_rank(np.matmul(dcn64, dcn64.T))
+				if r <= 0:
+					raise RuntimeError('Zero-rank covariates found.')
+				cov = eng.covariates(dcn64, mi)
+				res = eng.residualize(out, cov[0], cov[1], r)
+				out = res.data[:nt, :ns].to(tdt).contiguous()
+			dtn = eng.download(out)
+		assert np.isfinite(dtn).all() and np.isfinite(dcn).all()
+		ans = [dtn, dcn]
+		if dextra is not None:
+			dextran = dextra * w
+			assert np.isfinite(dextran).all()
+			ans.append(dextran)
+		del w64
+		return ans
 
 
 assert __name__ != "__main__"

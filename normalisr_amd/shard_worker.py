@@ -13,25 +13,57 @@ import sys
 import numpy as np
 
 
+def _tsv_data_lines(path):
+	"""Byte offsets (start, end) of the lines of a TSV that np.loadtxt counts as rows: not blank, not a '#' comment (loadtxt drops
+	both and counts neither towards skiprows / max_rows, so raw line numbers would shift the ranks' blocks).  One scan, no parsing."""
+	import gzip
+	op = gzip.open if path.endswith('.gz') else open
+	spans, pos = [], 0
+	with op(path, 'rb') as f:
+		for line in f:
+			body = line.split(b'#', 1)[0].strip()
+			if body:
+				spans.append((pos, pos + len(line)))
+			pos += len(line)
+	return spans
+
+
 def matrix_rows(path):
-	"""Row count of a matrix file without reading it: the .npy header, or the number of lines of a TSV."""
+	"""Row count of a matrix file without reading it: the .npy header, or the number of data lines of a TSV."""
 	if path.endswith('.npy'):
 		a = np.load(path, mmap_mode='r', allow_pickle=False)
 		return 1 if a.ndim < 2 else a.shape[0]
-	import gzip
-	op = gzip.open if path.endswith('.gz') else open
-	with op(path, 'rb') as f:
-		return sum(1 for line in f if line.strip())
+	return len(_tsv_data_lines(path))
 
 
-def read_rows(path, lo, hi):
-	"""Rows [lo, hi) of a matrix file, 2-D, without reading the others into memory."""
+def read_rows(path, lo, hi, spans=None):
+	"""Rows [lo, hi) of a matrix file, 2-D, without reading the others into memory (TSV: only this block's data lines are handed
+	to np.loadtxt).  An empty block comes back as shape (0, 0): the caller knows the column count."""
 	if path.endswith('.npy'):
 		a = np.load(path, mmap_mode='r', allow_pickle=False)
 		a = a.reshape(1, -1) if a.ndim < 2 else a
 		return np.ascontiguousarray(a[lo:hi])
-	a = np.loadtxt(path, delimiter='\t', skiprows=lo, max_rows=hi - lo, ndmin=2)
-	return a
+	if hi <= lo:
+		return np.zeros((0, 0))
+	import gzip
+	import io
+	spans = _tsv_data_lines(path) if spans is None else spans
+	op = gzip.open if path.endswith('.gz') else open
+	with op(path, 'rb') as f:
+		f.seek(spans[lo][0])
+		blob = f.read(spans[hi - 1][1] - spans[lo][0])  # (comment / blank lines inside the block are dropped by loadtxt itself)
+	return np.loadtxt(io.BytesIO(blob), delimiter='\t', ndmin=2)
+
+
+def block_bounds(rows, world, rank, balanced):
+	"""Gene rows [lo, hi) of `rank`.  coex needs equal blocks (ceil(rows / world), the tail padded by the caller: the block pair
+	schedule works on one block size); de takes balanced blocks, so that no rank is left without rows while rows >= world."""
+	if balanced:
+		base, extra = divmod(rows, world)
+		lo = rank * base + min(rank, extra)
+		return lo, lo + base + (1 if rank < extra else 0)
+	per = -(-rows // world)
+	return min(rows, rank * per), min(rows, (rank + 1) * per)
 
 
 def main(argv):
@@ -58,10 +90,12 @@ def main(argv):
 			raise ValueError('{} gene rows cannot be sharded over {} GPUs'.format(rows, world))
 		if cmd == 'coex':
 			per = -(-rows // world)
-			lo, hi = min(rows, rank * per), min(rows, (rank + 1) * per)
+			lo, hi = block_bounds(rows, world, rank, False)
 			x = read_rows(args['exp_in'], lo, hi)
 			if x.dtype not in (np.float32, np.float64):
 				x = x.astype(np.float64)
+			if x.shape[0] == 0:  # a tail rank without rows of its own (e.g. 9 genes on 8 GPUs): all padding
+				x = np.zeros((0, dc.shape[1]), dtype=x.dtype)
 			if x.shape[0] < per:  # the last block(s): zero rows up to the common block size
 				x = np.vstack([x, np.zeros((per - x.shape[0], dc.shape[1]), dtype=x.dtype)])
 			logging.debug('rows %d..%d of %d loaded', lo, hi, rows)
@@ -70,8 +104,7 @@ def main(argv):
 				p, dot, var = (np.asarray(a)[:rows] for a in res)
 				out = dict(pv_out=p[:, :rows], dot_out=dot[:, :rows], var_out=var)
 		else:
-			per = -(-rows // world)
-			lo, hi = min(rows, rank * per), min(rows, (rank + 1) * per)
+			lo, hi = block_bounds(rows, world, rank, True)
 			dg = file_read_tsv(args['design_in'])
 			y = read_rows(args['exp_in'], lo, hi)
 			if y.dtype not in (np.float32, np.float64):
@@ -86,8 +119,14 @@ def main(argv):
 				if args.get(key) is not None:
 					file_write_tsv(args[key], val, fmt=fmt_float)
 		dist.barrier()
-	finally:
-		dist.destroy_process_group()
+	except BaseException:
+		# no orderly teardown on the failure path: destroy_process_group() can block on collectives the peers will never match, the
+		# parent would then never see this rank exit and the survivors would sit in their collective for ever
+		import traceback
+		traceback.print_exc()
+		sys.stderr.flush()
+		os._exit(1)
+	dist.destroy_process_group()
 	return 0
 
 

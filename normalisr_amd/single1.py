@@ -52,81 +52,82 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	c64 = np.asarray(dc, dtype=np.float64)
 	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 	eng = _engine.get_engine()
-	torch = eng.torch
-	tdt = torch.float64 if out_dtype == np.float64 else torch.float32
-	nw = nc + 1
-	with torch.cuda.device(eng.device):
-		# cell selection on the device (association.py:914-918): the design matrix travels once, in its own dtype
-		d_dx = eng.upload(_engine.as_input(dx))
-		assert float(d_dx.max()) == 1  # association.py:914
-		sel = d_dx == torch.sum(d_dx, dim=0, dtype=torch.float64)  # association.py:915-916
-		big = torch.finfo(d_dx.dtype).max
-		lo = torch.where(sel, d_dx, big).amin(dim=1)
-		hi = torch.where(sel, d_dx, -big).amax(dim=1)
-		assert bool((hi > lo).all())  # >1 distinct value among the selected cells (:917-918)
-		del lo, hi
-		ns = sel.sum(dim=1).cpu().numpy().astype(np.float64)
-		if nc <= 32 and not bool((d_dx < 0).any()) and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
-			return _sparse(eng, d_dx, dx.dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt)
-		ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
-		y2 = Residualized_sq(ry, eng)
-		d_c = eng.upload(c64) if nc else None
-		p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-		stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-		vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-		alpha = None if lowmem else torch.zeros((nx, ny, nc), dtype=tdt, device=eng.device)
-		flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
-		varx = np.empty(nx)
-		pitch = 26 + nc + nc * nc
-		kp = ry.k_pad
-		for i0 in range(0, nx, chunk):
-			i1 = min(nx, i0 + chunk)
-			m = i1 - i0
-			d_sel = sel[i0:i1].to(torch.float64)  # (m, n)
-			d_x = d_dx[i0:i1].to(torch.float64)
-			wrows = _round_up(m * nw, ROW_TILE)
-			w = torch.zeros((wrows, kp), dtype=torch.float64, device=eng.device)
-			wv = w[:m * nw].view(m, nw, kp)
-			if nc:
-				wv[:, :nc, :n] = d_sel[:, None, :] * d_c[None, :, :]
-			wv[:, nc, :n] = d_sel * d_x
-			srows = _round_up(m, ROW_TILE)
-			s = torch.zeros((srows, kp), dtype=torch.float64, device=eng.device)
-			s[:m, :n] = d_sel
-			W = _engine.Residualized(m * nw, n, w, None, None)
-			S = _engine.Residualized(m, n, s, None, None)
-			g = eng.gram(ry, W, False)   # (ny_pad, wrows): y . (1_S C), y . (1_S x)
-			g2 = eng.gram(y2, S, False)  # (ny_pad, srows): |y_S|^2
-			# grouping-side statistics: M_i = C_S C_S^T, xC_i = C_S x_S, xx_i = |x_S|^2 (tiny; W against [C; x] rows)
-			xx = (wv[:, nc, :n] * d_x).sum(dim=1).cpu().numpy()
-			info = np.zeros((m, pitch))
-			rk = np.zeros(m, dtype=np.int64)
-			if nc:
-				mc = torch.einsum('icn,dn->icd', wv[:, :nc, :n], d_c).cpu().numpy()       # (m, nc, nc)
-				xc = torch.einsum('in,dn->id', wv[:, nc, :n], d_c).cpu().numpy()          # (m, nc)
-				mi, rk = inv_rank(mc)  # association.py:350-351, all groupings of the chunk
-				mi[rk == 0] = 0
-				ccx = np.einsum('icd,id->ic', mi, xc)
-				info[:, 26:26 + nc] = ccx
-				info[:, 26 + nc:] = mi.reshape(m, nc * nc)
-				xx = xx - np.einsum('ic,ic->i', xc, ccx)
-			vxx = xx / ns[i0:i1]
-			vxx[vxx == 0] = 1  # association.py:362-364
-			varx[i0:i1] = vxx
-			dof = ns[i0:i1] - 1 - rk - dimreduce
-			if (dof <= 0).any():
-				raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
-			info[:, 0], info[:, 1] = ns[i0:i1], vxx
-			dof = np.ascontiguousarray(dof, dtype=np.float64)
-			_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, m, info.ctypes.data + 16, pitch))
-			d_info = eng.upload(info)
-			code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
-			_lib.check(eng.lib.nrm_single1_sweep(g.data_ptr(), g.stride(0), g2.data_ptr(), g2.stride(0), d_info.data_ptr(), pitch, nc, m, ny,
-												 1 if return_dot else 0, p[i0:i1].data_ptr(), stat[i0:i1].data_ptr(), vary[i0:i1].data_ptr(),
-												 0 if alpha is None else alpha[i0:i1].data_ptr(), code, ny, flags.data_ptr(), eng._stream()))
-		eng.check_flags(flags)
-		return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), varx.astype(out_dtype),
-				eng.download(vary))
+	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
+		torch = eng.torch
+		tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+		nw = nc + 1
+		with torch.cuda.device(eng.device):
+			# cell selection on the device (association.py:914-918): the design matrix travels once, in its own dtype
+			d_dx = eng.upload(_engine.as_input(dx))
+			assert float(d_dx.max()) == 1  # association.py:914
+			sel = d_dx == torch.sum(d_dx, dim=0, dtype=torch.float64)  # association.py:915-916
+			big = torch.finfo(d_dx.dtype).max
+			lo = torch.where(sel, d_dx, big).amin(dim=1)
+			hi = torch.where(sel, d_dx, -big).amax(dim=1)
+			assert bool((hi > lo).all())  # >1 distinct value among the selected cells (:917-918)
+			del lo, hi
+			ns = sel.sum(dim=1).cpu().numpy().astype(np.float64)
+			if nc <= 32 and not bool((d_dx < 0).any()) and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
+				return _sparse(eng, d_dx, dx.dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt)
+			ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
+			y2 = Residualized_sq(ry, eng)
+			d_c = eng.upload(c64) if nc else None
+			p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+			stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+			vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+			alpha = None if lowmem else torch.zeros((nx, ny, nc), dtype=tdt, device=eng.device)
+			flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
+			varx = np.empty(nx)
+			pitch = 26 + nc + nc * nc
+			kp = ry.k_pad
+			for i0 in range(0, nx, chunk):
+				i1 = min(nx, i0 + chunk)
+				m = i1 - i0
+				d_sel = sel[i0:i1].to(torch.float64)  # (m, n)
+				d_x = d_dx[i0:i1].to(torch.float64)
+				wrows = _round_up(m * nw, ROW_TILE)
+				w = torch.zeros((wrows, kp), dtype=torch.float64, device=eng.device)
+				wv = w[:m * nw].view(m, nw, kp)
+				if nc:
+					wv[:, :nc, :n] = d_sel[:, None, :] * d_c[None, :, :]
+				wv[:, nc, :n] = d_sel * d_x
+				srows = _round_up(m, ROW_TILE)
+				s = torch.zeros((srows, kp), dtype=torch.float64, device=eng.device)
+				s[:m, :n] = d_sel
+				W = _engine.Residualized(m * nw, n, w, None, None)
+				S = _engine.Residualized(m, n, s, None, None)
+				g = eng.gram(ry, W, False)   # (ny_pad, wrows): y . (1_S C), y . (1_S x)
+				g2 = eng.gram(y2, S, False)  # (ny_pad, srows): |y_S|^2
+				# grouping-side statistics: M_i = C_S C_S^T, xC_i = C_S x_S, xx_i = |x_S|^2 (tiny; W against [C; x] rows)
+				xx = (wv[:, nc, :n] * d_x).sum(dim=1).cpu().numpy()
+				info = np.zeros((m, pitch))
+				rk = np.zeros(m, dtype=np.int64)
+				if nc:
+					mc = torch.einsum('icn,dn->icd', wv[:, :nc, :n], d_c).cpu().numpy()       # (m, nc, nc)
+					xc = torch.einsum('in,dn->id', wv[:, nc, :n], d_c).cpu().numpy()          # (m, nc)
+					mi, rk = inv_rank(mc)  # association.py:350-351, all groupings of the chunk
+					mi[rk == 0] = 0
+					ccx = np.einsum('icd,id->ic', mi, xc)
+					info[:, 26:26 + nc] = ccx
+					info[:, 26 + nc:] = mi.reshape(m, nc * nc)
+					xx = xx - np.einsum('ic,ic->i', xc, ccx)
+				vxx = xx / ns[i0:i1]
+				vxx[vxx == 0] = 1  # association.py:362-364
+				varx[i0:i1] = vxx
+				dof = ns[i0:i1] - 1 - rk - dimreduce
+				if (dof <= 0).any():
+					raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+				info[:, 0], info[:, 1] = ns[i0:i1], vxx
+				dof = np.ascontiguousarray(dof, dtype=np.float64)
+				_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, m, info.ctypes.data + 16, pitch))
+				d_info = eng.upload(info)
+				code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
+				_lib.check(eng.lib.nrm_single1_sweep(g.data_ptr(), g.stride(0), g2.data_ptr(), g2.stride(0), d_info.data_ptr(), pitch, nc, m, ny,
+													 1 if return_dot else 0, p[i0:i1].data_ptr(), stat[i0:i1].data_ptr(), vary[i0:i1].data_ptr(),
+													 0 if alpha is None else alpha[i0:i1].data_ptr(), code, ny, flags.data_ptr(), eng._stream()))
+			eng.check_flags(flags)
+			return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), varx.astype(out_dtype),
+					eng.download(vary))
 
 
 def _segment_sums(v, starts, counts):

@@ -224,99 +224,100 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		logging.warning('No covariate dc input.')
 	ik = dict(tol=tol, method=method, mpc=mpc, qr=qr)  # inv_rank options (association.py:527-528)
 	eng = _engine.get_engine()
-	torch = eng.torch
-	if dy is None:
-		out_dtype = dx.dtype if dx.dtype in (np.float32, np.float64) else np.dtype(np.float64)
-		return _single4_samexy(dx, dc, lowmem, return_dot, dimreduce, ik, eng, out_dtype)
-	dy = np.asarray(dy)
-	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
-	m = nx + nc
-	# A = [X; C] (association.py:935) is stacked on the device: X travels in its own dtype and is widened there
-	from .engine import Residualized
-	mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
-	with torch.cuda.device(eng.device):
-		a_dev = eng.zeros((mp, kp), torch.float64)
-		a_dev[:nx, :n] = eng.upload(_engine.as_input(dx))
-		if nc:
-			a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
-	ra = Residualized(m, n, a_dev, None, None)
-	ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y and sum y^2 (association.py:968)
-	prod_d = eng.gram(ra, ra, True)  # A A^T, tiles on/above the diagonal (association.py:936-950)
-	prod = prod_d[:m, :m].cpu().numpy()
-	prod = np.triu(prod) + np.triu(prod, 1).T
-	# Y A^T (association.py:952-967, transposed).  It is the K-operand of the next contraction (K = m_pad columns), and K2
-	# leaves 16-column sub-blocks that are pure padding unwritten: start from zeros so that no stale NaN/Inf bit pattern
-	# of the allocator can reach 0 * NaN there
-	with torch.cuda.device(eng.device):
-		prodyT_d = eng.zeros((ry.rows_pad, mp), torch.float64)
-	eng.gram(ry, ra, False, dot=prodyT_d)
-	# the spectrum decides whether the closed form applies; the inverse it needs is taken beside it on a second host thread (LAPACK
-	# releases the GIL; both take ~20 ms at 1000 groupings) and thrown away when it does not
-	spec = None
-	with _engine.host_blas():
-		if mpc == 0 and method in ('auto', 'scipy'):
-			from concurrent.futures import ThreadPoolExecutor
+	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
+		torch = eng.torch
+		if dy is None:
+			out_dtype = dx.dtype if dx.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+			return _single4_samexy(dx, dc, lowmem, return_dot, dimreduce, ik, eng, out_dtype)
+		dy = np.asarray(dy)
+		out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+		m = nx + nc
+		# A = [X; C] (association.py:935) is stacked on the device: X travels in its own dtype and is widened there
+		from .engine import Residualized
+		mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
+		with torch.cuda.device(eng.device):
+			a_dev = eng.zeros((mp, kp), torch.float64)
+			a_dev[:nx, :n] = eng.upload(_engine.as_input(dx))
+			if nc:
+				a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
+		ra = Residualized(m, n, a_dev, None, None)
+		ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y and sum y^2 (association.py:968)
+		prod_d = eng.gram(ra, ra, True)  # A A^T, tiles on/above the diagonal (association.py:936-950)
+		prod = prod_d[:m, :m].cpu().numpy()
+		prod = np.triu(prod) + np.triu(prod, 1).T
+		# Y A^T (association.py:952-967, transposed).  It is the K-operand of the next contraction (K = m_pad columns), and K2
+		# leaves 16-column sub-blocks that are pure padding unwritten: start from zeros so that no stale NaN/Inf bit pattern
+		# of the allocator can reach 0 * NaN there
+		with torch.cuda.device(eng.device):
+			prodyT_d = eng.zeros((ry.rows_pad, mp), torch.float64)
+		eng.gram(ry, ra, False, dot=prodyT_d)
+		# the spectrum decides whether the closed form applies; the inverse it needs is taken beside it on a second host thread (LAPACK
+		# releases the GIL; both take ~20 ms at 1000 groupings) and thrown away when it does not
+		spec = None
+		with _engine.host_blas():
+			if mpc == 0 and method in ('auto', 'scipy'):
+				from concurrent.futures import ThreadPoolExecutor
 
-			def _try_inverse():
-				try:
-					return _spd_inverse(prod)
-				except Exception:  # not positive definite: the spectrum will say so
-					return None
-			with ThreadPoolExecutor(1) as ex:
-				fut = ex.submit(_try_inverse)
+				def _try_inverse():
+					try:
+						return _spd_inverse(prod)
+					except Exception:  # not positive definite: the spectrum will say so
+						return None
+				with ThreadPoolExecutor(1) as ex:
+					fut = ex.submit(_try_inverse)
+					ev = np.linalg.eigvalsh(prod)
+					spec = fut.result()
+			else:
 				ev = np.linalg.eigvalsh(prod)
-				spec = fut.result()
+		closed = mpc == 0 and method in ('auto', 'scipy') and ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)
+		if not closed:
+			logging.info('single=4: no closed form (rank-deficient A A^T or truncated inverse); following the per-grouping algorithm on the host.')
+			with _engine.host_blas():
+				p, gam, alpha, vx, vy = _per_grouping_host(prod, prodyT_d[:ny, :m].cpu().numpy(), ry.ss[:ny].cpu().numpy(), nx, nc, n,
+														   dimreduce, lowmem, eng, ik)
+			stat = (gam.T * vx).T if return_dot else gam
+			cast = lambda v: None if v is None else v.astype(out_dtype, copy=False)
+			return (cast(p), cast(stat), cast(alpha), cast(vx), cast(vy))
+		if n <= m + np.max(dimreduce):
+			raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+		dr_groups = [int(dimreduce)] if np.ndim(dimreduce) == 0 else [int(v) for v in np.unique(dimreduce)]
+		if spec is not None:
+			ninv = spec
 		else:
-			ev = np.linalg.eigvalsh(prod)
-	closed = mpc == 0 and method in ('auto', 'scipy') and ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)
-	if not closed:
-		logging.info('single=4: no closed form (rank-deficient A A^T or truncated inverse); following the per-grouping algorithm on the host.')
-		with _engine.host_blas():
-			p, gam, alpha, vx, vy = _per_grouping_host(prod, prodyT_d[:ny, :m].cpu().numpy(), ry.ss[:ny].cpu().numpy(), nx, nc, n,
-													   dimreduce, lowmem, eng, ik)
-		stat = (gam.T * vx).T if return_dot else gam
-		cast = lambda v: None if v is None else v.astype(out_dtype, copy=False)
-		return (cast(p), cast(stat), cast(alpha), cast(vx), cast(vy))
-	if n <= m + np.max(dimreduce):
-		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
-	dr_groups = [int(dimreduce)] if np.ndim(dimreduce) == 0 else [int(v) for v in np.unique(dimreduce)]
-	if spec is not None:
-		ninv = spec
-	else:
-		with _engine.host_blas():
-			ninv = _spd_inverse(prod)  # N = M^-1 (symmetric)
-	dxx = 1.0 / (n * np.diag(ninv)[:nx])
-	n_pad = np.zeros((mp, mp))
-	n_pad[:m, :m] = ninv
-	with torch.cuda.device(eng.device):
-		d_n = eng.upload(n_pad)
-		pt = Residualized(ny, mp, prodyT_d, None, None)  # (ny_pad, m_pad): K dimension = rows of A, zero padded
-		bt_d = eng.gram(pt, Residualized(m, mp, d_n, None, None), False)  # Bt = (Y A^T) N
-		tdt = torch.float64 if out_dtype == np.float64 else torch.float32
-		p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-		stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-		vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-		work = torch.empty((ny, ), dtype=torch.float64, device=eng.device)
-		flags = eng.zeros((2, ), torch.int32)
-		d_dxx = eng.upload(dxx)
-		code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
-		p_host = None
-		# dof = n - 1 - (m - 1) - dimreduce (association.py:558): uniform, or one sweep per distinct per-gene dimreduce value
-		# (gamma and vary do not depend on it; the P-value columns of each group are kept)
-		for gi, dr in enumerate(dr_groups):
-			_lib.check(eng.lib.nrm_single4_sweep(bt_d.data_ptr(), prodyT_d.data_ptr(), bt_d.stride(0), ry.ss.data_ptr(), d_dxx.data_ptr(),
-												 nx, ny, m, n, float(n - m - dr), 1 if return_dot else 0, p.data_ptr(), stat.data_ptr(),
-												 vary.data_ptr(), code, ny, work.data_ptr(), flags.data_ptr(), eng._stream()))
-			if len(dr_groups) > 1:
-				if p_host is None:
-					p_host = np.empty((nx, ny), dtype=out_dtype)
-				cols = np.nonzero(dimreduce == dr)[0]
-				p_host[:, cols] = eng.download(p)[:, cols]
-		eng.check_flags(flags)
-		alpha = None
-		if not lowmem:
-			b_cov = bt_d[:ny, nx:m].cpu().numpy().astype(out_dtype)  # (ny, nc): identical for every grouping
-			alpha = np.broadcast_to(b_cov[None, :, :], (nx, ny, nc)).copy()
-		vx = dxx.copy()
-		vx[vx == 0] = 1
-		return (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary))
+			with _engine.host_blas():
+				ninv = _spd_inverse(prod)  # N = M^-1 (symmetric)
+		dxx = 1.0 / (n * np.diag(ninv)[:nx])
+		n_pad = np.zeros((mp, mp))
+		n_pad[:m, :m] = ninv
+		with torch.cuda.device(eng.device):
+			d_n = eng.upload(n_pad)
+			pt = Residualized(ny, mp, prodyT_d, None, None)  # (ny_pad, m_pad): K dimension = rows of A, zero padded
+			bt_d = eng.gram(pt, Residualized(m, mp, d_n, None, None), False)  # Bt = (Y A^T) N
+			tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+			p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+			stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+			vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+			work = torch.empty((ny, ), dtype=torch.float64, device=eng.device)
+			flags = eng.zeros((2, ), torch.int32)
+			d_dxx = eng.upload(dxx)
+			code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
+			p_host = None
+			# dof = n - 1 - (m - 1) - dimreduce (association.py:558): uniform, or one sweep per distinct per-gene dimreduce value
+			# (gamma and vary do not depend on it; the P-value columns of each group are kept)
+			for gi, dr in enumerate(dr_groups):
+				_lib.check(eng.lib.nrm_single4_sweep(bt_d.data_ptr(), prodyT_d.data_ptr(), bt_d.stride(0), ry.ss.data_ptr(), d_dxx.data_ptr(),
+													 nx, ny, m, n, float(n - m - dr), 1 if return_dot else 0, p.data_ptr(), stat.data_ptr(),
+													 vary.data_ptr(), code, ny, work.data_ptr(), flags.data_ptr(), eng._stream()))
+				if len(dr_groups) > 1:
+					if p_host is None:
+						p_host = np.empty((nx, ny), dtype=out_dtype)
+					cols = np.nonzero(dimreduce == dr)[0]
+					p_host[:, cols] = eng.download(p)[:, cols]
+			eng.check_flags(flags)
+			alpha = None
+			if not lowmem:
+				b_cov = bt_d[:ny, nx:m].cpu().numpy().astype(out_dtype)  # (ny, nc): identical for every grouping
+				alpha = np.broadcast_to(b_cov[None, :, :], (nx, ny, nc)).copy()
+			vx = dxx.copy()
+			vx[vx == 0] = 1
+			return (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary))

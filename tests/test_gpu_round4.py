@@ -87,7 +87,7 @@ def test_k1_rows_resident_on_chip(eng, monkeypatch, dtype, rows, n, nc, kind):
 	x, d_x, dc64, d_c, d_dci, dcr = _k1_case(eng, rng, dtype, rows, n, nc, kind)
 	code = 1 if dtype == np.float64 else 0
 	for ns in (6, 5):
-		monkeypatch.delenv('NRM_K1', raising=False)
+		monkeypatch.setenv('NRM_K1', 'res')
 		rp = 128 * ((rows + 127) // 128)
 		assert eng.k1_work(code, rp, n, nc)[0] != 0, 'the resident kernel does not take this shape'
 		r = eng.residualize(d_x, d_c, d_dci, dcr, nslices=ns, keep_fp64=False)
@@ -123,7 +123,7 @@ def test_k1_rows_resident_on_chip(eng, monkeypatch, dtype, rows, n, nc, kind):
 			else:
 				assert (fix[i] == 0).all()
 		# (c) the two-sweep kernel: same exponents, digits equal up to the rounding of b (different summation order)
-		monkeypatch.setenv('NRM_K1', 'v4')
+		monkeypatch.delenv('NRM_K1')
 		assert eng.k1_work(code, rp, n, nc) == (0, 0)
 		rv = eng.residualize(d_x, d_c, d_dci, dcr, nslices=ns, keep_fp64=False)
 		qv = decode_planes(rv._quant[0].cpu().numpy(), rv.rows_pad, nks, ns)
@@ -134,13 +134,13 @@ def test_k1_rows_resident_on_chip(eng, monkeypatch, dtype, rows, n, nc, kind):
 		lim = 2 + 1e-11 * np.abs(x64).max(axis=1)[same] / np.ldexp(1.0, exps[:rows][same].astype(np.int64))
 		assert (dq <= lim).all(), (dq / lim).max()
 		assert np.allclose(rv.ss.cpu().numpy(), ss, rtol=1e-12, atol=0)
-		monkeypatch.delenv('NRM_K1')
 
 
 def test_k1_resident_chunked_planes_and_coefficients(eng, monkeypatch):
 	"""The resident kernel writing cell chunks (what the sharded coex path sends piece by piece: nrm_residualize_q_chunked) and the
 	OLS coefficients (alpha, lowmem=False): chunks decode to the same integers as the dense planes; coefficients equal numpy's."""
 	import torch
+	monkeypatch.setenv('NRM_K1', 'res')
 	rng = np.random.default_rng(402)
 	rows, n, nc = 70, 20000, 4
 	x, d_x, dc64, d_c, d_dci, dcr = _k1_case(eng, rng, np.float32, rows, n, nc, 'gauss')
@@ -157,3 +157,76 @@ def test_k1_resident_chunked_planes_and_coefficients(eng, monkeypatch):
 		qc = decode_planes(rc._planes.cpu().numpy(), 128, nch * cks, 6, cks=cks)
 		assert np.array_equal(qc[:, :nks * 32], q[:128]) and (qc[:, nks * 32:] == 0).all()
 		assert torch.equal(rc._quant[1], r._quant[1]) and torch.equal(rc.ss, r.ss) and torch.equal(rc.fix, r.fix)
+
+
+def test_four_threads_share_one_device(norm, eng):
+	"""SURVEY section 8b, Threading: the reference calls its block kernel from a thread pool (association.py:895,997,
+	parallel.py:47-52).  Four Python threads x 20 mixed norm.coex / norm.de calls on ONE device (>= 2048 cells, so the integer
+	engine with its stream-K slabs, the shared Gram scratch and the fix-up launch are in play; several shapes, so the scratch is
+	reallocated in between): every result bit-equal to the serial answer."""
+	import threading
+	rng = np.random.default_rng(403)
+	cases = []
+	for i in range(10):
+		n = int(rng.choice([2304, 4096, 6000]))
+		ng = int(rng.integers(130, 700))
+		dt = np.log1p(rng.poisson(1.5, (ng, n)).astype(np.float32 if i % 2 else np.float64))
+		dc = np.vstack([rng.normal(size=(int(rng.integers(1, 4)), n)), np.ones((1, n))])
+		dg = (rng.random((int(rng.integers(1, 40)), n)) < 0.2).astype(np.float64)
+		cases.append(('coex', (dt, dc)))
+		cases.append(('de', (dg, dt, dc)))
+
+	def run(kind, a):
+		return norm.coex(*a) if kind == 'coex' else norm.de(*a)
+
+	serial = [run(k, a) for k, a in cases]
+	results = [[None] * len(cases) for _ in range(4)]
+	errors = []
+
+	def worker(t):
+		try:
+			order = np.random.default_rng(t).permutation(len(cases))
+			for j in order:
+				results[t][j] = run(*cases[j])
+		except Exception as e:  # noqa: BLE001
+			errors.append(e)
+
+	threads = [threading.Thread(target=worker, args=(t, )) for t in range(4)]
+	for t in threads:
+		t.start()
+	for t in threads:
+		t.join()
+	assert not errors, errors
+	for t in range(4):
+		for j, ref in enumerate(serial):
+			for got, want in zip(results[t][j], ref):
+				if want is None:
+					assert got is None
+				else:
+					assert np.array_equal(got, want, equal_nan=True), (t, j, cases[j][0])
+
+
+def test_reference_thread_pool_over_block_kernel(norm):
+	"""The reference's own pattern: autopooler(nth=4, dummy=True) over (association_test_1, args, kwargs) tiles
+	(association.py:905-909,997) -- here over this build's association_test_1 through normalisr_amd.parallel: the tiles' results
+	equal the serial ones bit for bit and the oracle's to tolerance."""
+	from normalisr_amd import parallel
+	from normalisr_amd.association import association_test_1, inv_rank
+	rng = np.random.default_rng(404)
+	n, nx, ny, bs = 3000, 300, 260, 64
+	dx = rng.normal(size=(nx, n))
+	dy = rng.normal(size=(ny, n)) + 0.2 * dx[:1]
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dci, dcr = inv_rank(dc @ dc.T)
+	tiles = [(association_test_1, (x0, y0, dx[x0:x0 + bs], dy[y0:y0 + bs], dc, dci, dcr), dict(lowmem=True))
+			 for x0 in range(0, nx, bs) for y0 in range(0, ny, bs)]
+	serial = parallel.autopooler(1, tiles, dummy=True)
+	pooled = parallel.autopooler(4, tiles, dummy=True)
+	for a, b in zip(serial, pooled):
+		assert a[0] == b[0] and a[1] == b[1]
+		for u, v in zip(a[2:], b[2:]):
+			assert (u is None and v is None) or np.array_equal(u, v)
+	ref = oracle.association_test_1(*tiles[3][1], lowmem=True)
+	got = pooled[3]
+	p_close(got[2], ref[2])
+	close(got[3], ref[3], floor=1e-12)
