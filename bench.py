@@ -5,16 +5,22 @@ Headline (`value`): BASELINE.json configs[1] -- norm.coex gene x gene on 5k gene
 3 covariates (2 random + intercept), seeded synthetic data.  A step is one full pass of
 the hot path over the matrix resident in HBM: residualise + quantise (K1) -> Gram contraction on the int8 matrix cores, exact
 for its 46-bit fixed-point operands (K2, k_gram_i8; problems under 2048 cells: the fp64-MFMA kernel k_gram_f64) -> per-pair
-sweep R^2 -> p, covariance with the integer engine's correction and accuracy guard (K3); outputs stay in HBM.  tests = ng(ng-1)/2 unique pairs.  For N>1 (one process per
-GPU, RCCL) the gene count grows as sqrt(N) so the pairs per GPU stay fixed (weak scaling); gene-row blocks are
-residualised locally and exchanged by all-gather.
+sweep R^2 -> p, covariance with the integer engine's correction and accuracy guard (K3); outputs stay in HBM.  tests = ng(ng-1)/2 unique pairs.
+
+For N>1 (one process per GPU, RCCL) the headline is the workload BASELINE.json's 8-GPU target is quoted on: configs[4], norm.coex
+on 3750 gene rows per rank x 500 000 cells fp64 (N=8: the full 30 000 x 30 000 problem) -- gene-row blocks residualised locally,
+their digit planes exchanged by all-gather in cell chunks; the rank count seen by the collective, the bytes a rank receives and the
+exchange time compute did not hide are in the line.  configs[1] weak-scaled (genes ~ sqrt(N)) moves to `extra_workloads.coex_c2` there.
 
 The same JSON line carries, under `extra_workloads`, the other BASELINE configs measured the same way (each
 with its own ms_per_step and roofline): de_c3 = configs[2] (1 x 20k genes x 100k cells, 20 covariates:
 HBM-bound streaming kernel), de_c4 = configs[3] (1k gRNAs x 15k genes x 50k cells, gene rows sharded over the
 ranks, no collective), coex_c5 = the per-rank shape of configs[4] (3750 gene rows per rank x 500k cells,
-fp64; at N=8 that is the full 30k x 30k problem, residual blocks exchanged by all-gather).  `--workload X`
-makes X the headline instead; `--no-extras` skips them.
+fp64; at N=8 that is the full 30k x 30k problem, residual blocks exchanged by all-gather), de_c4_single4 / de_c4_single1 = the
+CRISPR screen of configs[3] as the reference's example runs it besides the naive test (`de -m covariate` / `-m single`,
+examples/GSE120861/code/cmd_highmoi.sh:19-22), coex_c2_f64 = configs[1] on the fp64 matrix cores (NRM_GRAM=f64: the dtype the
+north star names literally), binnet_c5 = binnet on a 30 000 x 30 000 fp64 P-value matrix (the consumer of configs[4]'s output).
+`--workload X` makes X the headline instead; `--no-extras` skips them.
 
 Launch: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when it is
 not already running under one; under `python -m torch.distributed.run ... bench.py --gpus N` it uses the
@@ -174,8 +180,27 @@ def cpu_baseline_worker(ng, n_cells, nc, seed, min_seconds, extras_too=False):
 		n4, g4 = 50000, 500 * max(1, min(cores // 2, 2))
 		dc4 = np.vstack([r.normal(size=(4, n4)), np.ones((1, n4))])
 		dg4 = (r.random((1000, n4)) < 0.01).astype(np.float64)
+		dg1 = (r.random((1000, n4)) < 0.001).astype(np.float64)  # (single=1: low MOI, see bench_de_method)
 		dt4 = r.normal(size=(g4, n4))
 		extras['de_c4'] = timed(lambda: oracle.de(dg4, dt4, dc4, nth=cores), 1000 * g4, 'norm.de 1000 gRNAs x {} of the 15000 genes x {} cells, 5 covariates'.format(g4, n4))
+		# the CRISPR screen as the reference's example runs it (cmd_highmoi.sh:19-22).  single=4 pays one SVD of (groupings + covariates
+		# - 1)^2 PER GROUPING whatever the gene count, so the sample is timed at two gene counts and the full problem's rate follows from
+		# t = t_groupings + genes * t_gene (the oracle restates association.py:421-576,926-980 literally)
+		def de4(g, single):
+			t0 = time.perf_counter()
+			oracle.de(dg4 if single == 4 else dg1, dt4[:g], dc4, single=single, nth=cores)
+			return time.perf_counter() - t0
+		for name, single in (('de_c4_single4', 4), ('de_c4_single1', 1)):
+			try:
+				ta, tb = de4(g4 // 2, single), de4(g4, single)
+				t_gene = max(tb - ta, 1e-9) / (g4 - g4 // 2)
+				t_fix = max(ta - t_gene * (g4 // 2), 0.0)
+				full = t_fix + 15000 * t_gene
+				extras[name] = dict(value=1000 * 15000 / full, unit='tests/s', cores=cores, kind='port', extrapolated=True,
+									sample='norm.de(single={}) on the 1000 gRNAs x {} and {} of the 15000 genes x {} cells in {:.1f} + {:.1f} s; per-grouping part {:.2f} s, per gene {:.2e} s; thread pool nth={}, BLAS threads=1'.format(
+										single, g4 // 2, g4, n4, ta, tb, t_fix, t_gene, cores))
+			except Exception as e:  # noqa: BLE001
+				extras[name] = dict(error='{}: {}'.format(type(e).__name__, e))
 		del dt4, dg4, dc4
 		n5, g5 = 500000, 264  # (the reference's tile size at this shape is 132)
 		dc5 = np.vstack([r.normal(size=(2, n5)), np.ones((1, n5))])
@@ -281,6 +306,32 @@ class Ranks:
 	def close(self):
 		if self.world > 1 or self.forced:
 			self.torch.distributed.destroy_process_group()
+
+
+def preflight_c5(rk, rows, cells):
+	"""Per-rank HBM budget of the configs[4] workload, printed (stderr) and enforced before anything is allocated: input rows, K1's
+	digit planes, the gather buffers of the exchange (every rank's planes), the dot blocks and results of the rank's block pairs.
+	Results stay in HBM in the bench (no /dev/shm arrays; the sharded CLI checks those itself)."""
+	torch = rk.torch
+	world = rk.world
+	rp = (rows + 127) // 128 * 128
+	ns = SLICES(cells) or 8
+	need = dict(input_rows=rows * cells * 8, digit_planes=rp * cells * ns, gather_buffers=(world * rp * cells * ns if world > 1 else 0),
+				dot_and_results=(world // 2 + 1) * rp * rp * (8 + 2 * 8), generator_temporaries=2 * min(rows, 512) * cells * 8)
+	total = sum(need.values())
+	free, cap = torch.cuda.mem_get_info(rk.device)
+	shm = None
+	try:
+		st = os.statvfs('/dev/shm')
+		shm = st.f_bavail * st.f_frsize
+	except OSError:
+		pass
+	msg = 'rank {}/{}: configs[4] workload needs {:.1f} GB of HBM ({}), {:.1f} GB free of {:.1f}; /dev/shm {} (not used by the bench: results stay in HBM)'.format(
+		rk.rank, world, total / 1e9, ', '.join('{} {:.1f}'.format(k, v / 1e9) for k, v in need.items()), free / 1e9, cap / 1e9,
+		'unknown' if shm is None else '{:.1f} GB free'.format(shm / 1e9))
+	print(msg, file=sys.stderr, flush=True)
+	if total > 0.95 * free:
+		raise SystemExit('bench.py: ' + msg + ' -- does not fit; use --c5-rows / --c5-cells to shrink the per-rank block')
 
 
 def timed_steps(rk, plan, steps, warmup, events_inside):
@@ -392,6 +443,103 @@ def bench_de(rk, nd, steps, warmup, which, covariates=20):
 				guard=guard_verdict(plan.result.get('flags'), eng))
 
 
+def bench_de_method(rk, steps, warmup, single):
+	"""BASELINE configs[3] as the reference's CRISPR example runs it besides the naive test (cmd_highmoi.sh:19-22): norm.de with
+	single=4 (`-m covariate`: every other gRNA a covariate, association.py:421-576,926-980) or single=1 (`-m single`: every gRNA on the
+	cells free of the others, :263-390,911-925).  1000 gRNAs x 15000 genes x 50000 cells, inputs resident in HBM, results left there;
+	a step is the whole call: A A^T and its rank certificate, K1 on design and genes, the large contraction on the integer engine,
+	the host's 1000 x 1000 inverse (overlapped), B = G N, the sweep.  Gene rows sharded over the ranks, no collective."""
+	torch = rk.torch
+	from normalisr_amd.engine import get_engine
+	world, rank, device = rk.world, rk.rank, rk.device
+	nx, ny, n, nc, seed = 1000, 15000, 50000, 5, 4
+	ny_local = ny // world
+	g = torch.Generator(device=device)
+	g.manual_seed(seed)
+	dc = torch.cat([torch.randn((nc - 1, n), generator=g, device=device, dtype=torch.float32), torch.ones((1, n), device=device, dtype=torch.float32)])
+	# single=1 tests a gRNA on the cells that carry no OTHER gRNA (association.py:915-918 asserts there are some): a low-MOI design, one
+	# gRNA per cell on average; single=4 takes the high-MOI design of configs[3] (10 per cell)
+	dx = (torch.rand((nx, n), generator=g, device=device) < (0.01 if single == 4 else 0.001)).to(torch.float32)
+	g2 = torch.Generator(device=device)
+	g2.manual_seed(seed * 7919 + rank)
+	dy = torch.randn((ny_local, n), generator=g2, device=device, dtype=torch.float32)
+	dy[:16] += 0.2 * dx[0]
+	dc_h = dc.cpu().numpy().astype(np.float64)
+	eng = get_engine(device.index)
+	if single == 4:
+		from normalisr_amd.single4 import association_tests_single4 as fn
+	else:
+		from normalisr_amd.single1 import association_tests_single1 as fn
+
+	class Plan:
+		out = None
+
+		def step(self, timed=False):
+			self.out = None  # (the previous step's results go back to the allocator first: no second set of GB-sized buffers)
+			self.out = fn(dx, dy, dc_h, return_dot=False, device_out=True)
+	plan = Plan()
+	for _ in range(3):  # the allocator's pool and the kernels' code objects settle in the first calls
+		plan.step()
+	elapsed = timed_steps(rk, plan, steps, warmup, False)
+	guard = dict(eng.last_guard)
+	eng.trace = []
+	for _ in range(2):
+		plan.step()
+	torch.cuda.synchronize()
+	split = {}
+	for name, e0, e1 in eng.trace:
+		split[name] = split.get(name, 0.0) + e0.elapsed_time(e1) / 2
+	eng.trace = None
+	tests = nx * ny_local * world
+	ms = 1e3 * elapsed / steps
+	if single == 4:
+		roof = gram_roofline(n, 2.0 * n * nx * ny_local, split.get('gram_yx', ms), 0, 0)  # the large contraction Y~ X~^T alone
+		roof['algorithmic_bytes'] = float(SLICES(n) or 8) * (nx + ny_local) * n
+		roof['step_ms'] = ms
+		dtype = ARITH(n)
+	else:
+		byts = 4.0 * n * ny_local  # every fp32 expression value read once
+		roof = dict(bound='hbm', kernel='k_s1_common + k_s1_sparse (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms,
+					note='the step also transposes the expression rows in the permuted cell order (torch index_select: plumbing) and takes 1000 small host SVDs')
+		dtype = 'f64'
+	return dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=ms, scaling='strong', dtype=dtype,
+				config=dict(workload='norm.de(single={}) {} gRNAs x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[3] as `normalisr de -m {}`, examples/GSE120861/code/cmd_highmoi.sh)'.format(
+					single, nx, ny, n, nc, 'covariate' if single == 4 else 'single') + ('' if single == 4 else '; gRNA incidence 0.1 % (low MOI: single=1 needs cells with one gRNA)'), parallelism='gene rows of Y x{}, no collective'.format(world)),
+				roofline=roof, kernels_ms={k: round(v, 4) for k, v in split.items()}, kernels_ms_from='2 extra steps after the timed region (HIP events around the engine\'s launches; the rest of a step is the host: rank certificate, inverse)',
+				guard=dict(uncertified_pairs=int(guard.get('hits', 0)), largest_relative_p_error_bound=float(guard.get('worst', 0.0)), tolerance=eng.guard_tol,
+						   fp64_rerun=bool(guard.get('fallback', False))), metric='association tests/sec (de)')
+
+
+def bench_binnet(rk, steps, warmup):
+	"""binnet (binnet.py:77-173) on a 30 000 x 30 000 fp64 P-value matrix resident in HBM -- the consumer of configs[4]'s output
+	(examples/GSE123139/code/cmd_coex.sh:40-42): per-row Benjamini-Hochberg threshold, one byte out per pair."""
+	torch = rk.torch
+	from normalisr_amd import binnet as nb
+	ng = 30000
+	if torch.cuda.mem_get_info(rk.device)[0] < 12 * (1 << 30):
+		return None
+	g = torch.Generator(device=rk.device)
+	g.manual_seed(7)
+	p = torch.rand((ng, ng), generator=g, device=rk.device, dtype=torch.float64)
+	p[:, :64] *= 1e-6  # some strong columns so that rows have something to keep
+	p = torch.triu(p, 1)
+	p = p + p.T
+
+	class Plan:
+		def step(self, timed=False):
+			self.out = nb.binnet(p, 0.05)
+	plan = Plan()
+	elapsed = timed_steps(rk, plan, steps, warmup, False)
+	ms = 1e3 * elapsed / steps
+	byts = float(ng) * ng * (8 + 1)
+	kept = int(plan.out.sum())
+	return dict(metric='binnet entries/sec', value=float(ng) * ng * steps / elapsed, unit='entries/s', steps=steps, warmup=warmup, ms_per_step=ms, scaling='single GPU',
+				dtype='f64 compare / count', config=dict(workload='binnet on a {0} x {0} fp64 P-value matrix, qcut 0.05 (the output of BASELINE configs[4])'.format(ng), edges_kept=kept),
+				roofline=dict(bound='hbm', kernel='k_binnet_rows', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+							  algorithmic_bytes=byts, traffic=None, kernel_ms=ms))
+
+
 def bench_c5_full(rk):
 	"""BASELINE configs[4] WHOLE on one GPU: 30 000 genes x 500 000 cells fp64 (4.5e8 pairs).  The 120 GB matrix is generated and
 	dropped in blocks of 3840 gene rows; only its 90 GB of digit planes stay resident (engine.coex_blocks_resident).  value = pairs /
@@ -439,12 +587,15 @@ def main():
 	ap.add_argument('--cells', type=int, default=10000)
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
 	ap.add_argument('--cpu-worker', nargs=6, default=None, help=argparse.SUPPRESS)
-	ap.add_argument('--workload', default='coex_c2', choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu'],
-					help='headline workload: coex_c2 = BASELINE configs[1] (default); de_c3 / de_c4 / coex_c5 = configs[2] / [3] / [4] shapes')
+	ap.add_argument('--workload', default=None, choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'binnet_c5'],
+					help='headline workload.  Default: coex_c2 = BASELINE configs[1] at N=1; coex_c5 = configs[4] (3750 gene rows per rank x 500k cells) at N>1, '
+					'the configuration the 8-GPU target is quoted on.  de_c3 / de_c4 = configs[2] / [3]')
+	ap.add_argument('--c5-rows', type=int, default=C5_ROWS_PER_RANK, help='gene rows per rank of the coex_c5 workload (smaller: functional runs)')
+	ap.add_argument('--c5-cells', type=int, default=C5_CELLS, help='cells of the coex_c5 workload (smaller: functional runs)')
 	ap.add_argument('--no-extras', action='store_true', help='skip the extra_workloads entries (the other BASELINE configs)')
 	ap.add_argument('--extras', default='', help='comma-separated subset of the extra workloads to run (default: all)')
 	ap.add_argument('--extras-steps', type=int, default=5)
-	ap.add_argument('--extras-timeout', type=float, default=300.0, help='seconds after which a stuck extra workload is abandoned and the headline line printed')
+	ap.add_argument('--extras-timeout', type=float, default=480.0, help='seconds after which a stuck extra workload is abandoned and the headline line printed')
 	ap.add_argument('--covariates', type=int, default=20, help='covariates of the de_c3 workload (<= 15 selects the half-width streaming kernel)')
 	ap.add_argument('--seed', type=int, default=2)
 	ap.add_argument('--e2e', type=int, default=2, help='repetitions of the numpy-in/numpy-out end-to-end timing (0 = skip)')
@@ -459,6 +610,8 @@ def main():
 	world = int(os.environ.get('WORLD_SIZE', '1'))
 	if args.gpus != world:
 		raise SystemExit('bench.py --gpus {} inside a launcher with WORLD_SIZE={}'.format(args.gpus, world))
+	if args.workload is None:
+		args.workload = 'coex_c2' if world == 1 else 'coex_c5'
 	cpu = None
 	if world == 1 and args.cpu_seconds > 0 and args.workload == 'coex_c2':
 		# CPU baseline first, in a child process, before this process touches the GPU
@@ -501,9 +654,10 @@ def main():
 				pmc_traffic('coex_c2', out['roofline'])
 			return out
 		if which == 'coex_c5':
-			out, plan = bench_coex(rk, nd, steps, warmup, C5_ROWS_PER_RANK, C5_CELLS, 5, torch.float64,
-								   'norm.coex gene x gene, {genes} genes x {cells} cells, fp64 input, 3 covariates (BASELINE configs[4] at 3750 gene rows per rank' +
-								   ('; N=8 is the full 30k x 30k problem)' if world != 8 else ': the full problem)'), loading=0.05)
+			preflight_c5(rk, args.c5_rows, args.c5_cells)
+			out, plan = bench_coex(rk, nd, steps, warmup, args.c5_rows, args.c5_cells, 5, torch.float64,
+								   'norm.coex gene x gene, {genes} genes x {cells} cells, fp64 input, 3 covariates (BASELINE configs[4] at %d gene rows per rank' % args.c5_rows +
+								   ('; N=8 is the full 30k x 30k problem)' if world != 8 or args.c5_rows != C5_ROWS_PER_RANK else ': the full problem)'), loading=0.05)
 			out['metric'] = 'association tests/sec (gene x gene coex)'
 			out['scaling'] = 'rows per rank fixed (block pairs per rank grow as (N+1)/2)'
 			if world == 1:
@@ -511,6 +665,23 @@ def main():
 			return out
 		if which == 'coex_c5_full_1gpu':
 			return bench_c5_full(rk)
+		if which in ('de_c4_single4', 'de_c4_single1'):
+			return bench_de_method(rk, steps, warmup, 4 if which.endswith('4') else 1)
+		if which == 'binnet_c5':
+			return bench_binnet(rk, steps, warmup)
+		if which == 'coex_c2_f64':  # configs[1] on the fp64 matrix cores: the dtype the north star names literally
+			prev = os.environ.get('NRM_GRAM')
+			os.environ['NRM_GRAM'] = 'f64'
+			try:
+				out = run('coex_c2', steps, warmup)
+			finally:
+				if prev is None:
+					del os.environ['NRM_GRAM']
+				else:
+					os.environ['NRM_GRAM'] = prev
+			out['roofline'].pop('traffic', None)
+			out['roofline']['traffic'] = None
+			return out
 		out = bench_de(rk, nd, steps, warmup, which, args.covariates)
 		out['metric'] = 'association tests/sec (de)'
 		if world == 1:
@@ -548,7 +719,10 @@ def main():
 		dog = threading.Timer(args.extras_timeout, give_up)
 		dog.daemon = True
 		dog.start()
-		names = [w for w in ('de_c3', 'de_c4', 'coex_c5') if w != args.workload] + (['coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
+		names = [w for w in ('coex_c2', 'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64') if w != args.workload and not (w == 'coex_c2' and world == 1)] + (
+			['binnet_c5', 'coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
+		if world > 1:
+			names = [w for w in names if w != 'coex_c2_f64']
 		if args.extras:
 			names = [w for w in names if w in args.extras.split(',')]
 		for w in names:

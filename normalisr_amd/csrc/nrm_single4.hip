@@ -2,6 +2,7 @@
 // regression of every gene on A = [dx; dc] replaces the reference's per-grouping SVD loop.
 // The heavy contractions A A^T, Y A^T and (Y A^T) N run on K2; this file is the per-pair sweep.
 #include "nrm_pvalue.h"
+#include "nrm_fix.h"
 
 extern "C" int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof);
 
@@ -18,12 +19,53 @@ __global__ void __launch_bounds__(256) k_s4_rss(const double* __restrict__ bt, c
 	if (lane == 0) rss[y] = yy[y] - acc;
 }
 
+// The integer Gram engine's exact mean-product correction (nrm_fix.h) added to a raw dot matrix in place: dot[i, j] += sum_{s+t <= NS-2}
+// u_i[s] u_j[t] / n from the row records of the rows (fr) and of the columns (fc).  K3 does this inside its sweeps; single=4 needs the
+// corrected products themselves (they are the operand of the next contraction).
+__global__ void __launch_bounds__(256) k_fix_dot(double* __restrict__ dot, int64_t ld, const double* __restrict__ fr, const double* __restrict__ fc,
+												 int64_t rows, int64_t cols, int top, double inv_n) {
+	const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+	if (j >= cols) return;
+	const FixCol y = nrm_fix_col(fc + j * NRM_FIX_STRIDE);
+#pragma unroll
+	for (int it = 0; it < 4; it++) {  // 16 rows per workgroup, one of every four per wave
+		const int64_t i = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 6) + 4 * it;
+		if (i >= rows) break;
+		double ux[5];
+#pragma unroll
+		for (int s = 0; s < 5; s++) ux[s] = fr[i * NRM_FIX_STRIDE + s];
+		dot[i * ld + j] += nrm_fix_corr(ux, y, top, inv_n);
+	}
+}
+
+extern "C" int nrm_gram_i8_fix_dot(double* d_dot, int64_t ldd, const double* d_fix_rows, const double* d_fix_cols, int64_t rows, int64_t cols,
+								   int nslices, int64_t n_cells, void* stream) {
+	NRM_REQUIRE(d_dot && d_fix_rows && d_fix_cols && rows > 0 && cols > 0 && ldd >= cols && n_cells > 0, "nrm_gram_i8_fix_dot: bad arguments");
+	NRM_REQUIRE(nslices == 5 || nslices == 6, "nrm_gram_i8_fix_dot: 5 or 6 slices");
+	dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 15) / 16));
+	hipLaunchKernelGGL(k_fix_dot, grid, dim3(256), 0, (hipStream_t)stream, d_dot, ldd, d_fix_rows, d_fix_cols, rows, cols, nslices - 2, 1.0 / (double)n_cells);
+	return nrm_check_launch("k_fix_dot");
+}
+
+// What the single=4 sweep needs to certify P-values whose products Y~ X~^T came from the integer engine (fy == nullptr: fp64 Gram
+// kernel, nothing to certify).  |delta (y~ . x~_j)| <= e_y |y~| |x~_j| with e_y = K c_y c* + g_y + g* (c*, g*: the largest c and g
+// among the design rows, nrm_fix.h), so the regression coefficient B_yi = sum_j G_yj N_ji moves by at most e_y |y~| sum_j |x~_j| |N_ji|
+// and the partial correlation by  dr <= 2 e_y kappa_i |y~| / sqrt(n vary_iy),  kappa_i = sum_j |x~_j| |N_ji| / sqrt(N_ii)  (the factor 2
+// covers the matching change of the residual sum of squares).  A pair is counted when that could move its P-value by more than the
+// budget, with the P-value's sensitivity bounded as in nrm_fix_bound.
+struct S4Guard {
+	const double* fy;     // (ny, NRM_FIX_STRIDE) row records of the genes, or nullptr
+	const double* kappa;  // (nx)
+	const double* yy;     // (ny) |y~|^2
+	double kconst, cstar, gstar, budget, dof;
+};
+
 #define S4_T 64
 template <typename OutT>
 __global__ void __launch_bounds__(256) k_s4_sweep(const double* __restrict__ bt, int64_t ldb, const double* __restrict__ rss,
 												  const double* __restrict__ dxx, int64_t nx, int64_t ny, double ncells,
 												  int return_dot, PvalPlan pl, OutT* __restrict__ p_out, OutT* __restrict__ stat_out,
-												  OutT* __restrict__ vary_out, int64_t ldo, int32_t* __restrict__ flags) {
+												  OutT* __restrict__ vary_out, int64_t ldo, int32_t* __restrict__ flags, S4Guard gd) {
 	__shared__ double tile[S4_T][S4_T + 1];  // [gene][grouping]
 	const int bi = blockIdx.y, bj = blockIdx.x;  // grouping block, gene block
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -34,7 +76,13 @@ __global__ void __launch_bounds__(256) k_s4_sweep(const double* __restrict__ bt,
 	__syncthreads();
 	const int64_t gy = (int64_t)bj * S4_T + tx;
 	const double rs = gy < ny ? rss[gy] : 1.0;
-	int bad_nf = 0, bad_rng = 0;
+	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
+	float worst = 0.f;
+	double ey = 0.0, sqrt_dof = 0.0;
+	if (gd.fy && gy < ny) {
+		ey = 2.0 * (fma(gd.kconst * gd.fy[gy * NRM_FIX_STRIDE + 5], gd.cstar, gd.fy[gy * NRM_FIX_STRIDE + 6] + gd.gstar)) * sqrt(gd.yy[gy] / ncells);
+		sqrt_dof = sqrt(gd.dof);
+	}
 	for (int r = ty; r < S4_T; r += 4) {
 		const int64_t gi = (int64_t)bi * S4_T + r;
 		if (gi >= nx || gy >= ny) continue;
@@ -47,13 +95,30 @@ __global__ void __launch_bounds__(256) k_s4_sweep(const double* __restrict__ bt,
 		if (!isfinite(r2) || !isfinite(vy)) bad_nf = 1;
 		if (r2 > 1.0 + 1e-8 || vy < 0.0) bad_rng = 1;
 		const int64_t o = gi * ldo + gy;
-		p_out[o] = (OutT)nrm_pvalue(r2, pl);
+		const OutT pv = (OutT)nrm_pvalue(r2, pl);
+		p_out[o] = pv;
+		if (gd.fy) {  // the integer engine's products: could their error move this P-value by more than the budget?
+			const double dr = ey * gd.kappa[gi] * rsqrt(vy);
+			const double ar = (double)(sqrtf((float)r2) * 1.0000002f);
+			const double om = fmax(1.0 - r2, 1e-150);
+			const double num = dr * fma(gd.dof, ar, sqrt_dof), den = om * om;
+			if (num > gd.budget * den || !(num == num)) {
+				const double lo = fmax(ar - dr, 0.0);
+				if (pv != (OutT)0 || nrm_pvalue(lo * lo, pl) != 0.0) bad_fix++;  // (a P-value that is 0 on the whole interval is exempt)
+			} else
+				worst = fmaxf(worst, __fdividef((float)num, (float)den));
+		}
 		stat_out[o] = (OutT)(return_dot ? g * vx : g);
 		vary_out[o] = (OutT)vy;
 	}
 	if (flags) {
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
+		if (gd.fy) {
+			if (bad_fix && __hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (1 << 30)) atomicAdd(&flags[2], bad_fix);
+			const int w = __float_as_int(worst);  // non-negative floats order like their bit patterns
+			if (w > __hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[3], w);
+		}
 	}
 }
 
@@ -67,9 +132,9 @@ static PvalPlan s4_to_dev(const nrm_pvalue_plan& p) {
 	return d;
 }
 
-extern "C" int nrm_single4_sweep(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
-								 int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot, void* d_p,
-								 void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags, void* stream) {
+static int single4_sweep_impl(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
+							  int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot, void* d_p,
+							  void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags, S4Guard gd, void* stream) {
 	NRM_REQUIRE(nx > 0 && ny > 0 && m >= nx && n_cells > 0, "nrm_single4_sweep: bad sizes");
 	NRM_REQUIRE(ldb >= m && ldo >= ny, "nrm_single4_sweep: pitch too small");
 	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_single4_sweep: bad out_dtype");
@@ -83,9 +148,29 @@ extern "C" int nrm_single4_sweep(const double* d_bt, const double* d_pt, int64_t
 	dim3 grid((unsigned)((ny + S4_T - 1) / S4_T), (unsigned)((nx + S4_T - 1) / S4_T));
 	if (out_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_s4_sweep<double>, grid, dim3(256), 0, st, d_bt, ldb, rss, d_dxx, nx, ny, (double)n_cells, return_dot,
-						   s4_to_dev(plan), (double*)d_p, (double*)d_stat, (double*)d_vary, ldo, d_flags);
+						   s4_to_dev(plan), (double*)d_p, (double*)d_stat, (double*)d_vary, ldo, d_flags, gd);
 	else
 		hipLaunchKernelGGL(k_s4_sweep<float>, grid, dim3(256), 0, st, d_bt, ldb, rss, d_dxx, nx, ny, (double)n_cells, return_dot,
-						   s4_to_dev(plan), (float*)d_p, (float*)d_stat, (float*)d_vary, ldo, d_flags);
+						   s4_to_dev(plan), (float*)d_p, (float*)d_stat, (float*)d_vary, ldo, d_flags, gd);
 	return nrm_check_launch("k_s4_sweep");
+}
+
+extern "C" int nrm_single4_sweep(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
+								 int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot, void* d_p,
+								 void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags, void* stream) {
+	const S4Guard none = {nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, dof};
+	return single4_sweep_impl(d_bt, d_pt, ldb, d_yy, d_dxx, nx, ny, m, n_cells, dof, return_dot, d_p, d_stat, d_vary, out_dtype, ldo, d_work, d_flags, none, stream);
+}
+
+// The same for products that came from the integer Gram engine: d_fix_y = the genes' row records, d_kappa (nx) and c*, g* as described
+// at S4Guard; d_flags then has 4 entries (non-finite, R^2 out of range, pairs not certified, largest error estimate as float bits).
+extern "C" int nrm_single4_sweep_guarded(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
+										 int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot, void* d_p,
+										 void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags,
+										 const double* d_fix_y, const double* d_kappa, double cstar, double gstar, int nslices, double budget, void* stream) {
+	NRM_REQUIRE(d_fix_y && d_kappa && d_flags && (nslices == 5 || nslices == 6) && budget > 0.0, "nrm_single4_sweep_guarded: bad guard arguments");
+	double k = 0.0, w256 = 1.0;
+	for (int w = 0; w <= nslices - 2; w++, w256 *= 256.0) k += (w + 1) * w256;
+	const S4Guard gd = {d_fix_y, d_kappa, d_yy, k, cstar, gstar, budget, dof};
+	return single4_sweep_impl(d_bt, d_pt, ldb, d_yy, d_dxx, nx, ny, m, n_cells, dof, return_dot, d_p, d_stat, d_vary, out_dtype, ldo, d_work, d_flags, gd, stream);
 }

@@ -1105,15 +1105,29 @@ class Engine:
 		cov: optional (d_c, d_dci) already on the device (repeated calls with the same covariates).
 		A call whose P-values the integer engine's guard cannot certify (GuardHit) is redone on the fp64 Gram kernel; resident calls
 		leave that to whoever reads the flags (DePlan.results)."""
+		import logging
+		import time
+		t0 = time.perf_counter()
+		self._tls.path = None
 		try:
-			return self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident, state)
+			res = self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident, state)
 		except GuardHit as g:
-			import logging
 			logging.info('normalisr_amd: integer Gram engine: %s; redoing the call on the fp64 matrix cores.', g)
 			with self.forced_f64():
 				res = self._association_single0(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident, state)
 			self.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
-			return res
+		if not resident and logging.getLogger().isEnabledFor(logging.INFO):
+			# which engine ran, how fast, what the guard said (the reference logs its batch decisions: association.py:745-757, run.py:274-276)
+			el = time.perf_counter() - t0
+			nx, n = dx.shape
+			tests = nx * (nx - 1) // 2 if dy is None else nx * dy.shape[0]
+			g = self.last_guard
+			logging.info('normalisr_amd: %s, %d tests over %d cells on %s in %.1f ms (%.3g tests/s incl. transfers); %s', 'coex' if dy is None else 'de', tests, n,
+						 getattr(self._tls, 'path', None) or 'the device', 1e3 * el, tests / max(el, 1e-9),
+						 'fp64 matrix cores, no guard needed' if (g['hits'] == 0 and g['worst'] == 0 and not g['fallback']) else
+						 ('guard: %d pairs not certified by the integer engine (largest estimate %.2g): redone on the fp64 matrix cores' % (g['hits'], g['worst']) if g['fallback']
+						  else 'guard: every P-value certified by the integer engine (largest relative error bound %.2g, budget %.2g)' % (g['worst'], self.guard_tol)))
+		return res
 
 	def forced_f64(self):
 		"""Context: every Gram product of this engine goes to the fp64 kernel (the redo after a GuardHit)."""
@@ -1131,6 +1145,7 @@ class Engine:
 	def _association_single0(self, dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident, state=None):
 		samexy = dy is None
 		if self.de_streaming_ok(dx, dy, dc):
+			self._tls.path = 'the streaming de kernel (fp64 matrix cores, raw rows read once)'
 			return self.association_de_streaming(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov,
 												 resident=resident and not (want_alpha or want_rt), state=state)
 		nx, n = dx.shape
@@ -1138,10 +1153,14 @@ class Engine:
 		nc = dc.shape[0]
 		dof = n - 1 - rank - dimreduce
 		stat_kind = 0 if (samexy or return_dot) else 1
+		eng_name = (lambda k: 'the integer Gram engine (%d-bit fixed point on the int8 matrix cores)' % (8 * k - 2) if k else 'the fp64 Gram kernel')(self.gram_slices(n))
 		if samexy and not (device_out or resident or want_rt or want_alpha) and self.coex_pipelined_ok(dx, dc, n):
+			self._tls.path = eng_name + ', rows uploaded / results returned chunk by chunk beside the kernels'
 			return self.association_coex_pipelined(dx, dc, dci, rank, dimreduce, out_dtype, cov)
 		if not (samexy or device_out or resident or want_rt or want_alpha) and self.chunked_ok(dy):
+			self._tls.path = eng_name + ', expression rows uploaded in chunks beside the kernels'
 			return self.association_de_chunked(dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov)
+		self._tls.path = eng_name
 		d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
 		ns = self.gram_slices(n)  # integer engine: K1 writes the digit planes itself and the fp64 residuals are never stored
 		# a resident caller's state (a DePlan) lends the previous step's K1 outputs to be overwritten: no GB-sized allocation per step

@@ -27,8 +27,13 @@ def _round_up(v, m):
 	return (v + m - 1) // m * m
 
 
-def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, chunk=256, **ka):
-	"""Device path of association_tests(..., single=1); returns (p, gamma|dot, alpha|None, varx (n_x,), vary (n_x,n_y))."""
+def _is_dev(a):
+	return hasattr(a, 'is_cuda') and a.is_cuda
+
+
+def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, chunk=256, device_out=False, **ka):
+	"""Device path of association_tests(..., single=1); returns (p, gamma|dot, alpha|None, varx (n_x,), vary (n_x,n_y)).
+	dx / dy may be torch CUDA tensors already in HBM (a resident screen: bench.py); device_out=True leaves the large results there."""
 	if ka:
 		raise TypeError("association_test_2() got an unexpected keyword argument '{}'".format(next(iter(ka))))
 	if dy is None:
@@ -41,7 +46,7 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			raise NotImplementedError('Per-gene dimreduce arrays are not supported on the device path.')
 		dimreduce = d[0]
 	dimreduce = int(dimreduce)
-	dx, dy, dc = np.asarray(dx), np.asarray(dy), np.asarray(dc)
+	dx, dy, dc = (dx if _is_dev(dx) else np.asarray(dx)), (dy if _is_dev(dy) else np.asarray(dy)), np.asarray(dc)
 	nx, n = dx.shape
 	ny, nc = dy.shape[0], dc.shape[0]
 	if dy.shape[1] != n or dc.shape[1] != n:
@@ -50,7 +55,10 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		logging.warning('No covariate dc input.')
 	chunk = max(1, min(chunk, 8192 // (nc + 1)))  # bounds the masked-row operand W (chunk * (nc + 1) rows) for many covariates
 	c64 = np.asarray(dc, dtype=np.float64)
-	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	if _is_dev(dy):
+		out_dtype = np.dtype(np.float32 if str(dy.dtype) == 'torch.float32' else np.float64)
+	else:
+		out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 	eng = _engine.get_engine()
 	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
 		torch = eng.torch
@@ -58,7 +66,7 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		nw = nc + 1
 		with torch.cuda.device(eng.device):
 			# cell selection on the device (association.py:914-918): the design matrix travels once, in its own dtype
-			d_dx = eng.upload(_engine.as_input(dx))
+			d_dx = dx if _is_dev(dx) else eng.upload(_engine.as_input(dx))
 			assert float(d_dx.max()) == 1  # association.py:914
 			sel = d_dx == torch.sum(d_dx, dim=0, dtype=torch.float64)  # association.py:915-916
 			big = torch.finfo(d_dx.dtype).max
@@ -68,8 +76,8 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			del lo, hi
 			ns = sel.sum(dim=1).cpu().numpy().astype(np.float64)
 			if nc <= 32 and not bool((d_dx < 0).any()) and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
-				return _sparse(eng, d_dx, dx.dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt)
-			ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
+				return _sparse(eng, d_dx, dx.dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out)
+			ry = eng.residualize(dy if _is_dev(dy) else _engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
 			y2 = Residualized_sq(ry, eng)
 			d_c = eng.upload(c64) if nc else None
 			p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
@@ -139,7 +147,7 @@ def _segment_sums(v, starts, counts):
 	return out
 
 
-def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt):
+def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out=False):
 	"""single=1 for a design with entries >= 0 (csrc/nrm_single1.hip, second half): the cells every grouping shares (all of dx is 0)
 	are summed once per gene, each grouping adds its own few cells inside the sweep; no masked Gram contraction, no loop over chunks
 	of groupings.  The statistics of the groupings themselves (M_i = C_S C_S^T, C_S x_S, |x_S|^2: association.py:350-364) are taken on
@@ -185,7 +193,7 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 	dof = np.ascontiguousarray(dof, dtype=np.float64)
 	_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, nx, info.ctypes.data + 16, pitch))
 	# the expression matrix: uploaded in its own dtype, the cells that matter gathered in the permuted order, transposed
-	d_y = eng.upload(_engine.as_input(dy))
+	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
 	yt = d_y.index_select(1, perm).t().contiguous()  # (cells, ny)
 	del d_y
 	ct = eng.upload(np.ascontiguousarray(cp.T)) if nc else None
@@ -203,6 +211,8 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 										  1 if return_dot else 0, p.data_ptr(), stat.data_ptr(), vary.data_ptr(), 0 if alpha is None else alpha.data_ptr(),
 										  code, ny, work.data_ptr(), flags.data_ptr(), eng._stream()))
 	eng.check_flags(flags)
+	if device_out:
+		return (p, stat, alpha, vxx.astype(out_dtype), vary)
 	return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), vxx.astype(out_dtype), eng.download(vary))
 
 

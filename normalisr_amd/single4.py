@@ -19,6 +19,7 @@ association.py:77) the per-grouping ranks differ and the reference's own algorit
 using the device-computed Gram matrices (slow path, same results).
 """
 import logging
+import os
 
 import numpy as np
 
@@ -188,21 +189,94 @@ def _spd_inverse(m):
 		return (v / w) @ v.T
 
 
+def _is_dev(a):
+	return hasattr(a, 'is_cuda') and a.is_cuda
+
+
+class _Marks:
+	"""NRM_S4_TRACE=1: wall-clock of the phases of a single=4 call, each closed by a device synchronisation (profiling aid)."""
+
+	def __init__(self, eng):
+		import time
+		self.on = os.environ.get('NRM_S4_TRACE', '') == '1'
+		self.eng, self.clock, self.rows = eng, time.perf_counter, []
+		self.t = self.clock()
+
+	def __call__(self, name):
+		if self.on:
+			self.eng.torch.cuda.synchronize(self.eng.device)
+			t = self.clock()
+			self.rows.append((name, 1e3 * (t - self.t)))
+			self.t = t
+
+	def report(self):
+		if self.on:
+			logging.warning('single=4 phases (ms): ' + ', '.join('%s %.2f' % r for r in self.rows))
+
+
+def _spd_inverse_device(eng, m_d, nx):
+	"""Inverse of the symmetric positive definite nx x nx matrix in the upper tiles of m_d (a symmetric K2 product, padded to row
+	tiles) WITHOUT leaving the device: Newton-Schulz iteration X <- X (2 I - M X) from X = I / ||M||_1 on the fp64 matrix cores (two
+	1024^3 products per step; the iterates are polynomials in M, so every product is a K2 call A B^T).  Quadratic convergence once
+	||I - M X|| < 1: log2(cond) + ~6 steps -- 7 for the nearly orthogonal residual rows of a gRNA screen, against 25 - 90 ms for a
+	LAPACK inverse of a 1000 x 1000 matrix on the host.  Returns the padded device inverse (identity-like in the padding) or None when
+	the iteration has not converged in 60 steps (the caller falls back to the host)."""
+	from .engine import Residualized
+	torch = eng.torch
+	nxp = m_d.shape[0]
+	with torch.cuda.device(eng.device):
+		m = torch.triu(m_d[:nx, :nx])
+		m = m + torch.triu(m, 1).T
+		scale = m.abs().sum(dim=0).max()  # ||M||_1 >= lambda_max
+		if not bool(torch.isfinite(scale)) or float(scale) <= 0:
+			return None
+		mp = torch.zeros((nxp, nxp), dtype=torch.float64, device=eng.device)
+		mp[:nx, :nx] = m
+		if nxp > nx:  # padding block: a multiple of the identity inside the spectrum's range (does not slow the iteration down)
+			mp[range(nx, nxp), range(nx, nxp)] = m.diagonal().mean()
+		x = torch.zeros((nxp, nxp), dtype=torch.float64, device=eng.device)
+		x[range(nxp), range(nxp)] = 1.0 / scale
+		t = torch.empty_like(x)
+		xt = torch.empty_like(x)
+		eye = torch.eye(nxp, dtype=torch.float64, device=eng.device)
+		rm = Residualized(nxp, nxp, mp, None, None)
+		for it in range(60):
+			eng.gram(rm, Residualized(nxp, nxp, x, None, None), False, dot=t)            # T = M X   (X symmetric)
+			res = float((eye - t).norm()) if it >= 4 else np.inf  # ||I - M X||_F of the X going into this step
+			if np.isnan(res):
+				return None
+			eng.gram(Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, t, None, None), False, dot=xt)  # X T^T = X X M = X M X
+			x = x.mul(2.0).sub_(xt)
+			if res < 1e-7:  # the step just taken squares it: below the rounding floor
+				break
+		else:
+			return None
+		x = 0.5 * (x + x.T)
+		if nxp > nx:
+			x[nx:, :] = 0
+			x[:, nx:] = 0
+	return x
+
+
 def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, tol=1E-8,
-							  method='auto', mpc=0, qr=0, **ka):
+							  method='auto', mpc=0, qr=0, device_out=False, **ka):
 	"""Device path of association_tests(..., single=4); returns (p, gamma|dot, alpha|None, varx, vary) with vary of shape
 	(n_x, n_y) as the reference does for single=4.  dy=None tests every pair of rows of dx given all the others
 	(_single4_samexy).  dimreduce may be an int or one value per row of dy (association.py:449,558); tol / method / mpc /
 	qr go to inv_rank as in the reference (:527-528) -- a truncated inverse (mpc > 0) has no closed form and follows the
-	reference's per-grouping algorithm on the device-computed Gram matrices."""
+	reference's per-grouping algorithm on the device-computed Gram matrices.
+	dx / dy may be torch CUDA tensors already in HBM (a resident screen: bench.py, distributed.de); device_out=True leaves p, the
+	statistic and vary there too."""
 	if ka:
 		raise TypeError("association_test_4() got an unexpected keyword argument '{}'".format(next(iter(ka))))
 	if return_stats:
 		raise NotImplementedError('return_stats is only available for single=0.')
-	dx, dc = np.asarray(dx), np.asarray(dc)
+	dx, dc = dx if _is_dev(dx) else np.asarray(dx), np.asarray(dc)
+	if dy is not None and not _is_dev(dy):
+		dy = np.asarray(dy)
 	nx, n = dx.shape
 	nc = dc.shape[0]
-	ny = nx if dy is None else np.asarray(dy).shape[0]
+	ny = nx if dy is None else dy.shape[0]
 	if np.ndim(dimreduce) != 0:
 		dimreduce = np.asarray(dimreduce)
 		if dimreduce.shape != (ny, ):
@@ -216,7 +290,7 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		if int(dimreduce) != dimreduce:
 			raise ValueError('dimreduce must be an integer.')
 		dimreduce = int(dimreduce)
-	if dc.shape[1] != n or (dy is not None and np.asarray(dy).shape[1] != n):
+	if dc.shape[1] != n or (dy is not None and dy.shape[1] != n):
 		raise ValueError('Unmatching dx/dy/dc dimensions.')
 	if nx == 0 or ny == 0 or n == 0:
 		raise ValueError('Dimensions in na==0 detected.')
@@ -227,97 +301,204 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
 		torch = eng.torch
 		if dy is None:
+			if _is_dev(dx):
+				dx = dx.cpu().numpy()
 			out_dtype = dx.dtype if dx.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 			return _single4_samexy(dx, dc, lowmem, return_dot, dimreduce, ik, eng, out_dtype)
-		dy = np.asarray(dy)
-		out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+		if _is_dev(dy):
+			out_dtype = np.dtype(np.float32 if dy.dtype == torch.float32 else np.float64)
+		else:
+			out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 		m = nx + nc
-		# A = [X; C] (association.py:935) is stacked on the device: X travels in its own dtype and is widened there
+		mark = _Marks(eng)
+		# A = [X; C] (association.py:935) is stacked on the device: X travels in its own dtype and is widened there.  A A^T decides
+		# whether the closed form applies (the reference's own rank threshold on its spectrum) and feeds the per-grouping algorithm
+		# when it does not.
 		from .engine import Residualized
 		mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
 		with torch.cuda.device(eng.device):
+			d_x = dx if _is_dev(dx) else eng.upload(_engine.as_input(dx))
 			a_dev = eng.zeros((mp, kp), torch.float64)
-			a_dev[:nx, :n] = eng.upload(_engine.as_input(dx))
+			a_dev[:nx, :n] = d_x
 			if nc:
 				a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
 		ra = Residualized(m, n, a_dev, None, None)
-		ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y and sum y^2 (association.py:968)
 		prod_d = eng.gram(ra, ra, True)  # A A^T, tiles on/above the diagonal (association.py:936-950)
 		prod = prod_d[:m, :m].cpu().numpy()
 		prod = np.triu(prod) + np.triu(prod, 1).T
-		# Y A^T (association.py:952-967, transposed).  It is the K-operand of the next contraction (K = m_pad columns), and K2
-		# leaves 16-column sub-blocks that are pure padding unwritten: start from zeros so that no stale NaN/Inf bit pattern
-		# of the allocator can reach 0 * NaN there
+		mark('A A^T')
+		may_close = mpc == 0 and method in ('auto', 'scipy')
+		# The closed form runs speculatively: whether it applies is the reference's own rank threshold on the spectrum of A A^T
+		# (singular values >= tol x the largest, association.py:77).  The inverse the closed form computes anyway usually settles that
+		# without the spectrum (_surely_full_rank); otherwise the eigenvalues are taken (21 ms at 1000 groupings) and the speculative
+		# results thrown away when they say the design is rank deficient.
+		res, err, closed = None, None, False
+		if may_close:
+			from .association import inv_rank
+			dc64 = np.asarray(dc, dtype=np.float64)
+			dci, dcr = inv_rank(dc64 @ dc64.T, tol=tol) if nc and (dc64 != 0).any() else (np.zeros((nc, nc)), 0)
+			if dcr == nc:  # (a rank-deficient C C^T is a principal block of A A^T: no closed form then)
+				try:
+					res, ninv = _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, device_out=device_out, mark=mark)
+					closed = _surely_full_rank(prod, ninv, nx, tol)
+					mark('rank certificate')
+				except (AssertionError, RuntimeError, np.linalg.LinAlgError) as e:  # raised for good only if the closed form applies
+					err = e
+			if not closed:
+				with _engine.host_blas():
+					ev = np.linalg.eigvalsh(prod)
+				closed = ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)
+		mark.report()
+		if closed:
+			if err is not None:
+				raise err
+			return res
+		del res
+		if _is_dev(dy):
+			dy = dy.cpu().numpy()
+		logging.info('single=4: no closed form (rank-deficient A A^T or truncated inverse); following the per-grouping algorithm on the host.')
+		ry = eng.residualize(_engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y and sum y^2 (association.py:968)
+		# Y A^T (association.py:952-967, transposed).  K2 leaves 16-column sub-blocks that are pure padding unwritten: start from zeros
 		with torch.cuda.device(eng.device):
 			prodyT_d = eng.zeros((ry.rows_pad, mp), torch.float64)
 		eng.gram(ry, ra, False, dot=prodyT_d)
-		# the spectrum decides whether the closed form applies; the inverse it needs is taken beside it on a second host thread (LAPACK
-		# releases the GIL; both take ~20 ms at 1000 groupings) and thrown away when it does not
-		spec = None
 		with _engine.host_blas():
-			if mpc == 0 and method in ('auto', 'scipy'):
-				from concurrent.futures import ThreadPoolExecutor
+			p, gam, alpha, vx, vy = _per_grouping_host(prod, prodyT_d[:ny, :m].cpu().numpy(), ry.ss[:ny].cpu().numpy(), nx, nc, n,
+													   dimreduce, lowmem, eng, ik)
+		stat = (gam.T * vx).T if return_dot else gam
+		cast = lambda v: None if v is None else v.astype(out_dtype, copy=False)
+		return (cast(p), cast(stat), cast(alpha), cast(vx), cast(vy))
 
-				def _try_inverse():
-					try:
-						return _spd_inverse(prod)
-					except Exception:  # not positive definite: the spectrum will say so
-						return None
-				with ThreadPoolExecutor(1) as ex:
-					fut = ex.submit(_try_inverse)
-					ev = np.linalg.eigvalsh(prod)
-					spec = fut.result()
-			else:
-				ev = np.linalg.eigvalsh(prod)
-		closed = mpc == 0 and method in ('auto', 'scipy') and ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)
-		if not closed:
-			logging.info('single=4: no closed form (rank-deficient A A^T or truncated inverse); following the per-grouping algorithm on the host.')
+
+def _surely_full_rank(prod, ninv, nx, tol):
+	"""True when A A^T (prod) certainly passes the reference's rank test -- every singular value >= tol x the largest
+	(association.py:77) -- judged from norms instead of the spectrum: lambda_max <= ||M||_1 and lambda_min = 1 / ||M^-1||_2 >=
+	1 / ||M^-1||_1, with M^-1 assembled from the design block N~ the closed form has computed (the Schur complement's inverse) and the
+	small covariate block.  Asks for twice the margin; False means "take the eigenvalues"."""
+	m = prod.shape[0]
+	nc = m - nx
+	col = np.abs(ninv).sum(axis=0)
+	if nc:
+		# (the small products are taken element-wise: BLAS calls on operands this size cost tens of ms of thread wake-ups on a large host)
+		mcc_i = np.linalg.inv(prod[nx:, nx:])
+		mcx = prod[nx:, :nx]                                                        # (nc, nx)
+		w = (mcc_i[:, :, None] * mcx[None, :, :]).sum(axis=1)                        # M_cc^-1 M_cx
+		n_cx = -np.stack([(ninv * w[c][:, None]).sum(axis=0) for c in range(nc)])    # -(W N~), N~ symmetric
+		n_cc = mcc_i - (n_cx[:, None, :] * w[None, :, :]).sum(axis=2)                # M_cc^-1 + W N~ W^T
+		col = np.concatenate([col + np.abs(n_cx).sum(axis=0), np.abs(n_cx).sum(axis=1) + np.abs(n_cc).sum(axis=0)])
+	norm_inv, norm_m = col.max(), np.abs(prod).sum(axis=0).max()
+	return bool(np.isfinite(norm_inv) and norm_inv > 0 and 1.0 / (norm_inv * norm_m) >= 2.0 * tol)
+
+
+def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=False, device_out=False, mark=lambda name: None):
+	"""The closed form for a full-rank design, on rows residualised against the covariates (Frisch-Waugh): with X~, Y~ the residuals,
+	M~ = X~ X~^T is the Schur complement of C C^T in A A^T, so N~ = M~^-1 is the design block of (A A^T)^-1 and
+	    B = (Y~ X~^T) N~,   varx_i = 1 / (n N~_ii),   RSS_y = |y~|^2 - sum_j (Y~ X~^T)_yj B_yj,   alpha_y = b_y - B_y b_x
+	are the quantities of the module header.  That puts the one large contraction, Y~ X~^T (1.5e15 flop-equivalent at BASELINE
+	configs[3]), on K1's digit planes and the integer Gram engine exactly as in single=0 (with its row records, exact mean correction
+	and a guard: nrm_single4_sweep_guarded; hits -> this function again on the fp64 Gram kernel); the small M~ is taken on the fp64
+	matrix cores, its inverse on the host while the device works on the genes."""
+	from .engine import Residualized, GuardHit
+	torch = eng.torch
+	nx, n = d_x.shape
+	ny, nc = dy.shape[0], dc64.shape[0]
+	m = nx + nc
+	if n <= m + np.max(dimreduce):
+		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+	ns = 0 if force_f64 else eng.gram_slices(n)
+	with torch.cuda.device(eng.device):
+		d_c, d_dci = eng.covariates(dc64, dci) if nc else (None, None)
+		d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
+		if not (eng.k1_quantises(d_x, d_c) and eng.k1_quantises(d_y, d_c)):
+			ns = 0  # (rows K1 cannot quantise itself -- not 16-byte aligned: fp64 all the way)
+		rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=True)
+		nxp = rx.rows_pad
+		mark('K1 design')
+		mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
+		ssx = rx.ss[:nx].cpu().numpy()
+		# N~ = M~^-1 on the device (Newton-Schulz on the fp64 matrix cores); the host's LAPACK only if that does not converge
+		d_n = _spd_inverse_device(eng, mt_d, nx) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
+		if d_n is None:
+			mt = mt_d[:nx, :nx].cpu().numpy()
+			mt = np.triu(mt) + np.triu(mt, 1).T
 			with _engine.host_blas():
-				p, gam, alpha, vx, vy = _per_grouping_host(prod, prodyT_d[:ny, :m].cpu().numpy(), ry.ss[:ny].cpu().numpy(), nx, nc, n,
-														   dimreduce, lowmem, eng, ik)
-			stat = (gam.T * vx).T if return_dot else gam
-			cast = lambda v: None if v is None else v.astype(out_dtype, copy=False)
-			return (cast(p), cast(stat), cast(alpha), cast(vx), cast(vy))
-		if n <= m + np.max(dimreduce):
-			raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
-		dr_groups = [int(dimreduce)] if np.ndim(dimreduce) == 0 else [int(v) for v in np.unique(dimreduce)]
-		if spec is not None:
-			ninv = spec
-		else:
-			with _engine.host_blas():
-				ninv = _spd_inverse(prod)  # N = M^-1 (symmetric)
-		dxx = 1.0 / (n * np.diag(ninv)[:nx])
-		n_pad = np.zeros((mp, mp))
-		n_pad[:m, :m] = ninv
-		with torch.cuda.device(eng.device):
+				ninv = _spd_inverse(mt)
+			n_pad = np.zeros((nxp, nxp))
+			n_pad[:nx, :nx] = ninv
 			d_n = eng.upload(n_pad)
-			pt = Residualized(ny, mp, prodyT_d, None, None)  # (ny_pad, m_pad): K dimension = rows of A, zero padded
-			bt_d = eng.gram(pt, Residualized(m, mp, d_n, None, None), False)  # Bt = (Y A^T) N
-			tdt = torch.float64 if out_dtype == np.float64 else torch.float32
-			p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-			stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-			vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-			work = torch.empty((ny, ), dtype=torch.float64, device=eng.device)
-			flags = eng.zeros((2, ), torch.int32)
-			d_dxx = eng.upload(dxx)
-			code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
-			p_host = None
-			# dof = n - 1 - (m - 1) - dimreduce (association.py:558): uniform, or one sweep per distinct per-gene dimreduce value
-			# (gamma and vary do not depend on it; the P-value columns of each group are kept)
-			for gi, dr in enumerate(dr_groups):
-				_lib.check(eng.lib.nrm_single4_sweep(bt_d.data_ptr(), prodyT_d.data_ptr(), bt_d.stride(0), ry.ss.data_ptr(), d_dxx.data_ptr(),
-													 nx, ny, m, n, float(n - m - dr), 1 if return_dot else 0, p.data_ptr(), stat.data_ptr(),
-													 vary.data_ptr(), code, ny, work.data_ptr(), flags.data_ptr(), eng._stream()))
-				if len(dr_groups) > 1:
-					if p_host is None:
-						p_host = np.empty((nx, ny), dtype=out_dtype)
-					cols = np.nonzero(dimreduce == dr)[0]
-					p_host[:, cols] = eng.download(p)[:, cols]
+		else:
+			ninv = d_n[:nx, :nx].cpu().numpy()
+		mark('M~ and its inverse')
+		d = np.diag(ninv).copy()
+		if not (np.isfinite(ninv).all() and (d > 0).all()):
+			raise np.linalg.LinAlgError('design rows are linearly dependent given the covariates')
+		dxx = 1.0 / (n * d)
+		# the genes: K1 and the large contraction
+		ry = eng.residualize(d_y, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=not ns)
+		del d_y
+		mark('K1 genes')
+		g_d = eng.zeros((ry.rows_pad, nxp), torch.float64)  # (K2 leaves pure-padding sub-blocks unwritten)
+		with _engine._Span(eng, 'gram_yx'):
+			eng._gram(ry, rx, False, g_d, None, ns)
+		if ns:
+			_lib.check(eng.lib.nrm_gram_i8_fix_dot(g_d.data_ptr(), g_d.stride(0), ry.fix.data_ptr(), rx.fix.data_ptr(), ny, nx, ns, n, eng._stream()))
+		mark('Y~ X~^T')
+		bt_d = eng.gram(Residualized(ny, nxp, g_d, None, None), Residualized(nx, nxp, d_n, None, None), False)  # B^T = (Y~ X~^T) N~, K = design rows
+		mark('B')
+		tdt = torch.float64 if out_dtype == np.float64 else torch.float32
+		p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+		stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+		vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
+		work = torch.empty((ny, ), dtype=torch.float64, device=eng.device)
+		flags = eng.new_flags()
+		d_dxx = eng.upload(dxx)
+		code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
+		mark('result buffers')
+		guard = ()
+		if ns:
+			fx = rx.fix[:nx].cpu().numpy()
+			# (element-wise, not a BLAS call: a 1000 x 1000 matrix-vector product handed to a 256-thread BLAS pool costs 70 - 90 ms of wake-ups)
+			kappa = (np.abs(ninv) * np.sqrt(ssx)[None, :]).sum(axis=1) / np.sqrt(d)
+			d_kappa = eng.upload(kappa)
+			guard = (ry.fix.data_ptr(), d_kappa.data_ptr(), float(fx[:, 5].max()), float(fx[:, 6].max()), int(ns), float(eng.guard_tol))
+			mark('kappa')
+		dr_groups = [int(dimreduce)] if np.ndim(dimreduce) == 0 else [int(v) for v in np.unique(dimreduce)]
+		p_host = None
+		# dof = n - 1 - (m - 1) - dimreduce (association.py:558): uniform, or one sweep per distinct per-gene dimreduce value
+		# (gamma and vary do not depend on it; the P-value columns of each group are kept)
+		for dr in dr_groups:
+			args = (bt_d.data_ptr(), g_d.data_ptr(), bt_d.stride(0), ry.ss.data_ptr(), d_dxx.data_ptr(), nx, ny, nx, n, float(n - m - dr),
+					1 if return_dot else 0, p.data_ptr(), stat.data_ptr(), vary.data_ptr(), code, ny, work.data_ptr(), flags.data_ptr())
+			with _engine._Span(eng, 'sweep'):
+				if guard and eng.guard_tol > 0:
+					_lib.check(eng.lib.nrm_single4_sweep_guarded(*args, *guard, eng._stream()))
+				else:
+					_lib.check(eng.lib.nrm_single4_sweep(*args, eng._stream()))
+			if len(dr_groups) > 1:
+				if p_host is None:
+					p_host = np.empty((nx, ny), dtype=out_dtype)
+				cols = np.nonzero(dimreduce == dr)[0]
+				p_host[:, cols] = eng.download(p)[:, cols]
+		mark('sweep')
+		try:
 			eng.check_flags(flags)
-			alpha = None
-			if not lowmem:
-				b_cov = bt_d[:ny, nx:m].cpu().numpy().astype(out_dtype)  # (ny, nc): identical for every grouping
-				alpha = np.broadcast_to(b_cov[None, :, :], (nx, ny, nc)).copy()
-			vx = dxx.copy()
-			vx[vx == 0] = 1
-			return (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary))
+		except GuardHit as g:  # the integer engine could not certify every P-value: once more on the fp64 Gram kernel
+			logging.info('single=4: %s; redone on the fp64 Gram kernel', g)
+			out = _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=True, device_out=device_out)
+			eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
+			return out
+		alpha = None
+		if not lowmem:
+			# alpha_y = b_y - B_y b_x (nc values per gene, the same for every grouping: association.py:551-553 in the closed form)
+			b_cov = ry.coef[:ny].cpu().numpy()
+			if nx and nc:
+				cxt = eng.zeros((_engine._round_up(nc, _lib.ROW_TILE), nxp), torch.float64)
+				cxt[:nc, :nx] = rx.coef[:nx].T
+				bb = eng.gram(Residualized(ny, nxp, bt_d, None, None), Residualized(nc, nxp, cxt, None, None), False)
+				b_cov = b_cov - bb[:ny, :nc].cpu().numpy()
+			alpha = np.broadcast_to(b_cov.astype(out_dtype)[None, :, :], (nx, ny, nc)).copy()
+		vx = dxx.copy()
+		vx[vx == 0] = 1
+		if device_out and p_host is None:
+			return (p, stat, alpha, vx.astype(out_dtype), vary), ninv
+		return (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary)), ninv

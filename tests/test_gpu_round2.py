@@ -272,18 +272,26 @@ def _run_bench(extra_args, env_extra, timeout=900):
 def test_bench_self_launches_two_ranks_on_one_gpu():
 	"""`python bench.py --gpus 2` as a plain invocation starts its own ranks (here both on this GPU over gloo: functional
 	check of the launcher and the N>1 path; RCCL needs one GPU per rank) and prints exactly one JSON line."""
-	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--genes', '1200', '--cells', '2000', '--no-extras'],
+	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'coex_c2', '--genes', '1200', '--cells', '2000', '--no-extras'],
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
 	assert out['n_gpus'] == 2 and out['ranks_seen_by_collective'] == 2 and out['value'] > 0
 	assert out['roofline']['bound'] == 'mfma' and out['roofline']['kernel_ms'] > 0 and 'exchange' in out['kernels_ms']
 	assert out['config']['exchange'] == 'all-gather of raw fp32 blocks'  # below 2048 cells: fp64 engine, raw rows travel
-	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--genes', '1200', '--cells', '8192', '--no-extras'],
+	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'coex_c2', '--genes', '1200', '--cells', '8192', '--no-extras'],
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
 	assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['exchange'] == 'all-gather of raw fp32 blocks'  # auto on 2 ranks
-	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--genes', '1200', '--cells', '8192', '--no-extras'],
+	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'coex_c2', '--genes', '1200', '--cells', '8192', '--no-extras'],
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1', NRM_EXCHANGE='chunks'))
 	assert out['n_gpus'] == 2 and out['value'] > 0 and 'in 2 cell chunks' in out['config']['exchange']
 	assert out['kernels_ms']['gram'] > 0 and out['kernels_ms']['exchange'] >= 0
+	# the N > 1 DEFAULT is the workload the 8-GPU target is quoted on: configs[4] (here at a reduced per-rank block so that two ranks
+	# share one GPU in seconds): fp64 rows, digit planes exchanged in cell chunks, exchange accounting in the line
+	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--c5-rows', '384', '--c5-cells', '40000', '--no-extras'],
+					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
+	assert out['n_gpus'] == 2 and out['ranks_seen_by_collective'] == 2 and 'BASELINE configs[4]' in out['config']['workload']
+	assert out['config']['genes'] == 768 and out['config']['cells'] == 40000 and out['dtype'].startswith('i8 digits')
+	assert 'cell chunks' in out['config']['exchange'] and out['config']['exchange_bytes_per_rank'] == 384 * 40000 * 6
+	assert out['kernels_ms']['exchange'] >= 0 and out['kernels_ms']['gram'] > 0 and out['guard']['uncertified_pairs'] == 0
 
 
 def test_bench_default_line_carries_the_other_configs():
@@ -292,14 +300,17 @@ def test_bench_default_line_carries_the_other_configs():
 	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
 	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
 	ex = out['extra_workloads']
-	assert set(ex) == {'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu'}, ex
+	assert set(ex) == {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'coex_c5_full_1gpu'}, ex
+	assert ex['coex_c2_f64']['roofline']['kernel'] == 'k_gram_f64' and ex['coex_c2_f64']['dtype'] == 'f64'
+	assert ex['de_c4_single4']['roofline']['kernel'] == 'k_gram_i8' and ex['de_c4_single4']['guard']['uncertified_pairs'] == 0 and not ex['de_c4_single4']['guard']['fp64_rerun']
+	assert ex['de_c4_single4']['ms_per_step'] < 2.5 * ex['de_c4']['ms_per_step']
 	assert out['guard']['uncertified_pairs'] == 0 and 0 < out['guard']['largest_relative_p_error_bound'] < out['guard']['tolerance']
 	assert ex['coex_c5_full_1gpu']['config']['tests_per_step'] == 30000 * 29999 // 2 and ex['coex_c5_full_1gpu']['guard']['uncertified_pairs'] == 0
 	assert ex['de_c4']['kernels_ms']['gram'] < ex['de_c4']['ms_per_step'] and ex['de_c4']['roofline']['kernel_ms'] == pytest.approx(ex['de_c4']['kernels_ms']['gram'], rel=0.02)
 	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'mfma' and ex['coex_c5']['roofline']['bound'] == 'mfma'
 	for k, v in ex.items():
 		assert 'error' not in v, (k, v)
-		assert v['value'] > 0 and v['ms_per_step'] > 0 and 0 < v['roofline']['frac'] < 1.2
+		assert v['value'] > 0 and v['ms_per_step'] > 0 and 0 < v['roofline']['frac'] < 1.2, (k, v['roofline'])
 
 
 def test_single4_variants_golden_and_oracle(golden, norm):

@@ -230,3 +230,67 @@ def test_reference_thread_pool_over_block_kernel(norm):
 	got = pooled[3]
 	p_close(got[2], ref[2])
 	close(got[3], ref[3], floor=1e-12)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_single4_on_the_integer_engine(norm, eng, dtype):
+	"""single=4 (association.py:421-576,926-980) at cell counts where the large contraction Y~ X~^T runs on the integer Gram engine
+	(>= 2048 cells): sparse 0/1 design rows (GSE120861-like gRNA incidence), covariates with an intercept and one-hot batches,
+	lowmem=False (alpha), per-gene dimreduce -- against the oracle's per-grouping SVD loop; every pair certified by the guard."""
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(405)
+	nx, ny, n = 40, 260, 3072
+	dg = (rng.random((nx, n)) < 0.02).astype(np.float64)
+	batch = rng.integers(0, 3, n)
+	dc = np.vstack([(batch == 1).astype(float), (batch == 2).astype(float), rng.normal(size=(1, n)), np.ones((1, n))])
+	dt = (np.log1p(rng.poisson(2.0, (ny, n))) + (rng.normal(size=(ny, 6)) @ dg[:6]) * 0.8).astype(dtype)
+	rtol = 1e-6 if dtype == np.float64 else 2e-5  # (fp32 outputs)
+	pc = (lambda p, ref, rt: p_close(p, ref, rt)) if dtype == np.float64 else (
+		lambda p, ref, rt: p_close(np.where(ref < 1e-36, ref, p), ref, rt) and (p[ref < 1e-46] == 0).all())  # (fp32 P-values underflow at 1e-45)
+	p, gam, a, vx, vy = association_tests(dg, dt, dc, single=4, return_dot=False, lowmem=False)
+	assert eng.last_guard['hits'] == 0 and not eng.last_guard['fallback'] and eng.last_guard['worst'] > 0, eng.last_guard
+	po, go, ao, vxo, vyo = oracle.association_tests(dg, dt.astype(np.float64), dc, single=4, return_dot=False, lowmem=False)
+	assert p.dtype == dtype and p.shape == (nx, ny) and a.shape == (nx, ny, 4)
+	assert pc(p, po, rtol) and close(gam, go, rtol, 1e-10) and close(vx, vxo, rtol) and close(vy, vyo, rtol) and close(a, ao, 10 * rtol, 1e-8)
+	assert po.min() < 1e-20
+	# per-gene dimreduce and covariance output
+	dr = rng.integers(0, 3, ny)
+	p, d, a, vx, vy = association_tests(dg, dt, dc, single=4, return_dot=True, dimreduce=dr)
+	po, do, ao, vxo, vyo = oracle.association_tests(dg, dt.astype(np.float64), dc, single=4, return_dot=True, dimreduce=dr)
+	assert pc(p, po, rtol) and close(d, do, rtol, 1e-12) and a is None
+
+
+def test_single4_guard_reroutes_to_fp64(norm, eng):
+	"""Genes the integer engine cannot certify (single spikes over tiny noise: the fixed-point grid is coarse against the bulk of the
+	row) make single=4 redo its contraction on the fp64 Gram kernel; the results equal the oracle's either way."""
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(406)
+	nx, ny, n = 12, 64, 65536
+	lat = rng.normal(size=n)
+	dg = 1e-3 * (rng.normal(size=(nx, n)) + 0.05 * rng.normal(size=(nx, 1)) * lat)
+	dg[np.arange(nx), rng.choice(n, nx, replace=False)] = 50.0  # one spike per design row carries all of its variance
+	dc = np.ones((1, n))
+	dt = 1e-3 * (rng.normal(size=(ny, n)) + 0.05 * rng.normal(size=(ny, 1)) * lat)
+	dt[np.arange(ny), rng.choice(n, ny, replace=False)] = 50.0
+	p, gam, a, vx, vy = association_tests(dg, dt, dc, single=4, return_dot=False)
+	assert eng.last_guard['fallback'] and eng.last_guard['hits'] > 0, eng.last_guard
+	po, go, ao, vxo, vyo = oracle.association_tests(dg, dt, dc, single=4, return_dot=False)
+	assert p_close(p, po) and close(gam, go, floor=1e-12) and close(vy, vyo, 1e-9)
+
+
+def test_engine_path_and_throughput_are_logged(norm, caplog):
+	"""SURVEY section 5 (metrics / logging; the reference logs its batch decisions, association.py:745-757): under -v a call says
+	which engine ran, how fast, and what the accuracy guard decided."""
+	import logging
+	rng = np.random.default_rng(407)
+	dt = rng.normal(size=(150, 2304))
+	dc = np.ones((1, 2304))
+	with caplog.at_level(logging.INFO):
+		norm.coex(dt, dc)
+		norm.coex(dt[:, :300], dc[:, :300])
+		norm.de((rng.random((2, 2304)) < 0.3).astype(float), dt, dc)
+	msgs = [r.getMessage() for r in caplog.records if r.getMessage().startswith('normalisr_amd:')]
+	assert len(msgs) == 3, msgs
+	assert 'coex, 11175 tests over 2304 cells on the integer Gram engine (46-bit' in msgs[0] and 'every P-value certified' in msgs[0] and 'tests/s' in msgs[0]
+	assert 'the fp64 Gram kernel' in msgs[1] and 'no guard needed' in msgs[1]
+	assert msgs[2].startswith('normalisr_amd: de, 300 tests over 2304 cells')
