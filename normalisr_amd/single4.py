@@ -219,7 +219,7 @@ def _spd_inverse_device(eng, m_d, nx):
 	tiles) WITHOUT leaving the device: Newton-Schulz iteration X <- X (2 I - M X) from X = I / ||M||_1 on the fp64 matrix cores (two
 	1024^3 products per step; the iterates are polynomials in M, so every product is a K2 call A B^T).  Quadratic convergence once
 	||I - M X|| < 1: log2(cond) + ~6 steps -- 7 for the nearly orthogonal residual rows of a gRNA screen, against 25 - 90 ms for a
-	LAPACK inverse of a 1000 x 1000 matrix on the host.  Returns the padded device inverse (identity-like in the padding) or None when
+	LAPACK inverse of a 1000 x 1000 matrix on the host.  Returns (the padded device inverse, zero in the padding; ||M||_1) or None when
 	the iteration has not converged in 60 steps (the caller falls back to the host)."""
 	from .engine import Residualized
 	torch = eng.torch
@@ -255,7 +255,7 @@ def _spd_inverse_device(eng, m_d, nx):
 		if nxp > nx:
 			x[nx:, :] = 0
 			x[:, nx:] = 0
-	return x
+	return x, float(scale)
 
 
 def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, tol=1E-8,
@@ -311,40 +311,41 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 		m = nx + nc
 		mark = _Marks(eng)
-		# A = [X; C] (association.py:935) is stacked on the device: X travels in its own dtype and is widened there.  A A^T decides
-		# whether the closed form applies (the reference's own rank threshold on its spectrum) and feeds the per-grouping algorithm
-		# when it does not.
 		from .engine import Residualized
 		mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
 		with torch.cuda.device(eng.device):
 			d_x = dx if _is_dev(dx) else eng.upload(_engine.as_input(dx))
-			a_dev = eng.zeros((mp, kp), torch.float64)
-			a_dev[:nx, :n] = d_x
-			if nc:
-				a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
-		ra = Residualized(m, n, a_dev, None, None)
-		prod_d = eng.gram(ra, ra, True)  # A A^T, tiles on/above the diagonal (association.py:936-950)
-		prod = prod_d[:m, :m].cpu().numpy()
-		prod = np.triu(prod) + np.triu(prod, 1).T
-		mark('A A^T')
 		may_close = mpc == 0 and method in ('auto', 'scipy')
-		# The closed form runs speculatively: whether it applies is the reference's own rank threshold on the spectrum of A A^T
-		# (singular values >= tol x the largest, association.py:77).  The inverse the closed form computes anyway usually settles that
-		# without the spectrum (_surely_full_rank); otherwise the eigenvalues are taken (21 ms at 1000 groupings) and the speculative
-		# results thrown away when they say the design is rank deficient.
-		res, err, closed = None, None, False
+		# The closed form applies when A A^T (A = [X; C], association.py:935) passes the reference's own rank threshold -- every singular
+		# value >= tol x the largest (association.py:77).  It runs first; the norms of what it computes anyway (M~, its inverse, the
+		# covariate block) usually settle the question (_surely_full_rank).  Only when they do not is A A^T formed and its spectrum taken
+		# (21 ms at 1000 groupings), and the closed form's results thrown away if that says the design is rank deficient.
+		res, err, closed, dcr = None, None, False, -1
 		if may_close:
 			from .association import inv_rank
 			dc64 = np.asarray(dc, dtype=np.float64)
-			dci, dcr = inv_rank(dc64 @ dc64.T, tol=tol) if nc and (dc64 != 0).any() else (np.zeros((nc, nc)), 0)
+			mcc = dc64 @ dc64.T
+			dci, dcr = inv_rank(mcc, tol=tol) if nc and (dc64 != 0).any() else (np.zeros((nc, nc)), 0)
 			if dcr == nc:  # (a rank-deficient C C^T is a principal block of A A^T: no closed form then)
 				try:
-					res, ninv = _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, device_out=device_out, mark=mark)
-					closed = _surely_full_rank(prod, ninv, nx, tol)
+					res, cert = _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, device_out=device_out, mark=mark)
+					closed = _surely_full_rank(cert, mcc, dci, tol)
 					mark('rank certificate')
 				except (AssertionError, RuntimeError, np.linalg.LinAlgError) as e:  # raised for good only if the closed form applies
 					err = e
-			if not closed:
+		prod = None
+		if not closed:
+			with torch.cuda.device(eng.device):
+				a_dev = eng.zeros((mp, kp), torch.float64)
+				a_dev[:nx, :n] = d_x
+				if nc:
+					a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
+			ra = Residualized(m, n, a_dev, None, None)
+			prod_d = eng.gram(ra, ra, True)  # A A^T, tiles on/above the diagonal (association.py:936-950)
+			prod = prod_d[:m, :m].cpu().numpy()
+			prod = np.triu(prod) + np.triu(prod, 1).T
+			mark('A A^T')
+			if may_close and dcr == nc and (res is not None or err is not None):  # (a rank-deficient C C^T is a principal block of A A^T)
 				with _engine.host_blas():
 					ev = np.linalg.eigvalsh(prod)
 				closed = ev[-1] > 0 and ev[0] >= tol * ev[-1] * (1 + 1e-6)
@@ -370,24 +371,25 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		return (cast(p), cast(stat), cast(alpha), cast(vx), cast(vy))
 
 
-def _surely_full_rank(prod, ninv, nx, tol):
-	"""True when A A^T (prod) certainly passes the reference's rank test -- every singular value >= tol x the largest
-	(association.py:77) -- judged from norms instead of the spectrum: lambda_max <= ||M||_1 and lambda_min = 1 / ||M^-1||_2 >=
-	1 / ||M^-1||_1, with M^-1 assembled from the design block N~ the closed form has computed (the Schur complement's inverse) and the
-	small covariate block.  Asks for twice the margin; False means "take the eigenvalues"."""
-	m = prod.shape[0]
-	nc = m - nx
-	col = np.abs(ninv).sum(axis=0)
+def _surely_full_rank(cert, mcc, mcc_inv, tol):
+	"""True when A A^T certainly passes the reference's rank test -- every singular value >= tol x the largest (association.py:77) --
+	judged from norms the closed form has at hand instead of the spectrum.  With M = [[Mxx, Mxc], [Mcx, Mcc]], M~ = Mxx - Mxc Mcc^-1 Mcx
+	its Schur complement, N~ = M~^-1 and W = Mcc^-1 Mcx = b^T (the design rows' OLS coefficients):
+	    lambda_max(M) <= ||Mxx|| + ||Mcc|| <= ||M~||_1 + ||a||_F^2 ||Mcc^-1|| + ||Mcc||,       a = Mxc = b Mcc,
+	    1 / lambda_min(M) = ||M^-1|| <= ||N~||_1 (1 + ||W||_F)^2 + ||Mcc^-1||     (M^-1 = [[N~, -N~ W^T], [-W N~, Mcc^-1 + W N~ W^T]]).
+	Asks for twice the margin; False means "form A A^T and take its eigenvalues"."""
+	norm_mt, norm_ninv, bx = cert
+	nc = mcc.shape[0]
 	if nc:
-		# (the small products are taken element-wise: BLAS calls on operands this size cost tens of ms of thread wake-ups on a large host)
-		mcc_i = np.linalg.inv(prod[nx:, nx:])
-		mcx = prod[nx:, :nx]                                                        # (nc, nx)
-		w = (mcc_i[:, :, None] * mcx[None, :, :]).sum(axis=1)                        # M_cc^-1 M_cx
-		n_cx = -np.stack([(ninv * w[c][:, None]).sum(axis=0) for c in range(nc)])    # -(W N~), N~ symmetric
-		n_cc = mcc_i - (n_cx[:, None, :] * w[None, :, :]).sum(axis=2)                # M_cc^-1 + W N~ W^T
-		col = np.concatenate([col + np.abs(n_cx).sum(axis=0), np.abs(n_cx).sum(axis=1) + np.abs(n_cc).sum(axis=0)])
-	norm_inv, norm_m = col.max(), np.abs(prod).sum(axis=0).max()
-	return bool(np.isfinite(norm_inv) and norm_inv > 0 and 1.0 / (norm_inv * norm_m) >= 2.0 * tol)
+		ev = np.linalg.eigvalsh(mcc)
+		if not ev[0] > 0:
+			return False
+		a = np.stack([(bx * mcc[:, c][None, :]).sum(axis=1) for c in range(nc)], axis=1)  # b Mcc, element-wise (no BLAS on small operands)
+		lam_max = norm_mt + float((a * a).sum()) / ev[0] + ev[-1]
+		inv_norm = norm_ninv * (1.0 + float(np.sqrt((bx * bx).sum())))**2 + 1.0 / ev[0]
+	else:
+		lam_max, inv_norm = norm_mt, norm_ninv
+	return bool(np.isfinite(lam_max) and np.isfinite(inv_norm) and lam_max > 0 and inv_norm > 0 and 1.0 / (inv_norm * lam_max) >= 2.0 * tol)
 
 
 def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=False, device_out=False, mark=lambda name: None):
@@ -411,27 +413,31 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
 		if not (eng.k1_quantises(d_x, d_c) and eng.k1_quantises(d_y, d_c)):
 			ns = 0  # (rows K1 cannot quantise itself -- not 16-byte aligned: fp64 all the way)
-		rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=True)
+		rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=bool(nc), nslices=ns, keep_fp64=True)
 		nxp = rx.rows_pad
 		mark('K1 design')
 		mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
-		ssx = rx.ss[:nx].cpu().numpy()
 		# N~ = M~^-1 on the device (Newton-Schulz on the fp64 matrix cores); the host's LAPACK only if that does not converge
-		d_n = _spd_inverse_device(eng, mt_d, nx) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
-		if d_n is None:
+		inv = _spd_inverse_device(eng, mt_d, nx) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
+		if inv is None:
 			mt = mt_d[:nx, :nx].cpu().numpy()
 			mt = np.triu(mt) + np.triu(mt, 1).T
 			with _engine.host_blas():
 				ninv = _spd_inverse(mt)
 			n_pad = np.zeros((nxp, nxp))
 			n_pad[:nx, :nx] = ninv
-			d_n = eng.upload(n_pad)
+			d_n, norm_mt = eng.upload(n_pad), float(np.abs(mt).sum(axis=0).max())
 		else:
-			ninv = d_n[:nx, :nx].cpu().numpy()
+			d_n, norm_mt = inv
+		# what the host needs of N~ -- its diagonal, kappa (see S4Guard in csrc/nrm_single4.hip) and ||N~||_1 -- is reduced on the device:
+		# three vectors travel instead of the 8 MB matrix
+		na = d_n[:nx, :nx].abs()
+		small = torch.stack([d_n.diagonal()[:nx], (na * rx.ss[:nx].sqrt()[None, :]).sum(dim=1), na.sum(dim=0)]).cpu().numpy()
+		d, norm_ninv = small[0].copy(), float(small[2].max())
 		mark('M~ and its inverse')
-		d = np.diag(ninv).copy()
-		if not (np.isfinite(ninv).all() and (d > 0).all()):
+		if not (np.isfinite(small).all() and (d > 0).all()):
 			raise np.linalg.LinAlgError('design rows are linearly dependent given the covariates')
+		kappa = small[1] / np.sqrt(d)
 		dxx = 1.0 / (n * d)
 		# the genes: K1 and the large contraction
 		ry = eng.residualize(d_y, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=not ns)
@@ -457,8 +463,6 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		guard = ()
 		if ns:
 			fx = rx.fix[:nx].cpu().numpy()
-			# (element-wise, not a BLAS call: a 1000 x 1000 matrix-vector product handed to a 256-thread BLAS pool costs 70 - 90 ms of wake-ups)
-			kappa = (np.abs(ninv) * np.sqrt(ssx)[None, :]).sum(axis=1) / np.sqrt(d)
 			d_kappa = eng.upload(kappa)
 			guard = (ry.fix.data_ptr(), d_kappa.data_ptr(), float(fx[:, 5].max()), float(fx[:, 6].max()), int(ns), float(eng.guard_tol))
 			mark('kappa')
@@ -499,6 +503,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 			alpha = np.broadcast_to(b_cov.astype(out_dtype)[None, :, :], (nx, ny, nc)).copy()
 		vx = dxx.copy()
 		vx[vx == 0] = 1
+		cert = (norm_mt, norm_ninv, rx.coef[:nx].cpu().numpy() if nc else np.zeros((nx, 0)))
 		if device_out and p_host is None:
-			return (p, stat, alpha, vx.astype(out_dtype), vary), ninv
-		return (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary)), ninv
+			return (p, stat, alpha, vx.astype(out_dtype), vary), cert
+		return (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary)), cert
