@@ -112,6 +112,8 @@ int64_t nrm_residualize_workspace_bytes(int x_dtype, int64_t rows_pad, int64_t n
 /* Profiling aid, not part of the product path: d_stamps = a device buffer of 8 int64 per work item of the resident kernel (see
  * csrc/nrm_residualize_res.hip) that later launches fill with time stamps of its phases; NULL switches it off (tools/k1_phases.py). */
 int nrm_k1_debug_buffer(void* d_stamps);
+/* The same for nrm_binnet*: 6 int64 per row (time stamps: start, row loaded, threshold found, mask written; counting passes; spare). */
+int nrm_binnet_debug_buffer(void* d_stamps);
 /* The same with the digit planes cut along the cells into chunks of 32 * chunk_ksteps cells: chunk c is a dense quantised operand
  * of its own (nslices planes of rows_pad / 32 * chunk_ksteps KB) at d_q + c * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices);
  * all chunks share d_exp; the last chunk is zero padded.  The sharded coex path (normalisr_amd/distributed.py; the N > 1 form of

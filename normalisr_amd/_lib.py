@@ -35,6 +35,7 @@ _SIGNATURES = {
 	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
 	'nrm_residualize_workspace_bytes': ([_i32, _i64, _i64, _i64, _i64], _i64),
 	'nrm_k1_debug_buffer': ([_vp], _i32),
+	'nrm_binnet_debug_buffer': ([_vp], _i32),
 	'nrm_residualize_q_chunked': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
 	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_f64_band': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),

@@ -87,7 +87,7 @@ def binnet(net, qcut):
 				raise AssertionError('P-values must be finite and within [0,1] (binnet.py:151-152).')
 			if int(total.item()) == 0:
 				raise RuntimeError('Empty binary network.')
-			return out.to(torch.bool) if on_device else eng.download(out).view(np.bool_)  # the kernel writes exact 0/1 bytes
+			return out.view(torch.bool) if on_device else eng.download(out).view(np.bool_)  # the kernel writes exact 0/1 bytes: a view, no pass over the mask
 
 
 assert __name__ != "__main__"
