@@ -38,6 +38,26 @@ struct Vec4Load<double> {
 	}
 };
 
+// four consecutive cells in the input's own type
+template <typename T>
+__device__ __forceinline__ void k1_ld4raw(const T* p, T (&v)[4]);
+template <>
+__device__ __forceinline__ void k1_ld4raw<float>(const float* p, float (&v)[4]) {
+	const float4 t = *reinterpret_cast<const float4*>(p);
+	v[0] = t.x;
+	v[1] = t.y;
+	v[2] = t.z;
+	v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void k1_ld4raw<double>(const double* p, double (&v)[4]) {
+	const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+	v[0] = a.x;
+	v[1] = a.y;
+	v[2] = b.x;
+	v[3] = b.y;
+}
+
 // Fixed-point output for the integer Gram engine (csrc/nrm_gram_i8.hip): digit planes in its tiled layout and one exponent per
 // row, written straight from K1 so that the fp64 residuals never make the round trip through HBM (NS = 0: none).
 struct QuantOut {

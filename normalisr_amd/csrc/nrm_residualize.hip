@@ -1,7 +1,10 @@
 // K1 + K4: residualise expression/design rows against the covariates once per row (the reference
 // redoes this inside every tile: association.py:224-229) and take the row sums of squares
-// (association.py:230-233) in the same pass.  HBM-bound: each input row is read from HBM once (second
-// sweep hits L2), the fp64 residual is written once.
+// (association.py:230-233) in the same pass.  HBM-bound.  A row is swept twice (products with the covariates, then residual -> digits):
+// the second sweep is served from L2 only for short rows (configs[1]: 10 000 cells); from 50 000 cells up the rows a chip-full of
+// workgroups holds between its sweeps (512 x 4 x 200 KB .. 4 MB) exceed L2 and the 256 MB Infinity Cache and every row is fetched from
+// HBM twice (round-3 counters: 1.6 - 1.8x the algorithmic traffic).  Round 4 built the alternative -- rows resident in registers
+// between the two phases, nrm_residualize_res.hip -- and measured why it does not win yet.
 //
 //   b_i  = (x_i C^T) dci          (association.py:226-227)
 //   x~_i = x_i - b_i C            (association.py:228-229)
@@ -345,15 +348,69 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			dsq[r][s] = 0u;
 		}
 	const int64_t kres = out ? ldo : ((n + 3) & ~(int64_t)3), kq = NS ? qo.nks * 32 : 0;
-#pragma unroll K1_U3
-	for (int64_t k = (int64_t)tid * 4; k < (kres > kq ? kres : kq); k += 1024) {
-		double v[RES_R][4];
-		if (k < n)
-			residual4(k, v);
-		else {
+	// The rows of the NEXT step are requested before this step's are used (raw values, 4 registers per row): without that a step waits
+	// for its own HBM loads -- 16 KB in flight per workgroup, ~3 TB/s on the chip (round-4 measurement: the same serialisation cost
+	// binnet 2.5x).  The covariates come from L2 inside the step.
+	T xnext[RES_R][4];
+	auto request = [&](int64_t k, T (&raw)[RES_R][4]) {
+		if (k < n4) {
 #pragma unroll
-			for (int r = 0; r < RES_R; r++) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
+			for (int r = 0; r < RES_R; r++) k1_ld4raw<T>(xr[r] + k, raw[r]);
+		} else {
+#pragma unroll
+			for (int r = 0; r < RES_R; r++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) raw[r][i] = (k + i < n) ? xr[r][k + i] : (T)0;
 		}
+	};
+	// residual of the 4 cells from raw values already in registers
+	auto residual_of = [&](int64_t k, const T (&raw)[RES_R][4], double (&v)[RES_R][4]) {
+#pragma unroll
+		for (int r = 0; r < RES_R; r++)
+#pragma unroll
+			for (int i = 0; i < 4; i++) v[r][i] = (double)raw[r][i];
+		if (active && k < n) {
+			if (k < n4) {
+				for (int q = 0; q < nc; q++) {
+					double cv[4];
+					Vec4Load<double>::ld(c + (int64_t)q * ldc + k, cv);
+#pragma unroll
+					for (int r = 0; r < RES_R; r++)
+#pragma unroll
+						for (int i = 0; i < 4; i++) v[r][i] = fma(-tb[r * nc + q], cv[i], v[r][i]);
+				}
+			} else {
+				for (int q = 0; q < nc; q++)
+#pragma unroll
+					for (int i = 0; i < 4; i++) {
+						const double cv = (k + i < n) ? c[(int64_t)q * ldc + k + i] : 0.0;
+#pragma unroll
+						for (int r = 0; r < RES_R; r++) v[r][i] = fma(-tb[r * nc + q], cv, v[r][i]);
+					}
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < RES_R; r++)
+			if (!live[r]) v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0;
+	};
+	// (fp32 rows: 3.70 -> 3.27 ms on 16 000 x 50 000 with 5 covariates; fp64 rows -- twice the registers for the same cells -- ran 4 % slower
+	// with it on the configs[4] slice, so they keep requesting their rows inside the step)
+	constexpr bool AHEAD = sizeof(T) == 4;
+	const int64_t kend = kres > kq ? kres : kq;
+	if (AHEAD && (int64_t)tid * 4 < kend) request((int64_t)tid * 4, xnext);
+#pragma unroll K1_U3
+	for (int64_t k = (int64_t)tid * 4; k < kend; k += 1024) {
+		T xcur[RES_R][4];
+		if (AHEAD) {
+#pragma unroll
+			for (int r = 0; r < RES_R; r++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) xcur[r][i] = xnext[r][i];
+			if (k + 1024 < kend) request(k + 1024, xnext);
+		} else
+			request(k, xcur);
+		double v[RES_R][4];
+		residual_of(k, xcur, v);
 #pragma unroll
 		for (int r = 0; r < RES_R; r++) {
 			if (out && k < ldo) {
