@@ -44,10 +44,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
 
-# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r03.sh), newest first
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r04.sh), newest first
 PMC_FILES = {w: [os.path.join(ROOT, 'profiles', f) for f in fs] for w, fs in dict(
-	coex_c2=('r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
-	de_c4=('r03_pmc_de_c4.json', ), coex_c5=('r03_pmc_coex_c5.json', )).items()}
+	coex_c2=('r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r04_pmc_de_c3.json', 'r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
+	de_c4=('r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'), de_c4_single4=('r04_pmc_de_c4_single4.json', ),
+	binnet_c5=('r04_pmc_binnet_c5.json', )).items()}
 
 
 def pmc_traffic(workload, roof, kernel=None):
@@ -666,9 +667,15 @@ def main():
 		if which == 'coex_c5_full_1gpu':
 			return bench_c5_full(rk)
 		if which in ('de_c4_single4', 'de_c4_single1'):
-			return bench_de_method(rk, steps, warmup, 4 if which.endswith('4') else 1)
+			out = bench_de_method(rk, steps, warmup, 4 if which.endswith('4') else 1)
+			if world == 1 and which == 'de_c4_single4':
+				pmc_traffic(which, out['roofline'], kernel='k_gram_i8')
+			return out
 		if which == 'binnet_c5':
-			return bench_binnet(rk, steps, warmup)
+			out = bench_binnet(rk, steps, warmup)
+			if out is not None:
+				pmc_traffic(which, out['roofline'], kernel='k_binnet_rows')
+			return out
 		if which == 'coex_c2_f64':  # configs[1] on the fp64 matrix cores: the dtype the north star names literally
 			prev = os.environ.get('NRM_GRAM')
 			os.environ['NRM_GRAM'] = 'f64'
