@@ -57,6 +57,10 @@ int nrm_copy_to_host(void* h_dst, const void* d_src, int64_t bytes, void* stream
 int nrm_host_alloc(void** ptr, int64_t bytes);
 int nrm_host_free(void* ptr);
 /* a rectangle (rows x row_bytes, pitches in bytes) of a device matrix -> the same rectangle of a host matrix, queued on `stream` */
+/* Host side of a symmetric result that arrives by rows: h[0:a, a:b] = h[a:b, 0:a]^T for a row-major matrix of 4- or 8-byte elements
+ * (`threads` host threads, 0 = one per 4 hardware threads up to 32).  The numpy-out coex path ships only the rows a..b up to column b over
+ * PCIe and mirrors them here while later rows are in flight (the reference mirrors on the host too: association.py:1049-1057). */
+int nrm_host_mirror_rows(void* h, int64_t ld_bytes, int elem_bytes, int64_t a, int64_t b, int threads);
 int nrm_copy_rect_to_host(void* h_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows, void* stream);
 /* Device-side assembly of the padded operand buffers (zero padding, stacking [C; X~] for the streaming path, gathering sums of
  * squares of row chunks): asynchronous on `stream`; pitches and row_bytes in BYTES. */

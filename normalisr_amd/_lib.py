@@ -50,6 +50,7 @@ _SIGNATURES = {
 	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _dbl, _vp], _i32),
 	'nrm_assoc_sweep_band': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _vp], _i32),
 	'nrm_assoc_sweep_mirror': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _vp, _vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _dbl, _vp], _i32),
+	'nrm_host_mirror_rows': ([_vp, _i64, _i32, _i64, _i64, _i32], _i32),
 	'nrm_copy_rect_to_host': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_single4_sweep': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
 	'nrm_gram_i8_fix_dot': ([_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i64, _vp], _i32),

@@ -36,6 +36,48 @@ extern "C" int nrm_set_device(int device) {
 	return NRM_OK;
 }
 
+// h[0:a, a:b] = h[a:b, 0:a]^T on the host, for a row-major matrix of elem_bytes (4 or 8) elements with ld_bytes between rows: the rows
+// a..b of a symmetric result matrix have arrived over PCIe up to column b, their mirror image above the diagonal is made here instead
+// of travelling too (the reference's gather loop mirrors on the host as well: association.py:1049-1057).  32 x 32 tiles, the destination
+// rows shared out over `threads` host threads (0: one per 4 hardware threads, at most 32).
+template <typename E>
+static void mirror_rows(char* h, int64_t ld, int64_t a, int64_t b, int64_t r0, int64_t r1) {
+	constexpr int64_t TB = 32;
+	for (int64_t i0 = r0; i0 < r1; i0 += TB)      // destination rows (columns of the source block)
+		for (int64_t j0 = a; j0 < b; j0 += TB) {   // destination columns (rows of the source block)
+			const int64_t i1 = std::min(i0 + TB, r1), j1 = std::min(j0 + TB, b);
+			for (int64_t i = i0; i < i1; i++) {
+				E* dst = reinterpret_cast<E*>(h + i * ld) + j0;
+				for (int64_t j = j0; j < j1; j++) dst[j - j0] = reinterpret_cast<const E*>(h + j * ld)[i];
+			}
+		}
+}
+
+extern "C" int nrm_host_mirror_rows(void* h, int64_t ld_bytes, int elem_bytes, int64_t a, int64_t b, int threads) {
+	NRM_REQUIRE(h && (elem_bytes == 4 || elem_bytes == 8) && 0 <= a && a <= b && ld_bytes >= b * elem_bytes, "nrm_host_mirror_rows: bad arguments");
+	if (a == 0 || a == b) return NRM_OK;
+	if (threads <= 0) threads = (int)std::min<int64_t>(32, std::max<int64_t>(1, std::thread::hardware_concurrency() / 4));
+	threads = (int)std::min<int64_t>(threads, (a + 31) / 32);
+	auto work = [&](int64_t r0, int64_t r1) {
+		if (elem_bytes == 4)
+			mirror_rows<uint32_t>((char*)h, ld_bytes, a, b, r0, r1);
+		else
+			mirror_rows<uint64_t>((char*)h, ld_bytes, a, b, r0, r1);
+	};
+	if (threads <= 1) {
+		work(0, a);
+		return NRM_OK;
+	}
+	const int64_t per = ((a + threads - 1) / threads + 31) / 32 * 32;
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; t++) {
+		const int64_t r0 = t * per, r1 = std::min<int64_t>(a, r0 + per);
+		if (r1 > r0) pool.emplace_back(work, r0, r1);
+	}
+	for (auto& th : pool) th.join();
+	return NRM_OK;
+}
+
 extern "C" int nrm_host_pin(void* ptr, int64_t bytes, int threads) {
 	NRM_REQUIRE(ptr != nullptr && bytes > 0, "nrm_host_pin: empty range");
 	const int64_t page = 4096;

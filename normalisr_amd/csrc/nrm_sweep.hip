@@ -330,8 +330,9 @@ __global__ void __launch_bounds__(256, 3) k_assoc_sweep_sym(const double* __rest
 // Off-diagonal rectangle of a symmetric (coex) problem: rows [r0, r0 + mx) against columns [c0, c0 + my) with c0 + my <= r0.
 // Every p-value is computed once and written twice -- at (r0 + i, c0 + j) and, through an LDS transpose, at (c0 + j, r0 + i) --
 // so that a pipelined coex (rows arriving chunk by chunk) can finish and ship both halves of a chunk's pairs at once.
+// (fp64 outputs need 195 registers: two waves per SIMD is what the kernel gets, and what it asks for)
 template <typename OutT>
-__global__ void __launch_bounds__(256, 3) k_assoc_sweep_mirror(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ssx,
+__global__ void __launch_bounds__(256, sizeof(OutT) == 8 ? 2 : 3) k_assoc_sweep_mirror(const double* __restrict__ dot, int64_t ldd, const double* __restrict__ ssx,
 															 const double* __restrict__ ssy, int64_t mx, int64_t my, double ncells, PvalPlan pl,
 															 OutT* __restrict__ p_out, OutT* __restrict__ stat_out, int64_t ldo, int64_t r0,
 															 int64_t c0, int32_t* __restrict__ flags, FixArgs fix) {

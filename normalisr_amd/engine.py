@@ -734,6 +734,30 @@ class Engine:
 			host = None
 			pending = []
 			row = ng * esz
+			# Half of P and of the covariance is the mirror image of the other half.  With enough host cores only the rows a..b up to
+			# column b cross PCIe (the 27 GB/s rectangular copy-out is the critical path of this call: 200 MB at configs[1]) and a helper
+			# thread mirrors each block above the diagonal as soon as it has landed (nrm_host_mirror_rows: bitwise symmetric by
+			# construction, like the reference's own triu + transpose, association.py:1049-1057).  NRM_HOST_MIRROR=0/1 overrides.
+			hm = os.environ.get('NRM_HOST_MIRROR', '')
+			host_mirror = (hm == '1') or (hm != '0' and (os.cpu_count() or 1) >= 32)
+			import queue
+			mirror_q, mirror_err = queue.Queue(), []
+
+			def mirror_worker():
+				while True:
+					item = mirror_q.get()
+					if item is None:
+						return
+					ev, ma, mb = item
+					try:
+						ev.synchronize()
+						for h in (host['p'], host['stat']):
+							_lib.check(self.lib.nrm_host_mirror_rows(h.ctypes.data, row, esz, ma, mb, 0))
+					except Exception as e:  # noqa: BLE001 -- re-raised by the caller
+						mirror_err.append(e)
+			mirror_thread = threading.Thread(target=mirror_worker) if host_mirror else None
+			if mirror_thread is not None:
+				mirror_thread.start()
 
 			def ship(block):
 				"""Queue the copy-out of every finished chunk whose rows of the result arrays are page-locked by now (all of them, waiting
@@ -752,9 +776,14 @@ class Engine:
 					self._copy_out.wait_event(done)
 					for h, d in ((host['p'], p), (host['stat'], stat)):
 						_lib.check(self.lib.nrm_copy_rect_to_host(h.ctypes.data + a * row, row, d.data_ptr() + a * row, row, b * esz, b - a, self._copy_out.cuda_stream))
-						for u, v in zip(cuts[:ci], cuts[1:ci + 1]):  # (one copy per band of rows: a copy must stay inside one page-locked range)
-							_lib.check(self.lib.nrm_copy_rect_to_host(h.ctypes.data + u * row + a * esz, row, d.data_ptr() + u * row + a * esz, row, (b - a) * esz, v - u,
-																	  self._copy_out.cuda_stream))
+						if not host_mirror:  # the mirrored halves travel too: columns a..b of the rows above
+							for u, v in zip(cuts[:ci], cuts[1:ci + 1]):  # (one copy per band of rows: a copy must stay inside one page-locked range)
+								_lib.check(self.lib.nrm_copy_rect_to_host(h.ctypes.data + u * row + a * esz, row, d.data_ptr() + u * row + a * esz, row, (b - a) * esz, v - u,
+																		  self._copy_out.cuda_stream))
+					if host_mirror and a > 0:  # ... or are made on the host from what has arrived, while later rows are in flight
+						arrived_out = torch.cuda.Event()
+						arrived_out.record(self._copy_out)
+						mirror_q.put((arrived_out, a, b))
 			mark('buffers')
 			try:
 				for ci, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
@@ -793,8 +822,14 @@ class Engine:
 				self._copy_out.synchronize()
 				mark('copied out')
 			finally:
+				if mirror_thread is not None:
+					mirror_q.put(None)
+					mirror_thread.join()
+					mark('mirrored')
 				if host is not None:
 					self.finish_host_results(host)
+			if mirror_err:
+				raise mirror_err[0]
 			mark('unpinned')
 			self.check_flags(flags)
 			res = dict(p=host['p'], stat=host['stat'], alpha=None, varx=None, vary=self.variances(ss, ng, n, out_dtype), dof=dof)

@@ -150,3 +150,22 @@ def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
 	assert r.returncode == 0, r.stdout
 	r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
 	assert r.returncode == 0 and 'host logic ok' in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_host_mirror_rows(dtype):
+	"""nrm_host_mirror_rows (host code of the library, no GPU): h[0:a, a:b] = h[a:b, 0:a]^T, any thread count, ragged tiles, nothing
+	else touched -- what the numpy-out coex path does to the rows that arrived over PCIe (association.py:1049-1057 mirrors on the host
+	too)."""
+	lib = _lib.load()
+	rng = np.random.default_rng(5)
+	n = 301
+	for threads in (1, 3, 0):
+		for a, b in ((0, 40), (40, 40), (33, 97), (128, 301), (300, 301)):
+			h = rng.normal(size=(n, n + 3)).astype(dtype)[:, :n]  # (a pitch larger than the row)
+			want = h.copy()
+			want[0:a, a:b] = want[a:b, 0:a].T
+			_lib.check(lib.nrm_host_mirror_rows(h.ctypes.data, h.strides[0], h.itemsize, a, b, threads))
+			assert np.array_equal(h, want), (threads, a, b)
+	with pytest.raises(ValueError):
+		_lib.check(lib.nrm_host_mirror_rows(h.ctypes.data, 8, h.itemsize, 3, 9, 1))
