@@ -106,8 +106,9 @@ int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int
 					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax, double* d_fix,
 					  void* d_work, int64_t work_bytes, void* stream);
 /* d_work / work_bytes (nrm_residualize_q, nrm_residualize_q_chunked): a device scratch of at least nrm_residualize_workspace_bytes()
- * bytes, 16-byte aligned, ZEROED ONCE by the caller when it is allocated (the kernel leaves its counters at zero again) and not
- * shared by launches that may run at the same time.  With it -- and d_out == NULL, at most 48 covariates, n % 4 == 0 -- K1 keeps every row ON CHIP between its two
+ * bytes, 16-byte aligned, ZEROED by the caller when it is allocated (the kernel leaves its counters at zero again; they are the first
+ * 16 + 4 * rows_pad bytes, the partials follow: a scratch reused for a launch with MORE rows must have that many leading bytes zeroed again) and
+ * not shared by launches that may run at the same time.  With it -- and d_out == NULL, at most 48 covariates, n % 4 == 0 -- K1 keeps every row ON CHIP between its two
  * phases (csrc/nrm_residualize_res.hip): one HBM read per input row instead of two; a row longer than 6144 fp32 / 3072 fp64 cells
  * is shared by the workgroups that hold its segments, which exchange their partial products through the scratch (summed in a
  * fixed order: results are bitwise reproducible).  NULL: the two-sweep kernel.  Returns 0 for shapes the resident kernel does not

@@ -385,6 +385,7 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 		if (want_alpha) NRM_TRY(by.alloc((size_t)ny * nc * 8));
 		if (want_alpha) NRM_HIP(hipMemsetAsync(by.p, 0, (size_t)ny * nc * 8, st));
 		if (nslices) {
+			if (k1_bytes) NRM_HIP(hipMemsetAsync(k1w.p, 0, (size_t)(16 + 4 * np_), st));  // (the x rows' partials lie where this launch's counters must be zero)
 			NRM_TRY(qy.alloc((size_t)nrm_quant_bytes(np_, kp, nslices)));
 			NRM_TRY(ey.alloc((size_t)np_ * 4));
 			NRM_TRY(fy.alloc((size_t)np_ * 8 * 8));

@@ -308,9 +308,15 @@ class Engine:
 		if need == 0:
 			return 0, 0
 		key = self._stream()
-		w = self._k1_ws.get(key)
+		w, groups_last = self._k1_ws.get(key, (None, 0))
+		groups = rows_pad // 4
 		if w is None or w.numel() < need:
-			w = self._k1_ws[key] = self.zeros((need + (need >> 2), ), self.torch.uint8)
+			w = self.zeros((need + (need >> 2), ), self.torch.uint8)
+		elif groups > groups_last:
+			# the counters sit at the start of the scratch, the partials behind them: a launch on more rows than the last one finds that
+			# one's partials where its counters must be zero
+			_lib.check(self.lib.nrm_fill_zero(w.data_ptr(), 16 + 16 * groups, self._stream()))
+		self._k1_ws[key] = (w, groups)
 		return w.data_ptr(), int(w.numel())
 
 	@serialised

@@ -92,7 +92,7 @@ def test_k1_rows_resident_on_chip(eng, monkeypatch, dtype, rows, n, nc, kind):
 		assert eng.k1_work(code, rp, n, nc)[0] != 0, 'the resident kernel does not take this shape'
 		r = eng.residualize(d_x, d_c, d_dci, dcr, nslices=ns, keep_fp64=False)
 		torch.cuda.synchronize()
-		w = list(eng._k1_ws.values())[0]
+		w = list(eng._k1_ws.values())[0][0]
 		assert int(w[:16 + 16 * (rp // 4)].view(torch.int32).abs().sum()) == 0, 'K1 left its counters dirty'
 		nks = (r.k_pad + 31) // 32
 		planes, exps, ss, fix = (t.cpu().numpy() for t in (r._quant[0], r._quant[1], r.ss, r.fix))
@@ -294,3 +294,24 @@ def test_engine_path_and_throughput_are_logged(norm, caplog):
 	assert 'coex, 11175 tests over 2304 cells on the integer Gram engine (46-bit' in msgs[0] and 'every P-value certified' in msgs[0] and 'tests/s' in msgs[0]
 	assert 'the fp64 Gram kernel' in msgs[1] and 'no guard needed' in msgs[1]
 	assert msgs[2].startswith('normalisr_amd: de, 300 tests over 2304 cells')
+
+
+def test_k1_resident_scratch_reused_across_shapes(eng, monkeypatch):
+	"""One scratch serves launches of different shapes on a stream (a de call residualises 1000 design rows, then 15 000 gene rows): the
+	partials of a launch on few rows lie where the counters of a launch on more rows must be zero -- the engine zeroes them again.  (Found
+	as a hang of `NRM_K1=res bench.py --workload de_c4`.)"""
+	import torch
+	monkeypatch.setenv('NRM_K1', 'res')
+	rng = np.random.default_rng(408)
+	n = 20000
+	x1, d1, dc64, d_c, d_dci, dcr = _k1_case(eng, rng, np.float32, 100, n, 3, 'gauss')
+	x2 = rng.normal(size=(1500, n)).astype(np.float32)
+	d2 = torch.from_numpy(x2).cuda()
+	want = {}
+	for name, d in (('big', d2), ('small', d1)):
+		r = eng.residualize(d, d_c, d_dci, dcr, nslices=6, keep_fp64=False)
+		want[name] = (r._quant[0].clone(), r.ss.clone(), r.fix.clone())
+	for name, d in (('small', d1), ('big', d2), ('small', d1), ('big', d2)):
+		r = eng.residualize(d, d_c, d_dci, dcr, nslices=6, keep_fp64=False)
+		torch.cuda.synchronize()
+		assert torch.equal(r._quant[0], want[name][0]) and torch.equal(r.ss, want[name][1]) and torch.equal(r.fix, want[name][2]), name
