@@ -740,12 +740,13 @@ class Engine:
 			host = None
 			pending = []
 			row = ng * esz
-			# Half of P and of the covariance is the mirror image of the other half.  With enough host cores only the rows a..b up to
-			# column b cross PCIe (the 27 GB/s rectangular copy-out is the critical path of this call: 200 MB at configs[1]) and a helper
-			# thread mirrors each block above the diagonal as soon as it has landed (nrm_host_mirror_rows: bitwise symmetric by
-			# construction, like the reference's own triu + transpose, association.py:1049-1057).  NRM_HOST_MIRROR=0/1 overrides.
-			hm = os.environ.get('NRM_HOST_MIRROR', '')
-			host_mirror = (hm == '1') or (hm != '0' and (os.cpu_count() or 1) >= 32)
+			# Half of P and of the covariance is the mirror image of the other half: with NRM_HOST_MIRROR=1 only the rows a..b up to column b
+			# cross PCIe and a helper thread mirrors each block above the diagonal as soon as it has landed (nrm_host_mirror_rows: bitwise
+			# symmetric by construction, like the reference's own triu + transpose, association.py:1049-1057).  Opt-in, because it measured
+			# SLOWER on the MI355X box (configs[1]: 11.6 ms against 7.7): the copies of all chunks but the last are hidden behind the uploads
+			# anyway, so halving them shortens the tail by 0.5 ms only (copied out at 6.9 instead of 7.4 ms), while 32 host threads transpose
+			# the 100 MB at ~16 GB/s -- below the 27 GB/s of the rectangular copy-out they replace.
+			host_mirror = os.environ.get('NRM_HOST_MIRROR', '0') == '1'
 			import queue
 			mirror_q, mirror_err = queue.Queue(), []
 

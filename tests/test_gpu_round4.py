@@ -315,3 +315,19 @@ def test_k1_resident_scratch_reused_across_shapes(eng, monkeypatch):
 		r = eng.residualize(d, d_c, d_dci, dcr, nslices=6, keep_fp64=False)
 		torch.cuda.synchronize()
 		assert torch.equal(r._quant[0], want[name][0]) and torch.equal(r.ss, want[name][1]) and torch.equal(r.fix, want[name][2]), name
+
+
+def test_host_mirrored_coex_results_equal_shipped_ones(norm, eng, monkeypatch):
+	"""NRM_HOST_MIRROR=1: the numpy-out coex path ships only the rows a..b up to column b and mirrors them on the host
+	(nrm_host_mirror_rows) -- bit for bit the arrays of the default path, which ships both halves (association.py:1049-1057)."""
+	rng = np.random.default_rng(409)
+	dt = rng.normal(size=(2600, 3328)).astype(np.float32)  # three row chunks of the pipelined path (>= 32 MB, > 1024 rows)
+	dc = np.vstack([rng.normal(size=(1, 3328)), np.ones((1, 3328))])
+	assert eng.coex_pipelined_ok(dt, dc, 3328)
+	monkeypatch.setenv('NRM_HOST_MIRROR', '0')
+	p0, d0, v0 = norm.coex(dt, dc)
+	p0, d0 = p0.copy(), d0.copy()
+	monkeypatch.setenv('NRM_HOST_MIRROR', '1')
+	p1, d1, v1 = norm.coex(dt, dc)
+	assert np.array_equal(p0, p1) and np.array_equal(d0, d1) and np.array_equal(v0, v1)
+	assert (p1 == p1.T).all() and (d1 == d1.T).all() and (np.diag(p1) == 0).all()
