@@ -176,7 +176,10 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 	rk = np.zeros(nx, dtype=np.int64)
 	if nc:
 		ce = cp[:, n_common:]
-		mc = (cp[:, :n_common] @ cp[:, :n_common].T)[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
+		cpc = cp[:, :n_common]
+		# (element-wise, not BLAS: a (nc x cells) x (cells x nc) product handed to a many-core BLAS pool costs tens of ms of thread wake-ups)
+		mcc = np.array([[float((cpc[a] * cpc[b]).sum()) for b in range(nc)] for a in range(nc)])
+		mc = mcc[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
 		xc = _segment_sums(ce * xe, starts, counts).T  # (nx, nc)
 		mi, rk = inv_rank(mc)  # association.py:350-351
 		mi[rk == 0] = 0
