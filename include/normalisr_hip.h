@@ -326,13 +326,14 @@ int nrm_single4_sweep(const double* d_bt, const double* d_pt, int64_t ldb, const
  *   nrm_single4_sweep_guarded: nrm_single4_sweep plus the accuracy guard: d_fix_y (ny, NRM_FIX_STRIDE) the genes' records, d_kappa (nx)
  *       = sum_j |x~_j| |N_ji| / sqrt(N_ii), cstar / gstar the largest c and g among the design rows' records; a pair whose P-value the
  *       products' error bound could move by more than `budget` (relative) is counted in d_flags[2], the largest estimate kept in
- *       d_flags[3] (float bits); d_flags has 4 entries.  The caller redoes a call with hits on the fp64 Gram kernel. */
+ *       d_flags[3] (float bits); d_flags has 4 entries.  The caller redoes the genes with hits (or the whole call) on the fp64 Gram kernel. */
 int nrm_gram_i8_fix_dot(double* d_dot, int64_t ldd, const double* d_fix_rows, const double* d_fix_cols, int64_t rows, int64_t cols,
 						int nslices, int64_t n_cells, void* stream);
 int nrm_single4_sweep_guarded(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
 							  int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot, void* d_p,
 							  void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags,
-							  const double* d_fix_y, const double* d_kappa, double cstar, double gstar, int nslices, double budget, void* stream);
+							  const double* d_fix_y, const double* d_kappa, double cstar, double gstar, int nslices, double budget,
+							  int32_t* d_gene_hits /* (ny) zeroed by the caller, or NULL: 1 for every gene with a counted pair */, void* stream);
 
 /*
  * single=1 sweep (every grouping tested on its own subset of cells, association.py:263-390).

@@ -55,7 +55,7 @@ _SIGNATURES = {
 	'nrm_single4_sweep': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
 	'nrm_gram_i8_fix_dot': ([_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i64, _vp], _i32),
 	'nrm_single4_sweep_guarded': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
-								  _vp, _vp, _dbl, _dbl, _i32, _dbl, _vp], _i32),
+								  _vp, _vp, _dbl, _dbl, _i32, _dbl, _vp, _vp], _i32),
 	'nrm_design_products_workspace_doubles': ([_i64, _i64], _i64),
 	'nrm_design_products': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp], _i32),
 	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp], _i32),

@@ -57,6 +57,7 @@ struct S4Guard {
 	const double* fy;     // (ny, NRM_FIX_STRIDE) row records of the genes, or nullptr
 	const double* kappa;  // (nx)
 	const double* yy;     // (ny) |y~|^2
+	int32_t* gene_hits;   // (ny) or nullptr: set to 1 for every gene with a counted pair (the caller redoes only those genes in fp64)
 	double kconst, cstar, gstar, budget, dof;
 };
 
@@ -104,7 +105,10 @@ __global__ void __launch_bounds__(256) k_s4_sweep(const double* __restrict__ bt,
 			const double num = dr * fma(gd.dof, ar, sqrt_dof), den = om * om;
 			if (num > gd.budget * den || !(num == num)) {
 				const double lo = fmax(ar - dr, 0.0);
-				if (pv != (OutT)0 || nrm_pvalue(lo * lo, pl) != 0.0) bad_fix++;  // (a P-value that is 0 on the whole interval is exempt)
+				if (pv != (OutT)0 || nrm_pvalue(lo * lo, pl) != 0.0) {  // (a P-value that is 0 on the whole interval is exempt)
+					bad_fix++;
+					if (gd.gene_hits) gd.gene_hits[gy] = 1;
+				}
 			} else
 				worst = fmaxf(worst, __fdividef((float)num, (float)den));
 		}
@@ -158,19 +162,21 @@ static int single4_sweep_impl(const double* d_bt, const double* d_pt, int64_t ld
 extern "C" int nrm_single4_sweep(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
 								 int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot, void* d_p,
 								 void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags, void* stream) {
-	const S4Guard none = {nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, dof};
+	const S4Guard none = {nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, dof};
 	return single4_sweep_impl(d_bt, d_pt, ldb, d_yy, d_dxx, nx, ny, m, n_cells, dof, return_dot, d_p, d_stat, d_vary, out_dtype, ldo, d_work, d_flags, none, stream);
 }
 
 // The same for products that came from the integer Gram engine: d_fix_y = the genes' row records, d_kappa (nx) and c*, g* as described
-// at S4Guard; d_flags then has 4 entries (non-finite, R^2 out of range, pairs not certified, largest error estimate as float bits).
+// at S4Guard; d_flags then has 4 entries (non-finite, R^2 out of range, pairs not certified, largest error estimate as float bits);
+// d_gene_hits (ny int32, zeroed by the caller) or NULL: set to 1 for every gene with a pair that was counted.
 extern "C" int nrm_single4_sweep_guarded(const double* d_bt, const double* d_pt, int64_t ldb, const double* d_yy, const double* d_dxx,
 										 int64_t nx, int64_t ny, int64_t m, int64_t n_cells, double dof, int return_dot, void* d_p,
 										 void* d_stat, void* d_vary, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags,
-										 const double* d_fix_y, const double* d_kappa, double cstar, double gstar, int nslices, double budget, void* stream) {
+										 const double* d_fix_y, const double* d_kappa, double cstar, double gstar, int nslices, double budget,
+										 int32_t* d_gene_hits, void* stream) {
 	NRM_REQUIRE(d_fix_y && d_kappa && d_flags && (nslices == 5 || nslices == 6) && budget > 0.0, "nrm_single4_sweep_guarded: bad guard arguments");
 	double k = 0.0, w256 = 1.0;
 	for (int w = 0; w <= nslices - 2; w++, w256 *= 256.0) k += (w + 1) * w256;
-	const S4Guard gd = {d_fix_y, d_kappa, d_yy, k, cstar, gstar, budget, dof};
+	const S4Guard gd = {d_fix_y, d_kappa, d_yy, d_gene_hits, k, cstar, gstar, budget, dof};
 	return single4_sweep_impl(d_bt, d_pt, ldb, d_yy, d_dxx, nx, ny, m, n_cells, dof, return_dot, d_p, d_stat, d_vary, out_dtype, ldo, d_work, d_flags, gd, stream);
 }

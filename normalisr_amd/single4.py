@@ -441,7 +441,6 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		dxx = 1.0 / (n * d)
 		# the genes: K1 and the large contraction
 		ry = eng.residualize(d_y, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=not ns)
-		del d_y
 		mark('K1 genes')
 		g_d = eng.zeros((ry.rows_pad, nxp), torch.float64)  # (K2 leaves pure-padding sub-blocks unwritten)
 		with _engine._Span(eng, 'gram_yx'):
@@ -464,7 +463,8 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		if ns:
 			fx = rx.fix[:nx].cpu().numpy()
 			d_kappa = eng.upload(kappa)
-			guard = (ry.fix.data_ptr(), d_kappa.data_ptr(), float(fx[:, 5].max()), float(fx[:, 6].max()), int(ns), float(eng.guard_tol))
+			gene_hits = eng.zeros((ny, ), torch.int32)
+			guard = (ry.fix.data_ptr(), d_kappa.data_ptr(), float(fx[:, 5].max()), float(fx[:, 6].max()), int(ns), float(eng.guard_tol), gene_hits.data_ptr())
 			mark('kappa')
 		dr_groups = [int(dimreduce)] if np.ndim(dimreduce) == 0 else [int(v) for v in np.unique(dimreduce)]
 		p_host = None
@@ -486,11 +486,36 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		mark('sweep')
 		try:
 			eng.check_flags(flags)
-		except GuardHit as g:  # the integer engine could not certify every P-value: once more on the fp64 Gram kernel
-			logging.info('single=4: %s; redone on the fp64 Gram kernel', g)
-			out = _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=True, device_out=device_out)
-			eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
-			return out
+		except GuardHit as g:  # the integer engine could not certify every P-value
+			idx = torch.nonzero(gene_hits).flatten() if len(dr_groups) == 1 else None
+			if idx is None or idx.numel() == 0 or idx.numel() > max(64, ny // 8):
+				# many genes (or per-gene dimreduce groups): the whole call once more on the fp64 Gram kernel
+				logging.info('single=4: %s; redone on the fp64 Gram kernel', g)
+				out = _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=True, device_out=device_out)
+				eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
+				return out
+			# A screen always has a few strongly associated genes, and those are the pairs a bound on the P-value's RELATIVE change is
+			# hardest on: only the genes with such a pair get their products again, from fp64 residuals on the fp64 Gram kernel (the
+			# design side -- X~ in fp64, M~, N~ -- is the same), and their columns of the results are replaced.
+			k = int(idx.numel())
+			logging.info('single=4: %s; the %d genes concerned redone on the fp64 Gram kernel', g, k)
+			ry_s = eng.residualize(d_y.index_select(0, idx), d_c, d_dci, dcr, want_coef=not lowmem, nslices=0, keep_fp64=True)
+			g_s = eng.zeros((ry_s.rows_pad, nxp), torch.float64)
+			eng.gram(ry_s, rx, False, dot=g_s)
+			bt_s = eng.gram(Residualized(k, nxp, g_s, None, None), Residualized(nx, nxp, d_n, None, None), False)
+			p_s, stat_s, vary_s = (torch.empty((nx, k), dtype=tdt, device=eng.device) for _ in range(3))
+			work_s = torch.empty((k, ), dtype=torch.float64, device=eng.device)
+			flags_s = eng.zeros((2, ), torch.int32)
+			_lib.check(eng.lib.nrm_single4_sweep(bt_s.data_ptr(), g_s.data_ptr(), bt_s.stride(0), ry_s.ss.data_ptr(), d_dxx.data_ptr(), nx, k, nx, n,
+												 float(n - m - dr_groups[0]), 1 if return_dot else 0, p_s.data_ptr(), stat_s.data_ptr(), vary_s.data_ptr(), code, k,
+												 work_s.data_ptr(), flags_s.data_ptr(), eng._stream()))
+			eng.check_flags(flags_s)
+			for whole, part in ((p, p_s), (stat, stat_s), (vary, vary_s)):
+				whole.index_copy_(1, idx, part)
+			bt_d.index_copy_(0, idx, bt_s[:k])  # (alpha below is formed from B and the genes' OLS coefficients)
+			if not lowmem and nc:
+				ry.coef.index_copy_(0, idx, ry_s.coef[:k])
+			eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True, genes_redone=k)
 		alpha = None
 		if not lowmem:
 			# alpha_y = b_y - B_y b_x (nc values per gene, the same for every grouping: association.py:551-553 in the closed form)
@@ -503,7 +528,10 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 			alpha = np.broadcast_to(b_cov.astype(out_dtype)[None, :, :], (nx, ny, nc)).copy()
 		vx = dxx.copy()
 		vx[vx == 0] = 1
+		mark('flags')
 		cert = (norm_mt, norm_ninv, rx.coef[:nx].cpu().numpy() if nc else np.zeros((nx, 0)))
 		if device_out and p_host is None:
 			return (p, stat, alpha, vx.astype(out_dtype), vary), cert
-		return (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary)), cert
+		out = (eng.download(p) if p_host is None else p_host, eng.download(stat), alpha, vx.astype(out_dtype), eng.download(vary))
+		mark('downloads')
+		return out, cert

@@ -331,3 +331,24 @@ def test_host_mirrored_coex_results_equal_shipped_ones(norm, eng, monkeypatch):
 	p1, d1, v1 = norm.coex(dt, dc)
 	assert np.array_equal(p0, p1) and np.array_equal(d0, d1) and np.array_equal(v0, v1)
 	assert (p1 == p1.T).all() and (d1 == d1.T).all() and (np.diag(p1) == 0).all()
+
+
+def test_single4_redoes_only_the_genes_the_guard_flags(norm, eng):
+	"""A screen with mutually exclusive gRNAs under an intercept (strongly correlated design rows: large kappa) and a few strongly
+	associated genes: the guard cannot certify those genes' P-values from the integer engine's products, and only THEY are redone from
+	fp64 residuals on the fp64 Gram kernel -- every result equal to the oracle's."""
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(410)
+	nx, ny, n = 60, 400, 16384
+	lab = rng.integers(0, nx + 12, n)
+	dg = np.zeros((nx, n))
+	dg[lab[lab < nx], np.nonzero(lab < nx)[0]] = 1
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dt = rng.normal(size=(ny, n))
+	dt[:10] += 0.8 * dg[:10]
+	p, gam, a, vx, vy = association_tests(dg, dt, dc, single=4, return_dot=False, lowmem=False)
+	g = dict(eng.last_guard)
+	po, go, ao, vxo, vyo = oracle.association_tests(dg, dt, dc, single=4, return_dot=False, lowmem=False)
+	assert p_close(p, po) and close(gam, go, floor=1e-10) and close(vy, vyo, 1e-9) and close(a, ao, 1e-5, 1e-8)
+	if g['fallback']:  # (what the guard decides depends on the bound's constants; when it fires here it must be for few genes)
+		assert 0 < g.get('genes_redone', ny) <= 64, g
