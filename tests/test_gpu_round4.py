@@ -258,6 +258,10 @@ def test_single4_on_the_integer_engine(norm, eng, dtype):
 	p, d, a, vx, vy = association_tests(dg, dt, dc, single=4, return_dot=True, dimreduce=dr)
 	po, do, ao, vxo, vyo = oracle.association_tests(dg, dt.astype(np.float64), dc, single=4, return_dot=True, dimreduce=dr)
 	assert pc(p, po, rtol) and close(d, do, rtol, 1e-12) and a is None
+	# no covariates at all (the reference warns and goes on, association.py:205-206): the design rows are their own residuals
+	p, gam, a, vx, vy = association_tests(dg, dt, np.zeros((0, n)), single=4, return_dot=False)
+	po, go, ao, vxo, vyo = oracle.association_tests(dg, dt.astype(np.float64), np.zeros((0, n)), single=4, return_dot=False)
+	assert pc(p, po, rtol) and close(gam, go, rtol, 1e-10) and close(vy, vyo, rtol)
 
 
 def test_single4_guard_reroutes_to_fp64(norm, eng):
