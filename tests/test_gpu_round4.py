@@ -356,3 +356,33 @@ def test_single4_redoes_only_the_genes_the_guard_flags(norm, eng):
 	assert p_close(p, po) and close(gam, go, floor=1e-10) and close(vy, vyo, 1e-9) and close(a, ao, 1e-5, 1e-8)
 	if g['fallback']:  # (what the guard decides depends on the bound's constants; when it fires here it must be for few genes)
 		assert 0 < g.get('genes_redone', ny) <= 64, g
+
+
+def test_config3_exact_shape_as_de_covariate():
+	"""BASELINE configs[3] at its exact shape as the reference's example runs it (`de -m covariate`, cmd_highmoi.sh:19-22): 1 000 gRNAs x
+	15 000 genes x 50 000 cells fp32 through single=4 on the device, resident; sampled gRNAs x sampled genes against the oracle.  The
+	oracle's per-grouping loop needs one 1004 x 1004 pseudo-inverse per tested gRNA, so it is run on 5 of them with the other 995 joined to
+	the covariates -- the same model for those 5 (single=4 IS "every other grouping a covariate", association.py:421-576)."""
+	import torch
+	from normalisr_amd.engine import get_engine
+	from normalisr_amd.single4 import association_tests_single4
+	eng = get_engine()
+	nx, ny, n, nc = 1000, 15000, 50000, 5
+	gen = torch.Generator(device='cuda').manual_seed(43)
+	dc = torch.cat([torch.randn((nc - 1, n), generator=gen, device='cuda'), torch.ones((1, n), device='cuda')]).cpu().numpy().astype(np.float64)
+	dx = (torch.rand((nx, n), generator=gen, device='cuda') < 0.01).float()
+	dy = torch.randn((ny, n), generator=gen, device='cuda')
+	dy[:15] += 0.5 * dx[:15]
+	p, gam, a, vx, vy = association_tests_single4(dx, dy, dc, return_dot=False, device_out=True)
+	g = dict(eng.last_guard)
+	assert tuple(p.shape) == (nx, ny) and g['worst'] > 0 and (not g['fallback'] or g.get('genes_redone', ny) <= 64), g
+	xs = np.array([0, 3, 14, 500, 999])
+	ys = np.concatenate([np.arange(16), np.arange(7490, 7500), np.arange(ny - 10, ny)])
+	dxh = dx.cpu().numpy().astype(np.float64)
+	others = np.delete(np.arange(nx), xs)
+	sub = dy[torch.from_numpy(ys).cuda()].cpu().numpy().astype(np.float64)
+	po, go, ao, vxo, vyo = oracle.association_tests(dxh[xs], sub, np.vstack([dxh[others], dc]), single=4, return_dot=False)
+	take = lambda t: t[torch.from_numpy(xs).cuda()][:, torch.from_numpy(ys).cuda()].cpu().numpy()
+	assert po.min() < 1e-20
+	assert close(take(p), po, 2e-5, 1e-38) and close(take(gam), go, 2e-5, 1e-7) and close(take(vy), vyo, 2e-5)  # (fp32 outputs)
+	assert close(vx[xs], vxo, 1e-6)
