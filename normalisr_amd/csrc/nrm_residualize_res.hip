@@ -18,6 +18,7 @@
 // Reference: association.py:224-233 (ccx = dci @ (dc @ dx.T); dx1 = dx - ccx @ dc; mean of squares).
 #include "nrm_k1.h"
 #include <cstdlib>
+#include <algorithm>
 
 #define RR_R 4         // rows per work item
 #define RR_NC_MAX 48   // covariates (partials of 4 (nc + 14) doubles per item); beyond: k_residualize_v4
@@ -118,7 +119,7 @@ template <typename T, int NS>
 __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx, const double* __restrict__ c, int nc,
 															 int64_t ldc, const double* __restrict__ dci, int active, double* __restrict__ ss,
 															 double* __restrict__ coef, QuantOut qo, int* __restrict__ ctr, double* __restrict__ part, int stride,
-															 int nseg, int gseg, int ngroups, long long* __restrict__ dbg, int ablate) {
+															 int nseg, int gseg, int ngroups, long long* __restrict__ dbg, int ablate, int teams) {
 	constexpr int R = RR_R, G = RRGeom<T>::G, CB = RR_CB, NP = NS - 1, NREC = 2 * NP + 1, B = 8 * NS - 2;
 	extern __shared__ double s_dyn[];
 	__shared__ double s_w[16][RR_SLOT];  // one slot per (wave, row of 16 lanes)
@@ -137,7 +138,12 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 		for (int i = tid; i < nc; i += 256) s_cmax[i] = qo.cmax ? qo.cmax[i] : 0.0;
 	}
 
-	if (tid == 0) s_item = atomicAdd(ctr, 1);
+	// Items come from the ticket counter -- or, teams > 0 (NRM_K1_TEAMS=1, an experiment: it needs all teams * nseg workgroups of the grid
+	// resident at once, which a plain launch cannot promise), from a fixed plan: workgroup b is member b % nseg of team b / nseg and
+	// takes that segment of row groups team, team + teams, ...  The members of a cluster then run in lock step instead of arriving
+	// as their previous items happen to end.
+	const int64_t stride_items = (int64_t)teams * nseg;
+	if (tid == 0) s_item = teams ? (int)blockIdx.x : atomicAdd(ctr, 1);
 	__syncthreads();
 	int64_t item = s_item;
 	while (item < items) {
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 		}
 		__syncthreads();
 		stamp(4);
-		if (tid == 0) s_item = atomicAdd(ctr, 1);  // the next ticket, drawn only now: it cannot lie in this cluster (see the header)
+		if (tid == 0) s_item = teams ? (int)(item + stride_items) : atomicAdd(ctr, 1);  // the next ticket, drawn only now: it cannot lie in this cluster (see the header)
 		if (active) {
 			for (int i = tid; i < R * ncp; i += 256) {
 				const int r = i / ncp, q = i - r * ncp;
@@ -558,7 +564,7 @@ __global__ void __launch_bounds__(256, 2) k_residualize_res(const T* __restrict_
 		item = s_item;
 	}
 	// every workgroup draws exactly one ticket past the end; the one that draws the last of them resets the ticket counter
-	if (tid == 0) {
+	if (tid == 0 && !teams) {
 		const int od = __hip_atomic_fetch_add(ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (od == (int)gridDim.x - 1) {
 			__hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -640,12 +646,16 @@ int nrm_k1_res_launch(const void* d_x, int x_dtype, int64_t rows, int64_t n, int
 	const int stride = RR_R * (nc + 14);
 	const int64_t items = groups * nseg;
 	const int slots = rr_slots();
-	const dim3 grid((unsigned)(items < slots ? items : slots));
+	// NRM_K1_TEAMS=1: whole teams of nseg workgroups, as many as fit the slots (see the kernel)
+	static const bool want_teams = getenv("NRM_K1_TEAMS") && atoi(getenv("NRM_K1_TEAMS")) > 0;
+	int teams = 0;
+	if (want_teams && nseg > 1 && nseg <= slots) teams = (int)std::min<int64_t>(slots / nseg, groups);
+	const dim3 grid(teams ? (unsigned)(teams * nseg) : (unsigned)(items < slots ? items : slots));
 	const int ncp = (nc + RR_CB - 1) / RR_CB * RR_CB;
 	const size_t lds = ((size_t)2 * RR_R * (ncp > 0 ? ncp : RR_CB) + (size_t)nc * nc + nc) * sizeof(double);
 #define RR_GO(T, NS)                                                                                                                            \
 	hipLaunchKernelGGL((k_residualize_res<T, NS>), grid, dim3(256), lds, st, (const T*)d_x, rows, n, ldx, d_c, nc, ldc, d_dci, active, d_ss, d_coef, qo, \
-					   ctr, part, stride, nseg, gseg, (int)groups, g_rr_dbg, g_rr_dbg ? g_rr_ablate : 0)
+					   ctr, part, stride, nseg, gseg, (int)groups, g_rr_dbg, g_rr_dbg ? g_rr_ablate : 0, teams)
 	if (x_dtype == NRM_F32) {
 		if (nslices == 6)
 			RR_GO(float, 6);
