@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
 }
 
-template <typename T, int CB, int NS>
+template <typename T, int CB, int NS, bool NT = false>
 __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
 														 const double* __restrict__ c, int nc, int64_t ldc,
 														 const double* __restrict__ dci, int active, double* __restrict__ out,
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 			for (int64_t k = (int64_t)tid * 4; k < n4; k += 1024) {
 				double xv[RES_R][4];
 #pragma unroll
-				for (int r = 0; r < RES_R; r++) Vec4Load<T>::ld(xr[r] + k, xv[r]);
+				for (int r = 0; r < RES_R; r++) RowLoad<T, NT>::ld(xr[r] + k, xv[r]);
 				if (NS && c0 == 0) {
 #pragma unroll
 					for (int r = 0; r < RES_R; r++)
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 	auto residual4 = [&](int64_t k, double (&v)[RES_R][4]) {
 		if (k < n4) {
 #pragma unroll
-			for (int r = 0; r < RES_R; r++) Vec4Load<T>::ld(xr[r] + k, v[r]);
+			for (int r = 0; r < RES_R; r++) RowLoad<T, NT>::ld(xr[r] + k, v[r]);
 			if (active) {
 				for (int q = 0; q < nc; q++) {
 					double cv[4];
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x,
 	auto request = [&](int64_t k, T (&raw)[RES_R][4]) {
 		if (k < n4) {
 #pragma unroll
-			for (int r = 0; r < RES_R; r++) k1_ld4raw<T>(xr[r] + k, raw[r]);
+			for (int r = 0; r < RES_R; r++) RawLoad<T, NT>::ld(xr[r] + k, raw[r]);
 		} else {
 #pragma unroll
 			for (int r = 0; r < RES_R; r++)
@@ -480,6 +480,8 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 							   int nslices, QuantOut qo, hipStream_t st) {
 	dim3 grid((unsigned)(rows_pad / RES_R));
 	const size_t lds = (size_t)2 * RES_R * (nc > 0 ? nc : 1) * sizeof(double);
+	// input rows loaded non-temporally (nrm_k1.h): fp32 rows against at least 8 MB of covariates, which then stay in L2
+	const bool stream_rows = active && sizeof(T) == 4 && (int64_t)nc * n * 8 >= (8 << 20);
 	auto go = [&](auto kern, auto... extra) {
 		if (lds > 48 * 1024)  // beyond the default dynamic-LDS window (more than 768 covariates)
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -488,9 +490,9 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 	if (!vec)
 		go(k_residualize<T>);
 	else if (nslices == 6)
-		nc <= 4 ? go(k_residualize_v4<T, 4, 6>, qo) : go(k_residualize_v4<T, 8, 6>, qo);
+		nc <= 4 ? go(k_residualize_v4<T, 4, 6>, qo) : (stream_rows ? go(k_residualize_v4<T, 8, 6, true>, qo) : go(k_residualize_v4<T, 8, 6>, qo));
 	else if (nslices == 5)
-		nc <= 4 ? go(k_residualize_v4<T, 4, 5>, qo) : go(k_residualize_v4<T, 8, 5>, qo);
+		nc <= 4 ? go(k_residualize_v4<T, 4, 5>, qo) : (stream_rows ? go(k_residualize_v4<T, 8, 5, true>, qo) : go(k_residualize_v4<T, 8, 5>, qo));
 	else
 		nc <= 4 ? go(k_residualize_v4<T, 4, 0>, qo) : go(k_residualize_v4<T, 8, 0>, qo);
 }
