@@ -740,6 +740,11 @@ def main():
 	def emit():
 		if rank == 0 and not printed.is_set():
 			printed.set()
+			try:  # RCCL's version banner sits in the C library's stdout buffer until exit: out with it first, so that the JSON line is the last line
+				import ctypes
+				ctypes.CDLL(None).fflush(None)
+			except Exception:  # noqa: BLE001
+				pass
 			print(json.dumps(head), flush=True)
 
 	extras = {}
