@@ -348,18 +348,24 @@ int nrm_single1_sweep(const double* d_g, int64_t ldg, const double* d_g2, int64_
 					  int out_dtype, int64_t ldo, int32_t* d_flags, void* stream);
 
 /*
- * The same single=1 statistics for designs with entries >= 0 (gRNA incidence), without the masked Gram contractions: the cells are
- * permuted -- first the n_common cells where every grouping is 0, then, grouping by grouping, the cells where only that grouping is
- * not 0 (d_seg[i] .. d_seg[i+1], positions in the permuted order; cells carrying several groupings are left out) -- and handed over as
- *   d_yt (cells, ldy): the expression matrix TRANSPOSED in that order (y_dtype), d_ct (cells, nc) fp64 the covariates likewise,
- *   d_xp (cells) fp64 the grouping's own value at each cell (0 on the common cells).
- * d_info, outputs and flags as nrm_single1_sweep.  d_work: nrm_single1_sparse_workspace_doubles(ny, nc, n_common) doubles.  nc <= 32.
+ * The same single=1 statistics for designs with entries >= 0 (gRNA incidence), without the masked Gram contractions and without a
+ * transposed copy of the expression matrix (association.py:263-390,911-925).  Every cell has a code (int32): a cell where every grouping
+ * is 0 is NRM_S1_COMMON (-2); a cell where exactly one grouping is not 0 carries its position (>= 0) in the list of such cells ordered
+ * by grouping (d_seg[i] .. d_seg[i+1] are the positions of grouping i); any other cell is NRM_S1_SKIP (-1).
+ *   nrm_single1_stream reads d_y (ny, ldy) once, where it lies (y_dtype), with d_c (nc, ldc) fp64 covariates, and leaves
+ *     d_common (nc + 1, ny) fp64: rows c < nc = the sums of y C_c over the common cells, row nc = the sum of y^2 over them;
+ *     d_ye (cells with a position, ldye) in y_dtype: the expression values at those cells, transposed (ldye: a multiple of 8, >= ny;
+ *     64-byte aligned; columns ny .. ldye are scratch).  nc <= 32 (more than 8 covariates: further passes over d_y).
+ *   nrm_single1_cells finishes every (grouping, gene) pair from d_common, d_ye, d_ce (cells with a position, nc) fp64 covariates and
+ *     d_xe (the same cells) fp64 own value of the grouping; d_info, outputs and flags as nrm_single1_sweep.
  */
-int64_t nrm_single1_sparse_workspace_doubles(int64_t ny, int64_t nc, int64_t n_common);
-int nrm_single1_sparse(const void* d_yt, int y_dtype, int64_t ldy, const double* d_ct, const double* d_xp, const int64_t* d_seg,
-					   int64_t n_common, const double* d_info, int64_t info_pitch, int64_t nc, int64_t nx, int64_t ny, int return_dot,
-					   void* d_p, void* d_stat, void* d_vary, void* d_alpha, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags,
-					   void* stream);
+#define NRM_S1_COMMON (-2)
+#define NRM_S1_SKIP (-1)
+int nrm_single1_stream(const void* d_y, int y_dtype, int64_t ldy, const double* d_c, int64_t ldc, int64_t nc, const int32_t* d_code,
+					   int64_t n, int64_t ny, double* d_common, void* d_ye, int64_t ldye, void* stream);
+int nrm_single1_cells(const void* d_ye, int y_dtype, int64_t ldye, const double* d_ce, const double* d_xe, const int64_t* d_seg,
+					  const double* d_common, const double* d_info, int64_t info_pitch, int64_t nc, int64_t nx, int64_t ny, int return_dot,
+					  void* d_p, void* d_stat, void* d_vary, void* d_alpha, int out_dtype, int64_t ldo, int32_t* d_flags, void* stream);
 
 /*
  * binnet -- binarise a (ng, ng) co-expression P-value matrix at a per-row Benjamini-Hochberg q-value cutoff

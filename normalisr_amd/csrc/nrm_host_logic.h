@@ -232,23 +232,41 @@ static inline int nrm_pvalue_plan_init_host(nrm_pvalue_plan* plan, double dof) {
 		return NRM_OK;
 	}
 	plan->umax = 1.5;
-	double al = plan->alpha;
+	// Products of half-integers that do not depend on dof, built once: cp[k] = prod_{i<2k} (i + 1/2), pr[j][k] = prod_{i=j+1}^{2k-1} (i + 1/2).
+	// (A single=1 screen asks for a plan per grouping: with powl() and these products inside the loops a plan cost 25 us.)
+	struct Tab {
+		long double cp[NRM_PCOEF / 2 + 1], pr[NRM_PCOEF][NRM_PCOEF / 2 + 1];
+		Tab() {
+			for (int k = 0; k <= NRM_PCOEF / 2; k++) {
+				cp[k] = 1;
+				for (int i = 0; i < 2 * k; i++) cp[k] *= (i + 0.5L);
+				for (int j = 0; j < NRM_PCOEF; j++) {
+					pr[j][k] = 1;
+					for (int i = j + 1; i < 2 * k; i++) pr[j][k] *= (i + 0.5L);
+				}
+			}
+		}
+	};
+	static const Tab tab;
+	long double ipow[NRM_PCOEF + 1];  // alpha^-m
+	{
+		long double pw = 1;
+		ipow[0] = 1;
+		for (int m = 1; m <= NRM_PCOEF; m++) {
+			pw *= (long double)plan->alpha;
+			ipow[m] = 1 / pw;
+		}
+	}
 	// S = sum_k h_k alpha^-2k c'_2k,  c'_m = prod_{i<m} (i + 1/2)
 	long double S = 0;
-	for (int k = 0; k <= K; k++) {
-		long double cp = 1;
-		for (int i = 0; i < 2 * k; i++) cp *= (i + 0.5L);
-		S += (long double)kNrmH[k] * powl(al, -2 * k) * cp;
-	}
+	for (int k = 0; k <= K; k++) S += (long double)kNrmH[k] * ipow[2 * k] * tab.cp[k];
 	// coef_j = (1/(S sqrt(pi))) sum_{k: 2k > j} h_k alpha^(j-2k) prod_{i=j+1}^{2k-1} (i + 1/2)
 	for (int j = 0; j < NRM_PCOEF; j++) {
 		long double c = 0;
 		for (int k = 1; k <= K; k++) {
 			int m = 2 * k;
 			if (j >= m) continue;
-			long double pr = 1;
-			for (int i = j + 1; i < m; i++) pr *= (i + 0.5L);
-			c += (long double)kNrmH[k] * powl(al, j - m) * pr;
+			c += (long double)kNrmH[k] * ipow[m - j] * tab.pr[j][k];
 		}
 		plan->coef[j] = (double)(c / (S * 1.7724538509055160272981674833411L));
 	}

@@ -82,53 +82,170 @@ extern "C" int nrm_single1_sweep(const double* d_g, int64_t ldg, const double* d
 // ---- the same statistics without the masked Gram contractions, for designs whose entries are >= 0 (gRNA incidence) -----------------
 // Then "cell k carries no OTHER grouping than i" (association.py:915-916) means: every other row of dx is 0 at k.  S_i is the union of
 // N (cells where ALL of dx is 0: the same for every grouping) and E_i (cells where only row i is not 0), so every sum over S_i is a sum
-// over N -- computed ONCE for every gene (k_s1_common) -- plus a sum over the few dozen cells of E_i, which k_s1_sparse takes inside
-// the sweep itself.  2 ny (nc + 2) (|N| + sum_i |E_i|) flop instead of 2 ny nx (nc + 2) n for the masked Gram: 1000 groupings cost
-// what one costs.  The cells are permuted (N first, then the E_i one after another) and the expression matrix is handed over
-// transposed in that order (YT: cells x genes), so that a thread per gene reads coalesced.
+// over N -- computed ONCE for every gene -- plus a sum over the few dozen cells of E_i, which k_s1_cells takes inside the sweep itself.
+// 2 ny (nc + 2) (|N| + sum_i |E_i|) flop instead of 2 ny nx (nc + 2) n for the masked Gram: 1000 groupings cost what one costs.
+//
+// Round 4: the expression matrix is read ONCE, where it lies and in its own layout (k_s1_stream: a workgroup per S1_R gene rows streams
+// them with 16-byte loads; the sums over N stay in registers, the values at the cells of the E_i -- a third of the matrix at one gRNA
+// per cell -- leave in the order of the groupings, transposed, so that the sweep reads them coalesced with a thread per gene).  Before,
+// torch gathered the permuted columns and transposed the result (two more passes over the matrix: 7.2 ms of the 9.9 ms of device time
+// at 15 000 genes x 50 000 cells).
 #define S1_NCMAX 32
-#define S1_PIECE 512
+#define S1_NCB 8  // covariates per pass of the stream kernel (more: further passes over the expression rows)
 
-// partial sums over piece blockIdx.y of the N cells: part[piece][y][0 .. nc) = sum y C_c, [nc] = sum y^2
 template <typename T>
-__global__ void __launch_bounds__(256) k_s1_common(const T* __restrict__ YT, int64_t ldy, const double* __restrict__ CT, int nc, int64_t n_common,
-													int64_t ny, double* __restrict__ part) {
-	const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (y >= ny) return;
-	const int64_t k0 = (int64_t)blockIdx.y * S1_PIECE, k1 = k0 + S1_PIECE < n_common ? k0 + S1_PIECE : n_common;
-	double a[S1_NCMAX], q = 0.0;
+struct S1Vec;
+template <>
+struct S1Vec<float> {
+	static constexpr int V = 4;
+	typedef float4 vec;
+};
+template <>
+struct S1Vec<double> {
+	static constexpr int V = 2;
+	typedef double2 vec;
+};
+
+// V consecutive elements: one 16-byte load when the row is aligned, element loads otherwise (a template switch, not a branch: loads
+// that meet behind a branch are issued one after the other)
+template <typename T, int V, bool ALIGNED>
+__device__ __forceinline__ void s1_ld(const T* __restrict__ p, T (&v)[V]) {
+	if constexpr (ALIGNED) {
+		typedef T vt __attribute__((ext_vector_type(V)));
+		const vt t = *reinterpret_cast<const vt*>(p);
 #pragma unroll
-	for (int c = 0; c < S1_NCMAX; c++) a[c] = 0.0;
-	for (int64_t k = k0; k < k1; k++) {
-		const double v = (double)YT[k * ldy + y];
-		const double* ck = CT + k * nc;
+		for (int j = 0; j < V; j++) v[j] = t[j];
+	} else {
 #pragma unroll
-		for (int c = 0; c < S1_NCMAX; c++)
-			if (c < nc) a[c] = fma(v, ck[c], a[c]);
-		q = fma(v, v, q);
+		for (int j = 0; j < V; j++) v[j] = p[j];
 	}
-	double* o = part + ((int64_t)blockIdx.y * ny + y) * (nc + 1);
+}
+
+// cell codes: >= 0 position of the cell among the cells of the E_i (ordered by grouping), S1_COMMON a cell of N, S1_SKIP neither
+#define S1_COMMON (-2)
+#define S1_SKIP (-1)
+
+// One workgroup = R gene rows, every cell.  common[(comp0 + c) * ny + y] = sum over N of y C_c (c < NC); FIRST: common[qrow * ny + y] =
+// sum over N of y^2 and YE[pos][y] = y at the cell of position pos.  Rows past ny repeat row ny - 1 (their sums are not stored; their
+// values land in the padding columns of YE, ldye >= ny rounded up to 8).
+template <typename T, int NC, int R, bool ALIGNED, bool FIRST>
+__global__ void __launch_bounds__(256, 2) k_s1_stream(const T* __restrict__ Y, int64_t ldy, const double* __restrict__ C, int64_t ldc,
+													   const int32_t* __restrict__ code, int64_t n, int64_t ny, double* __restrict__ common,
+													   int comp0, int qrow, T* __restrict__ YE, int64_t ldye) {
+	constexpr int V = S1Vec<T>::V;
+	const int tid = threadIdx.x;
+	const int64_t y0 = (int64_t)blockIdx.x * R;
+	const T* row[R];
 #pragma unroll
-	for (int c = 0; c < S1_NCMAX; c++)
-		if (c < nc) o[c] = a[c];
-	o[nc] = q;
+	for (int r = 0; r < R; r++) row[r] = Y + (y0 + r < ny ? y0 + r : ny - 1) * ldy;
+	double a[R][NC > 0 ? NC : 1], q[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		q[r] = 0.0;
+#pragma unroll
+		for (int c = 0; c < NC; c++) a[r][c] = 0.0;
+	}
+	auto take = [&](const int32_t(&cd)[V], const double(&cv)[NC > 0 ? NC : 1][V], const T(&yv)[R][V], int lanes) {
+#pragma unroll
+		for (int v = 0; v < V; v++) {
+			if (v >= lanes) break;
+			const bool m = cd[v] == S1_COMMON;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const double yd = (double)yv[r][v];
+				const double ym = m ? yd : 0.0;
+				if constexpr (FIRST) q[r] = fma(ym, yd, q[r]);
+#pragma unroll
+				for (int c = 0; c < NC; c++) a[r][c] = fma(ym, cv[c][v], a[r][c]);
+			}
+			if constexpr (FIRST) {
+				if (cd[v] >= 0) {
+					typedef T st __attribute__((ext_vector_type(R)));
+					st o;
+#pragma unroll
+					for (int r = 0; r < R; r++) o[r] = yv[r][v];
+					*reinterpret_cast<st*>(YE + (int64_t)cd[v] * ldye + y0) = o;  // R values: R * sizeof(T) bytes, aligned (ldye % 8 == 0)
+				}
+			}
+		}
+	};
+	const int64_t groups = n / V;
+	for (int64_t g = tid; g < groups; g += 256) {
+		const int64_t k = g * V;
+		int32_t cd[V];
+		double cv[NC > 0 ? NC : 1][V];
+		T yv[R][V];
+		s1_ld<int32_t, V, ALIGNED>(code + k, cd);
+#pragma unroll
+		for (int c = 0; c < NC; c++) {
+			if constexpr (ALIGNED) {
+#pragma unroll
+				for (int h = 0; h < V; h += 2) {
+					const double2 t = *reinterpret_cast<const double2*>(C + c * ldc + k + h);
+					cv[c][h] = t.x;
+					cv[c][h + 1] = t.y;
+				}
+			} else {
+#pragma unroll
+				for (int h = 0; h < V; h++) cv[c][h] = C[c * ldc + k + h];
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < R; r++) s1_ld<T, V, ALIGNED>(row[r] + k, yv[r]);
+		take(cd, cv, yv, V);
+	}
+	{  // the last n % V cells: one cell each for the first few threads
+		const int64_t k = groups * V + tid;
+		if (k < n) {
+			int32_t cd[V];
+			double cv[NC > 0 ? NC : 1][V];
+			T yv[R][V];
+			cd[0] = code[k];
+#pragma unroll
+			for (int c = 0; c < NC; c++) cv[c][0] = C[c * ldc + k];
+#pragma unroll
+			for (int r = 0; r < R; r++) yv[r][0] = row[r][k];
+			take(cd, cv, yv, 1);
+		}
+	}
+	// sums of the 256 threads: within a wave, then the four waves in order
+	constexpr int NV = R * (NC + (FIRST ? 1 : 0));
+	__shared__ double red[4][NV > 0 ? NV : 1];
+	const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+#pragma unroll
+		for (int c = 0; c < NC; c++) {
+			double t = a[r][c];
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+			if (lane == 0) red[w][r * NC + c] = t;
+		}
+		if constexpr (FIRST) {
+			double t = q[r];
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+			if (lane == 0) red[w][R * NC + r] = t;
+		}
+	}
+	__syncthreads();
+	if (tid < NV) {
+		const double t = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+		const int r = tid < R * NC ? tid / (NC > 0 ? NC : 1) : tid - R * NC;
+		const int comp = tid < R * NC ? comp0 + tid % (NC > 0 ? NC : 1) : qrow;
+		if (y0 + r < ny) common[(int64_t)comp * ny + y0 + r] = t;
+	}
 }
 
-// common[y][0 .. nc] = the pieces added in order
-__global__ void __launch_bounds__(256) k_s1_common_sum(const double* __restrict__ part, int pieces, int64_t ny, int nw, double* __restrict__ common) {
-	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= ny * nw) return;
-	double acc = 0.0;
-	for (int p = 0; p < pieces; p++) acc += part[(int64_t)p * ny * nw + e];
-	common[e] = acc;
-}
-
+// The sweep: thread (grouping i, gene y) adds the cells of E_i to the sums over N and finishes the pair.
+//   YE (cells of the E_i, ldye) expression values, CE (cells, nc) fp64 covariates, xe (cells) the grouping's own value, seg[i] .. seg[i+1]
+//   the cells of grouping i; common[c * ny + y] (c < nc), common[qrow * ny + y] from k_s1_stream.
 template <typename T, typename OutT>
-__global__ void __launch_bounds__(256) k_s1_sparse(const T* __restrict__ YT, int64_t ldy, const double* __restrict__ CT, const double* __restrict__ xp,
-													const int64_t* __restrict__ seg, const double* __restrict__ common, const double* __restrict__ info,
-													int64_t info_pitch, int nc, int64_t nx, int64_t ny, int return_dot, OutT* __restrict__ p_out,
-													OutT* __restrict__ stat_out, OutT* __restrict__ vary_out, OutT* __restrict__ alpha_out, int64_t ldo,
-													int32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(256) k_s1_cells(const T* __restrict__ YE, int64_t ldye, const double* __restrict__ CE, const double* __restrict__ xe,
+												   const int64_t* __restrict__ seg, const double* __restrict__ common, int qrow,
+												   const double* __restrict__ info, int64_t info_pitch, int nc, int64_t nx, int64_t ny, int return_dot,
+												   OutT* __restrict__ p_out, OutT* __restrict__ stat_out, OutT* __restrict__ vary_out,
+												   OutT* __restrict__ alpha_out, int64_t ldo, int32_t* __restrict__ flags) {
 	const int64_t i = blockIdx.y;
 	const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (y >= ny) return;
@@ -144,17 +261,32 @@ __global__ void __launch_bounds__(256) k_s1_sparse(const T* __restrict__ YT, int
 	const double* ccx = rec + S1_HEAD;
 	const double* mi = ccx + nc;
 	// a = y C_S^T, xy = y . x_S, q = |y_S|^2: the common part (x is 0 on N) plus this grouping's own cells
-	const double* cm = common + y * (nc + 1);
-	double a[S1_NCMAX], xy = 0.0, q = cm[nc];
+	double a[S1_NCMAX], xy = 0.0, q = common[(int64_t)qrow * ny + y];
 #pragma unroll
-	for (int c = 0; c < S1_NCMAX; c++) a[c] = c < nc ? cm[c] : 0.0;
-	for (int64_t k = seg[i]; k < seg[i + 1]; k++) {
-		const double v = (double)YT[k * ldy + y];
-		const double* ck = CT + k * nc;
+	for (int c = 0; c < S1_NCMAX; c++) a[c] = c < nc ? common[(int64_t)c * ny + y] : 0.0;
+	int64_t k = seg[i];
+	const int64_t k1 = seg[i + 1];
+	for (; k + 4 <= k1; k += 4) {  // four cells per step: their loads are in flight together
+		double v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) v[u] = (double)YE[(k + u) * ldye + y];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const double* ck = CE + (k + u) * nc;
+#pragma unroll
+			for (int c = 0; c < S1_NCMAX; c++)
+				if (c < nc) a[c] = fma(v[u], ck[c], a[c]);
+			xy = fma(v[u], xe[k + u], xy);
+			q = fma(v[u], v[u], q);
+		}
+	}
+	for (; k < k1; k++) {
+		const double v = (double)YE[k * ldye + y];
+		const double* ck = CE + k * nc;
 #pragma unroll
 		for (int c = 0; c < S1_NCMAX; c++)
 			if (c < nc) a[c] = fma(v, ck[c], a[c]);
-		xy = fma(v, xp[k], xy);
+		xy = fma(v, xe[k], xy);
 		q = fma(v, v, q);
 	}
 	double ady = 0.0, adx = 0.0;  // a.ccy, a.ccx
@@ -194,35 +326,73 @@ __global__ void __launch_bounds__(256) k_s1_sparse(const T* __restrict__ YT, int
 	}
 }
 
-extern "C" int64_t nrm_single1_sparse_workspace_doubles(int64_t ny, int64_t nc, int64_t n_common) {
-	return ny * (nc + 1) * ((n_common + S1_PIECE - 1) / S1_PIECE + 1);
+template <typename T, int NC, int R, bool FIRST>
+static void s1_stream_go(const void* d_y, int64_t ldy, const double* d_c, int64_t ldc, const int32_t* d_code, int64_t n, int64_t ny, double* d_common,
+						 int comp0, int qrow, void* d_ye, int64_t ldye, hipStream_t st) {
+	const bool aligned = ((uintptr_t)d_y % 16 == 0) && (ldy * sizeof(T)) % 16 == 0 && ((uintptr_t)d_code % 16 == 0) &&
+						 (NC == 0 || (((uintptr_t)d_c % 16 == 0) && ldc % 2 == 0));
+	const dim3 grid((unsigned)((ny + R - 1) / R));
+	if (aligned)
+		hipLaunchKernelGGL((k_s1_stream<T, NC, R, true, FIRST>), grid, dim3(256), 0, st, (const T*)d_y, ldy, d_c, ldc, d_code, n, ny, d_common, comp0, qrow,
+						   (T*)d_ye, ldye);
+	else
+		hipLaunchKernelGGL((k_s1_stream<T, NC, R, false, FIRST>), grid, dim3(256), 0, st, (const T*)d_y, ldy, d_c, ldc, d_code, n, ny, d_common, comp0, qrow,
+						   (T*)d_ye, ldye);
 }
 
-extern "C" int nrm_single1_sparse(const void* d_yt, int y_dtype, int64_t ldy, const double* d_ct, const double* d_xp, const int64_t* d_seg,
-								  int64_t n_common, const double* d_info, int64_t info_pitch, int64_t nc, int64_t nx, int64_t ny, int return_dot,
-								  void* d_p, void* d_stat, void* d_vary, void* d_alpha, int out_dtype, int64_t ldo, double* d_work, int32_t* d_flags,
-								  void* stream) {
-	NRM_REQUIRE(nx > 0 && ny > 0 && nc >= 0 && nc <= S1_NCMAX && n_common >= 0, "nrm_single1_sparse: bad sizes (at most %d covariates)", S1_NCMAX);
-	NRM_REQUIRE(info_pitch >= S1_HEAD + nc + nc * nc && ldo >= ny && ldy >= ny, "nrm_single1_sparse: pitch too small");
-	NRM_REQUIRE((y_dtype == NRM_F32 || y_dtype == NRM_F64) && (out_dtype == NRM_F32 || out_dtype == NRM_F64), "nrm_single1_sparse: bad dtype");
-	NRM_REQUIRE(d_yt && d_xp && d_seg && d_info && d_p && d_stat && d_vary && d_work && (d_ct || nc == 0), "nrm_single1_sparse: null pointer");
-	hipStream_t st = (hipStream_t)stream;
-	const int nw = (int)nc + 1;
-	const int pieces = (int)((n_common + S1_PIECE - 1) / S1_PIECE);
-	double* common = d_work;                 // (ny, nc + 1)
-	double* part = d_work + ny * nw;         // (pieces, ny, nc + 1)
-	const unsigned gy = (unsigned)((ny + 255) / 256);
-	if (pieces > 0) {
-		if (y_dtype == NRM_F64)
-			hipLaunchKernelGGL(k_s1_common<double>, dim3(gy, (unsigned)pieces), dim3(256), 0, st, (const double*)d_yt, ldy, d_ct, (int)nc, n_common, ny, part);
-		else
-			hipLaunchKernelGGL(k_s1_common<float>, dim3(gy, (unsigned)pieces), dim3(256), 0, st, (const float*)d_yt, ldy, d_ct, (int)nc, n_common, ny, part);
+template <typename T>
+static int s1_stream(const void* d_y, int64_t ldy, const double* d_c, int64_t ldc, int64_t nc, const int32_t* d_code, int64_t n, int64_t ny,
+					 double* d_common, void* d_ye, int64_t ldye, hipStream_t st) {
+	const int qrow = (int)nc;
+#define S1_FIRST(NC, R)                                                                                           \
+	case NC:                                                                                                      \
+		s1_stream_go<T, NC, R, true>(d_y, ldy, d_c, ldc, d_code, n, ny, d_common, 0, qrow, d_ye, ldye, st); \
+		break;
+	const int first = (int)(nc <= S1_NCB ? nc : S1_NCB);
+	switch (first) {
+		S1_FIRST(0, 8)
+		S1_FIRST(1, 8)
+		S1_FIRST(2, 8)
+		S1_FIRST(3, 8)
+		S1_FIRST(4, 8)
+		S1_FIRST(5, 8)
+		S1_FIRST(6, 4)
+		S1_FIRST(7, 4)
+		S1_FIRST(8, 4)
 	}
-	hipLaunchKernelGGL(k_s1_common_sum, dim3((unsigned)((ny * nw + 255) / 256)), dim3(256), 0, st, part, pieces, ny, nw, common);
-	const dim3 grid(gy, (unsigned)nx);
-#define S1_GO(T, O)                                                                                                                         \
-	hipLaunchKernelGGL((k_s1_sparse<T, O>), grid, dim3(256), 0, st, (const T*)d_yt, ldy, d_ct, d_xp, d_seg, common, d_info, info_pitch, (int)nc, nx, \
-					   ny, return_dot, (O*)d_p, (O*)d_stat, (O*)d_vary, (O*)d_alpha, ldo, d_flags)
+#undef S1_FIRST
+	// further covariates, up to eight per pass over the expression rows (the last pass may reach back over covariates already done:
+	// the same sums, stored twice)
+	for (int64_t c0 = S1_NCB; c0 < nc; c0 += S1_NCB) {
+		const int64_t b = c0 + S1_NCB <= nc ? c0 : nc - S1_NCB;
+		s1_stream_go<T, S1_NCB, 4, false>(d_y, ldy, d_c + b * ldc, ldc, d_code, n, ny, d_common, (int)b, qrow, nullptr, ldye, st);
+	}
+	return nrm_check_launch("k_s1_stream");
+}
+
+extern "C" int nrm_single1_stream(const void* d_y, int y_dtype, int64_t ldy, const double* d_c, int64_t ldc, int64_t nc, const int32_t* d_code,
+								  int64_t n, int64_t ny, double* d_common, void* d_ye, int64_t ldye, void* stream) {
+	NRM_REQUIRE(n > 0 && ny > 0 && nc >= 0 && nc <= S1_NCMAX, "nrm_single1_stream: bad sizes (at most %d covariates)", S1_NCMAX);
+	NRM_REQUIRE(y_dtype == NRM_F32 || y_dtype == NRM_F64, "nrm_single1_stream: bad dtype");
+	NRM_REQUIRE(ldy >= n && (nc == 0 || ldc >= n) && ldye >= ny && ldye % 8 == 0, "nrm_single1_stream: bad pitch (ldye: a multiple of 8, at least ny)");
+	NRM_REQUIRE(d_y && d_code && d_common && d_ye && (d_c || nc == 0), "nrm_single1_stream: null pointer");
+	NRM_REQUIRE((uintptr_t)d_ye % 64 == 0, "nrm_single1_stream: d_ye must be 64-byte aligned");
+	if (y_dtype == NRM_F64) return s1_stream<double>(d_y, ldy, d_c, ldc, nc, d_code, n, ny, d_common, d_ye, ldye, (hipStream_t)stream);
+	return s1_stream<float>(d_y, ldy, d_c, ldc, nc, d_code, n, ny, d_common, d_ye, ldye, (hipStream_t)stream);
+}
+
+extern "C" int nrm_single1_cells(const void* d_ye, int y_dtype, int64_t ldye, const double* d_ce, const double* d_xe, const int64_t* d_seg,
+								 const double* d_common, const double* d_info, int64_t info_pitch, int64_t nc, int64_t nx, int64_t ny, int return_dot,
+								 void* d_p, void* d_stat, void* d_vary, void* d_alpha, int out_dtype, int64_t ldo, int32_t* d_flags, void* stream) {
+	NRM_REQUIRE(nx > 0 && ny > 0 && nc >= 0 && nc <= S1_NCMAX, "nrm_single1_cells: bad sizes (at most %d covariates)", S1_NCMAX);
+	NRM_REQUIRE(info_pitch >= S1_HEAD + nc + nc * nc && ldo >= ny && ldye >= ny, "nrm_single1_cells: pitch too small");
+	NRM_REQUIRE((y_dtype == NRM_F32 || y_dtype == NRM_F64) && (out_dtype == NRM_F32 || out_dtype == NRM_F64), "nrm_single1_cells: bad dtype");
+	NRM_REQUIRE(d_ye && d_xe && d_seg && d_common && d_info && d_p && d_stat && d_vary && (d_ce || nc == 0), "nrm_single1_cells: null pointer");
+	hipStream_t st = (hipStream_t)stream;
+	const dim3 grid((unsigned)((ny + 255) / 256), (unsigned)nx);
+#define S1_GO(T, O)                                                                                                                              \
+	hipLaunchKernelGGL((k_s1_cells<T, O>), grid, dim3(256), 0, st, (const T*)d_ye, ldye, d_ce, d_xe, d_seg, d_common, (int)nc, d_info, info_pitch, \
+					   (int)nc, nx, ny, return_dot, (O*)d_p, (O*)d_stat, (O*)d_vary, (O*)d_alpha, ldo, d_flags)
 	if (y_dtype == NRM_F64) {
 		if (out_dtype == NRM_F64)
 			S1_GO(double, double);
@@ -235,5 +405,5 @@ extern "C" int nrm_single1_sparse(const void* d_yt, int y_dtype, int64_t ldy, co
 			S1_GO(float, float);
 	}
 #undef S1_GO
-	return nrm_check_launch("k_s1_sparse");
+	return nrm_check_launch("k_s1_cells");
 }

@@ -150,39 +150,56 @@ def _segment_sums(v, starts, counts):
 def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out=False):
 	"""single=1 for a design with entries >= 0 (csrc/nrm_single1.hip, second half): the cells every grouping shares (all of dx is 0)
 	are summed once per gene, each grouping adds its own few cells inside the sweep; no masked Gram contraction, no loop over chunks
-	of groupings.  The statistics of the groupings themselves (M_i = C_S C_S^T, C_S x_S, |x_S|^2: association.py:350-364) are taken on
-	the host from the same decomposition, in a fixed order."""
+	of groupings, no transposed copy of the expression matrix (the stream kernel reads it once, where it lies).  The statistics of the
+	groupings themselves (M_i = C_S C_S^T, C_S x_S, |x_S|^2: association.py:350-364) are taken on the host from the same decomposition,
+	in a fixed order, WHILE the stream kernel runs."""
 	torch = eng.torch
+	from .single4 import _Marks
+	mark = _Marks(eng, 'NRM_S1_TRACE', 'single=1')
+	mark('selection')
 	nzm = d_dx != 0
 	cnt = nzm.sum(dim=0)
-	idx_n = torch.nonzero(cnt == 0).flatten()
+	is_common = cnt == 0
 	idx_e = torch.nonzero(cnt == 1).flatten()
 	owner = torch.argmax(nzm[:, idx_e].to(torch.int8), dim=0)
 	order = torch.argsort(owner, stable=True)
 	idx_e, owner = idx_e[order], owner[order]
-	n_common = int(idx_n.numel())
-	perm = torch.cat([idx_n, idx_e])
-	counts = torch.bincount(owner, minlength=nx).cpu().numpy()
-	seg = np.concatenate([[0], np.cumsum(counts)]) + n_common
-	xp = torch.cat([torch.zeros(n_common, dtype=torch.float64, device=eng.device), d_dx[owner, idx_e].to(torch.float64)])
+	n_e = int(idx_e.numel())
+	code = torch.where(is_common, _lib.NRM_S1_COMMON, _lib.NRM_S1_SKIP).to(torch.int32)
+	code[idx_e] = torch.arange(n_e, dtype=torch.int32, device=eng.device)
+	xe_d = d_dx[owner, idx_e].to(torch.float64) if n_e else torch.zeros(1, dtype=torch.float64, device=eng.device)
+	mark('cell order')
+	# the device's share first: it needs nothing of the host's
+	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
+	d_c = eng.upload(c64) if nc else None
+	ldye = _round_up(ny, 8)
+	ye = torch.empty((max(n_e, 1), ldye), dtype=d_y.dtype, device=eng.device)
+	common = torch.empty((nc + 1, ny), dtype=torch.float64, device=eng.device)
+	ycode = _lib.NRM_F64 if d_y.dtype == torch.float64 else _lib.NRM_F32
+	_lib.check(eng.lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), 0 if d_c is None else d_c.data_ptr(), n, nc, code.data_ptr(), n, ny,
+										  common.data_ptr(), ye.data_ptr(), ldye, eng._stream()))
 	# grouping-side statistics on the host
-	perm_h = perm.cpu().numpy()
-	xe = xp[n_common:].cpu().numpy()
-	cp = c64[:, perm_h]  # (nc, cells in the permuted order)
-	starts = (seg[:-1] - n_common).astype(np.int64)
+	if nc:  # covariate Gram of the shared cells (element-wise and in a fixed order: no BLAS, on either side)
+		cm = d_c * is_common
+		mcc = (cm[:, None, :] * d_c[None, :, :]).sum(dim=2).cpu().numpy()
+	counts = torch.bincount(owner, minlength=nx).cpu().numpy()
+	seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+	idx_h = idx_e.cpu().numpy()
+	xe = xe_d.cpu().numpy()[:n_e]
+	starts = seg[:-1]
 	pitch = 26 + nc + nc * nc
 	info = np.zeros((nx, pitch))
 	xx = _segment_sums(xe * xe, starts, counts)
 	rk = np.zeros(nx, dtype=np.int64)
+	mark('downloads')
+	ce = c64[:, idx_h]  # (nc, cells of the E_i in the order of the groupings)
 	if nc:
-		ce = cp[:, n_common:]
-		cpc = cp[:, :n_common]
-		# (element-wise, not BLAS: a (nc x cells) x (cells x nc) product handed to a many-core BLAS pool costs tens of ms of thread wake-ups)
-		mcc = np.array([[float((cpc[a] * cpc[b]).sum()) for b in range(nc)] for a in range(nc)])
 		mc = mcc[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
 		xc = _segment_sums(ce * xe, starts, counts).T  # (nx, nc)
+		mark('host sums')
 		mi, rk = inv_rank(mc)  # association.py:350-351
 		mi[rk == 0] = 0
+		mark('inv_rank')
 		ccx = np.einsum('icd,id->ic', mi, xc)
 		info[:, 26:26 + nc] = ccx
 		info[:, 26 + nc:] = mi.reshape(nx, nc * nc)
@@ -195,25 +212,22 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 	info[:, 0], info[:, 1] = ns, vxx
 	dof = np.ascontiguousarray(dof, dtype=np.float64)
 	_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, nx, info.ctypes.data + 16, pitch))
-	# the expression matrix: uploaded in its own dtype, the cells that matter gathered in the permuted order, transposed
-	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
-	yt = d_y.index_select(1, perm).t().contiguous()  # (cells, ny)
-	del d_y
-	ct = eng.upload(np.ascontiguousarray(cp.T)) if nc else None
+	mark('p-value plans')
+	d_ce = eng.upload(np.ascontiguousarray(ce.T)) if nc else None
 	p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	alpha = None if lowmem else torch.zeros((nx, ny, nc), dtype=tdt, device=eng.device)
 	flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
-	work = torch.empty((int(eng.lib.nrm_single1_sparse_workspace_doubles(ny, nc, n_common)), ), dtype=torch.float64, device=eng.device)
-	d_seg = eng.upload(np.ascontiguousarray(seg, dtype=np.int64))
+	d_seg = eng.upload(seg)
 	d_info = eng.upload(info)
-	code = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
-	_lib.check(eng.lib.nrm_single1_sparse(yt.data_ptr(), _lib.NRM_F64 if yt.dtype == torch.float64 else _lib.NRM_F32, yt.stride(0),
-										  0 if ct is None else ct.data_ptr(), xp.data_ptr(), d_seg.data_ptr(), n_common, d_info.data_ptr(), pitch, nc, nx, ny,
-										  1 if return_dot else 0, p.data_ptr(), stat.data_ptr(), vary.data_ptr(), 0 if alpha is None else alpha.data_ptr(),
-										  code, ny, work.data_ptr(), flags.data_ptr(), eng._stream()))
+	code_o = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
+	_lib.check(eng.lib.nrm_single1_cells(ye.data_ptr(), ycode, ldye, 0 if d_ce is None else d_ce.data_ptr(), xe_d.data_ptr(), d_seg.data_ptr(),
+										 common.data_ptr(), d_info.data_ptr(), pitch, nc, nx, ny, 1 if return_dot else 0, p.data_ptr(), stat.data_ptr(),
+										 vary.data_ptr(), 0 if alpha is None else alpha.data_ptr(), code_o, ny, flags.data_ptr(), eng._stream()))
 	eng.check_flags(flags)
+	mark('sweep')
+	mark.report()
 	if device_out:
 		return (p, stat, alpha, vxx.astype(out_dtype), vary)
 	return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), vxx.astype(out_dtype), eng.download(vary))

@@ -194,11 +194,12 @@ def _is_dev(a):
 
 
 class _Marks:
-	"""NRM_S4_TRACE=1: wall-clock of the phases of a single=4 call, each closed by a device synchronisation (profiling aid)."""
+	"""NRM_S4_TRACE=1 (NRM_S1_TRACE=1 from single1.py): wall-clock of the phases of a call, each closed by a device synchronisation (profiling aid)."""
 
-	def __init__(self, eng):
+	def __init__(self, eng, env='NRM_S4_TRACE', label='single=4'):
 		import time
-		self.on = os.environ.get('NRM_S4_TRACE', '') == '1'
+		self.on = os.environ.get(env, '') == '1'
+		self.label = label
 		self.eng, self.clock, self.rows = eng, time.perf_counter, []
 		self.t = self.clock()
 
@@ -211,7 +212,7 @@ class _Marks:
 
 	def report(self):
 		if self.on:
-			logging.warning('single=4 phases (ms): ' + ', '.join('%s %.2f' % r for r in self.rows))
+			logging.warning(self.label + ' phases (ms): ' + ', '.join('%s %.2f' % r for r in self.rows))
 
 
 def _spd_inverse_device(eng, m_d, nx):

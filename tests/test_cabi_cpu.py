@@ -169,3 +169,22 @@ def test_host_mirror_rows(dtype):
 			assert np.array_equal(h, want), (threads, a, b)
 	with pytest.raises(ValueError):
 		_lib.check(lib.nrm_host_mirror_rows(h.ctypes.data, 8, h.itemsize, 3, 9, 1))
+
+
+def test_pvalue_plans_of_a_screen_are_cheap():
+	"""A single=1 screen asks for one P-value plan per grouping (nrm_pvalue_plan_init_many): 1000 of them took 25 ms with powl() in the
+	inner loops; the tables of half-integer products are built once now.  The plans still satisfy G12-level accuracy (checked by the
+	parity tests); here: the time, and that a plan does not depend on what was asked before."""
+	import time
+	from normalisr_amd import _lib
+	lib = _lib.load()
+	dof = np.ascontiguousarray(np.arange(30, 30 + 4000, dtype=np.float64))
+	out = np.zeros((dof.size, 24))
+	lib.nrm_pvalue_plan_init_many(dof.ctypes.data, 1, out.ctypes.data, 24)
+	t0 = time.perf_counter()
+	assert lib.nrm_pvalue_plan_init_many(dof.ctypes.data, dof.size, out.ctypes.data, 24) == 0
+	dt = time.perf_counter() - t0
+	assert dt < 0.02, dt  # 5 us per plan at most
+	again = np.zeros((1, 24))
+	lib.nrm_pvalue_plan_init_many(dof[1234:].ctypes.data, 1, again.ctypes.data, 24)
+	assert np.array_equal(again[0], out[1234])

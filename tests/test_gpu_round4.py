@@ -386,3 +386,38 @@ def test_config3_exact_shape_as_de_covariate():
 	assert po.min() < 1e-20
 	assert close(take(p), po, 2e-5, 1e-38) and close(take(gam), go, 2e-5, 1e-7) and close(take(vy), vyo, 2e-5)  # (fp32 outputs)
 	assert close(vx[xs], vxo, 1e-6)
+
+
+@pytest.mark.parametrize('dtype,nc,n,ny', [(np.float32, 5, 6003, 301), (np.float64, 12, 6001, 13), (np.float32, 8, 6000, 64), (np.float64, 9, 6002, 100),
+										   (np.float64, 20, 5999, 9)])
+def test_single1_streams_the_expression_matrix_once(dtype, nc, n, ny):
+	"""single=1 without a transposed copy of the expression matrix (csrc/nrm_single1.hip k_s1_stream + k_s1_cells): rows that are not
+	16-byte aligned (n % 4 != 0: the element-load instantiation), gene counts that are not a multiple of the 8 (4) rows a workgroup takes,
+	5 / 8 / 9 / 12 / 20 covariates (one pass, one full pass, several passes of which the last reaches back), device-resident inputs and
+	outputs; against the oracle (association.py:263-390)."""
+	import torch
+	from normalisr_amd.association import association_tests
+	from normalisr_amd.single1 import association_tests_single1
+	rng = np.random.default_rng(500 + nc)
+	nx = 23
+	lab = rng.integers(0, nx + 20, n)
+	dg = np.zeros((nx, n))
+	has = lab < nx
+	dg[lab[has], np.nonzero(has)[0]] = 1.0
+	dbl = rng.choice(np.nonzero(has)[0], 150, replace=False)
+	dg[rng.integers(0, nx, 150), dbl] = 1.0
+	dg[2, np.nonzero(lab == 2)[0][::3]] = 0.25
+	dt = (rng.normal(size=(ny, n)) + 0.5 * dg[rng.integers(0, nx, ny)] * rng.normal(size=(ny, 1))).astype(dtype)
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+	ref = oracle.association_tests(dg, dt.astype(np.float64), dc, single=1, lowmem=False, return_dot=False)
+	f32 = dtype == np.float32
+	out = association_tests(dg, dt, dc, single=1, lowmem=False, return_dot=False)
+	dev = association_tests_single1(torch.as_tensor(dg.astype(dtype)).cuda(), torch.as_tensor(dt).cuda(), dc, lowmem=False, return_dot=False, device_out=True)
+	dev = tuple(v.cpu().numpy() if hasattr(v, 'is_cuda') else v for v in dev)
+	for p, gam, a, vx, vy in (out, dev):
+		ok = ref[0] > (1e-30 if f32 else 1e-290)
+		assert relerr(p[ok], ref[0][ok]) < (2e-4 if f32 else 1e-8)
+		assert close(gam, ref[1], 2e-5 if f32 else 1e-9, 1e-6 if f32 else 1e-12) and close(vy, ref[4], 2e-6 if f32 else 1e-10)
+		assert close(vx, ref[3], 2e-6 if f32 else 1e-10)
+		assert close(a, ref[2], 2e-4 if f32 else 1e-8, 1e-5 if f32 else 1e-10)
+	assert np.array_equal(out[0], dev[0])  # the same kernels on the same values, wherever the inputs lay
