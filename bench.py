@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r04.sh), newest first
 PMC_FILES = {w: [os.path.join(ROOT, 'profiles', f) for f in fs] for w, fs in dict(
 	coex_c2=('r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r04_pmc_de_c3.json', 'r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
-	de_c4=('r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'), de_c4_single4=('r04_pmc_de_c4_single4.json', ),
+	de_c4=('r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'), de_c4_single4=('r04_pmc_de_c4_single4.json', ), de_c4_single1=('r04_pmc_de_c4_single1.json', ),
 	binnet_c5=('r04_pmc_binnet_c5.json', )).items()}
 
 
@@ -526,10 +526,12 @@ def bench_de_method(rk, steps, warmup, single):
 		roof['step_ms'] = ms
 		dtype = ARITH(n)
 	else:
-		byts = 4.0 * n * ny_local  # every fp32 expression value read once
-		roof = dict(bound='hbm', kernel='k_s1_common + k_s1_sparse (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
-					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms,
-					note='the step also transposes the expression rows in the permuted cell order (torch index_select: plumbing) and takes 1000 small host SVDs')
+		kept = int(getattr(eng, 's1_cells_kept', 0))
+		byts = 4.0 * ny_local * (n + kept)  # every fp32 expression value read once + the values at the cells that carry one gRNA written once (transposed)
+		kms = split.get('s1_stream', ms)
+		roof = dict(bound='hbm', kernel='k_s1_stream', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+					frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms, cells_with_one_grna=kept,
+					note='the stream kernel runs beside the host\'s 1000 small SVDs (the statistics of the gRNAs themselves: inv_rank, association.py:350-351); a step is bound by those, not by the device')
 		dtype = 'f64'
 	return dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=ms, scaling='strong', dtype=dtype,
 				config=dict(workload='norm.de(single={}) {} gRNAs x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[3] as `normalisr de -m {}`, examples/GSE120861/code/cmd_highmoi.sh)'.format(
@@ -695,8 +697,8 @@ def main():
 			return bench_c5_full(rk)
 		if which in ('de_c4_single4', 'de_c4_single1'):
 			out = bench_de_method(rk, steps, warmup, 4 if which.endswith('4') else 1)
-			if world == 1 and which == 'de_c4_single4':
-				pmc_traffic(which, out['roofline'], kernel='k_gram_i8')
+			if world == 1:
+				pmc_traffic(which, out['roofline'], kernel='k_gram_i8' if which == 'de_c4_single4' else 'k_s1_stream')
 			return out
 		if which == 'binnet_c5':
 			out = bench_binnet(rk, steps, warmup)

@@ -128,13 +128,21 @@ __device__ __forceinline__ void s1_ld(const T* __restrict__ p, T (&v)[V]) {
 // One workgroup = R gene rows, every cell.  common[(comp0 + c) * ny + y] = sum over N of y C_c (c < NC); FIRST: common[qrow * ny + y] =
 // sum over N of y^2 and YE[pos][y] = y at the cell of position pos.  Rows past ny repeat row ny - 1 (their sums are not stored; their
 // values land in the padding columns of YE, ldye >= ny rounded up to 8).
+// (Measured and not kept: YE in blocks of R rows with the positions in the order of the cells, so that a wave's stores are one
+// contiguous piece -- this kernel 1.28 -> 1.06 ms, but the sweep then gathers 32-byte pieces: 0.35 -> 0.78 ms, and the sweep is the
+// one the host waits for.)
 template <typename T, int NC, int R, bool ALIGNED, bool FIRST>
 __global__ void __launch_bounds__(256, 2) k_s1_stream(const T* __restrict__ Y, int64_t ldy, const double* __restrict__ C, int64_t ldc,
 													   const int32_t* __restrict__ code, int64_t n, int64_t ny, double* __restrict__ common,
 													   int comp0, int qrow, T* __restrict__ YE, int64_t ldye) {
 	constexpr int V = S1Vec<T>::V;
 	const int tid = threadIdx.x;
-	const int64_t y0 = (int64_t)blockIdx.x * R;
+	// Workgroups are dealt to the 8 XCDs in turn; blocks of rows that are neighbours in YE (their R values of a cell share a 128-byte
+	// line) go to the SAME XCD one after the other, so that the pieces of a line meet in one L2 before it is written back (1.50 -> 1.28 ms).
+	const int64_t per = (gridDim.x + 7) / 8;
+	const int64_t blk = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+	const int64_t y0 = blk * R;
+	if (y0 >= ny) return;
 	const T* row[R];
 #pragma unroll
 	for (int r = 0; r < R; r++) row[r] = Y + (y0 + r < ny ? y0 + r : ny - 1) * ldy;
@@ -240,12 +248,21 @@ __global__ void __launch_bounds__(256, 2) k_s1_stream(const T* __restrict__ Y, i
 // The sweep: thread (grouping i, gene y) adds the cells of E_i to the sums over N and finishes the pair.
 //   YE (cells of the E_i, ldye) expression values, CE (cells, nc) fp64 covariates, xe (cells) the grouping's own value, seg[i] .. seg[i+1]
 //   the cells of grouping i; common[c * ny + y] (c < nc), common[qrow * ny + y] from k_s1_stream.
-template <typename T, typename OutT>
+// NCT: the number of covariates when it is at most 8 (loops unrolled, sums in registers without predicates: the generic form spends
+// its time on 32 compare-and-branch pairs per cell), -1: any number up to S1_NCMAX.
+template <typename OutT>
+__device__ __forceinline__ void s1_put(void* base, int64_t o, double v) {
+	reinterpret_cast<OutT*>(base)[o] = (OutT)v;
+}
+
+template <typename T, int NCT>
 __global__ void __launch_bounds__(256) k_s1_cells(const T* __restrict__ YE, int64_t ldye, const double* __restrict__ CE, const double* __restrict__ xe,
 												   const int64_t* __restrict__ seg, const double* __restrict__ common, int qrow,
-												   const double* __restrict__ info, int64_t info_pitch, int nc, int64_t nx, int64_t ny, int return_dot,
-												   OutT* __restrict__ p_out, OutT* __restrict__ stat_out, OutT* __restrict__ vary_out,
-												   OutT* __restrict__ alpha_out, int64_t ldo, int32_t* __restrict__ flags) {
+												   const double* __restrict__ info, int64_t info_pitch, int nc_rt, int64_t nx, int64_t ny, int return_dot,
+												   void* __restrict__ p_out, void* __restrict__ stat_out, void* __restrict__ vary_out,
+												   void* __restrict__ alpha_out, int out_f64, int64_t ldo, int32_t* __restrict__ flags) {
+	constexpr int NA = NCT >= 0 ? (NCT > 0 ? NCT : 1) : S1_NCMAX;
+	const int nc = NCT >= 0 ? NCT : nc_rt;
 	const int64_t i = blockIdx.y;
 	const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (y >= ny) return;
@@ -261,9 +278,9 @@ __global__ void __launch_bounds__(256) k_s1_cells(const T* __restrict__ YE, int6
 	const double* ccx = rec + S1_HEAD;
 	const double* mi = ccx + nc;
 	// a = y C_S^T, xy = y . x_S, q = |y_S|^2: the common part (x is 0 on N) plus this grouping's own cells
-	double a[S1_NCMAX], xy = 0.0, q = common[(int64_t)qrow * ny + y];
+	double a[NA], xy = 0.0, q = common[(int64_t)qrow * ny + y];
 #pragma unroll
-	for (int c = 0; c < S1_NCMAX; c++) a[c] = c < nc ? common[(int64_t)c * ny + y] : 0.0;
+	for (int c = 0; c < NA; c++) a[c] = c < nc ? common[(int64_t)c * ny + y] : 0.0;
 	int64_t k = seg[i];
 	const int64_t k1 = seg[i + 1];
 	for (; k + 4 <= k1; k += 4) {  // four cells per step: their loads are in flight together
@@ -274,7 +291,7 @@ __global__ void __launch_bounds__(256) k_s1_cells(const T* __restrict__ YE, int6
 		for (int u = 0; u < 4; u++) {
 			const double* ck = CE + (k + u) * nc;
 #pragma unroll
-			for (int c = 0; c < S1_NCMAX; c++)
+			for (int c = 0; c < NA; c++)
 				if (c < nc) a[c] = fma(v[u], ck[c], a[c]);
 			xy = fma(v[u], xe[k + u], xy);
 			q = fma(v[u], v[u], q);
@@ -284,23 +301,36 @@ __global__ void __launch_bounds__(256) k_s1_cells(const T* __restrict__ YE, int6
 		const double v = (double)YE[k * ldye + y];
 		const double* ck = CE + k * nc;
 #pragma unroll
-		for (int c = 0; c < S1_NCMAX; c++)
+		for (int c = 0; c < NA; c++)
 			if (c < nc) a[c] = fma(v, ck[c], a[c]);
 		xy = fma(v, xe[k], xy);
 		q = fma(v, v, q);
 	}
 	double ady = 0.0, adx = 0.0;  // a.ccy, a.ccx
-	for (int c = 0; c < nc; c++) {
-		double ccy = 0.0;
+	double ccy_[NCT > 0 ? NCT : 1];
+	if constexpr (NCT >= 0) {
 #pragma unroll
-		for (int e = 0; e < S1_NCMAX; e++)
-			if (e < nc) ccy = fma(mi[c * nc + e], a[e], ccy);
-		double ac = 0.0;
+		for (int c = 0; c < NCT; c++) {
+			double ccy = 0.0;
 #pragma unroll
-		for (int e = 0; e < S1_NCMAX; e++)
-			if (e == c) ac = a[e];
-		ady = fma(ac, ccy, ady);
-		adx = fma(ac, ccx[c], adx);
+			for (int e = 0; e < NCT; e++) ccy = fma(mi[c * NCT + e], a[e], ccy);
+			ccy_[c] = ccy;
+			ady = fma(a[c], ccy, ady);
+			adx = fma(a[c], ccx[c], adx);
+		}
+	} else {
+		for (int c = 0; c < nc; c++) {
+			double ccy = 0.0;
+#pragma unroll
+			for (int e = 0; e < NA; e++)
+				if (e < nc) ccy = fma(mi[c * nc + e], a[e], ccy);
+			double ac = 0.0;
+#pragma unroll
+			for (int e = 0; e < NA; e++)
+				if (e == c) ac = a[e];
+			ady = fma(ac, ccy, ady);
+			adx = fma(ac, ccx[c], adx);
+		}
 	}
 	const double yy = q - ady;
 	xy -= adx;
@@ -312,16 +342,33 @@ __global__ void __launch_bounds__(256) k_s1_cells(const T* __restrict__ YE, int6
 		else if (r2 > 1.0 + 1e-8) atomicAdd(&flags[1], 1);
 	}
 	const int64_t o = i * ldo + y;
-	p_out[o] = (OutT)nrm_pvalue(r2, pl);
-	stat_out[o] = (OutT)(return_dot ? gam * vx : gam);
-	vary_out[o] = (OutT)vy;
+	const double pv = nrm_pvalue(r2, pl), st = return_dot ? gam * vx : gam;
+	if (out_f64) {
+		s1_put<double>(p_out, o, pv);
+		s1_put<double>(stat_out, o, st);
+		s1_put<double>(vary_out, o, vy);
+	} else {
+		s1_put<float>(p_out, o, pv);
+		s1_put<float>(stat_out, o, st);
+		s1_put<float>(vary_out, o, vy);
+	}
 	if (alpha_out) {
 		for (int c = 0; c < nc; c++) {
 			double ccy = 0.0;
+			if constexpr (NCT >= 0) {
 #pragma unroll
-			for (int e = 0; e < S1_NCMAX; e++)
-				if (e < nc) ccy = fma(mi[c * nc + e], a[e], ccy);
-			alpha_out[o * nc + c] = (OutT)(ccy - gam * ccx[c]);  // association.py:368-370
+				for (int e = 0; e < NCT; e++)
+					if (e == c) ccy = ccy_[e];
+			} else {
+#pragma unroll
+				for (int e = 0; e < NA; e++)
+					if (e < nc) ccy = fma(mi[c * nc + e], a[e], ccy);
+			}
+			const double al = ccy - gam * ccx[c];  // association.py:368-370
+			if (out_f64)
+				s1_put<double>(alpha_out, o * nc + c, al);
+			else
+				s1_put<float>(alpha_out, o * nc + c, al);
 		}
 	}
 }
@@ -331,7 +378,7 @@ static void s1_stream_go(const void* d_y, int64_t ldy, const double* d_c, int64_
 						 int comp0, int qrow, void* d_ye, int64_t ldye, hipStream_t st) {
 	const bool aligned = ((uintptr_t)d_y % 16 == 0) && (ldy * sizeof(T)) % 16 == 0 && ((uintptr_t)d_code % 16 == 0) &&
 						 (NC == 0 || (((uintptr_t)d_c % 16 == 0) && ldc % 2 == 0));
-	const dim3 grid((unsigned)((ny + R - 1) / R));
+	const dim3 grid((unsigned)(((ny + R - 1) / R + 7) / 8 * 8));
 	if (aligned)
 		hipLaunchKernelGGL((k_s1_stream<T, NC, R, true, FIRST>), grid, dim3(256), 0, st, (const T*)d_y, ldy, d_c, ldc, d_code, n, ny, d_common, comp0, qrow,
 						   (T*)d_ye, ldye);
@@ -390,20 +437,30 @@ extern "C" int nrm_single1_cells(const void* d_ye, int y_dtype, int64_t ldye, co
 	NRM_REQUIRE(d_ye && d_xe && d_seg && d_common && d_info && d_p && d_stat && d_vary && (d_ce || nc == 0), "nrm_single1_cells: null pointer");
 	hipStream_t st = (hipStream_t)stream;
 	const dim3 grid((unsigned)((ny + 255) / 256), (unsigned)nx);
-#define S1_GO(T, O)                                                                                                                              \
-	hipLaunchKernelGGL((k_s1_cells<T, O>), grid, dim3(256), 0, st, (const T*)d_ye, ldye, d_ce, d_xe, d_seg, d_common, (int)nc, d_info, info_pitch, \
-					   (int)nc, nx, ny, return_dot, (O*)d_p, (O*)d_stat, (O*)d_vary, (O*)d_alpha, ldo, d_flags)
-	if (y_dtype == NRM_F64) {
-		if (out_dtype == NRM_F64)
-			S1_GO(double, double);
-		else
-			S1_GO(double, float);
-	} else {
-		if (out_dtype == NRM_F64)
-			S1_GO(float, double);
-		else
-			S1_GO(float, float);
+	const int f64 = out_dtype == NRM_F64;
+#define S1_GO(T, NCT)                                                                                                                           \
+	hipLaunchKernelGGL((k_s1_cells<T, NCT>), grid, dim3(256), 0, st, (const T*)d_ye, ldye, d_ce, d_xe, d_seg, d_common, (int)nc, d_info, info_pitch, \
+					   (int)nc, nx, ny, return_dot, d_p, d_stat, d_vary, d_alpha, f64, ldo, d_flags)
+#define S1_CASE(NCT)               \
+	case NCT:                      \
+		if (y_dtype == NRM_F64)    \
+			S1_GO(double, NCT);    \
+		else                       \
+			S1_GO(float, NCT);     \
+		break;
+	switch (nc <= 8 ? (int)nc : -1) {
+		S1_CASE(0)
+		S1_CASE(1)
+		S1_CASE(2)
+		S1_CASE(3)
+		S1_CASE(4)
+		S1_CASE(5)
+		S1_CASE(6)
+		S1_CASE(7)
+		S1_CASE(8)
+		S1_CASE(-1)
 	}
+#undef S1_CASE
 #undef S1_GO
 	return nrm_check_launch("k_s1_cells");
 }

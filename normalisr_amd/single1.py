@@ -166,19 +166,11 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 	idx_e, owner = idx_e[order], owner[order]
 	n_e = int(idx_e.numel())
 	code = torch.where(is_common, _lib.NRM_S1_COMMON, _lib.NRM_S1_SKIP).to(torch.int32)
-	code[idx_e] = torch.arange(n_e, dtype=torch.int32, device=eng.device)
+	code[idx_e] = torch.arange(n_e, dtype=torch.int32, device=eng.device)  # positions in the order of the groupings
 	xe_d = d_dx[owner, idx_e].to(torch.float64) if n_e else torch.zeros(1, dtype=torch.float64, device=eng.device)
 	mark('cell order')
-	# the device's share first: it needs nothing of the host's
-	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
+	# what the host needs of the cell order (before the stream kernel is queued: a download behind it would wait for it)
 	d_c = eng.upload(c64) if nc else None
-	ldye = _round_up(ny, 8)
-	ye = torch.empty((max(n_e, 1), ldye), dtype=d_y.dtype, device=eng.device)
-	common = torch.empty((nc + 1, ny), dtype=torch.float64, device=eng.device)
-	ycode = _lib.NRM_F64 if d_y.dtype == torch.float64 else _lib.NRM_F32
-	_lib.check(eng.lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), 0 if d_c is None else d_c.data_ptr(), n, nc, code.data_ptr(), n, ny,
-										  common.data_ptr(), ye.data_ptr(), ldye, eng._stream()))
-	# grouping-side statistics on the host
 	if nc:  # covariate Gram of the shared cells (element-wise and in a fixed order: no BLAS, on either side)
 		cm = d_c * is_common
 		mcc = (cm[:, None, :] * d_c[None, :, :]).sum(dim=2).cpu().numpy()
@@ -186,12 +178,23 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 	seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
 	idx_h = idx_e.cpu().numpy()
 	xe = xe_d.cpu().numpy()[:n_e]
+	# the device's share: it needs nothing of the host's statistics and runs while they are taken
+	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
+	ldye = _round_up(ny, 8)
+	ye = torch.empty((max(n_e, 1), ldye), dtype=d_y.dtype, device=eng.device)
+	common = torch.empty((nc + 1, ny), dtype=torch.float64, device=eng.device)
+	ycode = _lib.NRM_F64 if d_y.dtype == torch.float64 else _lib.NRM_F32
+	with _engine._Span(eng, 's1_stream'):
+		_lib.check(eng.lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), 0 if d_c is None else d_c.data_ptr(), n, nc, code.data_ptr(), n, ny,
+											  common.data_ptr(), ye.data_ptr(), ldye, eng._stream()))
+	eng.s1_cells_kept = n_e  # (bench.py: the bytes the stream kernel writes)
+	# grouping-side statistics on the host
 	starts = seg[:-1]
 	pitch = 26 + nc + nc * nc
 	info = np.zeros((nx, pitch))
 	xx = _segment_sums(xe * xe, starts, counts)
 	rk = np.zeros(nx, dtype=np.int64)
-	mark('downloads')
+	mark('downloads, stream kernel')
 	ce = c64[:, idx_h]  # (nc, cells of the E_i in the order of the groupings)
 	if nc:
 		mc = mcc[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
@@ -222,9 +225,10 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 	d_seg = eng.upload(seg)
 	d_info = eng.upload(info)
 	code_o = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
-	_lib.check(eng.lib.nrm_single1_cells(ye.data_ptr(), ycode, ldye, 0 if d_ce is None else d_ce.data_ptr(), xe_d.data_ptr(), d_seg.data_ptr(),
-										 common.data_ptr(), d_info.data_ptr(), pitch, nc, nx, ny, 1 if return_dot else 0, p.data_ptr(), stat.data_ptr(),
-										 vary.data_ptr(), 0 if alpha is None else alpha.data_ptr(), code_o, ny, flags.data_ptr(), eng._stream()))
+	with _engine._Span(eng, 's1_cells'):
+		_lib.check(eng.lib.nrm_single1_cells(ye.data_ptr(), ycode, ldye, 0 if d_ce is None else d_ce.data_ptr(), xe_d.data_ptr(), d_seg.data_ptr(),
+											 common.data_ptr(), d_info.data_ptr(), pitch, nc, nx, ny, 1 if return_dot else 0, p.data_ptr(), stat.data_ptr(),
+											 vary.data_ptr(), 0 if alpha is None else alpha.data_ptr(), code_o, ny, flags.data_ptr(), eng._stream()))
 	eng.check_flags(flags)
 	mark('sweep')
 	mark.report()
