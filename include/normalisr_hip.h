@@ -423,6 +423,25 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
 							   void* h_p, void* h_stat, void* h_alpha, void* h_varx, void* h_vary,
 							   void* h_r, void* h_t, int out_dtype);
 
+/*
+ * Text matrices of the command line (host only): the reference reads with numpy.loadtxt(delimiter='\t') and writes with
+ * numpy.savetxt(fmt='%.8G') (run.py:20-35).  Same text in, same text out, parsed / printed by `threads` host threads (0 = choose).
+ *   nrm_tsv_shape: rows = lines with data ('#' comments and blank lines skipped), cols = fields of the first such line.
+ *   nrm_tsv_parse: the matrix into out (rows, ld), NRM_F32 or NRM_F64; a field that is not a number, or a row with another number of
+ *     fields: NRM_E_ARG (ValueError, as numpy.loadtxt), the place in nrm_last_error().
+ *   nrm_tsv_format: rows x cols as text; kind 0 = '%.8G' (NRM_F32 / NRM_F64), kind 1 = '%i' (NRM_TSV_I64 / _I32 / _U8).  Rows are dealt in
+ *     order to `parts` threads; part t writes at out + t * part_cap, its length to lens[t];
+ *     part_cap >= ceil(rows / parts) * max(cols, 1) * nrm_tsv_width(kind).
+ */
+#define NRM_TSV_I64 16
+#define NRM_TSV_I32 17
+#define NRM_TSV_U8 18
+int nrm_tsv_shape(const char* buf, int64_t len, int delim, int threads, int64_t* rows, int64_t* cols);
+int nrm_tsv_parse(const char* buf, int64_t len, int delim, int threads, void* out, int out_dtype, int64_t rows, int64_t cols, int64_t ld);
+int64_t nrm_tsv_width(int kind);
+int nrm_tsv_format(const void* data, int dtype, int64_t rows, int64_t cols, int64_t ld, int delim, int kind, char* out, int64_t part_cap,
+				   int64_t* lens, int parts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnormalisr_hip.so')
 
 NRM_F32, NRM_F64 = 0, 1
+NRM_TSV_I64, NRM_TSV_I32, NRM_TSV_U8 = 16, 17, 18  # integer dtypes of nrm_tsv_format
 NRM_S1_COMMON, NRM_S1_SKIP = -2, -1  # cell codes of nrm_single1_stream (include/normalisr_hip.h)
 NRM_E_ARG, NRM_E_DEVICE, NRM_E_NUMERIC = -1, -2, -3
 ROW_TILE, K_TILE, PCOEF, FIX_STRIDE = 128, 16, 20, 8
@@ -68,6 +69,10 @@ _SIGNATURES = {
 	'nrm_skinny_i8': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp], _i32),
 	'nrm_skinny_i8_workspace_bytes': ([], _i64),
 	'nrm_single1_sweep': ([_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+	'nrm_tsv_shape': ([_vp, _i64, _i32, _i32, _vp, _vp], _i32),
+	'nrm_tsv_parse': ([_vp, _i64, _i32, _i32, _vp, _i32, _i64, _i64, _i64], _i32),
+	'nrm_tsv_width': ([_i32], _i64),
+	'nrm_tsv_format': ([_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32], _i32),
 	'nrm_single1_stream': ([_vp, _i32, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp], _i32),
 	'nrm_single1_cells': ([_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_binnet': ([_vp, _i32, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),

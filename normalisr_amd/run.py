@@ -4,8 +4,9 @@ Every sub-command is one row of COMMANDS: which files are read (and how they are
 options become which keyword arguments, which function runs, and which of its results go to which file.
 The file contract is the reference's (run.py:20-35,258-321): tab-delimited text without headers, one row
 per line, '%.8G' for floats, '.gz' by suffix (numpy handles it), a single row read back as shape (1, n).
-Extension of this build: names ending in '.npy' are read / written as binary numpy arrays --
-parsing a 20k x 100k TSV takes minutes, the association itself milliseconds.
+Extension of this build: names ending in '.npy' are read / written as binary numpy arrays; and the text files themselves go
+through the library's threaded parser / printer (csrc/nrm_tsv.hip: the same numbers in, byte for byte the same text out) instead of
+numpy.loadtxt / numpy.savetxt, which take minutes for a 20k x 100k matrix where the association takes milliseconds (NRM_TSV=numpy: back).
 """
 import logging
 
@@ -19,17 +20,101 @@ def _is_binary(name):
 	return name.endswith('.npy')
 
 
+def _native_text():
+	"""The library's text reader / writer unless NRM_TSV=numpy asks for numpy.loadtxt / numpy.savetxt (the reference's own calls)."""
+	import os
+	return os.environ.get('NRM_TSV', 'native') != 'numpy'
+
+
+def _open_bytes(f):
+	if f.endswith('.gz'):  # '.gz' by suffix, as numpy does for the reference
+		import gzip
+		with gzip.open(f, 'rb') as fh:
+			return np.frombuffer(fh.read(), dtype=np.uint8)
+	if f.endswith('.bz2') or f.endswith('.xz'):
+		return None
+	return np.fromfile(f, dtype=np.uint8)
+
+
+def _read_text(f, delimiter, dtype):
+	"""numpy.loadtxt(f, delimiter=delimiter) through the library's threaded parser (csrc/nrm_tsv.hip): the same numbers (correctly rounded,
+	as float()), '#' comments and blank lines skipped, ValueError for a field that is not a number or a row of another length."""
+	import ctypes
+	from . import _lib
+	lib = _lib.load()
+	buf = _open_bytes(f)
+	if buf is None:
+		return None
+	rows, cols = ctypes.c_int64(), ctypes.c_int64()
+	_lib.check(lib.nrm_tsv_shape(buf.ctypes.data, buf.size, ord(delimiter), 0, ctypes.addressof(rows), ctypes.addressof(cols)))
+	if rows.value == 0:
+		return None  # (numpy warns about an empty file and returns an empty array: leave that to numpy)
+	out = np.empty((rows.value, cols.value), dtype=dtype)
+	_lib.check(lib.nrm_tsv_parse(buf.ctypes.data, buf.size, ord(delimiter), 0, out.ctypes.data, _lib.NRM_F64 if out.dtype == np.float64 else _lib.NRM_F32,
+								 rows.value, cols.value, cols.value))
+	return out.squeeze()  # loadtxt's own squeeze (a single row or column comes back 1-D)
+
+
 def file_read_tsv(f, delimiter='\t', **ka):
 	"""Matrix from a TSV (or .npy) file, always 2-D."""
 	logging.debug('Start reading file ' + f)
+	ans = None
 	if _is_binary(f):
 		ans = np.load(f, allow_pickle=False)
 		if 'dtype' in ka:
 			ans = ans.astype(ka['dtype'], copy=False)
-	else:
+	elif _native_text() and len(delimiter) == 1 and set(ka) <= {'dtype'} and np.dtype(ka.get('dtype', np.float64)) in (np.dtype(np.float32), np.dtype(np.float64)):
+		ans = _read_text(f, delimiter, np.dtype(ka.get('dtype', np.float64)))
+	if ans is None:
 		ans = np.loadtxt(f, delimiter=delimiter, **ka)
 	logging.debug('Finish reading file ' + f)
 	return ans.reshape(1, -1) if ans.ndim < 2 else ans
+
+
+def _write_text(f, d, delimiter, fmt):
+	"""numpy.savetxt(f, d, delimiter=delimiter, fmt=fmt) for the two formats the command line writes ('%.8G' of floats, '%i' of integers),
+	printed by the library's threads in blocks of rows; byte for byte the text numpy writes.  False: not a case of ours."""
+	import os
+	from . import _lib
+	d = np.asarray(d)
+	if d.ndim == 1:
+		d = d.reshape(-1, 1)  # savetxt writes a vector as a column
+	if d.ndim != 2 or len(delimiter) != 1 or f.endswith('.bz2') or f.endswith('.xz'):
+		return False
+	if fmt == fmt_float and d.dtype in (np.float32, np.float64):
+		kind, code = 0, _lib.NRM_F64 if d.dtype == np.float64 else _lib.NRM_F32
+	elif fmt == fmt_int and d.dtype.kind in 'biu' and d.dtype != np.uint64:
+		kind = 1
+		if d.dtype.itemsize == 1 and d.dtype.kind in 'bu':
+			d, code = d.view(np.uint8), _lib.NRM_TSV_U8
+		elif d.dtype == np.int32:
+			code = _lib.NRM_TSV_I32
+		else:
+			d, code = d.astype(np.int64), _lib.NRM_TSV_I64
+	else:
+		return False
+	lib = _lib.load()
+	d = np.ascontiguousarray(d)
+	rows, cols = d.shape
+	width = int(lib.nrm_tsv_width(kind)) * max(cols, 1)
+	block = max(1, min(rows, (256 << 20) // width))  # rows per call: at most 256 MB of text at a time
+	parts = max(1, min(os.cpu_count() or 1, 64, block))
+	cap = -(-block // parts) * width
+	text = np.empty(parts * cap, dtype=np.uint8)
+	lens = np.zeros(parts, dtype=np.int64)
+	if f.endswith('.gz'):
+		import gzip
+		fh = gzip.open(f, 'wb')
+	else:
+		fh = open(f, 'wb')
+	with fh:
+		for r0 in range(0, rows, block):
+			r1 = min(rows, r0 + block)
+			_lib.check(lib.nrm_tsv_format(d[r0:r1].ctypes.data, code, r1 - r0, cols, cols, ord(delimiter), kind, text.ctypes.data, cap, lens.ctypes.data, parts))
+			for t in range(parts):
+				if lens[t]:
+					fh.write(memoryview(text[t * cap:t * cap + int(lens[t])]))
+	return True
 
 
 def file_write_tsv(f, d, delimiter='\t', fmt=fmt_float, **ka):
@@ -37,7 +122,7 @@ def file_write_tsv(f, d, delimiter='\t', fmt=fmt_float, **ka):
 	logging.debug('Start writing file ' + f)
 	if _is_binary(f):
 		np.save(f, np.asarray(d), allow_pickle=False)
-	else:
+	elif not (_native_text() and not ka and _write_text(f, d, delimiter, fmt)):
 		np.savetxt(f, d, delimiter=delimiter, fmt=fmt, **ka)
 	logging.debug('Finish writing file ' + f)
 
