@@ -36,23 +36,31 @@ def _open_bytes(f):
 	return np.fromfile(f, dtype=np.uint8)
 
 
-def _read_text(f, delimiter, dtype):
-	"""numpy.loadtxt(f, delimiter=delimiter) through the library's threaded parser (csrc/nrm_tsv.hip): the same numbers (correctly rounded,
-	as float()), '#' comments and blank lines skipped, ValueError for a field that is not a number or a row of another length."""
+def parse_text(buf, delimiter='\t', dtype=np.float64):
+	"""The matrix in a buffer of text (uint8 array), 2-D, through the library's threaded parser (csrc/nrm_tsv.hip): the numbers
+	numpy.loadtxt reads (correctly rounded, as float()), '#' comments and blank lines skipped, ValueError for a field that is not a number
+	or a row of another length.  None for a buffer without data (numpy warns and returns an empty array: left to numpy)."""
 	import ctypes
 	from . import _lib
 	lib = _lib.load()
-	buf = _open_bytes(f)
-	if buf is None:
-		return None
+	buf = np.ascontiguousarray(buf, dtype=np.uint8)
 	rows, cols = ctypes.c_int64(), ctypes.c_int64()
 	_lib.check(lib.nrm_tsv_shape(buf.ctypes.data, buf.size, ord(delimiter), 0, ctypes.addressof(rows), ctypes.addressof(cols)))
 	if rows.value == 0:
-		return None  # (numpy warns about an empty file and returns an empty array: leave that to numpy)
+		return None
 	out = np.empty((rows.value, cols.value), dtype=dtype)
 	_lib.check(lib.nrm_tsv_parse(buf.ctypes.data, buf.size, ord(delimiter), 0, out.ctypes.data, _lib.NRM_F64 if out.dtype == np.float64 else _lib.NRM_F32,
 								 rows.value, cols.value, cols.value))
-	return out.squeeze()  # loadtxt's own squeeze (a single row or column comes back 1-D)
+	return out
+
+
+def _read_text(f, delimiter, dtype):
+	"""numpy.loadtxt(f, delimiter=delimiter) through parse_text."""
+	buf = _open_bytes(f)
+	if buf is None:
+		return None
+	out = parse_text(buf, delimiter, dtype)
+	return None if out is None else out.squeeze()  # loadtxt's own squeeze (a single row or column comes back 1-D)
 
 
 def file_read_tsv(f, delimiter='\t', **ka):

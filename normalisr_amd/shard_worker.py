@@ -51,7 +51,12 @@ def read_rows(path, lo, hi, spans=None):
 	op = gzip.open if path.endswith('.gz') else open
 	with op(path, 'rb') as f:
 		f.seek(spans[lo][0])
-		blob = f.read(spans[hi - 1][1] - spans[lo][0])  # (comment / blank lines inside the block are dropped by loadtxt itself)
+		blob = f.read(spans[hi - 1][1] - spans[lo][0])  # (comment / blank lines inside the block are dropped by the parser itself)
+	from . import run
+	if run._native_text():
+		out = run.parse_text(np.frombuffer(blob, dtype=np.uint8))
+		if out is not None:
+			return out
 	return np.loadtxt(io.BytesIO(blob), delimiter='\t', ndmin=2)
 
 
