@@ -19,7 +19,8 @@ ranks, no collective), coex_c5 = the per-rank shape of configs[4] (3750 gene row
 fp64; at N=8 that is the full 30k x 30k problem, residual blocks exchanged by all-gather), de_c4_single4 / de_c4_single1 = the
 CRISPR screen of configs[3] as the reference's example runs it besides the naive test (`de -m covariate` / `-m single`,
 examples/GSE120861/code/cmd_highmoi.sh:19-22), coex_c2_f64 = configs[1] on the fp64 matrix cores (NRM_GRAM=f64: the dtype the
-north star names literally), binnet_c5 = binnet on a 30 000 x 30 000 fp64 P-value matrix (the consumer of configs[4]'s output).
+north star names literally), binnet_c5 = binnet on a 30 000 x 30 000 fp64 P-value matrix (the consumer of configs[4]'s output), normvar_c2 = norm.normvar on a
+configs[1]-sized matrix, numpy in -> numpy out (the step in front of the hot path).
 `--workload X` makes X the headline instead; `--no-extras` skips them.
 
 Launch: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when it is
@@ -570,6 +571,32 @@ def bench_binnet(rk, steps, warmup):
 							  algorithmic_bytes=byts, traffic=None, kernel_ms=ms))
 
 
+def bench_normvar(rk, steps, warmup):
+	"""norm.normvar (norm.py:166-289) on a configs[1]-sized matrix, the step in front of the hot path: 5000 genes x 10 000 cells fp32,
+	5 covariates, numpy in -> numpy out (the function has no resident form: its results are a new expression matrix and new covariates
+	for the next command)."""
+	torch = rk.torch
+	import normalisr_amd.normalisr as norm
+	ng, n, nc = 5000, 10000, 5
+	rng = np.random.default_rng(1)
+	dt = rng.standard_normal((ng, n), dtype=np.float32) - 9
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+	w, wt = np.exp(0.25 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
+
+	class Plan:
+		def step(self, timed=False):
+			self.out = norm.normvar(dt, dc, w, wt)
+	plan = Plan()
+	plan.step()
+	elapsed = timed_steps(rk, plan, steps, warmup, False)
+	ms = 1e3 * elapsed / steps
+	byts = float(ng) * n * (4 + 8)  # the fp32 matrix in, the fp64 matrix out: over PCIe here, and that is what bounds the call
+	return dict(metric='normvar values/sec (numpy in -> numpy out)', value=float(ng) * n * steps / elapsed, unit='values/s', steps=steps, warmup=warmup, ms_per_step=ms,
+				scaling='single GPU', dtype='f64', config=dict(workload='norm.normvar {} genes x {} cells fp32, {} covariates, numpy -> numpy'.format(ng, n, nc)),
+				roofline=dict(bound='hbm', kernel='whole call (PCIe-inclusive: 0.2 GB up, 0.4 GB down into pageable memory; two K2 launches, 5000 host SVDs, two element-wise passes)',
+							  achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=byts, traffic=None, kernel_ms=ms))
+
+
 def bench_c5_full(rk):
 	"""BASELINE configs[4] WHOLE on one GPU: 30 000 genes x 500 000 cells fp64 (4.5e8 pairs).  The 120 GB matrix is generated and
 	dropped in blocks of 3840 gene rows; only its 90 GB of digit planes stay resident (engine.coex_blocks_resident).  value = pairs /
@@ -617,7 +644,7 @@ def main():
 	ap.add_argument('--cells', type=int, default=10000)
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
 	ap.add_argument('--cpu-worker', nargs=6, default=None, help=argparse.SUPPRESS)
-	ap.add_argument('--workload', default=None, choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'binnet_c5'],
+	ap.add_argument('--workload', default=None, choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'binnet_c5', 'normvar_c2'],
 					help='headline workload.  Default: coex_c2 = BASELINE configs[1] at N=1; coex_c5 = configs[4] (3750 gene rows per rank x 500k cells) at N>1, '
 					'the configuration the 8-GPU target is quoted on.  de_c3 / de_c4 = configs[2] / [3]')
 	ap.add_argument('--c5-rows', type=int, default=C5_ROWS_PER_RANK, help='gene rows per rank of the coex_c5 workload (smaller: functional runs)')
@@ -700,6 +727,8 @@ def main():
 			if world == 1:
 				pmc_traffic(which, out['roofline'], kernel='k_gram_i8' if which == 'de_c4_single4' else 'k_s1_stream')
 			return out
+		if which == 'normvar_c2':
+			return bench_normvar(rk, steps, warmup)
 		if which == 'binnet_c5':
 			out = bench_binnet(rk, steps, warmup)
 			if out is not None:
@@ -761,7 +790,7 @@ def main():
 		dog.daemon = True
 		dog.start()
 		names = [w for w in ('coex_c2', 'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64') if w != args.workload and not (w == 'coex_c2' and world == 1)] + (
-			['binnet_c5', 'coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
+			['binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
 		if world > 1:
 			names = [w for w in names if w != 'coex_c2_f64']
 		if args.extras:

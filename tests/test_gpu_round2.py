@@ -300,7 +300,8 @@ def test_bench_default_line_carries_the_other_configs():
 	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
 	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
 	ex = out['extra_workloads']
-	assert set(ex) == {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'coex_c5_full_1gpu'}, ex
+	assert set(ex) == {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'}, ex
+	assert ex['de_c4_single1']['roofline']['kernel'] == 'k_s1_stream' and ex['de_c4_single1']['ms_per_step'] < ex['de_c4_single4']['ms_per_step']
 	assert ex['coex_c2_f64']['roofline']['kernel'] == 'k_gram_f64' and ex['coex_c2_f64']['dtype'] == 'f64'
 	assert ex['de_c4_single4']['roofline']['kernel'] == 'k_gram_i8' and ex['de_c4_single4']['guard']['uncertified_pairs'] == 0 and not ex['de_c4_single4']['guard']['fp64_rerun']
 	assert ex['de_c4_single4']['ms_per_step'] < 2.5 * ex['de_c4']['ms_per_step']
