@@ -1,0 +1,99 @@
+"""de with a sparse design matrix (a CRISPR screen's gRNA incidence): csrc/nrm_de_sparse.hip.
+
+The reference multiplies residualised design and expression rows densely (association.py:224-235).  Because a residual is orthogonal to
+the covariates, y~ . x~ = y . x - (y C^T) . b_x: a design row with few cells set needs the expression values at those cells only.  This
+module decides whether a call qualifies, turns the design matrix into the kernel's ELL lists (on the device, a dozen torch passes over
+its non-zero entries) and runs K1 on the design rows alone, the one-pass kernel on the raw expression rows, and K3 as always."""
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import ROW_TILE
+
+MAX_DENSITY = 1.0 / 16  # (break-even against K1 + the integer Gram engine is near one entry in ten)
+
+
+def _round_up(v, m):
+	return (v + m - 1) // m * m
+
+
+def candidate(eng, dx, dy, dc, samexy):
+	"""Cheap conditions that need no look at the data."""
+	if samexy or dy is None or os.environ.get('NRM_DE_SPARSE', '1') == '0':
+		return False
+	nx, n = dx.shape
+	return nx >= 32 and dc.shape[0] <= int(eng.lib.nrm_de_sparse_max_covariates()) and dy.shape[0] >= 64 and n >= 2048 and nx * n >= (1 << 22)
+
+
+class Lists:
+	"""The design matrix as the kernel reads it: for every chunk of cells and every 64 design rows ("slots": rows ordered by their number
+	of entries, so that rows of similar length share a wave), the entries of the 64 rows side by side, padded to the longest."""
+
+	def __init__(self, eng, d_x):
+		torch = eng.torch
+		nx, n = d_x.shape
+		ch = int(eng.lib.nrm_de_sparse_chunk())
+		nz = torch.nonzero(d_x)  # row-major: by design row, then by cell
+		xi, k = nz[:, 0], nz[:, 1]
+		self.nnz = int(xi.numel())
+		self.ok = 0 < self.nnz <= MAX_DENSITY * nx * n
+		if not self.ok:
+			return
+		vals = d_x[xi, k]
+		self.binary = bool((vals == 1).all())
+		cnt_x = torch.bincount(xi, minlength=nx)
+		order = torch.argsort(cnt_x, descending=True, stable=True)  # slot -> design row
+		nslots = _round_up(nx, 64)
+		self.ngroups = nslots // 64
+		slot_of_x = torch.empty(nx, dtype=torch.int64, device=eng.device)
+		slot_of_x[order] = torch.arange(nx, device=eng.device)
+		self.slot2x = torch.full((nslots, ), -1, dtype=torch.int32, device=eng.device)
+		self.slot2x[:nx] = order.to(torch.int32)
+		nch = (n + ch - 1) // ch
+		c = k // ch
+		key = c * nslots + slot_of_x[xi]
+		perm = torch.argsort(key, stable=True)  # by chunk, then slot; cells ascending inside (nonzero() listed them so)
+		key_s, k_s = key[perm], k[perm]
+		cnt = torch.bincount(key_s, minlength=nch * nslots)
+		w = cnt.view(nch, self.ngroups, 64).max(dim=2).values  # longest list of every (chunk, 64 slots)
+		w64 = w.flatten() * 64
+		base = torch.cumsum(w64, 0) - w64
+		start = torch.cumsum(cnt, 0) - cnt
+		j = torch.arange(self.nnz, device=eng.device) - start[key_s]
+		pos = base[key_s // 64] + j * 64 + key_s % 64
+		total = int(w64.sum())
+		self.ell = torch.full((max(total, 1), ), ch, dtype=torch.int16, device=eng.device)  # padding: the record of zeros
+		self.ell[pos] = (k_s - (key_s // nslots) * ch).to(torch.int16)
+		self.vals = None
+		if not self.binary:
+			self.vals = torch.zeros((max(total, 1), ), dtype=torch.float64, device=eng.device)
+			self.vals[pos] = vals[perm].to(torch.float64)
+		self.base = base.contiguous()
+		self.w = w.flatten().to(torch.int32).contiguous()
+		self.padded = total
+
+
+def run(eng, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_coef):
+	"""K1 on the design rows (their sums of squares and coefficients), the one-pass kernel on the expression rows.
+	Returns (dot (nx_pad, ny_pad) fp64 with dot[i, y] = x~_i . y~_y, rx, ssy, coefy)."""
+	from . import engine as _engine
+	torch = eng.torch
+	active = rank > 0 and nc > 0
+	rx = eng.residualize(d_x, d_c, d_dci, rank, want_coef=True, nslices=0)
+	d_y = dy if not isinstance(dy, np.ndarray) else eng.upload(_engine.as_input(dy))
+	nyp = _round_up(ny, ROW_TILE)
+	dot = torch.empty((_round_up(nx, ROW_TILE), nyp), dtype=torch.float64, device=eng.device)
+	ssy = torch.empty((nyp, ), dtype=torch.float64, device=eng.device)
+	ncu = nc if active else 0  # (covariates of rank 0 -- all zero -- leave the rows as they are: association.py:899-903)
+	coefy = eng.zeros((ny, nc), torch.float64) if want_coef else None
+	with _engine._Span(eng, 'de_sparse'):
+		_lib.check(eng.lib.nrm_de_sparse(d_y.data_ptr(), _lib.NRM_F64 if d_y.dtype == torch.float64 else _lib.NRM_F32, ny, n, d_y.stride(0),
+										 d_c.data_ptr() if ncu else 0, ncu, d_c.stride(0) if ncu else 0, d_dci.data_ptr() if ncu else 0, lists.ell.data_ptr(),
+										 0 if lists.vals is None else lists.vals.data_ptr(), -1 if lists.vals is None else _lib.NRM_F64, lists.base.data_ptr(),
+										 lists.w.data_ptr(), lists.ngroups, lists.slot2x.data_ptr(), rx.coef.data_ptr() if ncu else 0, max(nc, 1), dot.data_ptr(),
+										 dot.stride(0), ssy.data_ptr(), coefy.data_ptr() if (coefy is not None and ncu) else 0, eng._stream()))
+	return dot, rx, ssy, coefy
+
+
+assert __name__ != "__main__"

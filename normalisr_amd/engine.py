@@ -1190,6 +1190,20 @@ class Engine:
 			self._tls.path = 'the streaming de kernel (fp64 matrix cores, raw rows read once)'
 			return self.association_de_streaming(dx, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov,
 												 resident=resident and not (want_alpha or want_rt), state=state)
+		from . import de_sparse
+		if de_sparse.candidate(self, dx, dy, dc, samexy):
+			# a design matrix with few entries (gRNA incidence): the expression rows are read once, raw (csrc/nrm_de_sparse.hip)
+			with self.torch.cuda.device(self.device):
+				if isinstance(dx, np.ndarray):
+					dx = self.upload(as_input(dx))  # (kept for the dense path below if the matrix turns out not to be sparse)
+				lists = state.get('sparse') if state is not None else None
+				if lists is None or lists[0] is not dx:
+					lists = (dx, de_sparse.Lists(self, dx))
+					if state is not None:
+						state['sparse'] = lists
+			if lists[1].ok:
+				self._tls.path = 'the sparse-design kernel (expression rows read once, %d design entries)' % lists[1].nnz
+				return self._association_de_sparse(dx, lists[1], dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident)
 		nx, n = dx.shape
 		ny = nx if samexy else dy.shape[0]
 		nc = dc.shape[0]
@@ -1240,6 +1254,32 @@ class Engine:
 			res['r'] = self.download(r)
 			res['t'] = self.download(t)
 		return res
+
+
+	def _association_de_sparse(self, d_x, lists, dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident):
+		"""single=0 de through de_sparse.run: same results dictionary as the dense path of _association_single0."""
+		from . import de_sparse
+		nx, n = d_x.shape
+		ny, nc = dy.shape[0], dc.shape[0]
+		dof = n - 1 - rank - dimreduce
+		stat_kind = 0 if return_dot else 1
+		with self.torch.cuda.device(self.device):
+			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
+			dot, rx, ssy, coefy = de_sparse.run(self, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_alpha)
+			p, stat, r, t, flags = self.sweep(dot, rx.ss, ssy, nx, ny, n, dof, False, stat_kind, out_dtype, want_rt)
+			alpha = None
+			if want_alpha:
+				alpha = self.download(self.alpha(stat, stat_kind, rx.ss, n, rx.coef, coefy, nc)) if nc > 0 else np.zeros((nx, ny, nc), dtype=out_dtype)
+			self.last_guard = dict(hits=0, worst=0.0, fallback=False)  # (fp64 sums of a few hundred terms: nothing to certify)
+			if resident and not (want_alpha or want_rt):
+				return dict(p=p, stat=stat, alpha=alpha, ssx=rx.ss, ssy=ssy, flags=flags, dof=dof)
+			self.check_flags(flags)
+			keep = (lambda v: v) if device_out else self.download
+			res = dict(p=keep(p), stat=keep(stat), alpha=alpha, varx=self.variances(rx.ss, nx, n, out_dtype), vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
+			if want_rt:
+				res['r'] = self.download(r)
+				res['t'] = self.download(t)
+			return res
 
 
 _engines = {}

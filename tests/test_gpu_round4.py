@@ -421,3 +421,45 @@ def test_single1_streams_the_expression_matrix_once(dtype, nc, n, ny):
 		assert close(vx, ref[3], 2e-6 if f32 else 1e-10)
 		assert close(a, ref[2], 2e-4 if f32 else 1e-8, 1e-5 if f32 else 1e-10)
 	assert np.array_equal(out[0], dev[0])  # the same kernels on the same values, wherever the inputs lay
+
+
+@pytest.mark.parametrize('dtype,nc,n,nx,ny,binary', [(np.float32, 5, 9000, 70, 203, True), (np.float64, 3, 8191, 40, 101, False), (np.float32, 0, 4100, 33, 64, True),
+												   (np.float32, 8, 6002, 64, 130, False), (np.float64, 2, 5000, 1100, 66, True)])
+def test_de_with_a_sparse_design_reads_the_expression_rows_once(monkeypatch, caplog, dtype, nc, n, nx, ny, binary):
+	"""single=0 de with a sparse design matrix (csrc/nrm_de_sparse.hip: x~ . y~ = x . y - (y C^T) . b_x, the raw expression rows read once)
+	against the oracle (association.py:137-260) and against the dense path it replaces (K1 + K2): 0 / 1 and valued entries, fp32 and fp64
+	rows, 0 - 8 covariates, cell counts off the 16-byte grid and off the chunk size, more than 1024 design rows (two passes), gene
+	counts off the row blocks, alpha, Pearson r and t, an all-zero design row (constant: the reference's varx 0 -> 1 rule)."""
+	import logging
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(900 + nx)
+	dx = (rng.random((nx, n)) < 0.02).astype(np.float64)
+	if not binary:
+		dx *= rng.uniform(0.5, 2.0, dx.shape)
+	dx[5] = 0  # a design row without entries
+	dx = dx.astype(dtype)
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))]) if nc else np.zeros((0, n))
+	dy = (rng.normal(size=(ny, n)) + 3.0 + 0.8 * dx[rng.integers(0, nx, ny)].astype(np.float64) * rng.normal(size=(ny, 1))).astype(dtype)
+	ref = oracle.association_tests(dx.astype(np.float64), dy.astype(np.float64), dc, lowmem=False, return_dot=False)
+	f32 = dtype == np.float32
+	outs = {}
+	for mode in ('1', '0'):
+		monkeypatch.setenv('NRM_DE_SPARSE', mode)
+		with caplog.at_level(logging.DEBUG):
+			caplog.clear()
+			outs[mode] = association_tests(dx, dy, dc, lowmem=False, return_dot=False, return_stats=True)
+		assert ('sparse-design kernel' in caplog.text) == (mode == '1'), caplog.text[-400:]
+	for mode, got in outs.items():
+		p, gam, a, vx, vy = got[:5]
+		ok = ref[0] > (1e-30 if f32 else 1e-290)
+		assert relerr(p[ok], ref[0][ok]) < (2e-4 if f32 else 1e-8), mode
+		assert close(gam, ref[1], 2e-5 if f32 else 1e-9, 1e-6 if f32 else 1e-12) and close(vy, ref[4], 2e-6 if f32 else 1e-10), mode
+		assert close(vx, ref[3], 2e-6 if f32 else 1e-10), mode
+		if nc:
+			assert close(a, ref[2], 2e-4 if f32 else 1e-8, 1e-5 if f32 else 1e-10), mode
+		assert (p[5] == 1).all() and (gam[5] == 0).all()
+	s, d = outs['1'], outs['0']
+	ok = d[0] > (1e-30 if f32 else 1e-290)
+	assert relerr(s[0][ok], d[0][ok]) < (1e-5 if f32 else 1e-9)
+	for key in ('r', 't'):
+		assert close(s[5][key], d[5][key], 1e-5 if f32 else 1e-9, 1e-6 if f32 else 1e-10)
