@@ -460,12 +460,22 @@ def bench_de(rk, nd, steps, warmup, which, covariates=20):
 		byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
 		roof = dict(bound='hbm', kernel='k_gram_skinny + sweep (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
 					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms)
+	elif 'de_sparse' in split:
+		# the design matrix is sparse (gRNA incidence, 1 % of the entries set): no K1 on the genes, no K2 -- the raw expression rows are read
+		# (twice: sums with the covariates, then the gathers) and of each only the values at the design's entries are added up
+		byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
+		kms = split['de_sparse'] + split.get('row_sums', 0.0)
+		roof = dict(bound='hbm', kernel='k_de_sparse', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+					traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms,
+					note='kernel_ms = k_s1_stream (sums of the rows with the covariates: a pass at HBM rate) + k_de_sparse, which is bound by its vector ALU work '
+						 '(one fp32 -> fp64 conversion and one fp64 add per gathered value), not by HBM; NRM_DE_SPARSE=0 puts K1 + the integer Gram engine back',
+					dense_path_flop_equivalent_tflops=2.0 * n * nx * ny_local / (kms * 1e-3) / 1e12)
 	else:
 		roof = gram_roofline(n, 2.0 * n * nx * ny_local, split.get('gram', ms), 0, 0)  # K2 alone
 		roof['algorithmic_bytes'] = float(SLICES(n) or 8) * (nx + ny_local) * n
 		roof['step_ms'] = ms
 	return dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
-				scaling='strong', dtype='f64' if plan.streaming() else ARITH(n),
+				scaling='strong', dtype='f64' if (plan.streaming() or 'de_sparse' in split) else ARITH(n),
 				config=dict(workload='norm.de {} x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[{}])'.format(
 					nx, ny, n, nc, 2 if which == 'de_c3' else 3), parallelism='gene rows of Y x{}, no collective'.format(world)), roofline=roof,
 				kernels_ms={k: round(v, 4) for k, v in split.items()}, kernels_ms_from='3 extra eager steps after the timed region',
@@ -521,7 +531,15 @@ def bench_de_method(rk, steps, warmup, single):
 	eng.trace = None
 	tests = nx * ny_local * world
 	ms = 1e3 * elapsed / steps
-	if single == 4:
+	if single == 4 and 'de_sparse' in split:  # the design is sparse: Y~ X~^T from the raw expression rows at the design's entries (csrc/nrm_de_sparse.hip)
+		byts = 4.0 * n * ny_local
+		kms = split['de_sparse'] + split.get('row_sums', 0.0)
+		roof = dict(bound='hbm', kernel='k_de_sparse', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+					traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms,
+					note='kernel_ms = k_s1_stream (row sums with the covariates) + k_de_sparse (bound by its vector ALU work: a conversion and an fp64 add per gathered '
+						 'value); the rest of a step: K1 on the design, M~ = X~ X~^T and its Newton-Schulz inverse on the fp64 matrix cores, B = G N~, the sweep')
+		dtype = 'f64'
+	elif single == 4:
 		roof = gram_roofline(n, 2.0 * n * nx * ny_local, split.get('gram_yx', ms), 0, 0)  # the large contraction Y~ X~^T alone
 		roof['algorithmic_bytes'] = float(SLICES(n) or 8) * (nx + ny_local) * n
 		roof['step_ms'] = ms
@@ -725,7 +743,7 @@ def main():
 		if which in ('de_c4_single4', 'de_c4_single1'):
 			out = bench_de_method(rk, steps, warmup, 4 if which.endswith('4') else 1)
 			if world == 1:
-				pmc_traffic(which, out['roofline'], kernel='k_gram_i8' if which == 'de_c4_single4' else 'k_s1_stream')
+				pmc_traffic(which, out['roofline'], kernel=out['roofline']['kernel'].split(' ')[0])
 			return out
 		if which == 'normvar_c2':
 			return bench_normvar(rk, steps, warmup)

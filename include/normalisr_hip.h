@@ -427,20 +427,23 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
  * de with a SPARSE design matrix (a CRISPR screen's gRNA incidence), association.py:224-235 without the dense contraction: a residual is
  * orthogonal to the covariates, so x~_i . y~ = x_i . y - (y C^T) . b_i and |y~|^2 = |y|^2 - (y C^T) . b_y -- the raw expression rows are
  * read ONCE, and of each only the values at the cells where a design row is not zero are added up.
- *   d_y (ny, ldy) raw expression rows (y_dtype); d_c (nc, ldc) fp64 covariates, d_dci (nc, nc) the pseudo-inverse of C C^T, nc <=
- *   nrm_de_sparse_max_covariates() (nc = 0: no covariates, or covariates of rank 0).
+ *   d_y (ny, ldy) raw expression rows (y_dtype); d_common (nc + 1, ny) fp64 their products with the covariates and (row nc) sums of
+ *   squares, as nrm_single1_stream leaves them when every cell has the code NRM_S1_COMMON; d_dci (nc, nc) the pseudo-inverse of C C^T,
+ *   nc <= nrm_de_sparse_max_covariates() (nc = 0: no covariates, or covariates of rank 0).
  *   The design matrix as lists: its rows are assigned to slots 0 .. 64 * ngroups - 1 (d_slot2x: slot -> design row, -1 for an empty
  *   slot); the cells are cut into chunks of nrm_de_sparse_chunk().  For chunk c and the 64 slots of group g, d_w[c * ngroups + g] is the
- *   length of the longest list among them and d_base[c * ngroups + g] the start of their block in d_ell: entry j of slot 64 g + l at
- *   d_base[..] + 64 j + l = the offset of the cell inside its chunk, or nrm_de_sparse_chunk() for padding; d_ellv: the entries' values
- *   likewise (fp64), or NULL with v_dtype -1 when every entry is 1.  d_bx (design rows, ldb) the design rows' coefficients b_i from K1.
- * Out: d_dot[i * ldd + y] = x~_i . y~_y; d_ssy (ny) = |y~|^2; d_coefy (ny, nc) = b_y or NULL.  Then nrm_assoc_sweep as for K2's output.
+ *   length of the longest list among them rounded up to a multiple of 8, and d_base[c * ngroups + g] the start of their block in d_ell:
+ *   entry j of slot 64 g + l at d_base[..] + (64 (j / 8) + l) 8 + j % 8 (8 consecutive entries of a slot side by side: one 16-byte load)
+ *   = the offset of the cell inside its chunk, or nrm_de_sparse_chunk() for padding; d_ellv: the entries' values likewise (fp64), or NULL
+ *   when every entry is 1.  d_bx (design rows, ldb) the design rows' coefficients b_i from K1.
+ * Out: d_dot[i * ldd + y] = x~_i . y~_y (by_gene != 0: d_dot[y * ldd + i], the layout single=4 reads); d_ssy (ny) = |y~|^2; d_coefy (ny, nc)
+ *   = b_y or NULL.  Then nrm_assoc_sweep as for K2's output.
  */
 int64_t nrm_de_sparse_chunk(void);
 int64_t nrm_de_sparse_max_covariates(void);
-int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_c, int64_t nc, int64_t ldc, const double* d_dci,
-				  const int16_t* d_ell, const void* d_ellv, int v_dtype, const int64_t* d_base, const int32_t* d_w, int64_t ngroups,
-				  const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, double* d_ssy, double* d_coefy, void* stream);
+int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_common, int64_t nc, const double* d_dci,
+				  const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, int64_t ngroups, const int32_t* d_slot2x,
+				  const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, void* stream);
 
 /*
  * Text matrices of the command line (host only): the reference reads with numpy.loadtxt(delimiter='\t') and writes with

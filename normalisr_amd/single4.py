@@ -414,6 +414,16 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
 		if not (eng.k1_quantises(d_x, d_c) and eng.k1_quantises(d_y, d_c)):
 			ns = 0  # (rows K1 cannot quantise itself -- not 16-byte aligned: fp64 all the way)
+		# A design matrix with few entries (gRNA incidence): Y~ X~^T = Y X^T - (Y C^T) b_x^T needs of every expression row only its values
+		# at those entries -- the raw rows read once (csrc/nrm_de_sparse.hip), fp64 sums of a few hundred terms: no digit planes, no guard
+		lists = None
+		if not force_f64:
+			from . import de_sparse
+			if de_sparse.candidate(eng, d_x, d_y, dc64, False):
+				lists = de_sparse.Lists(eng, d_x)
+				lists = lists if lists.ok else None
+		if lists is not None:
+			ns = 0
 		rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=bool(nc), nslices=ns, keep_fp64=True)
 		nxp = rx.rows_pad
 		mark('K1 design')
@@ -441,14 +451,20 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		kappa = small[1] / np.sqrt(d)
 		dxx = 1.0 / (n * d)
 		# the genes: K1 and the large contraction
-		ry = eng.residualize(d_y, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=not ns)
-		mark('K1 genes')
-		g_d = eng.zeros((ry.rows_pad, nxp), torch.float64)  # (K2 leaves pure-padding sub-blocks unwritten)
-		with _engine._Span(eng, 'gram_yx'):
-			eng._gram(ry, rx, False, g_d, None, ns)
-		if ns:
-			_lib.check(eng.lib.nrm_gram_i8_fix_dot(g_d.data_ptr(), g_d.stride(0), ry.fix.data_ptr(), rx.fix.data_ptr(), ny, nx, ns, n, eng._stream()))
-		mark('Y~ X~^T')
+		if lists is not None:
+			from . import de_sparse
+			g_d, ssy, coefy = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, not lowmem, True)
+			ry = Residualized(ny, n, None, ssy, coefy, shape=(g_d.shape[0], _engine._round_up(n, _lib.K_TILE)))
+			mark('Y~ X~^T (sparse design: expression rows read once)')
+		else:
+			ry = eng.residualize(d_y, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=not ns)
+			mark('K1 genes')
+			g_d = eng.zeros((ry.rows_pad, nxp), torch.float64)  # (K2 leaves pure-padding sub-blocks unwritten)
+			with _engine._Span(eng, 'gram_yx'):
+				eng._gram(ry, rx, False, g_d, None, ns)
+			if ns:
+				_lib.check(eng.lib.nrm_gram_i8_fix_dot(g_d.data_ptr(), g_d.stride(0), ry.fix.data_ptr(), rx.fix.data_ptr(), ny, nx, ns, n, eng._stream()))
+			mark('Y~ X~^T')
 		bt_d = eng.gram(Residualized(ny, nxp, g_d, None, None), Residualized(nx, nxp, d_n, None, None), False)  # B^T = (Y~ X~^T) N~, K = design rows
 		mark('B')
 		tdt = torch.float64 if out_dtype == np.float64 else torch.float32

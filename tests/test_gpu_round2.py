@@ -301,14 +301,15 @@ def test_bench_default_line_carries_the_other_configs():
 	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
 	ex = out['extra_workloads']
 	assert set(ex) == {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'}, ex
-	assert ex['de_c4_single1']['roofline']['kernel'] == 'k_s1_stream' and ex['de_c4_single1']['ms_per_step'] < ex['de_c4_single4']['ms_per_step']
+	assert ex['de_c4_single1']['roofline']['kernel'] == 'k_s1_stream' and ex['de_c4_single1']['ms_per_step'] < 12
 	assert ex['coex_c2_f64']['roofline']['kernel'] == 'k_gram_f64' and ex['coex_c2_f64']['dtype'] == 'f64'
-	assert ex['de_c4_single4']['roofline']['kernel'] == 'k_gram_i8' and ex['de_c4_single4']['guard']['uncertified_pairs'] == 0 and not ex['de_c4_single4']['guard']['fp64_rerun']
-	assert ex['de_c4_single4']['ms_per_step'] < 2.5 * ex['de_c4']['ms_per_step']
+	assert ex['de_c4_single4']['roofline']['kernel'] == 'k_de_sparse' and ex['de_c4_single4']['guard']['uncertified_pairs'] == 0 and not ex['de_c4_single4']['guard']['fp64_rerun']
+	assert ex['de_c4_single4']['ms_per_step'] < 4 * ex['de_c4']['ms_per_step']
 	assert out['guard']['uncertified_pairs'] == 0 and 0 < out['guard']['largest_relative_p_error_bound'] < out['guard']['tolerance']
 	assert ex['coex_c5_full_1gpu']['config']['tests_per_step'] == 30000 * 29999 // 2 and ex['coex_c5_full_1gpu']['guard']['uncertified_pairs'] == 0
-	assert ex['de_c4']['kernels_ms']['gram'] < ex['de_c4']['ms_per_step'] and ex['de_c4']['roofline']['kernel_ms'] == pytest.approx(ex['de_c4']['kernels_ms']['gram'], rel=0.02)
-	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'mfma' and ex['coex_c5']['roofline']['bound'] == 'mfma'
+	# configs[3]'s design is gRNA incidence (1 % of the entries set): the sparse-design kernels, not K1 + K2 (tests/test_gpu_round4.py holds both to the oracle)
+	assert ex['de_c4']['roofline']['kernel'] == 'k_de_sparse' and ex['de_c4']['kernels_ms']['de_sparse'] < ex['de_c4']['ms_per_step'] < 8
+	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'hbm' and ex['coex_c5']['roofline']['bound'] == 'mfma'
 	for k, v in ex.items():
 		assert 'error' not in v, (k, v)
 		assert v['value'] > 0 and v['ms_per_step'] > 0 and 0 < v['roofline']['frac'] < 1.2, (k, v['roofline'])
