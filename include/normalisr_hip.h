@@ -437,13 +437,15 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
  *   = the offset of the cell inside its chunk, or nrm_de_sparse_chunk() for padding; d_ellv: the entries' values likewise (fp64), or NULL
  *   when every entry is 1.  d_bx (design rows, ldb) the design rows' coefficients b_i from K1.
  * Out: d_dot[i * ldd + y] = x~_i . y~_y (by_gene != 0: d_dot[y * ldd + i], the layout single=4 reads); d_ssy (ny) = |y~|^2; d_coefy (ny, nc)
- *   = b_y or NULL.  Then nrm_assoc_sweep as for K2's output.
+ *   = b_y or NULL; d_flags (int32[4], as nrm_assoc_sweep's) or NULL: [2] counts the expression rows whose residual is so small a part
+ *   of the row (|y~|^2 < 1e-4 |y|^2) that these differences have lost four digits -- redo such a call on nrm_residualize + nrm_gram_f64.
+ *   Then nrm_assoc_sweep as for K2's output.
  */
 int64_t nrm_de_sparse_chunk(void);
 int64_t nrm_de_sparse_max_covariates(void);
 int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_common, int64_t nc, const double* d_dci,
 				  const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, int64_t ngroups, const int32_t* d_slot2x,
-				  const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, void* stream);
+				  const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream);
 
 /*
  * Text matrices of the command line (host only): the reference reads with numpy.loadtxt(delimiter='\t') and writes with

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 															   const double* __restrict__ dci, const int16_t* __restrict__ ell, const double* __restrict__ ellv,
 															   const int64_t* __restrict__ ellbase, const int32_t* __restrict__ ellw, int ngroups, int group0,
 															   const int32_t* __restrict__ slot2x, const double* __restrict__ bx, int64_t ldb,
-															   double* __restrict__ dot, int64_t ldd, int by_gene, double* __restrict__ ssy, double* __restrict__ coefy, int first) {
+															   double* __restrict__ dot, int64_t ldd, int by_gene, double* __restrict__ ssy, double* __restrict__ coefy, int32_t* __restrict__ flags, int first) {
 	constexpr int V = DsVec<T>::V, R = DsVec<T>::R;
 	constexpr int NJ = DS_CH / (DS_T * V);  // groups of V consecutive cells a thread stages per chunk
 	typedef T rec_t __attribute__((ext_vector_type(R)));
@@ -151,6 +151,10 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 				yy = fma(-as[r][c], b, yy);
 			}
 			ssy[y] = yy > 0.0 ? yy : 0.0;
+			// |y~|^2 as a difference: a row whose residual is less than a hundredth of the row itself (|y~|^2 < 1e-4 |y|^2) has lost four of
+			// fp64's sixteen digits here, and its products with the design rows likewise -- counted like a pair the integer engine
+			// cannot certify (flags[2]): the caller redoes such a call on K1's two sweeps and the fp64 Gram kernel
+			if (flags && !(yy >= 1e-4 * common[(int64_t)nc * ny + y]) && common[(int64_t)nc * ny + y] > 0.0) atomicAdd(&flags[2], 1);
 		}
 	}
 	__syncthreads();
@@ -173,17 +177,17 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 template <typename T, bool BINARY>
 int ds_go(const void* d_y, int64_t ldy, int64_t n, int64_t ny, const double* d_common, int nc, const double* d_dci, const int16_t* d_ell, const double* d_ellv,
 		  const int64_t* d_base, const int32_t* d_w, int ngroups, const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd,
-		  int by_gene, double* d_ssy, double* d_coefy, hipStream_t st) {
+		  int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, hipStream_t st) {
 	constexpr int R = DsVec<T>::R;
 	const bool aligned = ((uintptr_t)d_y % 16 == 0) && (ldy * sizeof(T)) % 16 == 0 && n % DsVec<T>::V == 0;
 	const dim3 grid((unsigned)((ny + R - 1) / R));
 	for (int g0 = 0; g0 < ngroups; g0 += (DS_T / 64) * DS_G) {  // 1024 design rows per pass
 		if (aligned)
 			hipLaunchKernelGGL((k_de_sparse<T, true, BINARY>), grid, dim3(DS_T), 0, st, (const T*)d_y, ldy, n, ny, d_common, nc, d_dci, d_ell, d_ellv, d_base, d_w,
-							   ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, g0 == 0 ? 1 : 0);
+							   ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
 		else
 			hipLaunchKernelGGL((k_de_sparse<T, false, BINARY>), grid, dim3(DS_T), 0, st, (const T*)d_y, ldy, n, ny, d_common, nc, d_dci, d_ell, d_ellv, d_base, d_w,
-							   ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, g0 == 0 ? 1 : 0);
+							   ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
 	}
 	return nrm_check_launch("k_de_sparse");
 }
@@ -195,15 +199,15 @@ extern "C" int64_t nrm_de_sparse_max_covariates(void) { return DS_NCMAX; }
 
 extern "C" int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_common, int64_t nc, const double* d_dci,
 							 const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, int64_t ngroups, const int32_t* d_slot2x,
-							 const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, void* stream) {
+							 const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream) {
 	NRM_REQUIRE(ny > 0 && n > 0 && nc >= 0 && nc <= DS_NCMAX && ngroups > 0 && ngroups < (1 << 24), "nrm_de_sparse: bad sizes (at most %d covariates)", DS_NCMAX);
 	NRM_REQUIRE(y_dtype == NRM_F32 || y_dtype == NRM_F64, "nrm_de_sparse: bad dtype");
 	NRM_REQUIRE(ldy >= n && (nc == 0 || ldb >= nc) && (by_gene || ldd >= ny), "nrm_de_sparse: pitch too small");
 	NRM_REQUIRE(d_y && d_common && d_ell && d_base && d_w && d_slot2x && d_dot && d_ssy && (nc == 0 || (d_dci && d_bx)), "nrm_de_sparse: null pointer");
 	hipStream_t st = (hipStream_t)stream;
 	if (y_dtype == NRM_F64)
-		return d_ellv ? ds_go<double, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, st)
-					  : ds_go<double, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, st);
-	return d_ellv ? ds_go<float, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, st)
-				  : ds_go<float, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, st);
+		return d_ellv ? ds_go<double, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
+					  : ds_go<double, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
+	return d_ellv ? ds_go<float, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
+				  : ds_go<float, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
 }

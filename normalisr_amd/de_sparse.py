@@ -21,7 +21,7 @@ def _round_up(v, m):
 def candidate(eng, dx, dy, dc, samexy):
 	"""Cheap conditions that need no look at the data."""
 	mode = os.environ.get('NRM_DE_SPARSE', '1')
-	if samexy or dy is None or mode == '0':
+	if samexy or dy is None or mode == '0' or eng._force_f64:  # (_force_f64: the call is being redone after a guard hit)
 		return False
 	nx, n = dx.shape
 	if mode == 'force':  # (tests: small shapes through this path)
@@ -90,17 +90,18 @@ class Lists:
 		self.padded = total
 
 
-def run(eng, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_coef):
+def run(eng, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_coef, flags=None):
 	"""K1 on the design rows (their sums of squares and coefficients), the one-pass kernels on the expression rows.
 	Returns (dot (nx_pad, ny_pad) fp64 with dot[i, y] = x~_i . y~_y, rx, ssy, coefy)."""
 	rx = eng.residualize(d_x, d_c, d_dci, rank, want_coef=True, nslices=0)
-	dot, ssy, coefy = products(eng, lists, dy, d_c, d_dci, rank, rx.coef, nx, ny, n, nc, want_coef, False)
+	dot, ssy, coefy = products(eng, lists, dy, d_c, d_dci, rank, rx.coef, nx, ny, n, nc, want_coef, False, flags)
 	return dot, rx, ssy, coefy
 
 
-def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_gene):
+def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_gene, flags=None):
 	"""x~_i . y~_y for every design row and expression row from the RAW expression rows (csrc/nrm_de_sparse.hip), |y~|^2 and, on request,
-	the expression rows' coefficients b_y.  by_gene: the products as (ny_pad, nx_pad) (single=4 reads them so), else (nx_pad, ny_pad)."""
+	the expression rows' coefficients b_y.  by_gene: the products as (ny_pad, nx_pad) (single=4 reads them so), else (nx_pad, ny_pad).
+	flags: the call's device counters (engine.new_flags); [2] counts rows too close to the span of the covariates for these differences."""
 	from . import engine as _engine
 	torch = eng.torch
 	active = rank > 0 and nc > 0
@@ -123,7 +124,7 @@ def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_
 		_lib.check(eng.lib.nrm_de_sparse(d_y.data_ptr(), ycode, ny, n, d_y.stride(0), common.data_ptr(), ncu, d_dci.data_ptr() if ncu else 0, lists.ell.data_ptr(),
 										 0 if lists.vals is None else lists.vals.data_ptr(), lists.base.data_ptr(), lists.w.data_ptr(), lists.ngroups,
 										 lists.slot2x.data_ptr(), bx.data_ptr() if ncu else 0, max(nc, 1), dot.data_ptr(), dot.stride(0), 1 if by_gene else 0, ssy.data_ptr(),
-										 coefy.data_ptr() if (coefy is not None and ncu) else 0, eng._stream()))
+										 coefy.data_ptr() if (coefy is not None and ncu) else 0, 0 if flags is None else flags.data_ptr(), eng._stream()))
 	return dot, ssy, coefy
 
 

@@ -1265,8 +1265,9 @@ class Engine:
 		stat_kind = 0 if return_dot else 1
 		with self.torch.cuda.device(self.device):
 			d_c, d_dci = self.covariates(dc, dci) if cov is None else cov
-			dot, rx, ssy, coefy = de_sparse.run(self, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_alpha)
-			p, stat, r, t, flags = self.sweep(dot, rx.ss, ssy, nx, ny, n, dof, False, stat_kind, out_dtype, want_rt)
+			flags = self.new_flags()
+			dot, rx, ssy, coefy = de_sparse.run(self, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_alpha, flags)
+			p, stat, r, t, flags = self.sweep(dot, rx.ss, ssy, nx, ny, n, dof, False, stat_kind, out_dtype, want_rt, flags=flags)
 			alpha = None
 			if want_alpha:
 				alpha = self.download(self.alpha(stat, stat_kind, rx.ss, n, rx.coef, coefy, nc)) if nc > 0 else np.zeros((nx, ny, nc), dtype=out_dtype)

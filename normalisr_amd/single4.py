@@ -453,7 +453,11 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		# the genes: K1 and the large contraction
 		if lists is not None:
 			from . import de_sparse
-			g_d, ssy, coefy = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, not lowmem, True)
+			sp_flags = eng.new_flags()
+			g_d, ssy, coefy = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, not lowmem, True, sp_flags)
+			if int(sp_flags[2]) > 0:  # rows all but inside the span of the covariates: K1's two sweeps and the fp64 Gram kernel for this call
+				logging.info('single=4: %d expression rows too close to the span of the covariates for the sparse-design products; fp64 Gram kernel', int(sp_flags[2]))
+				return _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=True, device_out=device_out)
 			ry = Residualized(ny, n, None, ssy, coefy, shape=(g_d.shape[0], _engine._round_up(n, _lib.K_TILE)))
 			mark('Y~ X~^T (sparse design: expression rows read once)')
 		else:

@@ -358,14 +358,18 @@ def test_single4_redoes_only_the_genes_the_guard_flags(norm, eng):
 		assert 0 < g.get('genes_redone', ny) <= 64, g
 
 
-def test_config3_exact_shape_as_de_covariate():
-	"""BASELINE configs[3] at its exact shape as the reference's example runs it (`de -m covariate`, cmd_highmoi.sh:19-22): 1 000 gRNAs x
+@pytest.mark.parametrize('sparse', ['1', '0'])
+def test_config3_exact_shape_as_de_covariate(monkeypatch, sparse):
+	"""(sparse = 1: the products Y~ X~^T from the raw expression rows at the design's entries, csrc/nrm_de_sparse.hip -- what a call takes
+	for a gRNA design; 0: K1 + the integer Gram engine with its guard.)
+	BASELINE configs[3] at its exact shape as the reference's example runs it (`de -m covariate`, cmd_highmoi.sh:19-22): 1 000 gRNAs x
 	15 000 genes x 50 000 cells fp32 through single=4 on the device, resident; sampled gRNAs x sampled genes against the oracle.  The
 	oracle's per-grouping loop needs one 1004 x 1004 pseudo-inverse per tested gRNA, so it is run on 5 of them with the other 995 joined to
 	the covariates -- the same model for those 5 (single=4 IS "every other grouping a covariate", association.py:421-576)."""
 	import torch
 	from normalisr_amd.engine import get_engine
 	from normalisr_amd.single4 import association_tests_single4
+	monkeypatch.setenv('NRM_DE_SPARSE', sparse)
 	eng = get_engine()
 	nx, ny, n, nc = 1000, 15000, 50000, 5
 	gen = torch.Generator(device='cuda').manual_seed(43)
@@ -375,7 +379,7 @@ def test_config3_exact_shape_as_de_covariate():
 	dy[:15] += 0.5 * dx[:15]
 	p, gam, a, vx, vy = association_tests_single4(dx, dy, dc, return_dot=False, device_out=True)
 	g = dict(eng.last_guard)
-	assert tuple(p.shape) == (nx, ny) and g['worst'] > 0 and (not g['fallback'] or g.get('genes_redone', ny) <= 64), g
+	assert tuple(p.shape) == (nx, ny) and (g['worst'] > 0) == (sparse == '0') and (not g['fallback'] or g.get('genes_redone', ny) <= 64), g
 	xs = np.array([0, 3, 14, 500, 999])
 	ys = np.concatenate([np.arange(16), np.arange(7490, 7500), np.arange(ny - 10, ny)])
 	dxh = dx.cpu().numpy().astype(np.float64)
@@ -493,3 +497,30 @@ def test_single4_with_a_sparse_design(monkeypatch, dtype, nc):
 			assert close(a, ref[2], 3e-4 if f32 else 1e-6, 1e-5 if f32 else 1e-8), mode
 	ok = outs['0'][0] > (1e-30 if f32 else 1e-290)
 	assert relerr(outs['force'][0][ok], outs['0'][0][ok]) < (1e-5 if f32 else 1e-7)
+
+
+def test_sparse_design_path_hands_rows_near_the_covariate_span_back(monkeypatch, caplog):
+	"""Expression rows that are a large constant plus a small signal: |y~|^2 = |y|^2 - a . b_y loses its digits, the sparse-design kernel
+	counts such rows like pairs the integer engine cannot certify, and the call is redone on K1's two sweeps and the fp64 Gram kernel --
+	results as the oracle's either way."""
+	import logging
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(31)
+	nx, ny, n = 40, 70, 5000
+	dx = (rng.random((nx, n)) < 0.02).astype(np.float64)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dy = rng.normal(size=(ny, n)) * 1e-3 + 1e3  # residual^2 / row^2 = 1e-12
+	dy[3] += 0.0004 * dx[1]
+	ref = oracle.association_tests(dx, dy, dc, return_dot=False)
+	assert 1e-200 < ref[0].min() < 1e-4
+	monkeypatch.setenv('NRM_DE_SPARSE', 'force')
+	with caplog.at_level(logging.INFO):
+		p, gam, a, vx, vy = association_tests(dx, dy, dc, return_dot=False)
+	assert 'redoing the call on the fp64 matrix cores' in caplog.text
+	assert relerr(p, ref[0]) < 1e-6 and close(vy, ref[4], 1e-8)
+	dy2 = rng.normal(size=(ny, n)) + 9.0  # an ordinary log-expression row: mean 9, spread 1 -- no hand-back
+	caplog.clear()
+	with caplog.at_level(logging.INFO):
+		p2 = association_tests(dx, dy2, dc, return_dot=False)[0]
+	assert 'sparse-design kernel' in caplog.text and 'redoing' not in caplog.text
+	assert relerr(p2, oracle.association_tests(dx, dy2, dc, return_dot=False)[0]) < 1e-8
