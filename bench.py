@@ -48,7 +48,7 @@ if ROOT not in sys.path:
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r04.sh), newest first
 PMC_FILES = {w: [os.path.join(ROOT, 'profiles', f) for f in fs] for w, fs in dict(
 	coex_c2=('r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r04_pmc_de_c3.json', 'r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
-	de_c4=('r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'), de_c4_single4=('r04_pmc_de_c4_single4.json', ), de_c4_single1=('r04_pmc_de_c4_single1.json', ),
+	de_c4=('r04_pmc_de_c4_sparse.json', 'r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'), de_c4_single4=('r04_pmc_de_c4_single4_sparse.json', 'r04_pmc_de_c4_single4.json'), de_c4_single1=('r04_pmc_de_c4_single1.json', ),
 	binnet_c5=('r04_pmc_binnet_c5.json', )).items()}
 
 
