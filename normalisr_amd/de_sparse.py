@@ -37,12 +37,12 @@ class Lists:
 		torch = eng.torch
 		nx, n = d_x.shape
 		ch = int(eng.lib.nrm_de_sparse_chunk())
-		nz = torch.nonzero(d_x)  # row-major: by design row, then by cell
-		xi, k = nz[:, 0], nz[:, 1]
-		self.nnz = int(xi.numel())
+		self.nnz = int(torch.count_nonzero(d_x))  # (one cheap pass first: a dense design must not be listed entry by entry to find that out)
 		self.ok = 0 < self.nnz <= MAX_DENSITY * nx * n
 		if not self.ok:
 			return
+		nz = torch.nonzero(d_x)  # row-major: by design row, then by cell
+		xi, k = nz[:, 0], nz[:, 1]
 		vals = d_x[xi, k]
 		self.binary = bool((vals == 1).all())
 		cnt_x = torch.bincount(xi, minlength=nx)
