@@ -448,6 +448,13 @@ int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t l
 				  const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream);
 
 /*
+ * Pseudo-inverses and ranks of a stack of small symmetric matrices (host only): what single=1 needs per grouping (association.py:350-351)
+ * and normvar per gene (norm.py:232-246), by the reference's rule (association.py:77-80: singular values below tol x the largest count as
+ * zero) -- Jacobi iteration per matrix, the stack dealt to `threads` host threads (0 = choose).  m, inv (count, n, n) fp64; n <= 32.
+ */
+int nrm_small_pinv(const double* m, int64_t count, int64_t n, double tol, double* inv, int64_t* rank, int threads);
+
+/*
  * Text matrices of the command line (host only): the reference reads with numpy.loadtxt(delimiter='\t') and writes with
  * numpy.savetxt(fmt='%.8G') (run.py:20-35).  Same text in, same text out, parsed / printed by `threads` host threads (0 = choose).
  *   nrm_tsv_shape: rows = lines with data ('#' comments and blank lines skipped), cols = fields of the first such line.

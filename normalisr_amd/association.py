@@ -116,6 +116,28 @@ def inv_rank(m, tol=1E-8, method='auto', logger=None, mpc=0, qr=0, **ka):
 	return inv.reshape(m.shape), ranks.reshape(m.shape[:-2])
 
 
+def small_pinv(m, tol=1E-8):
+	"""inv_rank for a stack of small symmetric matrices (count, n, n) fp64 -- one per grouping in single=1, one per gene in normvar --
+	by the same rule (singular values below tol x the largest count as zero, association.py:77-80) through the library's threaded Jacobi
+	iteration (csrc/nrm_small_pinv.hip): numpy's stacked SVD is one LAPACK call per matrix under the GIL, 3.2 us each.  Ranks as LAPACK's
+	except for a singular value within rounding of the threshold; inverses to ~1e-14.  NRM_SMALL_SVD=lapack, matrices larger than
+	12 x 12 or a stack of fewer than 64: inv_rank itself."""
+	import os
+	m = np.ascontiguousarray(m, dtype=np.float64)
+	if m.ndim != 3 or m.shape[1] != m.shape[2]:
+		raise ValueError('Wrong shape for m.')
+	count, n = m.shape[0], m.shape[1]
+	if os.environ.get('NRM_SMALL_SVD', 'native') == 'lapack' or n > 12 or count < 64 or n == 0:
+		return inv_rank(m, tol=tol)
+	if not np.isfinite(m).all():
+		raise ValueError('array must not contain infs or NaNs')
+	from . import _lib
+	inv = np.empty_like(m)
+	ranks = np.empty(count, dtype=np.int64)
+	_lib.check(_lib.load().nrm_small_pinv(m.ctypes.data, count, n, float(tol), inv.ctypes.data, ranks.ctypes.data, 0))
+	return inv, ranks
+
+
 def _check_dimreduce(dimreduce):
 	if np.ndim(dimreduce) != 0:
 		d = np.unique(np.asarray(dimreduce))

@@ -1,0 +1,99 @@
+// Pseudo-inverses and ranks of a STACK of small symmetric matrices (host only, no device code).  single=1 needs one per grouping
+// (C_S C_S^T of the grouping's own cells, association.py:350-351), normvar one per gene (norm.py:232-246): a thousand to tens of thousands
+// of nc x nc matrices, nc ~ 5.  numpy's stacked SVD calls LAPACK once per matrix under the GIL (3.2 us each: 3.2 ms of the 7.1 ms of a
+// single=1 call at BASELINE configs[3] size).  Here: the cyclic Jacobi eigenvalue iteration, which for matrices this small converges in a
+// handful of sweeps and delivers every eigenvalue to full relative accuracy; the stack is dealt to host threads.  The rule is the
+// reference's (association.py:77-80): singular values (= |eigenvalues| of a symmetric matrix) below tol x the largest count as zero, the
+// rank is the number kept, M^+ = V_kept diag(1 / s_kept) V_kept^T.
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "nrm_common.h"
+
+#define SP_NMAX 32
+
+namespace {
+
+// a (n x n, row-major, symmetric; destroyed) -> eigenvalues w, eigenvectors as the COLUMNS of v
+void jacobi(double* a, double* v, double* w, int n) {
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) v[i * n + j] = i == j ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 60; sweep++) {
+		double off = 0.0, diag = 0.0;
+		for (int i = 0; i < n; i++) {
+			diag += a[i * n + i] * a[i * n + i];
+			for (int j = i + 1; j < n; j++) off += a[i * n + j] * a[i * n + j];
+		}
+		if (off == 0.0 || off <= 1e-34 * diag) break;  // (relative to the diagonal: the rotations below keep shrinking it quadratically)
+		for (int p = 0; p < n - 1; p++)
+			for (int q = p + 1; q < n; q++) {
+				const double apq = a[p * n + q];
+				if (apq == 0.0) continue;
+				const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+				const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+				const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+				for (int k = 0; k < n; k++) {  // columns p, q
+					const double akp = a[k * n + p], akq = a[k * n + q];
+					a[k * n + p] = c * akp - s * akq;
+					a[k * n + q] = s * akp + c * akq;
+				}
+				for (int k = 0; k < n; k++) {  // rows p, q
+					const double apk = a[p * n + k], aqk = a[q * n + k];
+					a[p * n + k] = c * apk - s * aqk;
+					a[q * n + k] = s * apk + c * aqk;
+				}
+				a[p * n + q] = a[q * n + p] = 0.0;
+				for (int k = 0; k < n; k++) {
+					const double vkp = v[k * n + p], vkq = v[k * n + q];
+					v[k * n + p] = c * vkp - s * vkq;
+					v[k * n + q] = s * vkp + c * vkq;
+				}
+			}
+	}
+	for (int i = 0; i < n; i++) w[i] = a[i * n + i];
+}
+
+void one(const double* m, int n, double tol, double* inv, int64_t* rank) {
+	double a[SP_NMAX * SP_NMAX], v[SP_NMAX * SP_NMAX], w[SP_NMAX];
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) a[i * n + j] = 0.5 * (m[i * n + j] + m[j * n + i]);
+	jacobi(a, v, w, n);
+	double smax = 0.0;
+	for (int i = 0; i < n; i++) smax = std::fmax(smax, std::fabs(w[i]));
+	int r = 0;
+	double iw[SP_NMAX];
+	for (int i = 0; i < n; i++) {
+		const bool keep = std::fabs(w[i]) >= tol * smax;  // (a zero matrix keeps everything and divides by zero, as the reference does)
+		r += keep;
+		iw[i] = keep ? 1.0 / w[i] : 0.0;
+	}
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j <= i; j++) {
+			double t = 0.0;
+			for (int k = 0; k < n; k++)
+				if (iw[k] != 0.0) t += v[i * n + k] * iw[k] * v[j * n + k];
+			inv[i * n + j] = inv[j * n + i] = t;
+		}
+	*rank = r;
+}
+
+}  // namespace
+
+// m (count, n, n) fp64 symmetric -> inv (count, n, n) = the pseudo-inverses, rank (count) int64.  n <= 32.  threads: 0 = choose.
+extern "C" int nrm_small_pinv(const double* m, int64_t count, int64_t n, double tol, double* inv, int64_t* rank, int threads) {
+	NRM_REQUIRE(count >= 0 && n >= 1 && n <= SP_NMAX && tol > 0 && (count == 0 || (m && inv && rank)), "nrm_small_pinv: bad arguments (matrices of at most %d x %d)", SP_NMAX, SP_NMAX);
+	int t = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+	if (t > 16) t = 16;
+	if (t > count / 256 + 1) t = (int)(count / 256 + 1);
+	if (t < 1) t = 1;
+	auto work = [&](int id) {
+		for (int64_t g = id; g < count; g += t) one(m + g * n * n, (int)n, tol, inv + g * n * n, rank + g);
+	};
+	std::vector<std::thread> th;
+	for (int id = 1; id < t; id++) th.emplace_back(work, id);
+	work(0);
+	for (auto& x : th) x.join();
+	return NRM_OK;
+}

@@ -72,13 +72,11 @@ def _normvar1_weighted(dt, dc, w2, tol=1E-8):
 			m = np.zeros((nt, nc, nc))
 			m[:, iu[0], iu[1]] = gm
 			m[:, iu[1], iu[0]] = gm
-			_, sv, vh = np.linalg.svd(m)
-			keep = sv >= tol * sv[:, :1]
-			if (keep.sum(axis=1) <= 0).any():
+			from .association import small_pinv
+			mi, rk = small_pinv(m, tol)  # per-gene pseudo-inverse by the rank rule of inv_rank (association.py:77), threaded in the library
+			if (np.asarray(rk) <= 0).any():
 				raise RuntimeError('Zero-rank covariates found.')
-			with np.errstate(divide='ignore'):
-				inv_s = np.where(keep, 1.0 / sv, 0.0)
-			b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)
+			b = np.einsum('gcd,gd->gc', mi, ga)  # b_g = M_g^+ a_g
 			tdt = torch.float64 if out_dtype == np.float64 else torch.float32
 			out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
 			d_b = eng.upload(b)
@@ -149,13 +147,11 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 			m = np.zeros((nt, nc, nc))
 			m[:, iu[0], iu[1]] = gm
 			m[:, iu[1], iu[0]] = gm
-			_, sv, vh = np.linalg.svd(m)
-			keep = sv >= tol * sv[:, :1]
-			if (keep.sum(axis=1) <= 0).any():
+			from .association import small_pinv
+			mi, rk = small_pinv(m, tol)  # per-gene pseudo-inverse by the rank rule of inv_rank (association.py:77), threaded in the library
+			if (np.asarray(rk) <= 0).any():
 				raise RuntimeError('Zero-rank covariates found.')
-			with np.errstate(divide='ignore'):
-				inv_s = np.where(keep, 1.0 / sv, 0.0)
-			b = np.einsum('gkc,gk,gkd,gd->gc', vh, inv_s, vh, ga)  # b_g = M_g^+ a_g
+			b = np.einsum('gcd,gd->gc', mi, ga)  # b_g = M_g^+ a_g
 			scale = np.ones(nt)
 			if keepvar:
 				mean = s1[:nt].cpu().numpy() / ns

@@ -20,7 +20,7 @@ import numpy as np
 from . import _lib
 from . import engine as _engine
 from ._lib import ROW_TILE
-from .association import inv_rank
+from .association import inv_rank, small_pinv
 
 
 def _round_up(v, m):
@@ -113,7 +113,7 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 				if nc:
 					mc = torch.einsum('icn,dn->icd', wv[:, :nc, :n], d_c).cpu().numpy()       # (m, nc, nc)
 					xc = torch.einsum('in,dn->id', wv[:, nc, :n], d_c).cpu().numpy()          # (m, nc)
-					mi, rk = inv_rank(mc)  # association.py:350-351, all groupings of the chunk
+					mi, rk = small_pinv(mc)  # association.py:350-351, all groupings of the chunk
 					mi[rk == 0] = 0
 					ccx = np.einsum('icd,id->ic', mi, xc)
 					info[:, 26:26 + nc] = ccx
@@ -200,7 +200,7 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 		mc = mcc[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
 		xc = _segment_sums(ce * xe, starts, counts).T  # (nx, nc)
 		mark('host sums')
-		mi, rk = inv_rank(mc)  # association.py:350-351
+		mi, rk = small_pinv(mc)  # association.py:350-351
 		mi[rk == 0] = 0
 		mark('inv_rank')
 		ccx = np.einsum('icd,id->ic', mi, xc)

@@ -188,3 +188,29 @@ def test_pvalue_plans_of_a_screen_are_cheap():
 	again = np.zeros((1, 24))
 	lib.nrm_pvalue_plan_init_many(dof[1234:].ctypes.data, 1, again.ctypes.data, 24)
 	assert np.array_equal(again[0], out[1234])
+
+
+@pytest.mark.parametrize('nc', [1, 2, 5, 8, 12])
+def test_small_pinv_matches_inv_rank(nc, monkeypatch):
+	"""The library's threaded Jacobi pseudo-inverse of a stack of small symmetric matrices (csrc/nrm_small_pinv.hip; single=1: one matrix per
+	grouping, normvar: one per gene) against inv_rank (LAPACK SVD, association.py:4-134): the same integer ranks -- rank-deficient
+	matrices (a covariate twice), tiny and huge scales included -- and the same pseudo-inverses to 1e-12."""
+	from normalisr_amd.association import inv_rank, small_pinv
+	rng = np.random.default_rng(nc)
+	a = rng.normal(size=(300, nc, 40))
+	m = a @ a.swapaxes(1, 2)
+	if nc >= 2:
+		for g in (7, 8, 9):  # the last covariate a copy of the first: rank nc - 1
+			m[g, :, nc - 1], m[g, nc - 1, :] = m[g, :, 0], m[g, 0, :]
+			m[g, nc - 1, nc - 1] = m[g, 0, 0]
+		m[11] *= 1e-30
+		m[12] *= 1e30
+	inv, rk = small_pinv(m)
+	ref, rr = inv_rank(m)
+	assert np.array_equal(rk, rr) and (nc < 2 or (rk[7:10] == nc - 1).all())
+	err = np.abs(inv - ref).max(axis=(1, 2)) / np.abs(ref).max(axis=(1, 2))
+	assert err.max() < 1e-12
+	assert np.array_equal(inv, inv.swapaxes(1, 2))
+	monkeypatch.setenv('NRM_SMALL_SVD', 'lapack')
+	inv2, rk2 = small_pinv(m)
+	assert np.array_equal(inv2, ref) and np.array_equal(rk2, rr)
