@@ -90,6 +90,19 @@ class Lists:
 		self.padded = total
 
 
+def lists_for(eng, d_x):
+	"""Lists(eng, d_x), kept for the next call on the SAME device tensor as long as it has not been written to (torch counts in-place
+	writes in ._version; a weak reference: the cache keeps no design matrix alive, and a new tensor at an old address is not the same
+	object) -- a resident screen analysed again and again pays for its lists once."""
+	import weakref
+	hit = getattr(eng, '_sparse_lists', None)
+	if hit is not None and hit[0]() is d_x and hit[1] == d_x._version:
+		return hit[2]
+	lists = Lists(eng, d_x)
+	eng._sparse_lists = (weakref.ref(d_x), d_x._version, lists)
+	return lists
+
+
 def run(eng, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_coef, flags=None):
 	"""K1 on the design rows (their sums of squares and coefficients), the one-pass kernels on the expression rows.
 	Returns (dot (nx_pad, ny_pad) fp64 with dot[i, y] = x~_i . y~_y, rx, ssy, coefy)."""

@@ -1198,7 +1198,7 @@ class Engine:
 					dx = self.upload(as_input(dx))  # (kept for the dense path below if the matrix turns out not to be sparse)
 				lists = state.get('sparse') if state is not None else None
 				if lists is None or lists[0] is not dx:
-					lists = (dx, de_sparse.Lists(self, dx))
+					lists = (dx, de_sparse.lists_for(self, dx))
 					if state is not None:
 						state['sparse'] = lists
 			if lists[1].ok:

@@ -420,7 +420,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		if not force_f64:
 			from . import de_sparse
 			if de_sparse.candidate(eng, d_x, d_y, dc64, False):
-				lists = de_sparse.Lists(eng, d_x)
+				lists = de_sparse.lists_for(eng, d_x)
 				lists = lists if lists.ok else None
 		if lists is not None:
 			ns = 0

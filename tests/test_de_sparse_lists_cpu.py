@@ -59,3 +59,16 @@ def test_a_dense_design_is_refused_before_it_is_listed():
 	lst = de_sparse.Lists(eng, dx)
 	assert not lst.ok and lst.nnz == 40 * 3000 and not hasattr(lst, 'ell')
 	assert not de_sparse.Lists(eng, torch.zeros((40, 3000))).ok
+
+
+def test_lists_are_kept_for_the_same_unmodified_tensor():
+	from normalisr_amd import de_sparse
+	eng = _CpuEngine()
+	dx = torch.as_tensor((np.random.default_rng(2).random((40, 5000)) < 0.02).astype(np.float32))
+	a = de_sparse.lists_for(eng, dx)
+	assert de_sparse.lists_for(eng, dx) is a
+	dx[3, 7] = 1.0  # an in-place write: analysed again
+	b = de_sparse.lists_for(eng, dx)
+	assert b is not a and b.nnz in (a.nnz, a.nnz + 1)
+	c = de_sparse.lists_for(eng, dx.clone())  # another tensor with the same content: its own lists
+	assert c is not b and c.nnz == b.nnz
