@@ -448,13 +448,6 @@ int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t l
 				  const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream);
 
 /*
- * X X^T of a design matrix whose entries are all 1 (single=4's M~ = X~ X~^T = X X^T - b_x (C C^T) b_x^T for a gRNA design): d_cell_ptr
- * (n + 1), d_rows: the design rows present in cell k are d_rows[d_cell_ptr[k] .. d_cell_ptr[k + 1]), ascending; d_counts (nx, nx) int32,
- * zeroed by the caller: [i][j], i <= j, receives the number of cells that design rows i and j share (integer atomics: exact).
- */
-int nrm_design_cooccurrence(const int64_t* d_cell_ptr, const int32_t* d_rows, int64_t n, int64_t nx, int32_t* d_counts, void* stream);
-
-/*
  * Pseudo-inverses and ranks of a stack of small symmetric matrices (host only): what single=1 needs per grouping (association.py:350-351)
  * and normvar per gene (norm.py:232-246), by the reference's rule (association.py:77-80: singular values below tol x the largest count as
  * zero) -- Jacobi iteration per matrix, the stack dealt to `threads` host threads (0 = choose).  m, inv (count, n, n) fp64; n <= 32.

@@ -212,27 +212,3 @@ extern "C" int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n
 	return d_ellv ? ds_go<float, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
 				  : ds_go<float, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
 }
-
-// ---- X X^T of a design matrix whose entries are all 1 (gRNA incidence): how many cells two design rows share ----------------------------
-// single=4 needs M~ = X~ X~^T (association.py:421-576 in the closed form of single4.py) = X X^T - b_x (C C^T) b_x^T: the first term is a
-// count.  A thread per cell walks the design rows present in it (ascending) and counts every pair on or above the diagonal: integer
-// atomics -- exact, so the order they arrive in does not matter -- on a 4 MB table that lives in L2.  1e11 flop on the fp64 matrix cores
-// (1.6 ms at BASELINE configs[3] size) become 2.7 M increments.
-__global__ void __launch_bounds__(256) k_cooccurrence(const int64_t* __restrict__ cell_ptr, const int32_t* __restrict__ rows, int64_t n, int64_t nx,
-													   int32_t* __restrict__ counts) {
-	const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (k >= n) return;
-	const int64_t a = cell_ptr[k], b = cell_ptr[k + 1];
-	for (int64_t i = a; i < b; i++) {
-		const int64_t ri = rows[i];
-		for (int64_t j = i; j < b; j++) atomicAdd(&counts[ri * nx + rows[j]], 1);
-	}
-}
-
-// cell_ptr (n + 1): the entries of cell k are rows[cell_ptr[k] .. cell_ptr[k + 1]) (design rows, ascending); counts (nx, nx) int32, zeroed
-// by the caller: counts[i][j] (i <= j) += the number of cells in which design rows i and j are both present.
-extern "C" int nrm_design_cooccurrence(const int64_t* d_cell_ptr, const int32_t* d_rows, int64_t n, int64_t nx, int32_t* d_counts, void* stream) {
-	NRM_REQUIRE(n > 0 && nx > 0 && d_cell_ptr && d_rows && d_counts, "nrm_design_cooccurrence: bad arguments");
-	hipLaunchKernelGGL(k_cooccurrence, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_cell_ptr, d_rows, n, nx, d_counts);
-	return nrm_check_launch("k_cooccurrence");
-}

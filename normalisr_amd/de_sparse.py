@@ -45,7 +45,6 @@ class Lists:
 		xi, k = nz[:, 0], nz[:, 1]
 		vals = d_x[xi, k]
 		self.binary = bool((vals == 1).all())
-		self._xi, self._k, self._shape, self._cells = xi, k, (nx, n), None
 		cnt_x = torch.bincount(xi, minlength=nx)
 		order = torch.argsort(cnt_x, descending=True, stable=True)  # slot -> design row
 		nslots = _round_up(nx, 64)
@@ -89,26 +88,6 @@ class Lists:
 		self.base = base.contiguous()
 		self.w = w.flatten().to(torch.int32).contiguous()
 		self.padded = total
-
-
-def cooccurrence(eng, lists):
-	"""X X^T (nx, nx) fp64 on the device for a design whose entries are all 1: the number of cells two design rows share, counted with
-	integer atomics (csrc/nrm_de_sparse.hip: k_cooccurrence).  None when the design has other values."""
-	if not lists.binary:
-		return None
-	torch = eng.torch
-	nx, n = lists._shape
-	if lists._cells is None:  # the entries by cell (design rows ascending inside a cell: nonzero() listed them row by row, the sort is stable)
-		order = torch.argsort(lists._k, stable=True)
-		cnt = torch.bincount(lists._k, minlength=n)
-		ptr = torch.zeros(n + 1, dtype=torch.int64, device=eng.device)
-		ptr[1:] = torch.cumsum(cnt, 0)
-		lists._cells = (ptr, lists._xi[order].to(torch.int32).contiguous())
-	ptr, rows = lists._cells
-	counts = eng.zeros((nx, nx), torch.int32)
-	_lib.check(eng.lib.nrm_design_cooccurrence(ptr.data_ptr(), rows.data_ptr(), n, nx, counts.data_ptr(), eng._stream()))
-	m = torch.triu(counts).to(torch.float64)
-	return m + torch.triu(m, 1).T
 
 
 def lists_for(eng, d_x):

@@ -427,20 +427,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=bool(nc), nslices=ns, keep_fp64=True)
 		nxp = rx.rows_pad
 		mark('K1 design')
-		xxt = None
-		if lists is not None and os.environ.get('NRM_S4_COOCCURRENCE', '1') != '0':
-			from . import de_sparse
-			xxt = de_sparse.cooccurrence(eng, lists)  # X X^T of a 0 / 1 design: counts
-		if xxt is not None:
-			# M~ = X~ X~^T = X X^T - b_x (C C^T) b_x^T (b_x (C C^T) = x C^T for rows in the span of C: the cross terms cancel one of the squares)
-			mt_d = eng.zeros((nxp, nxp), torch.float64)
-			if nc:
-				bx = rx.coef[:nx]
-				bm = (bx[:, :, None] * torch.as_tensor(dc64 @ dc64.T, device=eng.device)[None, :, :]).sum(dim=1)  # b_x (C C^T), element-wise: no BLAS handle for a 1000 x 5 x 5 product
-				xxt = xxt - (bm[:, None, :] * bx[None, :, :]).sum(dim=2)
-			mt_d[:nx, :nx] = xxt
-		else:
-			mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
+		mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
 		# N~ = M~^-1 on the device (Newton-Schulz on the fp64 matrix cores); the host's LAPACK only if that does not converge
 		inv = _spd_inverse_device(eng, mt_d, nx) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
 		if inv is None:
