@@ -473,14 +473,16 @@ def test_de_with_a_sparse_design_reads_the_expression_rows_once(monkeypatch, cap
 		assert close(s[5][key], d[5][key], 1e-5 if f32 else 1e-6, 1e-6 if f32 else 1e-7)
 
 
-@pytest.mark.parametrize('dtype,nc', [(np.float32, 4), (np.float64, 0), (np.float64, 3)])
-def test_single4_with_a_sparse_design(monkeypatch, dtype, nc):
+@pytest.mark.parametrize('dtype,nc,valued', [(np.float32, 4, False), (np.float64, 0, False), (np.float64, 3, False), (np.float64, 2, True)])
+def test_single4_with_a_sparse_design(monkeypatch, dtype, nc, valued):
 	"""single=4 (association.py:421-576) with the products Y~ X~^T taken from the raw expression rows at the design's entries
 	(de_sparse.products, by gene) against the oracle's per-grouping SVD loop and against the integer-engine path; alpha included."""
 	from normalisr_amd.association import association_tests
 	rng = np.random.default_rng(77 + nc)
 	nx, ny, n = 48, 150, 6004
 	dx = (rng.random((nx, n)) < 0.02).astype(dtype)
+	if valued:
+		dx = (dx * rng.uniform(0.5, 2.0, dx.shape)).astype(dtype)
 	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))]) if nc else np.zeros((0, n))
 	dy = (rng.normal(size=(ny, n)) + 2.0 + 0.7 * dx[rng.integers(0, nx, ny)].astype(np.float64) * rng.normal(size=(ny, 1))).astype(dtype)
 	ref = oracle.association_tests(dx.astype(np.float64), dy.astype(np.float64), dc, single=4, lowmem=False, return_dot=False)
