@@ -21,7 +21,7 @@
 #define DS_T 512     // threads per workgroup
 #define DS_G 2       // design rows per thread: 1024 per pass over the expression matrix
 #define DS_NCMAX 32  // (the sums over the covariates come from nrm_single1_stream: its limit)
-#define DS_WGS 2     // workgroups per CU: one gathers while the other fills its chunk
+#define DS_WGS 2     // waves per SIMD the register budget is set for (the 64 KB of LDS allow two workgroups per CU: one gathers while the other fills its chunk)
 
 namespace {
 
