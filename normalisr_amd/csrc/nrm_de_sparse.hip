@@ -17,7 +17,8 @@
 #include "nrm_common.h"
 
 #define DS_CH 4096   // cells per chunk: 64 KB of records (8192 with one workgroup per CU: 12 % fewer padded entries, but 2.11 ms instead of 1.82 -- the
-                     // kernel lives on the waves it has in flight)
+                     // kernel lives on the waves it has in flight; 2048 cells: 17 % more padded entries, 1.88 ms.  Time = 0.71 ms (the rows streamed and staged)
+                     // + 1.45 ms per million padded entries, measured from 0.2 % to 3 % of the design set)
 #define DS_T 512     // threads per workgroup
 #define DS_G 2       // design rows per thread: 1024 per pass over the expression matrix
 #define DS_NCMAX 32  // (the sums over the covariates come from nrm_single1_stream: its limit)
