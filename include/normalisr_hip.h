@@ -448,6 +448,14 @@ int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t l
 				  const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream);
 
 /*
+ * The design rows' own statistics from their entries (association.py:224-230 for a sparse design row): d_row_ptr (nx + 1), d_cells (int32),
+ * d_vals (fp64, or NULL: every entry 1) list the entries of design row i at [d_row_ptr[i], d_row_ptr[i + 1]); d_c (nc, ldc), d_dci as above.
+ * d_ss (nx) = |x~_i|^2 = |x_i|^2 - (x_i C^T) . b_i, d_coef (nx, nc) = b_i.
+ */
+int nrm_design_stats(const int64_t* d_row_ptr, const int32_t* d_cells, const double* d_vals, const double* d_c, int64_t ldc, int64_t nc,
+					 const double* d_dci, int64_t nx, double* d_ss, double* d_coef, void* stream);
+
+/*
  * Pseudo-inverses and ranks of a stack of small symmetric matrices (host only): what single=1 needs per grouping (association.py:350-351)
  * and normvar per gene (norm.py:232-246), by the reference's rule (association.py:77-80: singular values below tol x the largest count as
  * zero) -- Jacobi iteration per matrix, the stack dealt to `threads` host threads (0 = choose).  m, inv (count, n, n) fp64; n <= 32.

@@ -213,3 +213,56 @@ extern "C" int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n
 	return d_ellv ? ds_go<float, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
 				  : ds_go<float, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
 }
+
+// ---- the design rows' own statistics from their entries ---------------------------------------------------------------------------------
+// |x~_i|^2 = |x_i|^2 - (x_i C^T) . b_i and b_i = (x_i C^T)(C C^T)^+ (association.py:224-230) need of a sparse design row only its entries:
+// a wave per design row walks them (lane-strided, then a tree over the lanes: a fixed order), instead of K1's two sweeps over n cells.
+__global__ void __launch_bounds__(64) k_design_stats(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ cells, const double* __restrict__ vals,
+													  const double* __restrict__ C, int64_t ldc, int nc, const double* __restrict__ dci, int64_t nx,
+													  double* __restrict__ ss, double* __restrict__ coef) {
+	const int64_t i = blockIdx.x;
+	const int lane = threadIdx.x;
+	double a[DS_NCMAX], xx = 0.0;
+#pragma unroll
+	for (int c = 0; c < DS_NCMAX; c++) a[c] = 0.0;
+	for (int64_t e = row_ptr[i] + lane; e < row_ptr[i + 1]; e += 64) {
+		const double v = vals ? vals[e] : 1.0;
+		const int64_t k = cells[e];
+		xx = fma(v, v, xx);
+#pragma unroll
+		for (int c = 0; c < DS_NCMAX; c++)
+			if (c < nc) a[c] = fma(v, C[c * ldc + k], a[c]);
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		xx += __shfl_down(xx, o, 64);
+#pragma unroll
+		for (int c = 0; c < DS_NCMAX; c++)
+			if (c < nc) a[c] += __shfl_down(a[c], o, 64);
+	}
+	if (lane == 0) {
+		double s = xx;
+		for (int c = 0; c < nc; c++) {
+			double b = 0.0;
+#pragma unroll
+			for (int e = 0; e < DS_NCMAX; e++)
+				if (e < nc) b = fma(a[e], dci[e * nc + c], b);
+			coef[i * nc + c] = b;
+			double ac = 0.0;
+#pragma unroll
+			for (int e = 0; e < DS_NCMAX; e++)
+				if (e == c) ac = a[e];
+			s = fma(-ac, b, s);
+		}
+		ss[i] = s > 0.0 ? s : 0.0;
+	}
+}
+
+// d_row_ptr (nx + 1), d_cells (int32), d_vals (fp64 or NULL: every entry 1): the entries of design row i are [d_row_ptr[i], d_row_ptr[i + 1]).
+// d_ss (nx) = |x~_i|^2, d_coef (nx, nc) = b_i.  nc = 0: no covariates (d_ss = |x_i|^2).
+extern "C" int nrm_design_stats(const int64_t* d_row_ptr, const int32_t* d_cells, const double* d_vals, const double* d_c, int64_t ldc, int64_t nc,
+								const double* d_dci, int64_t nx, double* d_ss, double* d_coef, void* stream) {
+	NRM_REQUIRE(nx > 0 && nc >= 0 && nc <= DS_NCMAX && d_row_ptr && d_cells && d_ss && (nc == 0 || (d_c && d_dci && d_coef)), "nrm_design_stats: bad arguments");
+	hipLaunchKernelGGL(k_design_stats, dim3((unsigned)nx), dim3(64), 0, (hipStream_t)stream, d_row_ptr, d_cells, d_vals, d_c, ldc, (int)nc, d_dci, nx, d_ss, d_coef);
+	return nrm_check_launch("k_design_stats");
+}

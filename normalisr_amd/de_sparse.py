@@ -45,6 +45,11 @@ class Lists:
 		xi, k = nz[:, 0], nz[:, 1]
 		vals = d_x[xi, k]
 		self.binary = bool((vals == 1).all())
+		# the entries row by row (nonzero() lists them so): what the design rows' own statistics are taken from (design_stats)
+		self.row_ptr = torch.zeros(nx + 1, dtype=torch.int64, device=eng.device)
+		self.row_ptr[1:] = torch.cumsum(torch.bincount(xi, minlength=nx), 0)
+		self.cells = k.to(torch.int32).contiguous()
+		self.row_vals = None if self.binary else vals.to(torch.float64).contiguous()
 		cnt_x = torch.bincount(xi, minlength=nx)
 		order = torch.argsort(cnt_x, descending=True, stable=True)  # slot -> design row
 		nslots = _round_up(nx, 64)
@@ -103,10 +108,32 @@ def lists_for(eng, d_x):
 	return lists
 
 
+class DesignRows:
+	"""What the sweep and alpha need of the design rows: their sums of squares and coefficients (the fields of engine.Residualized they read)."""
+
+	def __init__(self, ss, coef):
+		self.ss, self.coef = ss, coef
+
+
+def design_stats(eng, lists, d_c, d_dci, rank, nx, nc):
+	"""|x~_i|^2 and b_i of every design row from its entries (csrc/nrm_de_sparse.hip: k_design_stats) -- K1 would sweep n cells twice
+	for rows that have a few hundred entries."""
+	from . import engine as _engine
+	torch = eng.torch
+	ncu = nc if (rank > 0 and nc > 0) else 0
+	ss = eng.zeros((_round_up(nx, ROW_TILE), ), torch.float64)
+	coef = eng.zeros((nx, nc), torch.float64) if nc else eng.zeros((nx, 1), torch.float64)[:, :0]  # (covariates of rank 0: the coefficients stay zero)
+	with _engine._Span(eng, 'design_stats'):
+		_lib.check(eng.lib.nrm_design_stats(lists.row_ptr.data_ptr(), lists.cells.data_ptr(), 0 if lists.row_vals is None else lists.row_vals.data_ptr(),
+											d_c.data_ptr() if ncu else 0, d_c.stride(0) if ncu else 0, ncu, d_dci.data_ptr() if ncu else 0, nx, ss.data_ptr(),
+											coef.data_ptr() if ncu else 0, eng._stream()))
+	return DesignRows(ss, coef)
+
+
 def run(eng, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_coef, flags=None):
-	"""K1 on the design rows (their sums of squares and coefficients), the one-pass kernels on the expression rows.
+	"""The design rows' statistics from their entries, the one-pass kernels on the expression rows.
 	Returns (dot (nx_pad, ny_pad) fp64 with dot[i, y] = x~_i . y~_y, rx, ssy, coefy)."""
-	rx = eng.residualize(d_x, d_c, d_dci, rank, want_coef=True, nslices=0)
+	rx = design_stats(eng, lists, d_c, d_dci, rank, nx, nc)
 	dot, ssy, coefy = products(eng, lists, dy, d_c, d_dci, rank, rx.coef, nx, ny, n, nc, want_coef, False, flags)
 	return dot, rx, ssy, coefy
 
