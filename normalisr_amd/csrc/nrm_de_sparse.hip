@@ -13,7 +13,9 @@
 // 1 KB load gives every lane its next 8), lists padded to the longest of the 64 (a multiple of 8) with the offset of a record of zeros.
 // The next chunk's HBM loads are in flight (in registers) while the current one is gathered.  The products with the covariates y C^T and
 // |y|^2 come from nrm_single1.hip's stream kernel (sums only: a second pass over the rows at HBM rate, 0.6 ms at configs[3] size; taken
-// inside THIS kernel -- covariate values fetched between the barriers of a chunk, every wave in the same phase -- they cost 1.1 ms).
+// inside THIS kernel they cost more both ways it was tried: covariate values fetched between the barriers of a chunk, every wave in the same
+// phase: +1.1 ms; a dense phase after the gathers -- consecutive lanes on consecutive records and covariate values, two cells at a time to stay
+// inside the registers: +2.0 ms, each batch waiting for its loads at two waves per SIMD).
 #include "nrm_common.h"
 
 #define DS_CH 4096   // cells per chunk: 64 KB of records (8192 with one workgroup per CU: 12 % fewer padded entries, but 2.11 ms instead of 1.82 -- the
