@@ -430,11 +430,14 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
  *   d_y (ny, ldy) raw expression rows (y_dtype); d_common (nc + 1, ny) fp64 their products with the covariates and (row nc) sums of
  *   squares, as nrm_single1_stream leaves them when every cell has the code NRM_S1_COMMON; d_dci (nc, nc) the pseudo-inverse of C C^T,
  *   nc <= nrm_de_sparse_max_covariates() (nc = 0: no covariates, or covariates of rank 0).
- *   The design matrix as lists: its rows are assigned to slots 0 .. 64 * ngroups - 1 (d_slot2x: slot -> design row, -1 for an empty
- *   slot); the cells are cut into chunks of nrm_de_sparse_chunk().  For chunk c and the 64 slots of group g, d_w[c * ngroups + g] is the
- *   length of the longest list among them rounded up to a multiple of 8, and d_base[c * ngroups + g] the start of their block in d_ell:
- *   entry j of slot 64 g + l at d_base[..] + (64 (j / 8) + l) 8 + j % 8 (8 consecutive entries of a slot side by side: one 16-byte load)
- *   = the offset of the cell inside its chunk, or nrm_de_sparse_chunk() for padding; d_ellv: the entries' values likewise (fp64), or NULL
+ *   The design matrix as lists: its rows are slots 0 .. 64 * ngroups - 1 (d_slot2x: slot -> design row, -1 for an empty slot); the cells
+ *   are cut into chunks of nrm_de_sparse_chunk().  In every chunk the slots are dealt anew to the 64 * ngroups POSITIONS of the workgroup's
+ *   lanes, d_sig[c * 64 * ngroups + p] = the slot position p gathers for in chunk c (a permutation inside every block of 1024 positions:
+ *   one pass of the kernel; sorted by the slots' number of entries in the chunk, so that the 64 lists a wave walks in step are equally
+ *   long).  For chunk c and the 64 positions of group g, d_w[c * ngroups + g] is the length of the longest list among them rounded up to a
+ *   multiple of 8, and d_base[c * ngroups + g] the start of their block in d_ell: entry j of position 64 g + l at
+ *   d_base[..] + (64 (j / 8) + l) 8 + j % 8 (8 consecutive entries of a position side by side: one 16-byte load) = the offset of the cell
+ *   inside its chunk, or nrm_de_sparse_chunk() for padding; d_ellv: the entries' values likewise (fp64), or NULL
  *   when every entry is 1.  d_bx (design rows, ldb) the design rows' coefficients b_i from K1.
  * Out: d_dot[i * ldd + y] = x~_i . y~_y (by_gene != 0: d_dot[y * ldd + i], the layout single=4 reads); d_ssy (ny) = |y~|^2; d_coefy (ny, nc)
  *   = b_y or NULL; d_flags (int32[4], as nrm_assoc_sweep's) or NULL: [2] counts the expression rows whose residual is so small a part
@@ -444,8 +447,9 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
 int64_t nrm_de_sparse_chunk(void);
 int64_t nrm_de_sparse_max_covariates(void);
 int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_common, int64_t nc, const double* d_dci,
-				  const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, int64_t ngroups, const int32_t* d_slot2x,
-				  const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream);
+				  const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, const int32_t* d_sig, int64_t ngroups,
+				  const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy,
+				  int32_t* d_flags, void* stream);
 
 /*
  * The design rows' own statistics from their entries (association.py:224-230 for a sparse design row): d_row_ptr (nx + 1), d_cells (int32),

@@ -42,7 +42,7 @@ struct DsVec<double> {
 template <typename T, bool ALIGNED, bool BINARY>
 __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict__ Y, int64_t ldy, int64_t n, int64_t ny, const double* __restrict__ common, int nc,
 															   const double* __restrict__ dci, const int16_t* __restrict__ ell, const double* __restrict__ ellv,
-															   const int64_t* __restrict__ ellbase, const int32_t* __restrict__ ellw, int ngroups, int group0,
+															   const int64_t* __restrict__ ellbase, const int32_t* __restrict__ ellw, const int32_t* __restrict__ sig, int ngroups, int group0,
 															   const int32_t* __restrict__ slot2x, const double* __restrict__ bx, int64_t ldb,
 															   double* __restrict__ dot, int64_t ldd, int by_gene, double* __restrict__ ssy, double* __restrict__ coefy, int32_t* __restrict__ flags, int first) {
 	constexpr int V = DsVec<T>::V, R = DsVec<T>::R;
@@ -94,8 +94,37 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 		}
 	};
 	request(0);
+	const int64_t nslots = (int64_t)ngroups * 64;
+	const int pos0 = group0 * 64;  // first position of this pass (positions pos0 .. pos0 + DS_G * DS_T - 1)
 	for (int c = 0; c < nchunks; c++) {
 		__syncthreads();  // the gathers of the previous chunk are done with LDS
+		if (c > 0) {
+			// Position p of the workgroup gathers, in chunk c, for the design row sig[c][p]: the rows are dealt anew for every chunk, sorted by
+			// the number of entries they have IN it, so that the 64 lists a wave walks in step are equally long (dealt once for all chunks a
+			// wave waited for its longest list: 750 000 padded entries for 500 000, now 560 000).  The sums move with the rows: through
+			// LDS, which is free between two chunks.
+			double* acc = reinterpret_cast<double*>(lds);  // [design row of this pass][R]
+#pragma unroll
+			for (int g = 0; g < DS_G; g++) {
+				const int p = pos0 + g * DS_T + tid;
+				if (p < nslots) {
+					const int sl = sig[(int64_t)(c - 1) * nslots + p] - pos0;
+#pragma unroll
+					for (int r = 0; r < R; r++) acc[sl * R + r] = S[g][r];
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int g = 0; g < DS_G; g++) {
+				const int p = pos0 + g * DS_T + tid;
+				if (p < nslots) {
+					const int sl = sig[(int64_t)c * nslots + p] - pos0;
+#pragma unroll
+					for (int r = 0; r < R; r++) S[g][r] = acc[sl * R + r];
+				}
+			}
+			__syncthreads();
+		}
 		const int64_t k0 = (int64_t)c * DS_CH;
 #pragma unroll
 		for (int j = 0; j < NJ; j++) {
@@ -165,9 +194,9 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 	// y~ . x~ for this thread's design rows
 #pragma unroll
 	for (int g = 0; g < DS_G; g++) {
-		const int slot = (group0 + g * (DS_T / 64)) * 64 + tid;
+		const int p = (group0 + g * (DS_T / 64)) * 64 + tid;
 		if ((group0 + g * (DS_T / 64) + wave) >= ngroups) break;
-		const int x = slot2x[slot];
+		const int x = slot2x[sig[(int64_t)(nchunks - 1) * nslots + p]];  // (the design row this position gathered for in the last chunk)
 		if (x < 0) continue;
 #pragma unroll
 		for (int r = 0; r < R; r++) {
@@ -180,7 +209,7 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 
 template <typename T, bool BINARY>
 int ds_go(const void* d_y, int64_t ldy, int64_t n, int64_t ny, const double* d_common, int nc, const double* d_dci, const int16_t* d_ell, const double* d_ellv,
-		  const int64_t* d_base, const int32_t* d_w, int ngroups, const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd,
+		  const int64_t* d_base, const int32_t* d_w, const int32_t* d_sig, int ngroups, const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd,
 		  int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, hipStream_t st) {
 	constexpr int R = DsVec<T>::R;
 	const bool aligned = ((uintptr_t)d_y % 16 == 0) && (ldy * sizeof(T)) % 16 == 0 && n % DsVec<T>::V == 0;
@@ -188,10 +217,10 @@ int ds_go(const void* d_y, int64_t ldy, int64_t n, int64_t ny, const double* d_c
 	for (int g0 = 0; g0 < ngroups; g0 += (DS_T / 64) * DS_G) {  // 1024 design rows per pass
 		if (aligned)
 			hipLaunchKernelGGL((k_de_sparse<T, true, BINARY>), grid, dim3(DS_T), 0, st, (const T*)d_y, ldy, n, ny, d_common, nc, d_dci, d_ell, d_ellv, d_base, d_w,
-							   ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
+							   d_sig, ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
 		else
 			hipLaunchKernelGGL((k_de_sparse<T, false, BINARY>), grid, dim3(DS_T), 0, st, (const T*)d_y, ldy, n, ny, d_common, nc, d_dci, d_ell, d_ellv, d_base, d_w,
-							   ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
+							   d_sig, ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
 	}
 	return nrm_check_launch("k_de_sparse");
 }
@@ -202,18 +231,18 @@ extern "C" int64_t nrm_de_sparse_chunk(void) { return DS_CH; }
 extern "C" int64_t nrm_de_sparse_max_covariates(void) { return DS_NCMAX; }
 
 extern "C" int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_common, int64_t nc, const double* d_dci,
-							 const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, int64_t ngroups, const int32_t* d_slot2x,
-							 const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream) {
+							 const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, const int32_t* d_sig, int64_t ngroups,
+							 const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream) {
 	NRM_REQUIRE(ny > 0 && n > 0 && nc >= 0 && nc <= DS_NCMAX && ngroups > 0 && ngroups < (1 << 24), "nrm_de_sparse: bad sizes (at most %d covariates)", DS_NCMAX);
 	NRM_REQUIRE(y_dtype == NRM_F32 || y_dtype == NRM_F64, "nrm_de_sparse: bad dtype");
 	NRM_REQUIRE(ldy >= n && (nc == 0 || ldb >= nc) && (by_gene || ldd >= ny), "nrm_de_sparse: pitch too small");
-	NRM_REQUIRE(d_y && d_common && d_ell && d_base && d_w && d_slot2x && d_dot && d_ssy && (nc == 0 || (d_dci && d_bx)), "nrm_de_sparse: null pointer");
+	NRM_REQUIRE(d_y && d_common && d_ell && d_base && d_w && d_sig && d_slot2x && d_dot && d_ssy && (nc == 0 || (d_dci && d_bx)), "nrm_de_sparse: null pointer");
 	hipStream_t st = (hipStream_t)stream;
 	if (y_dtype == NRM_F64)
-		return d_ellv ? ds_go<double, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
-					  : ds_go<double, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
-	return d_ellv ? ds_go<float, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
-				  : ds_go<float, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
+		return d_ellv ? ds_go<double, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
+					  : ds_go<double, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
+	return d_ellv ? ds_go<float, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
+				  : ds_go<float, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
 }
 
 // ---- the design rows' own statistics from their entries ---------------------------------------------------------------------------------

@@ -30,8 +30,9 @@ def candidate(eng, dx, dy, dc, samexy):
 
 
 class Lists:
-	"""The design matrix as the kernel reads it: for every chunk of cells and every 64 design rows ("slots": rows ordered by their number
-	of entries, so that rows of similar length share a wave), the entries of the 64 rows side by side, padded to the longest."""
+	"""The design matrix as the kernel reads it: for every chunk of cells and every 64 positions of the workgroup's lanes (the design rows
+	are dealt to the positions chunk by chunk, sorted by their number of entries in the chunk), the entries of the 64 rows side by side,
+	padded to the longest."""
 
 	def __init__(self, eng, d_x):
 		torch = eng.torch
@@ -50,17 +51,24 @@ class Lists:
 		self.row_ptr[1:] = torch.cumsum(torch.bincount(xi, minlength=nx), 0)
 		self.cells = k.to(torch.int32).contiguous()
 		self.row_vals = None if self.binary else vals.to(torch.float64).contiguous()
-		cnt_x = torch.bincount(xi, minlength=nx)
-		order = torch.argsort(cnt_x, descending=True, stable=True)  # slot -> design row
 		nslots = _round_up(nx, 64)
 		self.ngroups = nslots // 64
-		slot_of_x = torch.empty(nx, dtype=torch.int64, device=eng.device)
-		slot_of_x[order] = torch.arange(nx, device=eng.device)
 		self.slot2x = torch.full((nslots, ), -1, dtype=torch.int32, device=eng.device)
-		self.slot2x[:nx] = order.to(torch.int32)
+		self.slot2x[:nx] = torch.arange(nx, dtype=torch.int32, device=eng.device)  # (slot = design row; the dealing happens per chunk, below)
 		nch = (n + ch - 1) // ch
 		c = k // ch
-		key = c * nslots + slot_of_x[xi]
+		# In every chunk the slots are dealt anew to the positions of the workgroup's lanes, sorted by their number of entries IN that chunk
+		# (inside every block of 1024 positions -- one pass of the kernel): the 64 lists a wave walks in step are then equally long, where
+		# one dealing for all chunks left a third of the padded entries to the spread between a wave's lists.
+		cnt_cs = torch.bincount(c * nslots + xi, minlength=nch * nslots).view(nch, nslots)
+		sig = torch.empty((nch, nslots), dtype=torch.int64, device=eng.device)
+		for lo in range(0, nslots, 1024):
+			hi = min(nslots, lo + 1024)
+			sig[:, lo:hi] = torch.argsort(cnt_cs[:, lo:hi], dim=1, descending=True, stable=True) + lo
+		pos = torch.empty_like(sig)
+		pos.scatter_(1, sig, torch.arange(nslots, device=eng.device).expand(nch, nslots).contiguous())  # pos[c, slot] = its position in chunk c
+		self.sig = sig.to(torch.int32).contiguous()
+		key = c * nslots + pos[c, xi]  # (chunk, position)
 		# Inside a list the order is free.  ds_read_b128 serves a wave in four groups of 16 lanes, and two lanes of a group collide when
 		# their records share a bank quad (record index mod 16) without being the same record (MI355X_MICROARCH.md, LDS): every list is
 		# ordered by that residue, starting at a residue of its lane's own, so that the 16 lanes of a group walk the residues out of step.
@@ -74,22 +82,22 @@ class Lists:
 			res = (k - c * ch - rot[key % 64]) % 16
 			perm = torch.argsort(key * 16 + res, stable=True)
 		else:
-			perm = torch.argsort(key, stable=True)  # by chunk, then slot; cells ascending inside (nonzero() listed them so)
+			perm = torch.argsort(key, stable=True)  # by chunk, then position; cells ascending inside (nonzero() listed them so)
 		key_s, k_s = key[perm], k[perm]
 		cnt = torch.bincount(key_s, minlength=nch * nslots)
-		w = (cnt.view(nch, self.ngroups, 64).max(dim=2).values + 7) // 8 * 8  # longest list of every (chunk, 64 slots), in blocks of 8 entries
+		w = (cnt.view(nch, self.ngroups, 64).max(dim=2).values + 7) // 8 * 8  # longest list of every (chunk, 64 positions), in blocks of 8 entries
 		w64 = w.flatten() * 64
 		base = torch.cumsum(w64, 0) - w64
 		start = torch.cumsum(cnt, 0) - cnt
 		j = torch.arange(self.nnz, device=eng.device) - start[key_s]
-		pos = base[key_s // 64] + ((j // 8) * 64 + key_s % 64) * 8 + j % 8  # 8 consecutive entries of a slot side by side: one 16-byte load
+		pos_e = base[key_s // 64] + ((j // 8) * 64 + key_s % 64) * 8 + j % 8  # 8 consecutive entries of a position side by side: one 16-byte load
 		total = int(w64.sum())
 		self.ell = torch.full((max(total, 8), ), ch, dtype=torch.int16, device=eng.device)  # padding: the record of zeros
-		self.ell[pos] = (k_s - (key_s // nslots) * ch).to(torch.int16)
+		self.ell[pos_e] = (k_s - (key_s // nslots) * ch).to(torch.int16)
 		self.vals = None
 		if not self.binary:
 			self.vals = torch.zeros((max(total, 8), ), dtype=torch.float64, device=eng.device)
-			self.vals[pos] = vals[perm].to(torch.float64)
+			self.vals[pos_e] = vals[perm].to(torch.float64)
 		self.base = base.contiguous()
 		self.w = w.flatten().to(torch.int32).contiguous()
 		self.padded = total
@@ -162,7 +170,7 @@ def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_
 											  common.data_ptr(), common.data_ptr(), _round_up(ny, 8), eng._stream()))  # (no cell keeps its values: the last buffer is not written)
 	with _engine._Span(eng, 'de_sparse'):
 		_lib.check(eng.lib.nrm_de_sparse(d_y.data_ptr(), ycode, ny, n, d_y.stride(0), common.data_ptr(), ncu, d_dci.data_ptr() if ncu else 0, lists.ell.data_ptr(),
-										 0 if lists.vals is None else lists.vals.data_ptr(), lists.base.data_ptr(), lists.w.data_ptr(), lists.ngroups,
+										 0 if lists.vals is None else lists.vals.data_ptr(), lists.base.data_ptr(), lists.w.data_ptr(), lists.sig.data_ptr(), lists.ngroups,
 										 lists.slot2x.data_ptr(), bx.data_ptr() if ncu else 0, max(nc, 1), dot.data_ptr(), dot.stride(0), 1 if by_gene else 0, ssy.data_ptr(),
 										 coefy.data_ptr() if (coefy is not None and ncu) else 0, 0 if flags is None else flags.data_ptr(), eng._stream()))
 	return dot, ssy, coefy

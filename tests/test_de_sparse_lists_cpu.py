@@ -25,31 +25,38 @@ def test_lists_hold_every_entry_once(binary, nx, n):
 	ch = int(eng.lib.nrm_de_sparse_chunk())
 	lst = de_sparse.Lists(eng, torch.as_tensor(dx))
 	assert lst.ok and lst.nnz == np.count_nonzero(dx) and lst.binary == binary and (lst.vals is None) == binary
-	ell, base, w, slot2x = lst.ell.numpy(), lst.base.numpy(), lst.w.numpy(), lst.slot2x.numpy()
+	ell, base, w, slot2x, sig = lst.ell.numpy(), lst.base.numpy(), lst.w.numpy(), lst.slot2x.numpy(), lst.sig.numpy()
 	ng = lst.ngroups
 	nch = (n + ch - 1) // ch
-	assert w.shape == (nch * ng, ) and (w % 8 == 0).all() and slot2x.shape == (ng * 64, )
-	assert sorted(slot2x[slot2x >= 0].tolist()) == list(range(nx)) and (slot2x[nx:] == -1).all()
+	assert w.shape == (nch * ng, ) and (w % 8 == 0).all() and slot2x.shape == (ng * 64, ) and sig.shape == (nch, ng * 64)
+	assert np.array_equal(slot2x[:nx], np.arange(nx)) and (slot2x[nx:] == -1).all()
+	for c in range(nch):  # the dealing of a chunk: a permutation inside every block of 1024 positions (one pass of the kernel)
+		for lo in range(0, ng * 64, 1024):
+			hi = min(ng * 64, lo + 1024)
+			assert sorted(sig[c, lo:hi].tolist()) == list(range(lo, hi))
 	back = np.zeros_like(dx)
+	padded = 0
 	for c in range(nch):
 		for g in range(ng):
 			b, wd = int(base[c * ng + g]), int(w[c * ng + g])
 			blk = ell[b:b + wd * 64].reshape(wd // 8, 64, 8)  # [block of 8 entries][lane][entry]
 			val = None if binary else lst.vals.numpy()[b:b + wd * 64].reshape(wd // 8, 64, 8)
+			padded += wd * 64
+			lens = []
 			for lane in range(64):
-				x = slot2x[g * 64 + lane]
+				x = slot2x[sig[c, g * 64 + lane]]
 				offs = blk[:, lane, :].ravel()
 				real = offs != ch
+				lens.append(int(real.sum()))
 				if x < 0:
 					assert not real.any()
 					continue
 				cells = c * ch + offs[real].astype(np.int64)
 				assert cells.size == np.unique(cells).size and (cells < n).all()
 				back[x, cells] += 1.0 if binary else val[:, lane, :].ravel()[real]
+			assert lens == sorted(lens, reverse=True) or g * 64 % 1024 + 64 > 1024  # positions sorted by the number of entries in the chunk
 	assert np.array_equal(back, dx)
-	# rows of similar length share a wave: the slots are ordered by their number of entries
-	cnt = (dx != 0).sum(axis=1)[slot2x[:nx]]
-	assert (np.diff(cnt) <= 0).all()
+	assert padded == lst.padded and (nx < 1000 or padded < 1.3 * lst.nnz)  # full groups: little padding beyond the rounding to blocks of 8
 
 
 def test_a_dense_design_is_refused_before_it_is_listed():
