@@ -96,32 +96,36 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 	request(0);
 	const int64_t nslots = (int64_t)ngroups * 64;
 	const int pos0 = group0 * 64;  // first position of this pass (positions pos0 .. pos0 + DS_G * DS_T - 1)
+	int sl_cur[DS_G], sl_nxt[DS_G];  // the design row (within the pass) this thread's position g gathers for in the current / next chunk, -1: none
+#pragma unroll
+	for (int g = 0; g < DS_G; g++) {
+		const int p = pos0 + g * DS_T + tid;
+		sl_cur[g] = p < nslots ? sig[p] - pos0 : -1;
+		sl_nxt[g] = -1;
+	}
 	for (int c = 0; c < nchunks; c++) {
 		__syncthreads();  // the gathers of the previous chunk are done with LDS
 		if (c > 0) {
 			// Position p of the workgroup gathers, in chunk c, for the design row sig[c][p]: the rows are dealt anew for every chunk, sorted by
 			// the number of entries they have IN it, so that the 64 lists a wave walks in step are equally long (dealt once for all chunks a
-			// wave waited for its longest list: 750 000 padded entries for 500 000, now 560 000).  The sums move with the rows: through
-			// LDS, which is free between two chunks.
+			// wave waited for its longest list: 750 000 padded entries for 500 000, now 570 000).  The sums move with the rows: through
+			// LDS, which is free between two chunks.  (sl_cur / sl_nxt were fetched while the previous chunk was gathered: fetched here,
+			// between the barriers, their latency was paid twice per chunk by every wave at once and ate what the shorter lists save.)
 			double* acc = reinterpret_cast<double*>(lds);  // [design row of this pass][R]
 #pragma unroll
-			for (int g = 0; g < DS_G; g++) {
-				const int p = pos0 + g * DS_T + tid;
-				if (p < nslots) {
-					const int sl = sig[(int64_t)(c - 1) * nslots + p] - pos0;
+			for (int g = 0; g < DS_G; g++)
+				if (sl_cur[g] >= 0) {
 #pragma unroll
-					for (int r = 0; r < R; r++) acc[sl * R + r] = S[g][r];
+					for (int r = 0; r < R; r++) acc[sl_cur[g] * R + r] = S[g][r];
 				}
-			}
 			__syncthreads();
 #pragma unroll
 			for (int g = 0; g < DS_G; g++) {
-				const int p = pos0 + g * DS_T + tid;
-				if (p < nslots) {
-					const int sl = sig[(int64_t)c * nslots + p] - pos0;
+				if (sl_nxt[g] >= 0) {
 #pragma unroll
-					for (int r = 0; r < R; r++) S[g][r] = acc[sl * R + r];
+					for (int r = 0; r < R; r++) S[g][r] = acc[sl_nxt[g] * R + r];
 				}
+				sl_cur[g] = sl_nxt[g];
 			}
 			__syncthreads();
 		}
@@ -138,7 +142,14 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 			}
 		}
 		__syncthreads();
-		if (c + 1 < nchunks) request(c + 1);
+		if (c + 1 < nchunks) {
+			request(c + 1);
+#pragma unroll
+			for (int g = 0; g < DS_G; g++) {
+				const int p = pos0 + g * DS_T + tid;
+				sl_nxt[g] = p < nslots ? sig[(int64_t)(c + 1) * nslots + p] - pos0 : -1;
+			}
+		}
 		// the design rows' cells of this chunk: 8 entries per lane and load (ix_t), the next 8 requested before these are gathered
 #pragma unroll
 		for (int g = 0; g < DS_G; g++) {
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 	for (int g = 0; g < DS_G; g++) {
 		const int p = (group0 + g * (DS_T / 64)) * 64 + tid;
 		if ((group0 + g * (DS_T / 64) + wave) >= ngroups) break;
-		const int x = slot2x[sig[(int64_t)(nchunks - 1) * nslots + p]];  // (the design row this position gathered for in the last chunk)
+		const int x = sl_cur[g] >= 0 ? slot2x[pos0 + sl_cur[g]] : -1;  // (the design row this position gathered for in the last chunk)
 		if (x < 0) continue;
 #pragma unroll
 		for (int r = 0; r < R; r++) {
