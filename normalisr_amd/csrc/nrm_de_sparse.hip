@@ -18,13 +18,13 @@
 // inside the registers: +2.0 ms, each batch waiting for its loads at two waves per SIMD).
 #include "nrm_common.h"
 
-#define DS_CH 4096   // cells per chunk: 64 KB of records (8192 with one workgroup per CU: 12 % fewer padded entries, but 2.11 ms instead of 1.82 -- the
-                     // kernel lives on the waves it has in flight; 2048 cells: 17 % more padded entries, 1.88 ms.  Time = 0.71 ms (the rows streamed and staged)
-                     // + 1.45 ms per million padded entries, measured from 0.2 % to 3 % of the design set)
+#define DS_CH 2048   // cells per chunk: 32 KB of records, three workgroups per CU.  Measured with the design rows dealt once for all chunks: 4096 cells (two
+                     // workgroups per CU) 1.82 ms, 8192 (one) 2.11, 2048 1.88 (17 % more padded entries); dealt per chunk (sig) the lists of a wave are
+                     // equally long whatever the chunk size and the waves in flight decide: 4096 cells 1.69 ms, 2048 cells 1.56.
 #define DS_T 512     // threads per workgroup
 #define DS_G 2       // design rows per thread: 1024 per pass over the expression matrix
 #define DS_NCMAX 32  // (the sums over the covariates come from nrm_single1_stream: its limit)
-#define DS_WGS 2     // waves per SIMD the register budget is set for (the 64 KB of LDS allow two workgroups per CU: one gathers while the other fills its chunk)
+#define DS_WGS 6     // waves per SIMD the register budget is set for (68 registers; three workgroups of 512 threads per CU; 8 waves per SIMD spill and gain nothing)
 
 namespace {
 
