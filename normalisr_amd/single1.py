@@ -67,7 +67,12 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		with torch.cuda.device(eng.device):
 			# cell selection on the device (association.py:914-918): the design matrix travels once, in its own dtype
 			d_dx = dx if _is_dev(dx) else eng.upload(_engine.as_input(dx))
-			assert float(d_dx.max()) == 1  # association.py:914
+			lohi = torch.stack(torch.aminmax(d_dx)).cpu().numpy()
+			assert float(lohi[1]) == 1  # association.py:914
+			if nc <= 32 and float(lohi[0]) >= 0 and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
+				# entries >= 0: the selection follows from the LIST of the design's entries (a cell is selected for grouping i when i is its
+				# only entry, and for every grouping when it has none) -- no (groupings x cells) selection matrix, no passes over one
+				return _sparse(eng, d_dx, dx.dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out)
 			sel = d_dx == torch.sum(d_dx, dim=0, dtype=torch.float64)  # association.py:915-916
 			big = torch.finfo(d_dx.dtype).max
 			lo = torch.where(sel, d_dx, big).amin(dim=1)
@@ -75,8 +80,6 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			assert bool((hi > lo).all())  # >1 distinct value among the selected cells (:917-918)
 			del lo, hi
 			ns = sel.sum(dim=1).cpu().numpy().astype(np.float64)
-			if nc <= 32 and not bool((d_dx < 0).any()) and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
-				return _sparse(eng, d_dx, dx.dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out)
 			ry = eng.residualize(dy if _is_dev(dy) else _engine.as_input(dy), None, None, 0)  # fp64 padded copy of Y
 			y2 = Residualized_sq(ry, eng)
 			d_c = eng.upload(c64) if nc else None
@@ -147,7 +150,7 @@ def _segment_sums(v, starts, counts):
 	return out
 
 
-def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out=False):
+def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out=False):
 	"""single=1 for a design with entries >= 0 (csrc/nrm_single1.hip, second half): the cells every grouping shares (all of dx is 0)
 	are summed once per gene, each grouping adds its own few cells inside the sweep; no masked Gram contraction, no loop over chunks
 	of groupings, no transposed copy of the expression matrix (the stream kernel reads it once, where it lies).  The statistics of the
@@ -157,24 +160,35 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, ns, nx, ny, n, nc, dimreduce, lowmem, r
 	from .single4 import _Marks
 	mark = _Marks(eng, 'NRM_S1_TRACE', 'single=1')
 	mark('selection')
-	nzm = d_dx != 0
-	cnt = nzm.sum(dim=0)
+	nz = torch.nonzero(d_dx)  # the design's entries, grouping by grouping, cells ascending
+	xi, k = nz[:, 0], nz[:, 1]
+	cnt = torch.bincount(k, minlength=n)
 	is_common = cnt == 0
-	idx_e = torch.nonzero(cnt == 1).flatten()
-	owner = torch.argmax(nzm[:, idx_e].to(torch.int8), dim=0)
-	order = torch.argsort(owner, stable=True)
-	idx_e, owner = idx_e[order], owner[order]
-	n_e = int(idx_e.numel())
+	alone = cnt[k] == 1  # entries that are the only one of their cell: that cell is selected for this grouping and no other (association.py:915-916)
+	owner, idx_e = xi[alone], k[alone]  # (still grouping by grouping: the positions of the stream kernel's output)
+	n_e = int(owner.numel())
 	code = torch.where(is_common, _lib.NRM_S1_COMMON, _lib.NRM_S1_SKIP).to(torch.int32)
-	code[idx_e] = torch.arange(n_e, dtype=torch.int32, device=eng.device)  # positions in the order of the groupings
+	code[idx_e] = torch.arange(n_e, dtype=torch.int32, device=eng.device)
 	xe_d = d_dx[owner, idx_e].to(torch.float64) if n_e else torch.zeros(1, dtype=torch.float64, device=eng.device)
+	counts_d = torch.bincount(owner, minlength=nx)
+	n_common = is_common.sum()
+	# > 1 distinct value among a grouping's selected cells (:917-918): 0 on the shared cells, if there are any, and its values on its own
+	inf = torch.full((nx, ), float('inf'), dtype=torch.float64, device=eng.device)
+	vlo = inf.clone().scatter_reduce_(0, owner, xe_d[:n_e], 'amin', include_self=True)
+	vhi = (-inf).scatter_reduce_(0, owner, xe_d[:n_e], 'amax', include_self=True)
+	shared = (n_common > 0).to(torch.float64)
+	vlo = torch.where(shared > 0, torch.minimum(vlo, torch.zeros_like(vlo)), vlo)
+	vhi = torch.where(shared > 0, torch.maximum(vhi, torch.zeros_like(vhi)), vhi)
+	small = torch.cat([(n_common + counts_d).to(torch.float64), (vhi > vlo).to(torch.float64)]).cpu().numpy()
+	ns = small[:nx].copy()
+	assert bool(small[nx:].all())
 	mark('cell order')
 	# what the host needs of the cell order (before the stream kernel is queued: a download behind it would wait for it)
 	d_c = eng.upload(c64) if nc else None
 	if nc:  # covariate Gram of the shared cells (element-wise and in a fixed order: no BLAS, on either side)
 		cm = d_c * is_common
 		mcc = (cm[:, None, :] * d_c[None, :, :]).sum(dim=2).cpu().numpy()
-	counts = torch.bincount(owner, minlength=nx).cpu().numpy()
+	counts = counts_d.cpu().numpy()
 	seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
 	idx_h = idx_e.cpu().numpy()
 	xe = xe_d.cpu().numpy()[:n_e]
