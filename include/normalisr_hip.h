@@ -366,6 +366,10 @@ int nrm_single1_stream(const void* d_y, int y_dtype, int64_t ldy, const double* 
 int nrm_single1_cells(const void* d_ye, int y_dtype, int64_t ldye, const double* d_ce, const double* d_xe, const int64_t* d_seg,
 					  const double* d_common, const double* d_info, int64_t info_pitch, int64_t nc, int64_t nx, int64_t ny, int return_dot,
 					  void* d_p, void* d_stat, void* d_vary, void* d_alpha, int out_dtype, int64_t ldo, int32_t* d_flags, void* stream);
+/* The groupings' own statistics over their own cells (association.py:350-364): d_seg (nx + 1) delimits grouping i's entries of d_cells (cell
+ * indices, int64) / d_xe (its value there); d_out (nx, nc (nc + 1) / 2 + nc + 1): the sums of C_c C_d (c <= d, row by row), of C_c x, of x x.  nc <= 8. */
+int nrm_single1_group_stats(const int64_t* d_seg, const int64_t* d_cells, const double* d_xe, const double* d_c, int64_t ldc, int64_t nc, int64_t nx,
+							double* d_out, void* stream);
 
 /*
  * binnet -- binarise a (ng, ng) co-expression P-value matrix at a per-row Benjamini-Hochberg q-value cutoff

@@ -78,6 +78,7 @@ _SIGNATURES = {
 	'nrm_tsv_parse': ([_vp, _i64, _i32, _i32, _vp, _i32, _i64, _i64, _i64], _i32),
 	'nrm_tsv_width': ([_i32], _i64),
 	'nrm_tsv_format': ([_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32], _i32),
+	'nrm_single1_group_stats': ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),
 	'nrm_single1_stream': ([_vp, _i32, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp], _i32),
 	'nrm_single1_cells': ([_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_binnet': ([_vp, _i32, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),

@@ -465,3 +465,65 @@ extern "C" int nrm_single1_cells(const void* d_ye, int y_dtype, int64_t ldye, co
 #undef S1_GO
 	return nrm_check_launch("k_s1_cells");
 }
+
+// ---- the groupings' own statistics over their own cells ------------------------------------------------------------------------------------
+// M_i = C_S C_S^T, C_S x_S and |x_S|^2 (association.py:350-364) are sums over the shared cells -- the same for every grouping, taken once
+// -- plus sums over the few dozen cells of E_i: a wave per grouping walks them (lane-strided, then a tree over the lanes: a fixed order).
+// out (nx, np): the nc (nc + 1) / 2 products C_c C_d (c <= d, row by row), then C_c x (nc), then x x.  The host did this with numpy
+// segment sums: 1.1 ms of the 3.9 ms of a call at BASELINE configs[3] size, on its critical path.
+#define S1_GS_NC 8
+__global__ void __launch_bounds__(64) k_s1_group_stats(const int64_t* __restrict__ seg, const int64_t* __restrict__ cells, const double* __restrict__ xe,
+														const double* __restrict__ C, int64_t ldc, int nc, int64_t nx, double* __restrict__ out) {
+	constexpr int NPMAX = S1_GS_NC * (S1_GS_NC + 1) / 2 + S1_GS_NC + 1;
+	const int64_t i = blockIdx.x;
+	const int lane = threadIdx.x;
+	double acc[NPMAX];
+#pragma unroll
+	for (int j = 0; j < NPMAX; j++) acc[j] = 0.0;
+	for (int64_t e = seg[i] + lane; e < seg[i + 1]; e += 64) {
+		const int64_t k = cells[e];
+		const double x = xe[e];
+		double cv[S1_GS_NC];
+#pragma unroll
+		for (int c = 0; c < S1_GS_NC; c++) cv[c] = c < nc ? C[c * ldc + k] : 0.0;
+		int j = 0;
+#pragma unroll
+		for (int c = 0; c < S1_GS_NC; c++)
+#pragma unroll
+			for (int d = c; d < S1_GS_NC; d++, j++) acc[j] = fma(cv[c], cv[d], acc[j]);
+#pragma unroll
+		for (int c = 0; c < S1_GS_NC; c++, j++) acc[j] = fma(cv[c], x, acc[j]);
+		acc[j] = fma(x, x, acc[j]);
+	}
+#pragma unroll
+	for (int j = 0; j < NPMAX; j++) {
+		double t = acc[j];
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+		acc[j] = t;
+	}
+	if (lane == 0) {
+		// the static tables hold S1_GS_NC covariates; the caller's layout is for nc of them
+		double* o = out + i * (nc * (nc + 1) / 2 + nc + 1);
+		int j = 0, w = 0;
+#pragma unroll
+		for (int c = 0; c < S1_GS_NC; c++)
+#pragma unroll
+			for (int d = c; d < S1_GS_NC; d++, j++)
+				if (c < nc && d < nc) o[w++] = acc[j];
+#pragma unroll
+		for (int c = 0; c < S1_GS_NC; c++, j++)
+			if (c < nc) o[w++] = acc[j];
+		o[w] = acc[j];
+	}
+}
+
+// d_seg (nx + 1): the own cells of grouping i are entries [d_seg[i], d_seg[i + 1]) of d_cells (cell indices) / d_xe (the grouping's value there);
+// d_out (nx, nc (nc + 1) / 2 + nc + 1) as above.  nc <= 8.
+extern "C" int nrm_single1_group_stats(const int64_t* d_seg, const int64_t* d_cells, const double* d_xe, const double* d_c, int64_t ldc, int64_t nc, int64_t nx,
+									   double* d_out, void* stream) {
+	NRM_REQUIRE(nx > 0 && nc >= 0 && nc <= S1_GS_NC && d_seg && d_cells && d_xe && d_out && (nc == 0 || d_c), "nrm_single1_group_stats: bad arguments (at most %d covariates)",
+				S1_GS_NC);
+	hipLaunchKernelGGL(k_s1_group_stats, dim3((unsigned)nx), dim3(64), 0, (hipStream_t)stream, d_seg, d_cells, d_xe, d_c, ldc, (int)nc, nx, d_out);
+	return nrm_check_launch("k_s1_group_stats");
+}

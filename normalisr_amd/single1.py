@@ -188,10 +188,21 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, retur
 	if nc:  # covariate Gram of the shared cells (element-wise and in a fixed order: no BLAS, on either side)
 		cm = d_c * is_common
 		mcc = (cm[:, None, :] * d_c[None, :, :]).sum(dim=2).cpu().numpy()
-	counts = counts_d.cpu().numpy()
-	seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-	idx_h = idx_e.cpu().numpy()
-	xe = xe_d.cpu().numpy()[:n_e]
+	d_seg = torch.zeros(nx + 1, dtype=torch.int64, device=eng.device)
+	d_seg[1:] = torch.cumsum(counts_d, 0)
+	on_device = nc <= 8  # the groupings' own sums by a wave each (k_s1_group_stats); more covariates: numpy segment sums on the host
+	if on_device:
+		npair = nc * (nc + 1) // 2
+		gs_d = torch.empty((nx, npair + nc + 1), dtype=torch.float64, device=eng.device)
+		_lib.check(eng.lib.nrm_single1_group_stats(d_seg.data_ptr(), idx_e.contiguous().data_ptr(), xe_d.data_ptr(), 0 if d_c is None else d_c.data_ptr(), n, nc, nx,
+												   gs_d.data_ptr(), eng._stream()))
+		gs = gs_d.cpu().numpy()
+		d_ce = d_c[:, idx_e].t().contiguous() if nc else None
+	else:
+		counts = counts_d.cpu().numpy()
+		seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+		idx_h = idx_e.cpu().numpy()
+		xe = xe_d.cpu().numpy()[:n_e]
 	# the device's share: it needs nothing of the host's statistics and runs while they are taken
 	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
 	ldye = _round_up(ny, 8)
@@ -203,16 +214,27 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, retur
 											  common.data_ptr(), ye.data_ptr(), ldye, eng._stream()))
 	eng.s1_cells_kept = n_e  # (bench.py: the bytes the stream kernel writes)
 	# grouping-side statistics on the host
-	starts = seg[:-1]
 	pitch = 26 + nc + nc * nc
 	info = np.zeros((nx, pitch))
-	xx = _segment_sums(xe * xe, starts, counts)
 	rk = np.zeros(nx, dtype=np.int64)
 	mark('downloads, stream kernel')
-	ce = c64[:, idx_h]  # (nc, cells of the E_i in the order of the groupings)
-	if nc:
+	if on_device:
+		xx = gs[:, -1].copy()
+		if nc:
+			iu = np.triu_indices(nc)
+			mc = np.empty((nx, nc, nc))
+			mc[:, iu[0], iu[1]] = gs[:, :npair]
+			mc[:, iu[1], iu[0]] = gs[:, :npair]
+			mc += mcc[None]
+			xc = gs[:, npair:npair + nc]
+	else:
+		starts = seg[:-1]
+		xx = _segment_sums(xe * xe, starts, counts)
+		ce = c64[:, idx_h]  # (nc, cells of the E_i in the order of the groupings)
 		mc = mcc[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
 		xc = _segment_sums(ce * xe, starts, counts).T  # (nx, nc)
+		d_ce = None
+	if nc:
 		mark('host sums')
 		mi, rk = small_pinv(mc)  # association.py:350-351
 		mi[rk == 0] = 0
@@ -230,13 +252,13 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, retur
 	dof = np.ascontiguousarray(dof, dtype=np.float64)
 	_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, nx, info.ctypes.data + 16, pitch))
 	mark('p-value plans')
-	d_ce = eng.upload(np.ascontiguousarray(ce.T)) if nc else None
+	if not on_device:
+		d_ce = eng.upload(np.ascontiguousarray(ce.T))
 	p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	alpha = None if lowmem else torch.zeros((nx, ny, nc), dtype=tdt, device=eng.device)
 	flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
-	d_seg = eng.upload(seg)
 	d_info = eng.upload(info)
 	code_o = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
 	with _engine._Span(eng, 's1_cells'):
