@@ -3,7 +3,8 @@
 The reference multiplies residualised design and expression rows densely (association.py:224-235).  Because a residual is orthogonal to
 the covariates, y~ . x~ = y . x - (y C^T) . b_x: a design row with few cells set needs the expression values at those cells only.  This
 module decides whether a call qualifies, turns the design matrix into the kernel's ELL lists (on the device, a dozen torch passes over
-its non-zero entries) and runs K1 on the design rows alone, the one-pass kernel on the raw expression rows, and K3 as always."""
+its non-zero entries), takes the design rows' own statistics from those entries, runs the one-pass kernels on the raw expression rows, and
+K3 as always."""
 import os
 
 import numpy as np
