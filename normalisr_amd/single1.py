@@ -165,7 +165,8 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, retur
 	cnt = torch.bincount(k, minlength=n)
 	is_common = cnt == 0
 	alone = cnt[k] == 1  # entries that are the only one of their cell: that cell is selected for this grouping and no other (association.py:915-916)
-	owner, idx_e = xi[alone], k[alone]  # (still grouping by grouping: the positions of the stream kernel's output)
+	which = torch.nonzero(alone).flatten()  # (one list of the entries kept: a mask as an index would be listed once per use)
+	owner, idx_e = xi[which], k[which]  # (still grouping by grouping: the positions of the stream kernel's output)
 	n_e = int(owner.numel())
 	code = torch.where(is_common, _lib.NRM_S1_COMMON, _lib.NRM_S1_SKIP).to(torch.int32)
 	code[idx_e] = torch.arange(n_e, dtype=torch.int32, device=eng.device)
