@@ -9,7 +9,7 @@ from normalisr_amd.association import inv_rank
 eng = _engine.get_engine()
 nx, ny, n = 1000, 15000, 50000
 g = torch.Generator(device='cuda').manual_seed(4)
-dy = torch.randn((ny, n), generator=g, device='cuda')
+dy = torch.randn((ny, n), generator=g, device='cuda', dtype=torch.float64 if 'f64' in sys.argv else torch.float32)
 for nc, dens in ((5, 0.01), (0, 0.01), (5, 0.00002), (0, 0.00002), (5, 0.002), (5, 0.03)):
 	dc = np.vstack([np.random.default_rng(1).normal(size=(max(nc - 1, 0), n)), np.ones((1, n))])[:nc] if nc else np.zeros((0, n))
 	dx = (torch.rand((nx, n), generator=g, device='cuda') < dens).float()
