@@ -471,6 +471,15 @@ int nrm_design_stats(const int64_t* d_row_ptr, const int32_t* d_cells, const dou
 int nrm_small_pinv(const double* m, int64_t count, int64_t n, double tol, double* inv, int64_t* rank, int threads);
 
 /*
+ * Host -> device copy of a caller's (pageable) array through a ring of page-locked staging blocks the library owns: host threads fill
+ * the next block while the previous block's DMA runs, so the copy runs at the DMA's rate without page-locking the caller's memory.
+ * Returns once the last block has been handed to the DMA engine (completion is in stream order; h_src may be reused at once).
+ * threads: host threads per block, 0 = choose.  nrm_upload_release frees the ring.
+ */
+int nrm_upload(const void* h_src, void* d_dst, int64_t bytes, int threads, void* stream);
+int nrm_upload_release(void);
+
+/*
  * Text matrices of the command line (host only): the reference reads with numpy.loadtxt(delimiter='\t') and writes with
  * numpy.savetxt(fmt='%.8G') (run.py:20-35).  Same text in, same text out, parsed / printed by `threads` host threads (0 = choose).
  *   nrm_tsv_shape: rows = lines with data ('#' comments and blank lines skipped), cols = fields of the first such line.
