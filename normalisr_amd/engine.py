@@ -605,7 +605,7 @@ class Engine:
 			for a in range(0, ny, rows):
 				b = min(ny, a + rows)
 				with torch.cuda.stream(self._copy):
-					yc = torch.from_numpy(dy[a:b]).to(self.device)  # host blocks here; the GPU is busy with the previous chunk
+					yc = self.upload(dy[a:b])  # (staged copy on the copy stream; the GPU is busy with the previous chunk)
 				arrived = torch.cuda.Event()
 				arrived.record(self._copy)
 				main.wait_event(arrived)
@@ -806,7 +806,7 @@ class Engine:
 			try:
 				for ci, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
 					with torch.cuda.stream(self._copy):
-						xc = torch.from_numpy(dx[a:b]).to(self.device)  # the host blocks here while the GPU works on the previous chunk
+						xc = self.upload(dx[a:b])  # (staged copy on the copy stream while the GPU works on the previous chunk)
 					mark('upload %d returned' % ci)
 					arrived = torch.cuda.Event()
 					arrived.record(self._copy)
