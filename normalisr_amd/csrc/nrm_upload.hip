@@ -1,9 +1,11 @@
 // Host -> device copies of the caller's (pageable) arrays.  torch's / HIP's pageable copy of the 3 GB expression matrix of BASELINE
 // configs[3] runs at 37 GB/s on this platform; page-locking the caller's array first costs 25 ms for the same 3 GB and then copies at
 // 57 GB/s -- no faster in sum.  Here: a ring of page-locked staging blocks owned by the library; host threads copy the next block of the
-// source into the ring while the previous block's DMA runs, so the call runs at the DMA's rate and the caller's array is never
+// source into the ring while the previous block's DMA runs (32 MB blocks: 3 GB in 55 ms = 54 GB/s; 200 MB in 4.8 ms, where the runtime's
+// pageable copy takes 3.6 -- callers use this from half a GB up), so the call runs at the DMA's rate and the caller's array is never
 // page-locked (and may be reused the moment the call returns: what is still in flight comes from the ring).
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -13,13 +15,13 @@
 
 namespace {
 
-constexpr int64_t UP_BLOCK = 128ll << 20;  // bytes per staging block
-constexpr int UP_SLOTS = 3;
+constexpr int64_t UP_BLOCK_MAX = 128ll << 20;  // bytes per staging block (allocated; NRM_UPLOAD_BLOCK_MB uses less of it)
+constexpr int UP_SLOTS = 4;
 
 struct Ring {
-	void* slot[UP_SLOTS] = {nullptr, nullptr, nullptr};
-	hipEvent_t done[UP_SLOTS] = {nullptr, nullptr, nullptr};
-	bool used[UP_SLOTS] = {false, false, false};
+	void* slot[UP_SLOTS] = {};
+	hipEvent_t done[UP_SLOTS] = {};
+	bool used[UP_SLOTS] = {};
 	int device = -1;
 	std::mutex lock;  // one upload at a time per process through the ring
 	~Ring() { release(); }
@@ -64,9 +66,9 @@ extern "C" int nrm_upload(const void* h_src, void* d_dst, int64_t bytes, int thr
 		NRM_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, st));
 		return NRM_OK;
 	}
-	if (threads <= 0) {
+	if (threads <= 0) {  // (measured: 4 threads fill a 32 MB block in ~0.5 ms, faster than its DMA; 16 threads cost more to start than they save)
 		threads = (int)std::thread::hardware_concurrency() / 2;
-		threads = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+		threads = threads < 1 ? 1 : (threads > 4 ? 4 : threads);
 	}
 	std::lock_guard<std::mutex> guard(g_ring.lock);
 	int dev = 0;
@@ -74,11 +76,15 @@ extern "C" int nrm_upload(const void* h_src, void* d_dst, int64_t bytes, int thr
 	if (g_ring.device != dev) {  // (page-locked memory is mapped for the device current at allocation)
 		g_ring.release();
 		for (int i = 0; i < UP_SLOTS; i++) {
-			NRM_HIP(hipHostMalloc(&g_ring.slot[i], (size_t)UP_BLOCK, hipHostMallocDefault));
+			NRM_HIP(hipHostMalloc(&g_ring.slot[i], (size_t)UP_BLOCK_MAX, hipHostMallocDefault));
 			NRM_HIP(hipEventCreateWithFlags(&g_ring.done[i], hipEventDisableTiming));
 		}
 		g_ring.device = dev;
 	}
+	int64_t UP_BLOCK = 32ll << 20;
+	if (const char* e = getenv("NRM_UPLOAD_BLOCK_MB")) UP_BLOCK = (int64_t)atoi(e) << 20;
+	if (UP_BLOCK < (1 << 20) || UP_BLOCK > UP_BLOCK_MAX) UP_BLOCK = UP_BLOCK_MAX;
+	if (const char* e = getenv("NRM_UPLOAD_THREADS")) threads = atoi(e) > 0 ? atoi(e) : threads;
 	const char* src = (const char*)h_src;
 	char* dst = (char*)d_dst;
 	int i = 0;

@@ -191,10 +191,11 @@ class Engine:
 
 	@serialised
 	def upload(self, a, dtype=None):
-		"""numpy array -> device tensor.  Large arrays go through the library's staged copy (csrc/nrm_upload.hip: host threads fill
-		page-locked blocks beside the DMA; 37 -> ~55 GB/s for the expression matrix of BASELINE configs[3]); NRM_UPLOAD=torch: torch's copy."""
+		"""numpy array -> device tensor.  Arrays of half a GB and more go through the library's staged copy (csrc/nrm_upload.hip: host threads
+		fill page-locked blocks beside the DMA: 38 -> 54 GB/s for the 3 GB expression matrix of BASELINE configs[3]; at 200 MB the runtime's
+		own pageable copy already runs at 56 GB/s and stays); NRM_UPLOAD=torch: torch's copy whatever the size."""
 		a = np.ascontiguousarray(a)
-		if dtype is None and a.nbytes >= (32 << 20) and str(a.dtype) in self._NPT and os.environ.get('NRM_UPLOAD', 'staged') != 'torch':
+		if dtype is None and a.nbytes >= (512 << 20) and str(a.dtype) in self._NPT and os.environ.get('NRM_UPLOAD', 'staged') != 'torch':
 			torch = self.torch
 			with torch.cuda.device(self.device):
 				t = torch.empty(a.shape, dtype=getattr(torch, self._NPT[str(a.dtype)]), device=self.device)
@@ -605,7 +606,7 @@ class Engine:
 			for a in range(0, ny, rows):
 				b = min(ny, a + rows)
 				with torch.cuda.stream(self._copy):
-					yc = self.upload(dy[a:b])  # (staged copy on the copy stream; the GPU is busy with the previous chunk)
+					yc = torch.from_numpy(dy[a:b]).to(self.device)  # host blocks here; the GPU is busy with the previous chunk
 				arrived = torch.cuda.Event()
 				arrived.record(self._copy)
 				main.wait_event(arrived)
@@ -806,7 +807,7 @@ class Engine:
 			try:
 				for ci, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
 					with torch.cuda.stream(self._copy):
-						xc = self.upload(dx[a:b])  # (staged copy on the copy stream while the GPU works on the previous chunk)
+						xc = torch.from_numpy(dx[a:b]).to(self.device)  # the host blocks here while the GPU works on the previous chunk
 					mark('upload %d returned' % ci)
 					arrived = torch.cuda.Event()
 					arrived.record(self._copy)

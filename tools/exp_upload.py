@@ -6,7 +6,8 @@ import torch
 sys.path.insert(0, '.')
 from normalisr_amd import engine as _engine, _lib
 eng = _engine.get_engine()
-a = np.random.default_rng(0).standard_normal((15000, 50000), dtype=np.float32)
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 15000
+a = np.random.default_rng(0).standard_normal((rows, 50000), dtype=np.float32)
 d = torch.empty(a.shape, dtype=torch.float32, device='cuda')
 for name in ('pageable', 'pinned for the copy', 'staged (nrm_upload)', 'pageable', 'pinned for the copy', 'staged (nrm_upload)', 'staged (nrm_upload)'):
 	torch.cuda.synchronize()
