@@ -30,6 +30,16 @@ def _varying_rows(dg):
 	return varying
 
 
+def _finite_within(a, lo=None, hi=None):
+	"""np.isfinite(a).all() and (a >= lo).all() and (a <= hi).all() (the reference's assertions on its results, de.py:124-131) from the
+	array's minimum and maximum -- a NaN anywhere makes both NaN and every comparison False; two passes without temporaries instead
+	of up to five with (the assertions were 12 ms of an 85 ms call at BASELINE configs[3] size)."""
+	if a.size == 0:
+		return True
+	mn, mx = float(a.min()), float(a.max())
+	return np.isfinite(mn) and np.isfinite(mx) and (lo is None or mn >= lo) and (hi is None or mx <= hi)
+
+
 def de(dg, dt, dc, bs=0, **ka):
 	"""Differential expression of every gene (rows of dt) against every grouping (rows of dg) with
 	covariates dc: Y = gamma*X + alpha*C + eps, H0: gamma = 0.  Same contract as reference de.py:4-132.
@@ -52,8 +62,7 @@ def de(dg, dt, dc, bs=0, **ka):
 	if allrows and p.dtype == odt:  # nothing to re-inflate (de.py:107-122 is the identity then)
 		P, G, A, VG = p, gam, alpha, varg
 		VT = vart if np.ndim(vart) == 2 else np.broadcast_to(vart, (ng0, nt)).copy()  # single=0: (n_gene,) for every row
-		assert np.isfinite(P).all() and np.isfinite(G).all() and np.isfinite(VG).all() and np.isfinite(VT).all()
-		assert (P >= 0).all() and (P <= 1).all() and (VG >= 0).all() and (VT >= 0).all()
+		assert _finite_within(P, 0, 1) and _finite_within(G) and _finite_within(VG, 0) and _finite_within(VT, 0)
 		return (P, G, A, VG, VT)
 	P = np.ones((ng0, nt), dtype=odt)
 	P[gid] = p
@@ -67,8 +76,7 @@ def de(dg, dt, dc, bs=0, **ka):
 	VG[gid] = varg
 	VT = np.zeros((ng0, nt), dtype=odt)
 	VT[gid] = vart  # (n_gene,) for single=0 broadcasts to every tested row
-	assert np.isfinite(P).all() and np.isfinite(G).all() and np.isfinite(VG).all() and np.isfinite(VT).all()
-	assert (P >= 0).all() and (P <= 1).all() and (VG >= 0).all() and (VT >= 0).all()
+	assert _finite_within(P, 0, 1) and _finite_within(G) and _finite_within(VG, 0) and _finite_within(VT, 0)
 	return (P, G, A, VG, VT)
 
 
