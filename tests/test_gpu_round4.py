@@ -526,3 +526,28 @@ def test_sparse_design_path_hands_rows_near_the_covariate_span_back(monkeypatch,
 		p2 = association_tests(dx, dy2, dc, return_dot=False)[0]
 	assert 'sparse-design kernel' in caplog.text and 'redoing' not in caplog.text
 	assert relerr(p2, oracle.association_tests(dx, dy2, dc, return_dot=False)[0]) < 1e-8
+
+
+def test_staged_upload_moves_every_byte(eng):
+	"""Engine.upload of half a GB and more goes through the library's ring of page-locked staging blocks (csrc/nrm_upload.hip): every
+	byte arrives, whatever the size is modulo the 32 MB blocks; the source may be overwritten the moment the call returns (what is
+	still in flight comes from the ring); nrm_upload itself also for sizes below its own threshold."""
+	import torch
+	from normalisr_amd import _lib
+	rng = np.random.default_rng(8)
+	a = rng.integers(0, 255, size=(512 << 20) + 12345, dtype=np.uint8)  # 16 blocks and a bit
+	keep = a.copy()
+	d = eng.upload(a)
+	a[:] = 0  # the caller's array is its own again
+	torch.cuda.synchronize()
+	assert d.dtype == torch.uint8 and d.shape == keep.shape
+	assert bool((d.cpu() == torch.from_numpy(keep)).all())
+	b = rng.standard_normal((3000, 50000), dtype=np.float32)  # 600 MB, a 2-D float array as the expression matrices are
+	db = eng.upload(b)
+	assert db.dtype == torch.float32 and torch.equal(db.cpu(), torch.from_numpy(b))
+	for nbytes in (1, 4096, (32 << 20) - 1, (32 << 20) + 7, (96 << 20)):
+		src = rng.integers(0, 255, size=nbytes, dtype=np.uint8)
+		dst = torch.zeros(nbytes, dtype=torch.uint8, device='cuda')
+		_lib.check(eng.lib.nrm_upload(src.ctypes.data, dst.data_ptr(), nbytes, 0, eng._stream()))
+		torch.cuda.synchronize()
+		assert bool((dst.cpu() == torch.from_numpy(src)).all()), nbytes
