@@ -15,7 +15,9 @@
 // |y|^2 come from nrm_single1.hip's stream kernel (sums only: a second pass over the rows at HBM rate, 0.6 ms at configs[3] size; taken
 // inside THIS kernel they cost more both ways it was tried: covariate values fetched between the barriers of a chunk, every wave in the same
 // phase: +1.1 ms; a dense phase after the gathers -- consecutive lanes on consecutive records and covariate values, two cells at a time to stay
-// inside the registers: +2.0 ms, each batch waiting for its loads at two waves per SIMD).
+// inside the registers: +2.0 ms, each batch waiting for its loads at two waves per SIMD; the covariate values travelling with the rows, requested a
+// chunk ahead: +1.0 ms -- a workgroup of 4 rows re-reads the covariates once per 4 rows, 7.5 GB through L2 beside the 3 GB of rows, where the
+// stream kernel's 8 rows per workgroup and its own pass cost 0.64).
 #include "nrm_common.h"
 
 #define DS_CH 2048   // cells per chunk: 32 KB of records, three workgroups per CU.  Measured with the design rows dealt once for all chunks: 4096 cells (two
