@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int64_t UP_BLOCK_MAX = 128ll << 20;  // bytes per staging block (allocated; NRM_UPLOAD_BLOCK_MB uses less of it)
+constexpr int64_t UP_BLOCK_MAX = 32ll << 20;  // bytes per staging block (4 blocks = 128 MB page-locked once, ~10 ms; NRM_UPLOAD_BLOCK_MB uses less of a block)
 constexpr int UP_SLOTS = 4;
 
 struct Ring {
