@@ -424,10 +424,20 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 				lists = lists if lists.ok else None
 		if lists is not None:
 			ns = 0
-		rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=bool(nc), nslices=ns, keep_fp64=True)
-		nxp = rx.rows_pad
-		mark('K1 design')
-		mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
+		if lists is not None and os.environ.get('NRM_S4_SPARSE_M', '1') != '0':
+			# M~ = X~ X~^T is the same product with the design rows in the place of the expression rows: x~_i . x~_j = x_i . x_j - (x_j C^T) . b_i
+			# -- the design's own statistics from its entries and one more run of the sparse-design kernels over the 200 MB design matrix,
+			# instead of K1's fp64 residuals of it (400 MB) and a 1e11-flop product of them
+			from . import de_sparse
+			rx = de_sparse.design_stats(eng, lists, d_c, d_dci, dcr, nx, nc)
+			nxp = _engine._round_up(nx, _lib.ROW_TILE)
+			mark('design rows')
+			mt_d, _, _ = de_sparse.products(eng, lists, d_x, d_c, d_dci, dcr, rx.coef, nx, nx, n, nc, False, False)  # (rows i, columns j; its upper triangle is used)
+		else:
+			rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=bool(nc), nslices=ns, keep_fp64=True)
+			nxp = rx.rows_pad
+			mark('K1 design')
+			mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
 		# N~ = M~^-1 on the device (Newton-Schulz on the fp64 matrix cores); the host's LAPACK only if that does not converge
 		inv = _spd_inverse_device(eng, mt_d, nx) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
 		if inv is None:
