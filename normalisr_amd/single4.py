@@ -235,22 +235,36 @@ def _spd_inverse_device(eng, m_d, nx):
 		mp[:nx, :nx] = m
 		if nxp > nx:  # padding block: a multiple of the identity inside the spectrum's range (does not slow the iteration down)
 			mp[range(nx, nxp), range(nx, nxp)] = m.diagonal().mean()
-		x = torch.zeros((nxp, nxp), dtype=torch.float64, device=eng.device)
-		x[range(nxp), range(nxp)] = 1.0 / scale
-		t = torch.empty_like(x)
-		xt = torch.empty_like(x)
+		t = torch.empty((nxp, nxp), dtype=torch.float64, device=eng.device)
+		xt = torch.empty_like(t)
 		eye = torch.eye(nxp, dtype=torch.float64, device=eng.device)
 		rm = Residualized(nxp, nxp, mp, None, None)
-		for it in range(60):
-			eng.gram(rm, Residualized(nxp, nxp, x, None, None), False, dot=t)            # T = M X   (X symmetric)
-			res = float((eye - t).norm()) if it >= 4 else np.inf  # ||I - M X||_F of the X going into this step
-			if np.isnan(res):
-				return None
-			eng.gram(Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, t, None, None), False, dot=xt)  # X T^T = X X M = X M X
-			x = x.mul(2.0).sub_(xt)
-			if res < 1e-7:  # the step just taken squares it: below the rounding floor
+		# Two starts.  X = diag(1 / M_ii) first: the residual rows of a gRNA screen are nearly orthogonal, I - M X then has a spectral radius of
+		# ~0.3 and five steps suffice; it need not converge for every design (it does iff 2 diag(M) - M is positive definite), so the residual
+		# is looked at after two steps and, unless it is falling, the iteration starts over from X = I / ||M||_1, which always converges
+		# (log2(cond) + ~6 steps: 8 for the same matrices).  NRM_S4_START=norm: the second start only.
+		done = False
+		for start in (('diagonal', 'norm') if os.environ.get('NRM_S4_START', 'diagonal') != 'norm' else ('norm', )):
+			x = torch.zeros((nxp, nxp), dtype=torch.float64, device=eng.device)
+			x[range(nxp), range(nxp)] = (1.0 / mp.diagonal()) if start == 'diagonal' else (1.0 / scale)
+			look_from = 2 if start == 'diagonal' else 4
+			diverged = False
+			for it in range(60):
+				eng.gram(rm, Residualized(nxp, nxp, x, None, None), False, dot=t)            # T = M X   (X symmetric)
+				res = float((eye - t).norm()) if it >= look_from else np.inf  # ||I - M X||_F of the X going into this step
+				if np.isnan(res) or (start == 'diagonal' and it == look_from and not res < 1.0):
+					diverged = True
+					break
+				eng.gram(Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, t, None, None), False, dot=xt)  # X T^T = X X M = X M X
+				x = x.mul(2.0).sub_(xt)
+				if res < 1e-7:  # the step just taken squares it: below the rounding floor
+					done = True
+					break
+			if done:
 				break
-		else:
+			if start == 'norm' and diverged:
+				return None
+		if not done:
 			return None
 		x = 0.5 * (x + x.T)
 		if nxp > nx:

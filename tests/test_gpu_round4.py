@@ -551,3 +551,29 @@ def test_staged_upload_moves_every_byte(eng):
 		_lib.check(eng.lib.nrm_upload(src.ctypes.data, dst.data_ptr(), nbytes, 0, eng._stream()))
 		torch.cuda.synchronize()
 		assert bool((dst.cpu() == torch.from_numpy(src)).all()), nbytes
+
+
+def test_single4_inverse_restarts_when_the_diagonal_start_diverges(monkeypatch, caplog):
+	"""The Newton-Schulz inverse of M~ = X~ X~^T starts from diag(1 / M_ii), which converges iff 2 diag(M) - M is positive definite -- true of
+	the nearly orthogonal rows of a gRNA screen, false for three design rows that share most of their cells; then the iteration must
+	notice after two steps and start over from I / ||M||_1.  Results against the oracle either way, and the same from either start."""
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(5)
+	nx, ny, n = 40, 90, 6000
+	dx = (rng.random((nx, n)) < 0.02).astype(np.float64)
+	base = (rng.random(n) < 0.03).astype(np.float64)
+	for i in (3, 4, 5):  # three rows that are one row with a handful of cells changed: pairwise correlation ~0.9
+		dx[i] = base
+		flip = rng.choice(n, 12, replace=False)
+		dx[i, flip] = 1 - dx[i, flip]
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dy = rng.normal(size=(ny, n)) + 2.0 + 0.5 * dx[rng.integers(0, nx, ny)] * rng.normal(size=(ny, 1))
+	ref = oracle.association_tests(dx, dy, dc, single=4, return_dot=False)
+	monkeypatch.setenv('NRM_DE_SPARSE', 'force')
+	outs = {}
+	for start in ('diagonal', 'norm'):
+		monkeypatch.setenv('NRM_S4_START', start)
+		outs[start] = association_tests(dx, dy, dc, single=4, return_dot=False)
+		ok = ref[0] > 1e-290
+		assert relerr(outs[start][0][ok], ref[0][ok]) < 1e-7 and close(outs[start][1], ref[1], 1e-7, 1e-9) and close(outs[start][3], ref[3], 1e-9), start
+	assert relerr(outs['diagonal'][0], outs['norm'][0]) < 1e-9
