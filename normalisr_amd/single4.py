@@ -255,7 +255,9 @@ def _spd_inverse_device(eng, m_d, nx):
 				if np.isnan(res) or (start == 'diagonal' and it == look_from and not res < 1.0):
 					diverged = True
 					break
-				eng.gram(Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, t, None, None), False, dot=xt)  # X T^T = X X M = X M X
+				# X M X = X T.  K2 forms A B^T, and T^T = X M equals T only while X commutes with M -- true from the norm start (every iterate a
+				# polynomial in M), not from the diagonal one: the transpose is taken explicitly
+				eng.gram(Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, t.T.contiguous(), None, None), False, dot=xt)
 				x = x.mul(2.0).sub_(xt)
 				if res < 1e-7:  # the step just taken squares it: below the rounding floor
 					done = True
