@@ -214,3 +214,20 @@ def test_small_pinv_matches_inv_rank(nc, monkeypatch):
 	monkeypatch.setenv('NRM_SMALL_SVD', 'lapack')
 	inv2, rk2 = small_pinv(m)
 	assert np.array_equal(inv2, ref) and np.array_equal(rk2, rr)
+
+
+def test_result_assertions_from_minima_and_maxima():
+	"""de._finite_within(a, lo, hi) == np.isfinite(a).all() and (a >= lo).all() and (a <= hi).all() (the reference's assertions on its
+	results, de.py:124-131), taken from the minimum and the maximum: NaN and infinities anywhere, bounds on either side, empty arrays."""
+	from normalisr_amd.de import _finite_within
+	rng = np.random.default_rng(0)
+	base = rng.random((50, 70)).astype(np.float32)
+	cases = [base, base.astype(np.float64), np.zeros((0, 5)), np.ones((3, 3))]
+	for bad in (np.nan, np.inf, -np.inf, -1e-9, 1 + 1e-6):
+		a = base.astype(np.float64).copy()
+		a[17, 33] = bad
+		cases.append(a)
+	for a in cases:
+		for lo, hi in ((None, None), (0, None), (0, 1), (None, 1)):
+			want = bool(np.isfinite(a).all() and (lo is None or (a >= lo).all()) and (hi is None or (a <= hi).all()))
+			assert _finite_within(a, lo, hi) == want, (a.shape, lo, hi)
