@@ -480,6 +480,12 @@ int nrm_upload(const void* h_src, void* d_dst, int64_t bytes, int threads, void*
 int nrm_upload_release(void);
 
 /*
+ * Minimum, maximum and number of NaNs of a host array in one threaded pass (host only): what the reference's assertions on its results
+ * (de.py:124-131, norm.py:286-289: finite, within range) need.  out[0] = minimum, out[1] = maximum (NaNs left out), out[2] = NaN count.
+ */
+int nrm_host_minmax(const void* p, int dtype, int64_t count, int threads, double* out);
+
+/*
  * Text matrices of the command line (host only): the reference reads with numpy.loadtxt(delimiter='\t') and writes with
  * numpy.savetxt(fmt='%.8G') (run.py:20-35).  Same text in, same text out, parsed / printed by `threads` host threads (0 = choose).
  *   nrm_tsv_shape: rows = lines with data ('#' comments and blank lines skipped), cols = fields of the first such line.

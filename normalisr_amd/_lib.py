@@ -75,6 +75,7 @@ _SIGNATURES = {
 	'nrm_design_stats': ([_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_upload': ([_vp, _vp, _i64, _i32, _vp], _i32),
 	'nrm_upload_release': ([], _i32),
+	'nrm_host_minmax': ([_vp, _i32, _i64, _i32, _vp], _i32),
 	'nrm_small_pinv': ([_vp, _i64, _i64, _dbl, _vp, _vp, _i32], _i32),
 	'nrm_tsv_shape': ([_vp, _i64, _i32, _i32, _vp, _vp], _i32),
 	'nrm_tsv_parse': ([_vp, _i64, _i32, _i32, _vp, _i32, _i64, _i64, _i64], _i32),

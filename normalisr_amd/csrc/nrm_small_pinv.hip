@@ -97,3 +97,55 @@ extern "C" int nrm_small_pinv(const double* m, int64_t count, int64_t n, double 
 	for (auto& x : th) x.join();
 	return NRM_OK;
 }
+
+// ---- minimum, maximum and NaN count of a host array, threaded --------------------------------------------------------------------------
+// The reference asserts on every result array that it is finite and within its range (de.py:124-131, norm.py:286-289); with numpy that is
+// up to five passes with temporaries (12 ms of an 85 ms de call at BASELINE configs[3] size, 35 ms of a 50 ms normvar call on 400 MB of
+// fp64 results).  One pass here, dealt to host threads: the three numbers answer every one of those assertions.
+namespace {
+template <typename T>
+void minmax_range(const T* p, int64_t a, int64_t b, double* out) {
+	double mn = INFINITY, mx = -INFINITY;
+	int64_t nan = 0;
+	for (int64_t i = a; i < b; i++) {
+		const double v = (double)p[i];
+		nan += v != v;
+		mn = v < mn ? v : mn;  // (comparisons with NaN are false: NaNs are counted, not propagated)
+		mx = v > mx ? v : mx;
+	}
+	out[0] = mn;
+	out[1] = mx;
+	out[2] = (double)nan;
+}
+}  // namespace
+
+// out[0] = minimum, out[1] = maximum (NaNs left out; +inf / -inf for an array without numbers), out[2] = number of NaNs.
+extern "C" int nrm_host_minmax(const void* p, int dtype, int64_t count, int threads, double* out) {
+	NRM_REQUIRE(count >= 0 && out && (p || count == 0) && (dtype == NRM_F32 || dtype == NRM_F64), "nrm_host_minmax: bad arguments");
+	int t = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+	if (t > 16) t = 16;
+	if (t > count / (1 << 20) + 1) t = (int)(count / (1 << 20) + 1);
+	if (t < 1) t = 1;
+	std::vector<double> part(3 * (size_t)t);
+	const int64_t per = (count + t - 1) / t;
+	auto work = [&](int id) {
+		const int64_t a = per * id < count ? per * id : count, b = a + per < count ? a + per : count;
+		if (dtype == NRM_F64)
+			minmax_range<double>((const double*)p, a, b, &part[3 * id]);
+		else
+			minmax_range<float>((const float*)p, a, b, &part[3 * id]);
+	};
+	std::vector<std::thread> th;
+	for (int id = 1; id < t; id++) th.emplace_back(work, id);
+	work(0);
+	for (auto& x : th) x.join();
+	out[0] = INFINITY;
+	out[1] = -INFINITY;
+	out[2] = 0.0;
+	for (int id = 0; id < t; id++) {
+		out[0] = part[3 * id] < out[0] ? part[3 * id] : out[0];
+		out[1] = part[3 * id + 1] > out[1] ? part[3 * id + 1] : out[1];
+		out[2] += part[3 * id + 2];
+	}
+	return NRM_OK;
+}
