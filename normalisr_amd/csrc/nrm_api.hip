@@ -362,7 +362,7 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 	}
 	const double guard_tol = guard_tolerance();
 	NRM_TRY(dx.alloc((size_t)nx * n * esize(x_dtype)));
-	NRM_HIP(hipMemcpy(dx.p, h_dx, (size_t)nx * n * esize(x_dtype), hipMemcpyHostToDevice));
+	NRM_TRY_RC(nrm_upload(h_dx, dx.p, (int64_t)nx * n * esize(x_dtype), 0, (void*)st));  // (from half a GB up: host threads fill page-locked blocks beside the DMA, nrm_upload.hip)
 	NRM_TRY(ssx.alloc((size_t)mp * 8));
 	if (want_alpha) NRM_TRY(bx.alloc((size_t)nx * nc * 8));
 	if (want_alpha) NRM_HIP(hipMemsetAsync(bx.p, 0, (size_t)nx * nc * 8, st));
@@ -380,7 +380,7 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 	}
 	if (!samexy) {
 		NRM_TRY(dy.alloc((size_t)ny * n * esize(y_dtype)));
-		NRM_HIP(hipMemcpy(dy.p, h_dy, (size_t)ny * n * esize(y_dtype), hipMemcpyHostToDevice));
+		NRM_TRY_RC(nrm_upload(h_dy, dy.p, (int64_t)ny * n * esize(y_dtype), 0, (void*)st));
 		NRM_TRY(ssy.alloc((size_t)np_ * 8));
 		if (want_alpha) NRM_TRY(by.alloc((size_t)ny * nc * 8));
 		if (want_alpha) NRM_HIP(hipMemsetAsync(by.p, 0, (size_t)ny * nc * 8, st));

@@ -62,7 +62,7 @@ extern "C" int nrm_upload(const void* h_src, void* d_dst, int64_t bytes, int thr
 	if (bytes == 0) return NRM_OK;
 	NRM_REQUIRE(h_src && d_dst, "nrm_upload: null pointer");
 	hipStream_t st = (hipStream_t)stream;
-	if (bytes < (32 << 20)) {  // small: the runtime's own pageable path
+	if (bytes < (512ll << 20) && !getenv("NRM_UPLOAD_BLOCK_MB")) {  // below half a GB the runtime's own pageable copy is the faster one (200 MB: 3.6 against 4.8 ms)
 		NRM_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, st));
 		return NRM_OK;
 	}
