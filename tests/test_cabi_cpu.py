@@ -231,3 +231,31 @@ def test_result_assertions_from_minima_and_maxima():
 		for lo, hi in ((None, None), (0, None), (0, 1), (None, 1)):
 			want = bool(np.isfinite(a).all() and (lo is None or (a >= lo).all()) and (hi is None or (a <= hi).all()))
 			assert _finite_within(a, lo, hi) == want, (a.shape, lo, hi)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_host_minmax_in_one_threaded_pass(dtype):
+	"""nrm_host_minmax (minimum, maximum, NaN count of a host array, dealt to host threads) against numpy on arrays large enough for several
+	threads, with NaNs and infinities planted at thread boundaries and at the ends; and through de._finite_within, which uses it from 2^18
+	elements on."""
+	from normalisr_amd import _lib
+	from normalisr_amd.de import _finite_within
+	lib = _lib.load()
+	rng = np.random.default_rng(3)
+	a = rng.standard_normal(3 * (1 << 20) + 17).astype(dtype)
+	out = np.empty(3)
+	code = _lib.NRM_F64 if dtype == np.float64 else _lib.NRM_F32
+	for threads in (0, 1, 3, 16):
+		assert lib.nrm_host_minmax(a.ctypes.data, code, a.size, threads, out.ctypes.data) == 0
+		assert out[0] == a.min() and out[1] == a.max() and out[2] == 0
+	assert _finite_within(a) and not _finite_within(a, 0) and _finite_within(a, float(a.min()), float(a.max()))
+	for where in (0, a.size - 1, a.size // 3, (1 << 20), (1 << 20) - 1):
+		for bad, nans, fin in ((np.nan, 1, False), (np.inf, 0, False), (-np.inf, 0, False)):
+			b = a.copy()
+			b[where] = bad
+			lib.nrm_host_minmax(b.ctypes.data, code, b.size, 0, out.ctypes.data)
+			assert out[2] == nans and _finite_within(b) == fin
+			if bad == np.inf:
+				assert out[1] == np.inf
+	lib.nrm_host_minmax(a.ctypes.data, code, 0, 0, out.ctypes.data)
+	assert out[0] == np.inf and out[1] == -np.inf and out[2] == 0
