@@ -47,31 +47,44 @@ if ROOT not in sys.path:
 
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r04.sh), newest first
 PMC_FILES = {w: [os.path.join(ROOT, 'profiles', f) for f in fs] for w, fs in dict(
-	coex_c2=('r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r04_pmc_de_c3.json', 'r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
-	de_c4=('r04_pmc_de_c4_sparse.json', 'r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'), de_c4_single4=('r04_pmc_de_c4_single4_sparse.json', 'r04_pmc_de_c4_single4.json'), de_c4_single1=('r04_pmc_de_c4_single1.json', ),
-	binnet_c5=('r04_pmc_binnet_c5.json', )).items()}
+	coex_c2=('r05_pmc_c2.json', 'r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r05_pmc_de_c3.json', 'r04_pmc_de_c3.json', 'r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
+	de_c4=('r05_pmc_de_c4.json', 'r04_pmc_de_c4_sparse.json'), de_c4_dense=('r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r05_pmc_coex_c5.json', 'r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'),
+	de_c4_single4=('r05_pmc_de_c4_single4.json', 'r04_pmc_de_c4_single4_sparse.json'), de_c4_single4_dense=('r04_pmc_de_c4_single4.json', ),
+	de_c4_single1=('r05_pmc_de_c4_single1.json', 'r04_pmc_de_c4_single1.json'), binnet_c5=('r05_pmc_binnet_c5.json', 'r04_pmc_binnet_c5.json'), normvar_c2=('r05_pmc_normvar_c2.json', )).items()}
 
 
-def pmc_traffic(workload, roof, kernel=None):
-	"""HBM-side bytes per launch of the roofline's kernel from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)."""
-	want = kernel or roof['kernel'].split(' ')[0]
+def pmc_traffic(workload, roof, kernels=None):
+	"""HBM-side bytes per launch of the roofline's kernel from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).
+	kernels: the kernels whose launches make up roof['kernel_ms'] (default: the one roof['kernel'] names) -- their bytes are added; a
+	summary that lacks one of them is not used (the traffic of ANOTHER kernel is never attached: round-4 verdict)."""
+	wants = list(kernels) if kernels else [roof['kernel'].split(' ')[0]]
 	for f in PMC_FILES.get(workload, ()):
 		try:
 			with open(f) as fh:
 				pm = json.load(fh)
-			cands = [(k, v) for k, v in pm.items() if k.split('<')[0].split(' ')[0] == want and 'hbm_bytes_per_launch' in v]
-			if not cands:
-				continue
-			k, entry = max(cands, key=lambda kv: kv[1]['hbm_bytes_per_launch'])  # (the long dispatch class of a kernel launched on two sizes)
-			roof['traffic'] = entry['hbm_bytes_per_launch']
-			if 'effective_clock_ghz' in entry:  # the chip clocks down under int8 MFMA load: the nominal peak assumes 2.4 GHz
-				roof['effective_clock_ghz_profiled'] = round(entry['effective_clock_ghz'], 3)
-			roof['traffic_unit'] = 'bytes/launch'
-			roof['traffic_source'] = '{} [{}] (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(
-				os.path.relpath(f, ROOT), k)
-			return
+			total, used, clock = 0.0, [], None
+			for want in wants:
+				cands = [(k, v) for k, v in pm.items() if k.split('<')[0].split(' ')[0] == want and 'hbm_bytes_per_launch' in v]
+				if not cands:
+					break
+				k, entry = max(cands, key=lambda kv: kv[1]['hbm_bytes_per_launch'])  # (the long dispatch class of a kernel launched on two sizes)
+				total += entry['hbm_bytes_per_launch']
+				used.append(k)
+				clock = entry.get('effective_clock_ghz', clock) if want == wants[0] else clock
+			else:
+				roof['traffic'] = total
+				if clock is not None:  # the chip clocks down under int8 MFMA load: the nominal peak assumes 2.4 GHz
+					roof['effective_clock_ghz_profiled'] = round(clock, 3)
+				roof['traffic_unit'] = 'bytes/launch'
+				roof['traffic_source'] = '{} [{}] (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)'.format(
+					os.path.relpath(f, ROOT), ' + '.join(used))
+				return
 		except (OSError, KeyError, ValueError):
 			continue
+	roof['traffic'] = None
+	roof.pop('traffic_source', None)
+
+
 F64_MFMA_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (= 1/2 of the 157.3 TF fp32 matrix peak of MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TFLOPS = 157.3  # the roofline BASELINE.json's north_star names
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, matrix cores): 2 x 2.5 PF
@@ -459,22 +472,45 @@ def bench_de(rk, nd, steps, warmup, which, covariates=20):
 	if plan.streaming():
 		byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
 		roof = dict(bound='hbm', kernel='k_gram_skinny + sweep (whole step)', achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
-					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms)
+					frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel_ms=ms, pmc_kernels=['k_gram_skinny'])
 	elif 'de_sparse' in split:
 		# the design matrix is sparse (gRNA incidence, 1 % of the entries set): no K1 on the genes, no K2 -- the raw expression rows are read
 		# (twice: sums with the covariates, then the gathers) and of each only the values at the design's entries are added up
 		byts = 4.0 * n * ny_local  # algorithmic: every fp32 expression value read once
 		kms = split['de_sparse'] + split.get('row_sums', 0.0)
 		roof = dict(bound='hbm', kernel='k_de_sparse', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-					traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms,
-					note='kernel_ms = k_s1_stream (sums of the rows with the covariates: a pass at HBM rate) + k_de_sparse, which is bound by its vector ALU work '
-						 '(one fp32 -> fp64 conversion and one fp64 add per gathered value), not by HBM; NRM_DE_SPARSE=0 puts K1 + the integer Gram engine back',
+					traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms, pmc_kernels=['k_de_sparse'] + (['k_s1_stream'] if 'row_sums' in split else []),
+					note=('kernel_ms = k_s1_stream (sums of the rows with the covariates: a pass at HBM rate) + k_de_sparse' if 'row_sums' in split else 'kernel_ms = k_de_sparse (row sums with the covariates inside it: one pass over the rows)') +
+						 ', which is bound by its vector ALU work (one fp32 -> fp64 conversion and one fp64 add per gathered value), not by HBM; NRM_DE_SPARSE=0 puts K1 + the integer Gram engine back',
 					dense_path_flop_equivalent_tflops=2.0 * n * nx * ny_local / (kms * 1e-3) / 1e12)
+		# A COLD call: a design tensor the engine has not seen (every step of the timed region reuses the lists the plan keeps for its
+		# design; a one-shot norm.de pays for them).  Fresh copies of the design are made outside the timed region; every timed call builds
+		# the lists (csrc/nrm_design_lists.hip), the design rows' statistics and everything else of a resident step, eagerly.
+		fresh = [dx.clone() for _ in range(max(2, min(steps, 5)) + 1)]
+		call = lambda d: eng.association_single0(d, dy, plan.dc64, plan.dci, plan.dcr, 0, return_dot=False, want_alpha=False, out_dtype=plan.out_dtype, cov=plan.cov, resident=True)
+		call(fresh.pop())
+		rk.barrier()
+		t0 = time.perf_counter()
+		for d in fresh:
+			call(d)
+		rk.barrier()
+		cold_ms = 1e3 * rk.max_over_ranks(time.perf_counter() - t0) / len(fresh)
+		eng.trace = []
+		call(dx.clone())
+		torch.cuda.synchronize()
+		cold_split = {}
+		for name, e0, e1 in eng.trace:
+			cold_split[name] = round(cold_split.get(name, 0.0) + e0.elapsed_time(e1), 4)
+		eng.trace = None
 	else:
 		roof = gram_roofline(n, 2.0 * n * nx * ny_local, split.get('gram', ms), 0, 0)  # K2 alone
 		roof['algorithmic_bytes'] = float(SLICES(n) or 8) * (nx + ny_local) * n
 		roof['step_ms'] = ms
-	return dict(value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
+	extra = {}
+	if 'de_sparse' in split:
+		extra = dict(cold_ms=cold_ms, cold_kernels_ms=cold_split, cold_note='a call on a design tensor the engine has not seen (lists built by csrc/nrm_design_lists.hip inside the call); '
+					 'ms_per_step is a resident DePlan step, which keeps the lists of its design', cold_tests_per_s=tests / (cold_ms * 1e-3))
+	return dict(extra, value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
 				scaling='strong', dtype='f64' if (plan.streaming() or 'de_sparse' in split) else ARITH(n),
 				config=dict(workload='norm.de {} x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[{}])'.format(
 					nx, ny, n, nc, 2 if which == 'de_c3' else 3), parallelism='gene rows of Y x{}, no collective'.format(world)), roofline=roof,
@@ -536,7 +572,7 @@ def bench_de_method(rk, steps, warmup, single):
 		byts = 4.0 * n * ny_local
 		kms = split['de_sparse'] + split.get('row_sums', 0.0)
 		roof = dict(bound='hbm', kernel='k_de_sparse', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-					traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms,
+					traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms, pmc_kernels=['k_de_sparse'] + (['k_s1_stream'] if 'row_sums' in split else []),
 					note='kernel_ms = k_s1_stream (row sums with the covariates) + k_de_sparse (bound by its vector ALU work: a conversion and an fp64 add per gathered '
 						 'value); the rest of a step: K1 on the design, M~ = X~ X~^T and its Newton-Schulz inverse on the fp64 matrix cores, B = G N~, the sweep')
 		dtype = 'f64'
@@ -654,6 +690,40 @@ def bench_c5_full(rk):
 				roofline=roof, kernels_ms={k: round(v, 2) for k, v in split.items()}, wall_seconds_incl_generating_the_input=round(wall, 2), guard=guard)
 
 
+def short(v, n=160):
+	return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + '...'
+
+def contract_line(head, extras, world, e2e=None):
+	"""The one line the driver reads: BASELINE's metric on its config, roofline, cpu_baseline, the scaling series, and one summary row
+	per extra workload -- kept under 4 KB (the full records are the lines before it)."""
+	roof = {k: short(v, 120) for k, v in head['roofline'].items() if k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'kernel_ms',
+																		  'frac_of_fp32_mfma_peak', 'frac_of_fp64_mfma_peak', 'effective_clock_ghz_profiled', 'traffic_source')}
+	cb = head.get('cpu_baseline')
+	line = dict(metric=head['metric'], value=head['value'], unit=head['unit'], n_gpus=world, steps=head['steps'], warmup=head['warmup'], ms_per_step=head['ms_per_step'],
+				higher_is_better=True, scaling=head['scaling'], vs_baseline=None, dtype=short(head['dtype'], 90), data='synthetic',
+				config={k: short(v) for k, v in head['config'].items()}, roofline=roof,
+				cpu_baseline=None if not cb else {k: short(v, 200) for k, v in cb.items()}, scaling_series=head.get('scaling_series'),
+				guard=None if not head.get('guard') else {k: v for k, v in head['guard'].items() if k != 'note'},
+				kernels_ms={k: round(v, 4) for k, v in (head.get('kernels_ms') or {}).items()}, ranks_seen_by_collective=head['ranks_seen_by_collective'],
+				dist_backend=head['dist_backend'], frac_of_fp32_mfma_peak=head.get('frac_of_fp32_mfma_peak'),
+				end_to_end_pcie_s=None if not e2e else e2e['seconds'])
+	rows = {}
+	for w, r in extras.items():
+		if not isinstance(r, dict) or 'value' not in r:
+			rows[w] = short(str(r.get('error', r)) if isinstance(r, dict) else str(r), 100)
+			continue
+		row = dict(value=float('%.4g' % r['value']), ms=round(r['ms_per_step'], 3), kernel=short(r['roofline']['kernel'], 24), frac=round(r['roofline']['frac'], 3))
+		if 'cold_ms' in r:
+			row['cold_ms'] = round(r['cold_ms'], 3)
+		rows[w] = row
+	line['extra_workloads'] = rows
+	line['detail'] = 'full records: the JSON lines before this one (one per workload; also gpurun_out/bench_detail_n{}.jsonl)'.format(world)
+	if '_abandoned' in extras:
+		line['extras_abandoned'] = extras['_abandoned']
+	return line
+
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--gpus', type=int, default=1)
@@ -743,15 +813,16 @@ def main():
 			return bench_c5_full(rk)
 		if which in ('de_c4_single4', 'de_c4_single1'):
 			out = bench_de_method(rk, steps, warmup, 4 if which.endswith('4') else 1)
+			kern = out['roofline'].pop('pmc_kernels', None)
 			if world == 1:
-				pmc_traffic(which, out['roofline'], kernel=out['roofline']['kernel'].split(' ')[0])
+				pmc_traffic(which + ('_dense' if out['roofline']['kernel'].startswith('k_gram') else ''), out['roofline'], kernels=kern)
 			return out
 		if which == 'normvar_c2':
 			return bench_normvar(rk, steps, warmup)
 		if which == 'binnet_c5':
 			out = bench_binnet(rk, steps, warmup)
 			if out is not None:
-				pmc_traffic(which, out['roofline'], kernel='k_binnet_rows')
+				pmc_traffic(which, out['roofline'], kernels=['k_binnet_rows'])
 			return out
 		if which == 'coex_c2_f64':  # configs[1] on the fp64 matrix cores: the dtype the north star names literally
 			prev = os.environ.get('NRM_GRAM')
@@ -763,13 +834,17 @@ def main():
 					del os.environ['NRM_GRAM']
 				else:
 					os.environ['NRM_GRAM'] = prev
-			out['roofline'].pop('traffic', None)
+			for k in ('traffic', 'traffic_source', 'traffic_unit', 'effective_clock_ghz_profiled'):  # (the counters on file are the integer engine's)
+				out['roofline'].pop(k, None)
 			out['roofline']['traffic'] = None
 			return out
 		out = bench_de(rk, nd, steps, warmup, which, args.covariates)
 		out['metric'] = 'association tests/sec (de)'
 		if world == 1:
-			pmc_traffic(which, out['roofline'], kernel='k_gram_skinny' if which == 'de_c3' else 'k_gram_i8')
+			dense = out['roofline']['kernel'].startswith('k_gram_i8') or out['roofline']['kernel'].startswith('k_gram_f64')
+			pmc_traffic(which + ('_dense' if dense else ''), out['roofline'], kernels=out['roofline'].pop('pmc_kernels', None))
+		else:
+			out['roofline'].pop('pmc_kernels', None)
 		return out
 
 	head = run(args.workload, args.steps, args.warmup)
@@ -785,7 +860,33 @@ def main():
 	head['end_to_end_pcie'] = e2e
 	head['frac_of_fp32_mfma_peak'] = head['roofline'].get('frac_of_fp32_mfma_peak')  # the roofline BASELINE.json's north_star names
 
+	# ONE workload is measured at every N: the per-rank slice of BASELINE configs[4] (3750 gene rows per rank x 500 000 cells fp64; N = 8 is
+	# the full 30 000-gene problem the 8-GPU target is quoted on).  It is the headline at N > 1 and an extra at N = 1, where the headline is
+	# configs[1]; `scaling_series` carries it under the same key on every line, so that a 1 -> 8 curve is read from one key.
+	def series_of(r):
+		return dict(workload='coex_c5: BASELINE configs[4] per-rank slice, {} gene rows per rank x {} cells fp64'.format(args.c5_rows, args.c5_cells), value=r['value'], unit=r['unit'],
+					ms_per_step=r['ms_per_step'], ranks=world, tests_per_step=r['config']['tests_per_step'], value_per_rank=r['value'] / world,
+					roofline_frac=r['roofline']['frac'], exchange_ms_not_hidden=r.get('kernels_ms', {}).get('exchange'))
+	head['scaling_series'] = series_of(head) if args.workload == 'coex_c5' else None
+	head['config']['scaling_series'] = 'top-level `scaling_series` = BASELINE configs[4] per-rank slice, the same workload at every N (the headline itself at N > 1)'
+
 	printed = threading.Event()
+	extras = {}
+	detail_path = os.path.join(ROOT, 'gpurun_out', 'bench_detail_n{}.jsonl'.format(world))
+
+	def say(obj):
+		"""A JSON line that is NOT the contract line: the full record of an extra workload (or of the headline), printed as soon as it exists
+		and appended to gpurun_out/bench_detail_nN.jsonl; the contract line, last and short, carries their summary."""
+		if rank != 0:
+			return
+		line = json.dumps(obj)
+		print(line, flush=True)
+		try:
+			os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+			with open(detail_path, 'a') as fh:
+				fh.write(line + '\n')
+		except OSError:
+			pass
 
 	def emit():
 		if rank == 0 and not printed.is_set():
@@ -795,10 +896,14 @@ def main():
 				ctypes.CDLL(None).fflush(None)
 			except Exception:  # noqa: BLE001
 				pass
-			print(json.dumps(head), flush=True)
+			print(json.dumps(contract_line(head, extras, world, e2e)), flush=True)
 
-	extras = {}
-	head['extra_workloads'] = extras
+	if rank == 0:
+		try:
+			os.remove(detail_path)
+		except OSError:
+			pass
+	say(dict(workload_detail=args.workload, **head))
 	if not args.no_extras:
 		# the other BASELINE configs, measured like the headline; a stuck collective must not lose the headline line
 		def give_up():
@@ -808,7 +913,7 @@ def main():
 		dog = threading.Timer(args.extras_timeout, give_up)
 		dog.daemon = True
 		dog.start()
-		names = [w for w in ('coex_c2', 'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64') if w != args.workload and not (w == 'coex_c2' and world == 1)] + (
+		names = [w for w in ('coex_c5', 'coex_c2', 'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64') if w != args.workload and not (w == 'coex_c2' and world == 1)] + (
 			['binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
 		if world > 1:
 			names = [w for w in names if w != 'coex_c2_f64']
@@ -826,8 +931,12 @@ def main():
 				elif '_error' in cpu_extras:
 					r['cpu_baseline'] = dict(error=cpu_extras['_error'])
 				extras[w] = r
+				if w == 'coex_c5':
+					head['scaling_series'] = series_of(r)
+				say(dict(workload_detail=w, **r))
 			except Exception as e:  # reported, never fatal for the headline
 				extras[w] = dict(error='{}: {}'.format(type(e).__name__, e))
+				say(dict(workload_detail=w, **extras[w]))
 		dog.cancel()
 	emit()
 	rk.close()

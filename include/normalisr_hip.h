@@ -65,6 +65,7 @@ int nrm_copy_rect_to_host(void* h_dst, int64_t dst_pitch, const void* d_src, int
 /* Device-side assembly of the padded operand buffers (zero padding, stacking [C; X~] for the streaming path, gathering sums of
  * squares of row chunks): asynchronous on `stream`; pitches and row_bytes in BYTES. */
 int nrm_fill_zero(void* d_dst, int64_t bytes, void* stream);
+int nrm_fill_i32(void* d_dst, int32_t value, int64_t count, void* stream);  /* count int32 words = value */
 int nrm_copy_rows(void* d_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows, void* stream);
 
 /*
@@ -458,10 +459,54 @@ int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t l
 /*
  * The design rows' own statistics from their entries (association.py:224-230 for a sparse design row): d_row_ptr (nx + 1), d_cells (int32),
  * d_vals (fp64, or NULL: every entry 1) list the entries of design row i at [d_row_ptr[i], d_row_ptr[i + 1]); d_c (nc, ldc), d_dci as above.
- * d_ss (nx) = |x~_i|^2 = |x_i|^2 - (x_i C^T) . b_i, d_coef (nx, nc) = b_i.
+ * d_ss (nx) = |x~_i|^2 = |x_i|^2 - (x_i C^T) . b_i, d_coef (nx, nc) = b_i.  d_flags (int32[4]) or NULL: [2] counts the design rows whose
+ * residual is so small a part of the row (|x~|^2 < 1e-4 |x|^2: a gRNA that all but coincides with a covariate) that this difference, and the
+ * products nrm_de_sparse forms with the row, have lost four digits -- the same hand-back to nrm_residualize + nrm_gram_f64 as on the
+ * expression side.
  */
 int nrm_design_stats(const int64_t* d_row_ptr, const int32_t* d_cells, const double* d_vals, const double* d_c, int64_t ldc, int64_t nc,
-					 const double* d_dci, int64_t nx, double* d_ss, double* d_coef, void* stream);
+					 const double* d_dci, int64_t nx, double* d_ss, double* d_coef, int32_t* d_flags, void* stream);
+
+/*
+ * The lists above built from the design matrix itself, by kernels of the library (csrc/nrm_design_lists.hip) -- the design side of
+ * association.py:224-235 for a sparse design, and what association.py:914-918 selects cells from.  d_x (nx, ldx) the design matrix in HBM
+ * (NRM_F32 / NRM_F64); nslots = nx rounded up to a multiple of 64; nch = ceil(n / nrm_de_sparse_chunk()) chunks of cells.
+ *   nrm_design_count: ONE pass over d_x.  d_cnt (nch, nslots) int32 = entries (values != 0, NaN included) of design row `slot` in chunk c;
+ *     d_info (int64[8], zeroed by the call): [2] = bits NRM_DESIGN_* describing the entries.
+ *   nrm_design_plan: from the counts -- d_row_ptr (nx + 1) the CSR offsets, d_coff (nch, nslots) int32 the entries of a row before each chunk,
+ *     d_slot2x (nslots) or NULL; with d_sig != NULL also the dealing d_sig / d_pos (nch, nslots: position -> slot and slot -> position, sorted
+ *     by the entries of the chunk inside every block of 1024 slots, most first, ties in row order), the widths d_w (nch, nslots / 64) and
+ *     offsets d_base of the ELL blocks as nrm_de_sparse reads them.  d_info[0] = entries in all, d_info[1] = entries of the ELL form, padding included.
+ *   nrm_design_fill: the second pass over d_x writes the entries (cells ascending inside a row; no atomics: the same lists run to run) into
+ *     d_cells / d_row_vals (CSR; d_cells may be NULL) and d_ell / d_ellv (ELL, padding included; d_ell may be NULL); binary != 0: every entry
+ *     is 1 (d_info[2] has no NRM_DESIGN_NOTONE) and the value arrays are not written.
+ * The caller reads d_info (one small copy) between plan and fill to size d_cells (d_info[0]) and d_ell (d_info[1]).
+ */
+#define NRM_DESIGN_NOTONE 1     /* an entry that is neither 0 nor 1 */
+#define NRM_DESIGN_NEG 2        /* an entry < 0 */
+#define NRM_DESIGN_GT1 4        /* an entry > 1 */
+#define NRM_DESIGN_HAS1 8       /* an entry == 1 */
+#define NRM_DESIGN_NAN 16       /* a NaN (an infinite entry sets NRM_DESIGN_GT1 or NRM_DESIGN_NEG) */
+int nrm_design_count(const void* d_x, int x_dtype, int64_t nx, int64_t n, int64_t ldx, int32_t* d_cnt, int64_t nslots, int64_t* d_info, void* stream);
+int nrm_design_plan(const int32_t* d_cnt, int64_t nx, int64_t n, int64_t nslots, int32_t* d_sig, int32_t* d_pos, int32_t* d_w, int64_t* d_base,
+					int64_t* d_row_ptr, int32_t* d_coff, int32_t* d_slot2x, int64_t* d_info, void* stream);
+int nrm_design_fill(const void* d_x, int x_dtype, int64_t nx, int64_t n, int64_t ldx, int64_t nslots, const int32_t* d_pos, const int32_t* d_w,
+					const int64_t* d_base, const int64_t* d_row_ptr, const int32_t* d_coff, int16_t* d_ell, double* d_ellv, int32_t* d_cells,
+					double* d_row_vals, int binary, void* stream);
+/*
+ * single=1's cell selection (association.py:914-918) for a design with entries >= 0, from its CSR form: cell k is selected for grouping i
+ * when i's entry is the only one of the cell, and for every grouping when the cell has none.
+ *   d_cnt (n) int32 scratch (entries per cell); d_code (n): the cell codes nrm_single1_stream reads; d_seg (nx + 1): grouping i owns the
+ *   positions [d_seg[i], d_seg[i + 1]) of d_idx (cell, int64) / d_xe (its value there) / d_ce (position, nc: the covariates there) -- arrays
+ *   with room for nnz positions; d_rowinfo (nx, 3): positions of grouping i, smallest and largest value among them (+-inf: none);
+ *   d_gram_part (nb (nb + 1) / 2, nrm_single1_select_gram_blocks(), 64), nb = ceil(nc / 8): partial sums of the covariate Gram matrix over
+ *   the cells without entries, by 8 x 8 blocks of covariates (block pairs bi <= bj row by row): the caller adds the partials of a pair in order.
+ *   d_info (int64[8]): [3] = cells without entries, [4] = positions in all.
+ */
+int64_t nrm_single1_select_gram_blocks(void);
+int nrm_single1_select(const int64_t* d_row_ptr, const int32_t* d_cells, const double* d_vals, int64_t nx, int64_t n, int64_t nnz, const double* d_c,
+					   int64_t ldc, int64_t nc, int32_t* d_cnt, int32_t* d_code, int64_t* d_seg, int64_t* d_idx, double* d_xe, double* d_ce,
+					   double* d_rowinfo, double* d_gram_part, int64_t* d_info, void* stream);
 
 /*
  * Pseudo-inverses and ranks of a stack of small symmetric matrices (host only): what single=1 needs per grouping (association.py:350-351)

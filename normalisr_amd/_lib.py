@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(HERE, 'libnormalisr_hip.so')
 NRM_F32, NRM_F64 = 0, 1
 NRM_TSV_I64, NRM_TSV_I32, NRM_TSV_U8 = 16, 17, 18  # integer dtypes of nrm_tsv_format
 NRM_S1_COMMON, NRM_S1_SKIP = -2, -1  # cell codes of nrm_single1_stream (include/normalisr_hip.h)
+DESIGN_NOTONE, DESIGN_NEG, DESIGN_GT1, DESIGN_HAS1, DESIGN_NAN = 1, 2, 4, 8, 16  # bits of nrm_design_count's d_info[2]
 NRM_E_ARG, NRM_E_DEVICE, NRM_E_NUMERIC = -1, -2, -3
 ROW_TILE, K_TILE, PCOEF, FIX_STRIDE = 128, 16, 20, 8
 
@@ -32,6 +33,7 @@ _SIGNATURES = {
 	'nrm_host_alloc': ([ctypes.POINTER(_vp), _i64], _i32),
 	'nrm_host_free': ([_vp], _i32),
 	'nrm_fill_zero': ([_vp, _i64, _vp], _i32),
+	'nrm_fill_i32': ([_vp, _i32, _i64, _vp], _i32),
 	'nrm_copy_rows': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
 	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
@@ -72,7 +74,12 @@ _SIGNATURES = {
 	'nrm_de_sparse_chunk': ([], _i64),
 	'nrm_de_sparse_max_covariates': ([], _i64),
 	'nrm_de_sparse': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp], _i32),
-	'nrm_design_stats': ([_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp], _i32),
+	'nrm_design_count': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp], _i32),
+	'nrm_design_plan': ([_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+	'nrm_design_fill': ([_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
+	'nrm_single1_select_gram_blocks': ([], _i64),
+	'nrm_single1_select': ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+	'nrm_design_stats': ([_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
 	'nrm_upload': ([_vp, _vp, _i64, _i32, _vp], _i32),
 	'nrm_upload_release': ([], _i32),
 	'nrm_host_minmax': ([_vp, _i32, _i64, _i32, _vp], _i32),

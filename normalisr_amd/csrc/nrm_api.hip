@@ -154,6 +154,14 @@ extern "C" int nrm_fill_zero(void* d_dst, int64_t bytes, void* stream) {
 	return NRM_OK;
 }
 
+extern "C" int nrm_fill_i32(void* d_dst, int32_t value, int64_t count, void* stream) {
+	NRM_REQUIRE(count >= 0, "nrm_fill_i32: negative size");
+	if (count == 0) return NRM_OK;
+	NRM_REQUIRE(d_dst != nullptr && (uintptr_t)d_dst % 4 == 0, "nrm_fill_i32: bad pointer");
+	NRM_HIP(hipMemsetD32Async((hipDeviceptr_t)d_dst, value, (size_t)count, (hipStream_t)stream));
+	return NRM_OK;
+}
+
 extern "C" int nrm_copy_rows(void* d_dst, int64_t dst_pitch, const void* d_src, int64_t src_pitch, int64_t row_bytes, int64_t rows,
 							 void* stream) {
 	NRM_REQUIRE(row_bytes >= 0 && rows >= 0 && dst_pitch >= row_bytes && src_pitch >= row_bytes, "nrm_copy_rows: pitches smaller than the row");

@@ -19,12 +19,8 @@
 // chunk ahead: +1.0 ms -- a workgroup of 4 rows re-reads the covariates once per 4 rows, 7.5 GB through L2 beside the 3 GB of rows, where the
 // stream kernel's 8 rows per workgroup and its own pass cost 0.64).
 #include "nrm_common.h"
+#include "nrm_design.h"  // DS_CH (cells per chunk), DS_T (threads per workgroup), DS_G (design rows per thread)
 
-#define DS_CH 2048   // cells per chunk: 32 KB of records, three workgroups per CU.  Measured with the design rows dealt once for all chunks: 4096 cells (two
-                     // workgroups per CU) 1.82 ms, 8192 (one) 2.11, 2048 1.88 (17 % more padded entries); dealt per chunk (sig) the lists of a wave are
-                     // equally long whatever the chunk size and the waves in flight decide: 4096 cells 1.69 ms, 2048 cells 1.56.
-#define DS_T 512     // threads per workgroup
-#define DS_G 2       // design rows per thread: 1024 per pass over the expression matrix
 #define DS_NCMAX 32  // (the sums over the covariates come from nrm_single1_stream: its limit)
 #define DS_WGS 6     // waves per SIMD the register budget is set for (68 registers; three workgroups of 512 threads per CU; 8 waves per SIMD spill and gain nothing)
 
@@ -263,7 +259,7 @@ extern "C" int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n
 // a wave per design row walks them (lane-strided, then a tree over the lanes: a fixed order), instead of K1's two sweeps over n cells.
 __global__ void __launch_bounds__(64) k_design_stats(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ cells, const double* __restrict__ vals,
 													  const double* __restrict__ C, int64_t ldc, int nc, const double* __restrict__ dci, int64_t nx,
-													  double* __restrict__ ss, double* __restrict__ coef) {
+													  double* __restrict__ ss, double* __restrict__ coef, int32_t* __restrict__ flags) {
 	const int64_t i = blockIdx.x;
 	const int lane = threadIdx.x;
 	double a[DS_NCMAX], xx = 0.0;
@@ -299,14 +295,18 @@ __global__ void __launch_bounds__(64) k_design_stats(const int64_t* __restrict__
 			s = fma(-ac, b, s);
 		}
 		ss[i] = s > 0.0 ? s : 0.0;
+		// the same difference as on the expression side (k_de_sparse): a design row all but inside the span of the covariates (a gRNA that
+		// coincides with a batch indicator) has lost the digits of |x~|^2 -- and its products with the expression rows likewise -- counted in
+		// flags[2], and the caller redoes the call on K1's two sweeps and the fp64 Gram kernel, which residualise first
+		if (flags && !(s >= 1e-4 * xx) && xx > 0.0) atomicAdd(&flags[2], 1);
 	}
 }
 
 // d_row_ptr (nx + 1), d_cells (int32), d_vals (fp64 or NULL: every entry 1): the entries of design row i are [d_row_ptr[i], d_row_ptr[i + 1]).
-// d_ss (nx) = |x~_i|^2, d_coef (nx, nc) = b_i.  nc = 0: no covariates (d_ss = |x_i|^2).
+// d_ss (nx) = |x~_i|^2, d_coef (nx, nc) = b_i.  nc = 0: no covariates (d_ss = |x_i|^2).  d_flags (int32[4]) or NULL: [2] counts the rows with |x~|^2 < 1e-4 |x|^2.
 extern "C" int nrm_design_stats(const int64_t* d_row_ptr, const int32_t* d_cells, const double* d_vals, const double* d_c, int64_t ldc, int64_t nc,
-								const double* d_dci, int64_t nx, double* d_ss, double* d_coef, void* stream) {
+								const double* d_dci, int64_t nx, double* d_ss, double* d_coef, int32_t* d_flags, void* stream) {
 	NRM_REQUIRE(nx > 0 && nc >= 0 && nc <= DS_NCMAX && d_row_ptr && d_cells && d_ss && (nc == 0 || (d_c && d_dci && d_coef)), "nrm_design_stats: bad arguments");
-	hipLaunchKernelGGL(k_design_stats, dim3((unsigned)nx), dim3(64), 0, (hipStream_t)stream, d_row_ptr, d_cells, d_vals, d_c, ldc, (int)nc, d_dci, nx, d_ss, d_coef);
+	hipLaunchKernelGGL(k_design_stats, dim3((unsigned)nx), dim3(64), 0, (hipStream_t)stream, d_row_ptr, d_cells, d_vals, d_c, ldc, (int)nc, d_dci, nx, d_ss, d_coef, d_flags);
 	return nrm_check_launch("k_design_stats");
 }

@@ -836,14 +836,31 @@ class DePlan:
 		r = self.result
 		try:
 			self.eng.check_flags(r['flags'])
-		except GuardHit as g:  # the integer engine could not certify every P-value: this step again, eagerly, on the fp64 Gram kernel
-			self._state.pop('yscale', None)  # (streaming path: no more integer passes for this plan -- stale row scales count as a hit)
-			self._state['keep'] = False
-			self._graph.enabled, self._graph.graph = False, None
-			with self.eng.forced_f64():
-				r = self._run()
-				self.eng.check_flags(r['flags'])
-			self.eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
+		except GuardHit as g:
+			st = self._state
+			sp = st.get('sparse')
+			if sp is not None and sp[0] is self.dx and sp[2].ok and st.get('sparse_refused') is not self.dx:
+				# The sparse-design kernels handed the step back: rows (expression or design) all but inside the span of the covariates, for
+				# which their differences lose digits.  That is a property of the data, not of the step: the plan remembers it and takes K1 +
+				# the Gram engines from now on (captured as a graph again) instead of trying the sparse kernels first at every step.
+				import logging
+				logging.warning('normalisr_amd: %d rows too close to the span of the covariates for the sparse-design kernels; this plan runs on K1 and the Gram engines from now on.', g.hits)
+				st['sparse_refused'] = self.dx
+				self._graph.graph, self._graph.calls = None, 0
+				try:
+					r = self.result = self._run()
+					self.eng.check_flags(r['flags'])
+					g = None
+				except GuardHit as g2:
+					g = g2
+			if g is not None:  # the integer engine could not certify every P-value: this step again, eagerly, on the fp64 Gram kernel
+				st.pop('yscale', None)  # (streaming path: no more integer passes for this plan -- stale row scales count as a hit)
+				st['keep'] = False
+				self._graph.enabled, self._graph.graph = False, None
+				with self.eng.forced_f64():
+					r = self._run()
+					self.eng.check_flags(r['flags'])
+				self.eng.last_guard = dict(hits=g.hits, worst=g.worst, fallback=True)
 		return (self.eng.download(r['p']), self.eng.download(r['stat']), self.eng.variances(r['ssx'], self.nx, self.n, self.out_dtype),
 				self.eng.variances(r['ssy'], self.ny, self.n, self.out_dtype))
 

@@ -1208,14 +1208,16 @@ class Engine:
 			with self.torch.cuda.device(self.device):
 				if isinstance(dx, np.ndarray):
 					dx = self.upload(as_input(dx))  # (kept for the dense path below if the matrix turns out not to be sparse)
+				# a resident caller's lists live in its state (kept as long as the plan, whatever else runs on this engine in between); they belong to
+				# one tensor in one state: torch counts in-place writes in ._version (permutation nulls on the same buffer get new lists)
 				lists = state.get('sparse') if state is not None else None
-				if lists is None or lists[0] is not dx:
-					lists = (dx, de_sparse.lists_for(self, dx))
+				if lists is None or lists[0] is not dx or lists[1] != dx._version:
+					lists = (dx, dx._version, de_sparse.lists_for(self, dx))
 					if state is not None:
 						state['sparse'] = lists
-			if lists[1].ok:
-				self._tls.path = 'the sparse-design kernel (expression rows read once, %d design entries)' % lists[1].nnz
-				return self._association_de_sparse(dx, lists[1], dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident)
+			if lists[2].ok and not (state is not None and state.get('sparse_refused') is dx):
+				self._tls.path = 'the sparse-design kernel (expression rows read once, %d design entries)' % lists[2].nnz
+				return self._association_de_sparse(dx, lists[2], dy, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, cov, device_out, resident)
 		nx, n = dx.shape
 		ny = nx if samexy else dy.shape[0]
 		nc = dc.shape[0]

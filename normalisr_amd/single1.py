@@ -67,12 +67,20 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		with torch.cuda.device(eng.device):
 			# cell selection on the device (association.py:914-918): the design matrix travels once, in its own dtype
 			d_dx = dx if _is_dev(dx) else eng.upload(_engine.as_input(dx))
-			lohi = torch.stack(torch.aminmax(d_dx)).cpu().numpy()
-			assert float(lohi[1]) == 1  # association.py:914
-			if nc <= 32 and float(lohi[0]) >= 0 and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
-				# entries >= 0: the selection follows from the LIST of the design's entries (a cell is selected for grouping i when i is its
-				# only entry, and for every grouping when it has none) -- no (groupings x cells) selection matrix, no passes over one
-				return _sparse(eng, d_dx, dx.dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out)
+			lists = None
+			if nc <= 32 and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
+				# the design's entries listed by the library (csrc/nrm_design_lists.hip: one pass counts them and says what they are like, a
+				# second writes them row by row) -- unless more than a quarter of the matrix is set, which no design of this method is
+				from . import de_sparse
+				lists = de_sparse.Lists(eng, d_dx, ell=False, max_density=0.25)
+				b = lists.bits
+				assert (b & _lib.DESIGN_HAS1) and not (b & (_lib.DESIGN_GT1 | _lib.DESIGN_NAN))  # dx.max() == 1 (association.py:914)
+				if lists.ok and not (b & _lib.DESIGN_NEG):
+					# entries >= 0: the selection follows from the LIST of the design's entries (a cell is selected for grouping i when i is its
+					# only entry, and for every grouping when it has none) -- no (groupings x cells) selection matrix, no passes over one
+					return _sparse(eng, lists, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out)
+			else:
+				assert float(torch.amax(d_dx)) == 1  # association.py:914
 			sel = d_dx == torch.sum(d_dx, dim=0, dtype=torch.float64)  # association.py:915-916
 			big = torch.finfo(d_dx.dtype).max
 			lo = torch.where(sel, d_dx, big).amin(dim=1)
@@ -150,59 +158,67 @@ def _segment_sums(v, starts, counts):
 	return out
 
 
-def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out=False):
+def _sparse(eng, lists, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out=False):
 	"""single=1 for a design with entries >= 0 (csrc/nrm_single1.hip, second half): the cells every grouping shares (all of dx is 0)
 	are summed once per gene, each grouping adds its own few cells inside the sweep; no masked Gram contraction, no loop over chunks
-	of groupings, no transposed copy of the expression matrix (the stream kernel reads it once, where it lies).  The statistics of the
-	groupings themselves (M_i = C_S C_S^T, C_S x_S, |x_S|^2: association.py:350-364) are taken on the host from the same decomposition,
-	in a fixed order, WHILE the stream kernel runs."""
+	of groupings, no transposed copy of the expression matrix (the stream kernel reads it once, where it lies).  The cell selection
+	(association.py:914-918) comes from the design's entry lists by kernels of the library (nrm_single1_select); the statistics of the
+	groupings themselves (M_i = C_S C_S^T, C_S x_S, |x_S|^2: association.py:350-364) are finished on the host WHILE the stream kernel runs."""
 	torch = eng.torch
 	from .single4 import _Marks
 	mark = _Marks(eng, 'NRM_S1_TRACE', 'single=1')
-	mark('selection')
-	nz = torch.nonzero(d_dx)  # the design's entries, grouping by grouping, cells ascending
-	xi, k = nz[:, 0], nz[:, 1]
-	cnt = torch.bincount(k, minlength=n)
-	is_common = cnt == 0
-	alone = cnt[k] == 1  # entries that are the only one of their cell: that cell is selected for this grouping and no other (association.py:915-916)
-	which = torch.nonzero(alone).flatten()  # (one list of the entries kept: a mask as an index would be listed once per use)
-	owner, idx_e = xi[which], k[which]  # (still grouping by grouping: the positions of the stream kernel's output)
-	n_e = int(owner.numel())
-	code = torch.where(is_common, _lib.NRM_S1_COMMON, _lib.NRM_S1_SKIP).to(torch.int32)
-	code[idx_e] = torch.arange(n_e, dtype=torch.int32, device=eng.device)
-	xe_d = d_dx[owner, idx_e].to(torch.float64) if n_e else torch.zeros(1, dtype=torch.float64, device=eng.device)
-	counts_d = torch.bincount(owner, minlength=nx)
-	n_common = is_common.sum()
-	# > 1 distinct value among a grouping's selected cells (:917-918): 0 on the shared cells, if there are any, and its values on its own
-	inf = torch.full((nx, ), float('inf'), dtype=torch.float64, device=eng.device)
-	vlo = inf.clone().scatter_reduce_(0, owner, xe_d[:n_e], 'amin', include_self=True)
-	vhi = (-inf).scatter_reduce_(0, owner, xe_d[:n_e], 'amax', include_self=True)
-	shared = (n_common > 0).to(torch.float64)
-	vlo = torch.where(shared > 0, torch.minimum(vlo, torch.zeros_like(vlo)), vlo)
-	vhi = torch.where(shared > 0, torch.maximum(vhi, torch.zeros_like(vhi)), vhi)
-	small = torch.cat([(n_common + counts_d).to(torch.float64), (vhi > vlo).to(torch.float64)]).cpu().numpy()
-	ns = small[:nx].copy()
-	assert bool(small[nx:].all())
-	mark('cell order')
-	# what the host needs of the cell order (before the stream kernel is queued: a download behind it would wait for it)
+	mark('entry lists')
+	dev = eng.device
+	nnz = lists.nnz
 	d_c = eng.upload(c64) if nc else None
-	if nc:  # covariate Gram of the shared cells (element-wise and in a fixed order: no BLAS, on either side)
-		cm = d_c * is_common
-		mcc = (cm[:, None, :] * d_c[None, :, :]).sum(dim=2).cpu().numpy()
-	d_seg = torch.zeros(nx + 1, dtype=torch.int64, device=eng.device)
-	d_seg[1:] = torch.cumsum(counts_d, 0)
+	cnt = torch.empty(n, dtype=torch.int32, device=dev)
+	code = torch.empty(n, dtype=torch.int32, device=dev)
+	d_seg = torch.empty(nx + 1, dtype=torch.int64, device=dev)
+	idx_e = torch.empty(nnz, dtype=torch.int64, device=dev)
+	xe_d = torch.empty(nnz, dtype=torch.float64, device=dev)
+	d_ce = torch.empty((nnz, nc), dtype=torch.float64, device=dev) if nc else None
+	rowinfo = torch.empty((nx, 3), dtype=torch.float64, device=dev)
+	info = torch.empty(8, dtype=torch.int64, device=dev)
+	gb = int(eng.lib.nrm_single1_select_gram_blocks())
+	nb = (nc + 7) // 8
+	gpart = torch.empty((nb * (nb + 1) // 2, gb, 64), dtype=torch.float64, device=dev) if nc else None
+	ptr = lambda t: 0 if t is None else t.data_ptr()
+	_lib.check(eng.lib.nrm_single1_select(lists.row_ptr.data_ptr(), lists.cells.data_ptr(), ptr(lists.row_vals), nx, n, nnz, ptr(d_c), n, nc, cnt.data_ptr(),
+										  code.data_ptr(), d_seg.data_ptr(), idx_e.data_ptr(), xe_d.data_ptr(), ptr(d_ce), rowinfo.data_ptr(), ptr(gpart), info.data_ptr(),
+										  eng._stream()))
+	# what the host needs of the cell order (before the stream kernel is queued: a download behind it would wait for it)
+	h_info, h_rows = info.cpu().numpy(), rowinfo.cpu().numpy()
+	n_common, n_e = int(h_info[3]), int(h_info[4])
+	ns = n_common + h_rows[:, 0]
+	# > 1 distinct value among a grouping's selected cells (:917-918): 0 on the shared cells, if there are any, and its values on its own
+	vlo, vhi = h_rows[:, 1], h_rows[:, 2]
+	if n_common > 0:
+		vlo, vhi = np.minimum(vlo, 0.0), np.maximum(vhi, 0.0)
+	assert bool((vhi > vlo).all())
+	mark('cell order')
+	if nc:  # covariate Gram of the shared cells: the kernel's partial sums added up in a fixed order (no BLAS, on either side)
+		hp = gpart.cpu().numpy()
+		mcc = np.zeros((nb * 8, nb * 8))
+		q = 0
+		for bi in range(nb):
+			for bj in range(bi, nb):
+				blk = np.zeros(64)
+				for g in range(gb):
+					blk += hp[q, g]
+				mcc[bi * 8:bi * 8 + 8, bj * 8:bj * 8 + 8] = blk.reshape(8, 8)
+				mcc[bj * 8:bj * 8 + 8, bi * 8:bi * 8 + 8] = blk.reshape(8, 8).T
+				q += 1
+		mcc = np.ascontiguousarray(mcc[:nc, :nc])
 	on_device = nc <= 8  # the groupings' own sums by a wave each (k_s1_group_stats); more covariates: numpy segment sums on the host
 	if on_device:
 		npair = nc * (nc + 1) // 2
-		gs_d = torch.empty((nx, npair + nc + 1), dtype=torch.float64, device=eng.device)
-		_lib.check(eng.lib.nrm_single1_group_stats(d_seg.data_ptr(), idx_e.contiguous().data_ptr(), xe_d.data_ptr(), 0 if d_c is None else d_c.data_ptr(), n, nc, nx,
-												   gs_d.data_ptr(), eng._stream()))
+		gs_d = torch.empty((nx, npair + nc + 1), dtype=torch.float64, device=dev)
+		_lib.check(eng.lib.nrm_single1_group_stats(d_seg.data_ptr(), idx_e.data_ptr(), xe_d.data_ptr(), ptr(d_c), n, nc, nx, gs_d.data_ptr(), eng._stream()))
 		gs = gs_d.cpu().numpy()
-		d_ce = d_c[:, idx_e].t().contiguous() if nc else None
 	else:
-		counts = counts_d.cpu().numpy()
+		counts = h_rows[:, 0].astype(np.int64)
 		seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-		idx_h = idx_e.cpu().numpy()
+		idx_h = idx_e.cpu().numpy()[:n_e]
 		xe = xe_d.cpu().numpy()[:n_e]
 	# the device's share: it needs nothing of the host's statistics and runs while they are taken
 	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
@@ -234,7 +250,6 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, retur
 		ce = c64[:, idx_h]  # (nc, cells of the E_i in the order of the groupings)
 		mc = mcc[None] + np.moveaxis(_segment_sums(ce[:, None, :] * ce[None, :, :], starts, counts), -1, 0)
 		xc = _segment_sums(ce * xe, starts, counts).T  # (nx, nc)
-		d_ce = None
 	if nc:
 		mark('host sums')
 		mi, rk = small_pinv(mc)  # association.py:350-351
@@ -253,13 +268,11 @@ def _sparse(eng, d_dx, x_dtype, dy, c64, nx, ny, n, nc, dimreduce, lowmem, retur
 	dof = np.ascontiguousarray(dof, dtype=np.float64)
 	_lib.check(eng.lib.nrm_pvalue_plan_init_many(dof.ctypes.data, nx, info.ctypes.data + 16, pitch))
 	mark('p-value plans')
-	if not on_device:
-		d_ce = eng.upload(np.ascontiguousarray(ce.T))
 	p = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	stat = torch.empty((nx, ny), dtype=tdt, device=eng.device)
 	vary = torch.empty((nx, ny), dtype=tdt, device=eng.device)
-	alpha = None if lowmem else torch.zeros((nx, ny, nc), dtype=tdt, device=eng.device)
-	flags = torch.zeros(2, dtype=torch.int32, device=eng.device)
+	alpha = None if lowmem else eng.zeros((nx, ny, nc), tdt)
+	flags = eng.zeros((2, ), torch.int32)
 	d_info = eng.upload(info)
 	code_o = _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32
 	with _engine._Span(eng, 's1_cells'):

@@ -265,13 +265,20 @@ def _run_bench(extra_args, env_extra, timeout=900):
 					   timeout=timeout)
 	assert r.returncode == 0, r.stderr[-3000:]
 	lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-	assert len(lines) == 1, r.stdout[-2000:]
-	return json.loads(lines[0])
+	assert lines and r.stdout.rstrip().splitlines()[-1] == lines[-1], r.stdout[-2000:]  # the contract line is the LAST line
+	assert len(lines[-1]) < 4096, len(lines[-1])  # (the driver keeps the tail of stdout: round 4's 14 KB line lost its first extras there)
+	out = json.loads(lines[-1])
+	detail = {}
+	for ln in lines[:-1]:  # the full record of every workload, printed before it
+		d = json.loads(ln)
+		detail[d.pop('workload_detail')] = d
+	out['_detail'] = detail
+	return out
 
 
 def test_bench_self_launches_two_ranks_on_one_gpu():
 	"""`python bench.py --gpus 2` as a plain invocation starts its own ranks (here both on this GPU over gloo: functional
-	check of the launcher and the N>1 path; RCCL needs one GPU per rank) and prints exactly one JSON line."""
+	check of the launcher and the N>1 path; RCCL needs one GPU per rank); the contract line is the last line of stdout."""
 	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'coex_c2', '--genes', '1200', '--cells', '2000', '--no-extras'],
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
 	assert out['n_gpus'] == 2 and out['ranks_seen_by_collective'] == 2 and out['value'] > 0
@@ -285,30 +292,50 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 	assert out['n_gpus'] == 2 and out['value'] > 0 and 'in 2 cell chunks' in out['config']['exchange']
 	assert out['kernels_ms']['gram'] > 0 and out['kernels_ms']['exchange'] >= 0
 	# the N > 1 DEFAULT is the workload the 8-GPU target is quoted on: configs[4] (here at a reduced per-rank block so that two ranks
-	# share one GPU in seconds): fp64 rows, digit planes exchanged in cell chunks, exchange accounting in the line
+	# share one GPU in seconds): fp64 rows, digit planes exchanged in cell chunks, exchange accounting in the line -- and the SAME key,
+	# `scaling_series`, that the N = 1 line carries for this workload
 	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--c5-rows', '384', '--c5-cells', '40000', '--no-extras'],
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
 	assert out['n_gpus'] == 2 and out['ranks_seen_by_collective'] == 2 and 'BASELINE configs[4]' in out['config']['workload']
 	assert out['config']['genes'] == 768 and out['config']['cells'] == 40000 and out['dtype'].startswith('i8 digits')
 	assert 'cell chunks' in out['config']['exchange'] and out['config']['exchange_bytes_per_rank'] == 384 * 40000 * 6
 	assert out['kernels_ms']['exchange'] >= 0 and out['kernels_ms']['gram'] > 0 and out['guard']['uncertified_pairs'] == 0
+	ser = out['scaling_series']
+	assert ser['ranks'] == 2 and ser['value'] == out['value'] and ser['ms_per_step'] == out['ms_per_step'] and ser['workload'].startswith('coex_c5') and 'scaling_series' in out['config']
+	one = _run_bench(['--steps', '2', '--warmup', '1', '--c5-rows', '384', '--c5-cells', '40000', '--cpu-seconds', '0', '--e2e', '0', '--extras', 'coex_c5', '--extras-steps', '2'], {})
+	assert one['n_gpus'] == 1 and one['config']['genes'] == 5000 and one['scaling_series']['ranks'] == 1 and one['scaling_series']['workload'] == ser['workload']
+	assert one['scaling_series']['ms_per_step'] == one['_detail']['coex_c5']['ms_per_step'] and one['scaling_series']['tests_per_step'] == 384 * 383 // 2
 
 
 def test_bench_default_line_carries_the_other_configs():
-	"""The default N=1 line: configs[1] as `value` plus de_c3 / de_c4 / coex_c5 (the per-rank slice) and configs[4] whole on this one GPU
-	under extra_workloads, each with its roofline, kernel split and the guard's verdict."""
+	"""The default N=1 run: configs[1] as `value` on a contract line under 4 KB that is the LAST line of stdout, with one summary row per
+	extra workload (de_c3 / de_c4 / coex_c5 = the per-rank slice / configs[4] whole on this one GPU / ...) and the scaling series; the full
+	record of every workload -- roofline, kernel split, the guard's verdict -- on the lines before it."""
 	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
 	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
-	ex = out['extra_workloads']
-	assert set(ex) == {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'}, ex
+	ex = out['_detail']
+	names = {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'}
+	assert set(ex) == names | {'coex_c2'} and set(out['extra_workloads']) == names, (sorted(ex), sorted(out['extra_workloads']))
+	for w in names:  # the summary rows are the records' numbers
+		row, rec = out['extra_workloads'][w], ex[w]
+		assert abs(row['value'] / rec['value'] - 1) < 1e-3 and abs(row['ms'] - rec['ms_per_step']) < 1e-3 and abs(row['frac'] - rec['roofline']['frac']) < 1e-3, (w, row)
+	# (b) one workload at every N: the per-rank slice of configs[4], here from the coex_c5 extra
+	ser = out['scaling_series']
+	assert ser['ranks'] == 1 and ser['value'] == ex['coex_c5']['value'] and ser['ms_per_step'] == ex['coex_c5']['ms_per_step'] and ser['tests_per_step'] == 3750 * 3749 // 2
 	assert ex['de_c4_single1']['roofline']['kernel'] == 'k_s1_stream' and ex['de_c4_single1']['ms_per_step'] < 12
-	assert ex['coex_c2_f64']['roofline']['kernel'] == 'k_gram_f64' and ex['coex_c2_f64']['dtype'] == 'f64'
+	assert ex['coex_c2_f64']['roofline']['kernel'] == 'k_gram_f64' and ex['coex_c2_f64']['dtype'] == 'f64' and ex['coex_c2_f64']['roofline']['traffic'] is None
+	assert 'traffic_source' not in ex['coex_c2_f64']['roofline']
 	assert ex['de_c4_single4']['roofline']['kernel'] == 'k_de_sparse' and ex['de_c4_single4']['guard']['uncertified_pairs'] == 0 and not ex['de_c4_single4']['guard']['fp64_rerun']
 	assert ex['de_c4_single4']['ms_per_step'] < 4 * ex['de_c4']['ms_per_step']
 	assert out['guard']['uncertified_pairs'] == 0 and 0 < out['guard']['largest_relative_p_error_bound'] < out['guard']['tolerance']
 	assert ex['coex_c5_full_1gpu']['config']['tests_per_step'] == 30000 * 29999 // 2 and ex['coex_c5_full_1gpu']['guard']['uncertified_pairs'] == 0
 	# configs[3]'s design is gRNA incidence (1 % of the entries set): the sparse-design kernels, not K1 + K2 (tests/test_gpu_round4.py holds both to the oracle)
 	assert ex['de_c4']['roofline']['kernel'] == 'k_de_sparse' and ex['de_c4']['kernels_ms']['de_sparse'] < ex['de_c4']['ms_per_step'] < 8
+	# (a) its traffic is that of the kernels the step ran (or null) -- never the dense path's k_gram_i8
+	roof = ex['de_c4']['roofline']
+	assert roof['traffic'] is None or ('k_de_sparse' in roof['traffic_source'] and 'k_gram_i8' not in roof['traffic_source'] and roof['traffic'] < 4 * roof['algorithmic_bytes'])
+	# a cold call (a design tensor the engine has not seen: lists built inside the call) beside the resident step
+	assert ex['de_c4']['ms_per_step'] < ex['de_c4']['cold_ms'] < ex['de_c4']['ms_per_step'] + 1.0 and out['extra_workloads']['de_c4']['cold_ms'] == round(ex['de_c4']['cold_ms'], 3)
 	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'hbm' and ex['coex_c5']['roofline']['bound'] == 'mfma'
 	for k, v in ex.items():
 		assert 'error' not in v, (k, v)
