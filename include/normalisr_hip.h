@@ -337,6 +337,23 @@ int nrm_single4_sweep_guarded(const double* d_bt, const double* d_pt, int64_t ld
 							  int32_t* d_gene_hits /* (ny) zeroed by the caller, or NULL: 1 for every gene with a counted pair */, void* stream);
 
 /*
+ * The small steps around single=4's on-device inverse of M~ = X~ X~^T (normalisr_amd/single4.py: Newton-Schulz iteration X <- X (2 I - M X), its
+ * two products per step on nrm_gram_f64; replaces the per-grouping SVDs of association.py:527-528 for full-rank designs).  All matrices
+ * (nxp, nxp) fp64 row-major, nxp a multiple of 128 >= nx; every reduction in a fixed order.
+ *   nrm_spd_prepare: d_m (.., ldm) as a symmetric nrm_gram_f64 launch leaves it (entries i <= j valid) -> d_mp, the full symmetric matrix,
+ *       its padding rows carrying mean(diag) on the diagonal; d_scal[0] = ||M||_1, d_scal[1] = mean(diag); d_work: 2 nxp doubles.
+ *   nrm_spd_start: d_x = diag(1 / M_ii) (diagonal != 0) or I / ||M||_1.
+ *   nrm_spd_transpose_residual: d_tt = d_t^T, d_res[0] = ||I - d_t||_F; d_work: (nxp / 32)^2 doubles.
+ *   nrm_spd_update: d_x = 2 d_x - d_xt.
+ *   nrm_spd_finish: d_n = (d_x + d_x^T) / 2 inside nx x nx, 0 in the padding; d_small (3, nx) = diag(N), sum_j |N_ij| sqrt(d_ss[j]), sum_j |N_ij|.
+ */
+int nrm_spd_prepare(const double* d_m, int64_t ldm, int64_t nx, int64_t nxp, double* d_mp, double* d_scal, double* d_work, void* stream);
+int nrm_spd_start(const double* d_mp, int64_t nxp, int diagonal, const double* d_scal, double* d_x, void* stream);
+int nrm_spd_transpose_residual(const double* d_t, int64_t nxp, double* d_tt, double* d_res, double* d_work, void* stream);
+int nrm_spd_update(double* d_x, const double* d_xt, int64_t count, void* stream);
+int nrm_spd_finish(const double* d_x, int64_t nx, int64_t nxp, const double* d_ss, double* d_n, double* d_small, void* stream);
+
+/*
  * single=1 sweep (every grouping tested on its own subset of cells, association.py:263-390).
  *   d_g  (ny, ldg): Gram of the expression rows with the masked rows W_i = [1_Si C (nc rows); 1_Si x_i], i = 0..nx-1,
  *        column i*(nc+1)+c;  d_g2 (ny, ldg2): Gram of the squared expression rows with the masks 1_Si.
@@ -471,12 +488,13 @@ int nrm_design_stats(const int64_t* d_row_ptr, const int32_t* d_cells, const dou
  * The lists above built from the design matrix itself, by kernels of the library (csrc/nrm_design_lists.hip) -- the design side of
  * association.py:224-235 for a sparse design, and what association.py:914-918 selects cells from.  d_x (nx, ldx) the design matrix in HBM
  * (NRM_F32 / NRM_F64); nslots = nx rounded up to a multiple of 64; nch = ceil(n / nrm_de_sparse_chunk()) chunks of cells.
- *   nrm_design_count: ONE pass over d_x.  d_cnt (nch, nslots) int32 = entries (values != 0, NaN included) of design row `slot` in chunk c;
- *     d_info (int64[8], zeroed by the call): [2] = bits NRM_DESIGN_* describing the entries.
+ *   nrm_design_count: ONE pass over d_x.  d_cnt (nch, nslots) int32: low 16 bits = entries (values != 0, NaN included) of design row `slot` in
+ *     chunk c, above them bits NRM_DESIGN_* describing those entries; d_info (int64[8]) is zeroed by the call.
  *   nrm_design_plan: from the counts -- d_row_ptr (nx + 1) the CSR offsets, d_coff (nch, nslots) int32 the entries of a row before each chunk,
  *     d_slot2x (nslots) or NULL; with d_sig != NULL also the dealing d_sig / d_pos (nch, nslots: position -> slot and slot -> position, sorted
  *     by the entries of the chunk inside every block of 1024 slots, most first, ties in row order), the widths d_w (nch, nslots / 64) and
- *     offsets d_base of the ELL blocks as nrm_de_sparse reads them.  d_info[0] = entries in all, d_info[1] = entries of the ELL form, padding included.
+ *     offsets d_base of the ELL blocks as nrm_de_sparse reads them.  d_info[0] = entries in all, d_info[1] = entries of the ELL form, padding included,
+ *     d_info[2] = the NRM_DESIGN_* bits of all entries.
  *   nrm_design_fill: the second pass over d_x writes the entries (cells ascending inside a row; no atomics: the same lists run to run) into
  *     d_cells / d_row_vals (CSR; d_cells may be NULL) and d_ell / d_ellv (ELL, padding included; d_ell may be NULL); binary != 0: every entry
  *     is 1 (d_info[2] has no NRM_DESIGN_NOTONE) and the value arrays are not written.

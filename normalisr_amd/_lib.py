@@ -60,6 +60,11 @@ _SIGNATURES = {
 	'nrm_gram_i8_fix_dot': ([_vp, _i64, _vp, _vp, _i64, _i64, _i32, _i64, _vp], _i32),
 	'nrm_single4_sweep_guarded': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
 								  _vp, _vp, _dbl, _dbl, _i32, _dbl, _vp, _vp], _i32),
+	'nrm_spd_prepare': ([_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp], _i32),
+	'nrm_spd_start': ([_vp, _i64, _i32, _vp, _vp, _vp], _i32),
+	'nrm_spd_transpose_residual': ([_vp, _i64, _vp, _vp, _vp, _vp], _i32),
+	'nrm_spd_update': ([_vp, _vp, _i64, _vp], _i32),
+	'nrm_spd_finish': ([_vp, _i64, _i64, _vp, _vp, _vp, _vp], _i32),
 	'nrm_design_products_workspace_doubles': ([_i64, _i64], _i64),
 	'nrm_design_products': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp], _i32),
 	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp], _i32),

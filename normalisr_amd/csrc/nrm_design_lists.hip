@@ -42,9 +42,10 @@ __device__ __forceinline__ void dl_load(const T* __restrict__ row, int64_t k, in
 
 // ---- pass 1: entries per (chunk, design row) ------------------------------------------------------------------------------------------------
 // grid (ceil(nslots / 4), chunks), 256 threads: a wave per (row, chunk) -- 8 KB of the row, eight 16-byte loads per lane in flight.
+#define DL_FLAG_SHIFT 16
+#define DL_COUNT(v) ((v) & 0xffff)
 template <typename T, bool ALIGNED>
-__global__ void __launch_bounds__(256) k_dl_count(const T* __restrict__ X, int64_t ldx, int64_t nx, int64_t n, int64_t nslots, int32_t* __restrict__ cnt,
-												   int64_t* __restrict__ info) {
+__global__ void __launch_bounds__(256) k_dl_count(const T* __restrict__ X, int64_t ldx, int64_t nx, int64_t n, int64_t nslots, int32_t* __restrict__ cnt) {
 	constexpr int V = DlVec<T>::V, S = DlVec<T>::S;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int64_t slot = (int64_t)blockIdx.x * 4 + wave;
@@ -81,13 +82,9 @@ __global__ void __launch_bounds__(256) k_dl_count(const T* __restrict__ X, int64
 #pragma unroll
 	for (int b = 0; b < 5; b++)
 		if (__ballot((fl >> b) & 1)) wfl |= 1u << b;
-	if (lane == 0) {
-		cnt[(int64_t)c * nslots + slot] = mine;
-		// a wave looks at the word first and stays away unless it has a bit to add (25 000 atomics on one address would cost more than the pass)
-		unsigned* word = reinterpret_cast<unsigned*>(info + 2);
-		const unsigned cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if ((cur | wfl) != cur) atomicOr(word, wfl);
-	}
+	// the count (<= DS_CH = 2^11) and, above it, what the entries are like: 25 000 waves meeting at one word of flags -- even only to look
+	// at it -- took three times as long as the pass over the matrix (103 against 35 us); k_dl_rowsum ORs the bits of a row's chunks together
+	if (lane == 0) cnt[(int64_t)c * nslots + slot] = mine | (int32_t)(wfl << DL_FLAG_SHIFT);
 }
 
 // ---- the dealing of every chunk ---------------------------------------------------------------------------------------------------------------
@@ -100,7 +97,7 @@ __global__ void __launch_bounds__(DS_PASS) k_dl_plan(const int32_t* __restrict__
 	__shared__ int32_t keys[DS_PASS];
 	const int c = blockIdx.y, t = threadIdx.x;
 	const int64_t lo = (int64_t)blockIdx.x * DS_PASS, slot = lo + t;
-	const int my = slot < nslots ? cnt[(int64_t)c * nslots + slot] : -1;
+	const int my = slot < nslots ? DL_COUNT(cnt[(int64_t)c * nslots + slot]) : -1;
 	const int key = my < 0 ? -1 : (my << 10) | (DS_PASS - 1 - t);  // (entries <= DS_CH = 2^11: 21 bits)
 	keys[t] = key;
 	__syncthreads();
@@ -121,17 +118,26 @@ __global__ void __launch_bounds__(DS_PASS) k_dl_plan(const int32_t* __restrict__
 // entries of every design row before each chunk (coff[c][slot]: where the chunk's entries start inside the row's CSR segment), the rows' totals
 // (left at row_ptr[slot + 1] for the scan), slot -> design row.  A thread per slot.
 __global__ void __launch_bounds__(256) k_dl_rowsum(const int32_t* __restrict__ cnt, int64_t nx, int64_t nslots, int nch, int32_t* __restrict__ coff,
-													int64_t* __restrict__ row_ptr, int32_t* __restrict__ slot2x) {
+													int64_t* __restrict__ row_ptr, int32_t* __restrict__ slot2x, int64_t* __restrict__ info) {
 	const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (slot >= nslots) return;
 	int run = 0;
-	for (int c = 0; c < nch; c++) {
-		coff[(int64_t)c * nslots + slot] = run;
-		run += cnt[(int64_t)c * nslots + slot];
+	unsigned fl = 0;
+	if (slot < nslots) {
+		for (int c = 0; c < nch; c++) {
+			const int32_t v = cnt[(int64_t)c * nslots + slot];
+			coff[(int64_t)c * nslots + slot] = run;
+			run += DL_COUNT(v);
+			fl |= (unsigned)v >> DL_FLAG_SHIFT;
+		}
+		if (slot < nx) row_ptr[slot + 1] = run;
+		if (slot == 0) row_ptr[0] = 0;
+		if (slot2x) slot2x[slot] = slot < nx ? (int32_t)slot : -1;
 	}
-	if (slot < nx) row_ptr[slot + 1] = run;
-	if (slot == 0) row_ptr[0] = 0;
-	if (slot2x) slot2x[slot] = slot < nx ? (int32_t)slot : -1;
+	unsigned wfl = 0;
+#pragma unroll
+	for (int b = 0; b < 5; b++)
+		if (__ballot((fl >> b) & 1)) wfl |= 1u << b;
+	if ((threadIdx.x & 63) == 0 && wfl) atomicOr(reinterpret_cast<unsigned*>(info + 2), wfl);  // (a wave per 64 design rows: a handful of atomics)
 }
 
 // Prefix sums by ONE workgroup (a thread per contiguous range, the 1024 range sums scanned in LDS): block 0 turns the rows' totals at
@@ -265,14 +271,14 @@ extern "C" int nrm_design_count(const void* d_x, int x_dtype, int64_t nx, int64_
 	const dim3 grid((unsigned)((nslots + 3) / 4), (unsigned)nch);
 	if (x_dtype == NRM_F64) {
 		if (dl_aligned<double>(d_x, ldx, n))
-			hipLaunchKernelGGL((k_dl_count<double, true>), grid, dim3(256), 0, st, (const double*)d_x, ldx, nx, n, nslots, d_cnt, d_info);
+			hipLaunchKernelGGL((k_dl_count<double, true>), grid, dim3(256), 0, st, (const double*)d_x, ldx, nx, n, nslots, d_cnt);
 		else
-			hipLaunchKernelGGL((k_dl_count<double, false>), grid, dim3(256), 0, st, (const double*)d_x, ldx, nx, n, nslots, d_cnt, d_info);
+			hipLaunchKernelGGL((k_dl_count<double, false>), grid, dim3(256), 0, st, (const double*)d_x, ldx, nx, n, nslots, d_cnt);
 	} else {
 		if (dl_aligned<float>(d_x, ldx, n))
-			hipLaunchKernelGGL((k_dl_count<float, true>), grid, dim3(256), 0, st, (const float*)d_x, ldx, nx, n, nslots, d_cnt, d_info);
+			hipLaunchKernelGGL((k_dl_count<float, true>), grid, dim3(256), 0, st, (const float*)d_x, ldx, nx, n, nslots, d_cnt);
 		else
-			hipLaunchKernelGGL((k_dl_count<float, false>), grid, dim3(256), 0, st, (const float*)d_x, ldx, nx, n, nslots, d_cnt, d_info);
+			hipLaunchKernelGGL((k_dl_count<float, false>), grid, dim3(256), 0, st, (const float*)d_x, ldx, nx, n, nslots, d_cnt);
 	}
 	return nrm_check_launch("k_dl_count");
 }
@@ -286,7 +292,7 @@ extern "C" int nrm_design_plan(const int32_t* d_cnt, int64_t nx, int64_t n, int6
 	hipStream_t st = (hipStream_t)stream;
 	if (want_ell)
 		hipLaunchKernelGGL(k_dl_plan, dim3((unsigned)((nslots + DS_PASS - 1) / DS_PASS), (unsigned)nch), dim3(DS_PASS), 0, st, d_cnt, nslots, (int)ngroups, d_sig, d_pos, d_w);
-	hipLaunchKernelGGL(k_dl_rowsum, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, d_cnt, nx, nslots, (int)nch, d_coff, d_row_ptr, d_slot2x);
+	hipLaunchKernelGGL(k_dl_rowsum, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, d_cnt, nx, nslots, (int)nch, d_coff, d_row_ptr, d_slot2x, d_info);
 	hipLaunchKernelGGL(k_dl_scan, dim3(want_ell ? 2 : 1), dim3(1024), 0, st, d_row_ptr, nx, want_ell ? d_w : nullptr, nch * ngroups, d_base, d_info);
 	return nrm_check_launch("k_dl_plan");
 }

@@ -180,3 +180,217 @@ extern "C" int nrm_single4_sweep_guarded(const double* d_bt, const double* d_pt,
 	const S4Guard gd = {d_fix_y, d_kappa, d_yy, d_gene_hits, k, cstar, gstar, budget, dof};
 	return single4_sweep_impl(d_bt, d_pt, ldb, d_yy, d_dxx, nx, ny, m, n_cells, dof, return_dot, d_p, d_stat, d_vary, out_dtype, ldo, d_work, d_flags, gd, stream);
 }
+
+// ---- the small steps around the Newton-Schulz inverse of M~ (normalisr_amd/single4.py: _spd_inverse_device) ------------------------------------
+// X <- X (2 I - M X) runs its two 1024^3 products per step on the fp64 Gram kernel; what sits between them -- symmetrising the Gram
+// kernel's upper tiles, the start matrix, ||I - M X||_F, a transpose, 2 X - X T, the inverse's diagonal / kappa / 1-norm -- was a
+// dozen torch element-wise and reduction kernels per step (rounds 3-4: 144 + 120 + 48 ... launches in a configs[3] call).  Plain
+// tile kernels; every reduction in a fixed order (rows by one workgroup each, then one workgroup over the rows).
+namespace {
+
+// mp (nxp, nxp) = the symmetric matrix whose upper triangle (i <= j < nx) is in m (tiles on / above the diagonal of a symmetric K2
+// launch), zero outside nx x nx; tiles of 32 x 32, the mirror written from the transpose in LDS
+__global__ void __launch_bounds__(256) k_spd_sym(const double* __restrict__ m, int64_t ldm, int64_t nx, int64_t nxp, double* __restrict__ mp) {
+	__shared__ double tile[32][33];
+	const int bi = blockIdx.y, bj = blockIdx.x;
+	if (bj < bi) return;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+	for (int r = ty; r < 32; r += 8) {
+		const int64_t i = (int64_t)bi * 32 + r, j = (int64_t)bj * 32 + tx;
+		double v = 0.0;
+		if (i < nx && j < nx) v = i <= j ? m[i * ldm + j] : m[j * ldm + i];  // (inside a diagonal tile the lower half comes from the upper)
+		tile[r][tx] = v;
+		mp[i * nxp + j] = v;
+	}
+	__syncthreads();
+	if (bj > bi) {
+#pragma unroll
+		for (int r = ty; r < 32; r += 8) mp[((int64_t)bj * 32 + r) * nxp + (int64_t)bi * 32 + tx] = tile[tx][r];
+	}
+}
+
+// per row of a symmetric matrix: out0[i] = sum_j |a_ij| (= the column's: the 1-norm's candidates), out1[i] = sum_j |a_ij| wgt_j (or not), out2[i] = a_ii
+__global__ void __launch_bounds__(256) k_spd_rows(const double* __restrict__ a, int64_t ld, int64_t nx, const double* __restrict__ ss, double* __restrict__ out0,
+												  double* __restrict__ out1, double* __restrict__ out2) {
+	__shared__ double red[2][4];
+	const int64_t i = blockIdx.x;
+	double s0 = 0.0, s1 = 0.0;
+	for (int64_t j = threadIdx.x; j < nx; j += 256) {
+		const double v = fabs(a[i * ld + j]);
+		s0 += v;
+		if (ss) s1 = fma(v, sqrt(ss[j]), s1);
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		s0 += __shfl_down(s0, o, 64);
+		s1 += __shfl_down(s1, o, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		red[0][threadIdx.x >> 6] = s0;
+		red[1][threadIdx.x >> 6] = s1;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		out0[i] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+		if (out1) out1[i] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+		if (out2) out2[i] = a[i * ld + i];
+	}
+}
+
+// one workgroup: scal[0] = max_i rowsum[i] (||M||_1), scal[1] = mean of the diagonal; the padding block of mp (rows nx .. nxp) gets that
+// mean on its diagonal (a multiple of the identity inside the spectrum's range: it does not slow the iteration down)
+__global__ void __launch_bounds__(1024) k_spd_scale(const double* __restrict__ rowsum, const double* __restrict__ diag, int64_t nx, int64_t nxp, double* __restrict__ mp,
+													 double* __restrict__ scal) {
+	__shared__ double mx[1024], sm[1024];
+	const int t = threadIdx.x;
+	double a = 0.0, b = 0.0;
+	bool bad = false;
+	for (int64_t i = t; i < nx; i += 1024) {
+		bad |= !(rowsum[i] == rowsum[i]);
+		a = fmax(a, rowsum[i]);
+		b += diag[i];
+	}
+	mx[t] = bad ? NAN : a;
+	sm[t] = b;
+	__syncthreads();
+	for (int o = 512; o > 0; o >>= 1) {
+		if (t < o) {
+			mx[t] = (mx[t] != mx[t] || mx[t + o] != mx[t + o]) ? NAN : fmax(mx[t], mx[t + o]);
+			sm[t] += sm[t + o];
+		}
+		__syncthreads();
+	}
+	const double mean = sm[0] / (double)nx;
+	if (t == 0) {
+		scal[0] = mx[0];
+		scal[1] = mean;
+	}
+	for (int64_t i = nx + t; i < nxp; i += 1024) mp[i * nxp + i] = mean;
+}
+
+// the start of the iteration: x = diag(1 / mp_ii) (diagonal != 0) or I / scal[0]
+__global__ void __launch_bounds__(256) k_spd_start(const double* __restrict__ mp, int64_t nxp, int diagonal, const double* __restrict__ scal, double* __restrict__ x) {
+	const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (e >= nxp * nxp) return;
+	const int64_t i = e / nxp, j = e - i * nxp;
+	x[e] = i == j ? (diagonal ? 1.0 / mp[i * nxp + i] : 1.0 / scal[0]) : 0.0;
+}
+
+// tt = t^T (32 x 32 tiles through LDS) and, on the way, the squares of I - t row block by row block: part[tile] = sum over the tile
+__global__ void __launch_bounds__(256) k_spd_transpose_res(const double* __restrict__ t, int64_t nxp, double* __restrict__ tt, double* __restrict__ part) {
+	__shared__ double tile[32][33];
+	__shared__ double red[4];
+	const int bi = blockIdx.y, bj = blockIdx.x;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	double s = 0.0;
+#pragma unroll
+	for (int r = ty; r < 32; r += 8) {
+		const int64_t i = (int64_t)bi * 32 + r, j = (int64_t)bj * 32 + tx;
+		const double v = t[i * nxp + j];
+		tile[r][tx] = v;
+		const double d = (i == j ? 1.0 : 0.0) - v;
+		s = fma(d, d, s);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = ty; r < 32; r += 8) tt[((int64_t)bj * 32 + r) * nxp + (int64_t)bi * 32 + tx] = tile[tx][r];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) part[(int64_t)bi * gridDim.x + bj] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// one workgroup: res[0] = sqrt(sum of part[0 .. count)) in a fixed order
+__global__ void __launch_bounds__(1024) k_spd_res(const double* __restrict__ part, int64_t count, double* __restrict__ res) {
+	__shared__ double sm[1024];
+	const int t = threadIdx.x;
+	double b = 0.0;
+	for (int64_t i = t; i < count; i += 1024) b += part[i];
+	sm[t] = b;
+	__syncthreads();
+	for (int o = 512; o > 0; o >>= 1) {
+		if (t < o) sm[t] += sm[t + o];
+		__syncthreads();
+	}
+	if (t == 0) res[0] = sqrt(sm[0]);
+}
+
+// x = 2 x - xt
+__global__ void __launch_bounds__(256) k_spd_update(double* __restrict__ x, const double* __restrict__ xt, int64_t count) {
+	const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+	if (e + 1 < count) {
+		double2 a = *reinterpret_cast<const double2*>(x + e);
+		const double2 b = *reinterpret_cast<const double2*>(xt + e);
+		a.x = 2.0 * a.x - b.x;
+		a.y = 2.0 * a.y - b.y;
+		*reinterpret_cast<double2*>(x + e) = a;
+	} else if (e < count)
+		x[e] = 2.0 * x[e] - xt[e];
+}
+
+// out = (x + x^T) / 2 inside nx x nx, zero outside (out != x: the tiles of a pair are read by two workgroups)
+__global__ void __launch_bounds__(256) k_spd_finish(const double* __restrict__ x, int64_t nx, int64_t nxp, double* __restrict__ out) {
+	__shared__ double tile[32][33];
+	const int bi = blockIdx.y, bj = blockIdx.x;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+	for (int r = ty; r < 32; r += 8) tile[r][tx] = x[((int64_t)bj * 32 + r) * nxp + (int64_t)bi * 32 + tx];  // the mirror tile
+	__syncthreads();
+#pragma unroll
+	for (int r = ty; r < 32; r += 8) {
+		const int64_t i = (int64_t)bi * 32 + r, j = (int64_t)bj * 32 + tx;
+		out[i * nxp + j] = (i < nx && j < nx) ? 0.5 * (x[i * nxp + j] + tile[tx][r]) : 0.0;
+	}
+}
+
+}  // namespace
+
+// d_m (.., ldm): a symmetric positive definite nx x nx matrix as a symmetric K2 launch leaves it (entries i <= j valid).  d_mp (nxp, nxp), nxp a
+// multiple of 128 >= nx: the full symmetric matrix, padded with mean(diag) on the diagonal; d_scal[0] = ||M||_1, d_scal[1] = mean(diag) (NaN when
+// the matrix holds one); d_work: 2 nxp doubles.
+extern "C" int nrm_spd_prepare(const double* d_m, int64_t ldm, int64_t nx, int64_t nxp, double* d_mp, double* d_scal, double* d_work, void* stream) {
+	NRM_REQUIRE(d_m && d_mp && d_scal && d_work && nx > 0 && nxp >= nx && nxp % 32 == 0 && ldm >= nx, "nrm_spd_prepare: bad arguments");
+	hipStream_t st = (hipStream_t)stream;
+	const unsigned nt = (unsigned)(nxp / 32);
+	hipLaunchKernelGGL(k_spd_sym, dim3(nt, nt), dim3(256), 0, st, d_m, ldm, nx, nxp, d_mp);
+	hipLaunchKernelGGL(k_spd_rows, dim3((unsigned)nx), dim3(256), 0, st, d_mp, nxp, nx, nullptr, d_work, nullptr, d_work + nxp);
+	hipLaunchKernelGGL(k_spd_scale, dim3(1), dim3(1024), 0, st, d_work, d_work + nxp, nx, nxp, d_mp, d_scal);
+	return nrm_check_launch("nrm_spd_prepare");
+}
+
+// d_x (nxp, nxp) = the start of the Newton-Schulz iteration: diag(1 / M_ii) (diagonal != 0) or I / ||M||_1
+extern "C" int nrm_spd_start(const double* d_mp, int64_t nxp, int diagonal, const double* d_scal, double* d_x, void* stream) {
+	NRM_REQUIRE(d_mp && d_scal && d_x && nxp > 0, "nrm_spd_start: bad arguments");
+	hipLaunchKernelGGL(k_spd_start, dim3((unsigned)((nxp * nxp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_mp, nxp, diagonal, d_scal, d_x);
+	return nrm_check_launch("k_spd_start");
+}
+
+// d_tt = d_t^T and d_res[0] = ||I - d_t||_F for a (nxp, nxp) matrix; d_work: (nxp / 32)^2 doubles
+extern "C" int nrm_spd_transpose_residual(const double* d_t, int64_t nxp, double* d_tt, double* d_res, double* d_work, void* stream) {
+	NRM_REQUIRE(d_t && d_tt && d_res && d_work && nxp > 0 && nxp % 32 == 0, "nrm_spd_transpose_residual: bad arguments");
+	hipStream_t st = (hipStream_t)stream;
+	const unsigned nt = (unsigned)(nxp / 32);
+	hipLaunchKernelGGL(k_spd_transpose_res, dim3(nt, nt), dim3(256), 0, st, d_t, nxp, d_tt, d_work);
+	hipLaunchKernelGGL(k_spd_res, dim3(1), dim3(1024), 0, st, d_work, (int64_t)nt * nt, d_res);
+	return nrm_check_launch("nrm_spd_transpose_residual");
+}
+
+// d_x = 2 d_x - d_xt (count doubles, 16-byte aligned)
+extern "C" int nrm_spd_update(double* d_x, const double* d_xt, int64_t count, void* stream) {
+	NRM_REQUIRE(d_x && d_xt && count > 0, "nrm_spd_update: bad arguments");
+	hipLaunchKernelGGL(k_spd_update, dim3((unsigned)((count / 2 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, d_xt, count);
+	return nrm_check_launch("k_spd_update");
+}
+
+// d_n (nxp, nxp) = (d_x + d_x^T) / 2 inside nx x nx, zero in the padding; d_small (3, nx): the diagonal of d_n, kappa's numerator
+// sum_j |N_ij| sqrt(d_ss[j]) (S4Guard above) and the absolute row sums (their maximum is ||N||_1)
+extern "C" int nrm_spd_finish(const double* d_x, int64_t nx, int64_t nxp, const double* d_ss, double* d_n, double* d_small, void* stream) {
+	NRM_REQUIRE(d_x && d_n && d_small && d_ss && d_n != d_x && nx > 0 && nxp >= nx && nxp % 32 == 0, "nrm_spd_finish: bad arguments");
+	hipStream_t st = (hipStream_t)stream;
+	const unsigned nt = (unsigned)(nxp / 32);
+	hipLaunchKernelGGL(k_spd_finish, dim3(nt, nt), dim3(256), 0, st, d_x, nx, nxp, d_n);
+	hipLaunchKernelGGL(k_spd_rows, dim3((unsigned)nx), dim3(256), 0, st, d_n, nxp, nx, d_ss, d_small + 2 * nx, d_small + nx, d_small);
+	return nrm_check_launch("nrm_spd_finish");
+}

@@ -215,51 +215,51 @@ class _Marks:
 			logging.warning(self.label + ' phases (ms): ' + ', '.join('%s %.2f' % r for r in self.rows))
 
 
-def _spd_inverse_device(eng, m_d, nx):
+def _spd_inverse_device(eng, m_d, nx, ss):
 	"""Inverse of the symmetric positive definite nx x nx matrix in the upper tiles of m_d (a symmetric K2 product, padded to row
 	tiles) WITHOUT leaving the device: Newton-Schulz iteration X <- X (2 I - M X) from X = I / ||M||_1 on the fp64 matrix cores (two
 	1024^3 products per step; the iterates are polynomials in M, so every product is a K2 call A B^T).  Quadratic convergence once
 	||I - M X|| < 1: log2(cond) + ~6 steps -- 7 for the nearly orthogonal residual rows of a gRNA screen, against 25 - 90 ms for a
-	LAPACK inverse of a 1000 x 1000 matrix on the host.  Returns (the padded device inverse, zero in the padding; ||M||_1) or None when
-	the iteration has not converged in 60 steps (the caller falls back to the host)."""
+	LAPACK inverse of a 1000 x 1000 matrix on the host.  The steps between the products (symmetrising, the start, ||I - M X||_F, a
+	transpose, 2 X - X T, what the host needs of the result) are kernels of the library (csrc/nrm_single4.hip: nrm_spd_*).
+	ss: |x~_i|^2 of the design rows (for kappa).  Returns (the padded device inverse, zero in the padding; ||M||_1; small = the inverse's
+	diagonal, sum_j |N_ij| |x~_j|, sum_j |N_ij| as a (3, nx) numpy array) or None when the iteration has not converged in 60 steps (the
+	caller falls back to the host)."""
 	from .engine import Residualized
 	torch = eng.torch
 	nxp = m_d.shape[0]
+	lib, st = eng.lib, eng._stream()
 	with torch.cuda.device(eng.device):
-		m = torch.triu(m_d[:nx, :nx])
-		m = m + torch.triu(m, 1).T
-		scale = m.abs().sum(dim=0).max()  # ||M||_1 >= lambda_max
-		if not bool(torch.isfinite(scale)) or float(scale) <= 0:
+		mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=eng.device)
+		mp, t, tt, xt, x = mk(nxp, nxp), mk(nxp, nxp), mk(nxp, nxp), mk(nxp, nxp), mk(nxp, nxp)
+		scal, work, res = mk(2), mk(max(2 * nxp, (nxp // 32)**2)), mk(1)
+		_lib.check(lib.nrm_spd_prepare(m_d.data_ptr(), m_d.stride(0), nx, nxp, mp.data_ptr(), scal.data_ptr(), work.data_ptr(), st))
+		scale = float(scal.cpu().numpy()[0])  # ||M||_1 >= lambda_max
+		if not np.isfinite(scale) or scale <= 0:
 			return None
-		mp = torch.zeros((nxp, nxp), dtype=torch.float64, device=eng.device)
-		mp[:nx, :nx] = m
-		if nxp > nx:  # padding block: a multiple of the identity inside the spectrum's range (does not slow the iteration down)
-			mp[range(nx, nxp), range(nx, nxp)] = m.diagonal().mean()
-		t = torch.empty((nxp, nxp), dtype=torch.float64, device=eng.device)
-		xt = torch.empty_like(t)
-		eye = torch.eye(nxp, dtype=torch.float64, device=eng.device)
 		rm = Residualized(nxp, nxp, mp, None, None)
+		rx_, rtt = Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, tt, None, None)
 		# Two starts.  X = diag(1 / M_ii) first: the residual rows of a gRNA screen are nearly orthogonal, I - M X then has a spectral radius of
 		# ~0.3 and five steps suffice; it need not converge for every design (it does iff 2 diag(M) - M is positive definite), so the residual
 		# is looked at after two steps and, unless it is falling, the iteration starts over from X = I / ||M||_1, which always converges
 		# (log2(cond) + ~6 steps: 8 for the same matrices).  NRM_S4_START=norm: the second start only.
 		done = False
 		for start in (('diagonal', 'norm') if os.environ.get('NRM_S4_START', 'diagonal') != 'norm' else ('norm', )):
-			x = torch.zeros((nxp, nxp), dtype=torch.float64, device=eng.device)
-			x[range(nxp), range(nxp)] = (1.0 / mp.diagonal()) if start == 'diagonal' else (1.0 / scale)
+			_lib.check(lib.nrm_spd_start(mp.data_ptr(), nxp, 1 if start == 'diagonal' else 0, scal.data_ptr(), x.data_ptr(), st))
 			look_from = 2 if start == 'diagonal' else 4
 			diverged = False
 			for it in range(60):
-				eng.gram(rm, Residualized(nxp, nxp, x, None, None), False, dot=t)            # T = M X   (X symmetric)
-				res = float((eye - t).norm()) if it >= look_from else np.inf  # ||I - M X||_F of the X going into this step
-				if np.isnan(res) or (start == 'diagonal' and it == look_from and not res < 1.0):
+				eng.gram(rm, rx_, False, dot=t)  # T = M X   (X symmetric)
+				# X M X = X T.  K2 forms A B^T, and T^T = X M equals T only while X commutes with M -- true from the norm start (every iterate a
+				# polynomial in M), not from the diagonal one: the transpose is taken explicitly (with ||I - M X||_F of the X going into this step)
+				_lib.check(lib.nrm_spd_transpose_residual(t.data_ptr(), nxp, tt.data_ptr(), res.data_ptr(), work.data_ptr(), st))
+				r = float(res.cpu().numpy()[0]) if it >= look_from else np.inf
+				if np.isnan(r) or (start == 'diagonal' and it == look_from and not r < 1.0):
 					diverged = True
 					break
-				# X M X = X T.  K2 forms A B^T, and T^T = X M equals T only while X commutes with M -- true from the norm start (every iterate a
-				# polynomial in M), not from the diagonal one: the transpose is taken explicitly
-				eng.gram(Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, t.T.contiguous(), None, None), False, dot=xt)
-				x = x.mul(2.0).sub_(xt)
-				if res < 1e-7:  # the step just taken squares it: below the rounding floor
+				eng.gram(rx_, rtt, False, dot=xt)
+				_lib.check(lib.nrm_spd_update(x.data_ptr(), xt.data_ptr(), nxp * nxp, st))
+				if r < 1e-7:  # the step just taken squares it: below the rounding floor
 					done = True
 					break
 			if done:
@@ -268,11 +268,9 @@ def _spd_inverse_device(eng, m_d, nx):
 				return None
 		if not done:
 			return None
-		x = 0.5 * (x + x.T)
-		if nxp > nx:
-			x[nx:, :] = 0
-			x[:, nx:] = 0
-	return x, float(scale)
+		small = mk(3, nx)
+		_lib.check(lib.nrm_spd_finish(x.data_ptr(), nx, nxp, ss.data_ptr(), t.data_ptr(), small.data_ptr(), st))
+	return t, scale, small.cpu().numpy()
 
 
 def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, tol=1E-8,
@@ -456,7 +454,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 			mark('K1 design')
 			mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
 		# N~ = M~^-1 on the device (Newton-Schulz on the fp64 matrix cores); the host's LAPACK only if that does not converge
-		inv = _spd_inverse_device(eng, mt_d, nx) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
+		inv = _spd_inverse_device(eng, mt_d, nx, rx.ss) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
 		if inv is None:
 			mt = mt_d[:nx, :nx].cpu().numpy()
 			mt = np.triu(mt) + np.triu(mt, 1).T
@@ -465,12 +463,12 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 			n_pad = np.zeros((nxp, nxp))
 			n_pad[:nx, :nx] = ninv
 			d_n, norm_mt = eng.upload(n_pad), float(np.abs(mt).sum(axis=0).max())
+			na = np.abs(ninv)
+			small = np.stack([np.diag(ninv), (na * np.sqrt(rx.ss[:nx].cpu().numpy())[None, :]).sum(axis=1), na.sum(axis=0)])
 		else:
-			d_n, norm_mt = inv
-		# what the host needs of N~ -- its diagonal, kappa (see S4Guard in csrc/nrm_single4.hip) and ||N~||_1 -- is reduced on the device:
-		# three vectors travel instead of the 8 MB matrix
-		na = d_n[:nx, :nx].abs()
-		small = torch.stack([d_n.diagonal()[:nx], (na * rx.ss[:nx].sqrt()[None, :]).sum(dim=1), na.sum(dim=0)]).cpu().numpy()
+			# what the host needs of N~ -- its diagonal, kappa (see S4Guard in csrc/nrm_single4.hip) and ||N~||_1 -- was reduced on the device:
+			# three vectors travel instead of the 8 MB matrix
+			d_n, norm_mt, small = inv
 		d, norm_ninv = small[0].copy(), float(small[2].max())
 		mark('M~ and its inverse')
 		if not (np.isfinite(small).all() and (d > 0).all()):

@@ -202,7 +202,7 @@ def test_sparse_design_path_hands_design_rows_near_the_covariate_span_back(monke
 	dx = (rng.random((nx, n)) < 0.02).astype(np.float64)
 	dx[5] = batch * (1.0 + 1e-6 * rng.normal(size=n))
 	dy = rng.normal(size=(ny, n))
-	dy[3] += 2e5 * (dx[5] - batch)  # an effect carried by the part of the row the covariates do not explain
+	dy[3] += 3e6 * (dx[5] - batch)  # an effect carried by the part of the row the covariates do not explain
 	ref = oracle.association_tests(dx, dy, dc, return_dot=False)
 	assert ref[0][5].min() < 1e-6
 	monkeypatch.setenv('NRM_DE_SPARSE', 'force')
