@@ -468,10 +468,16 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
  */
 int64_t nrm_de_sparse_chunk(void);
 int64_t nrm_de_sparse_max_covariates(void);
-int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_common, int64_t nc, const double* d_dci,
+/*   d_ct != NULL (round 5): the rows' products with the covariates and their sums of squares are taken INSIDE the kernel, on the fp64 matrix
+ *   cores, from the chunk of rows it holds in LDS anyway -- ONE pass over the expression matrix -- and left in d_common ((nc + 1, ny), then
+ *   an output; nrm_single1_stream need not run).  d_c (nc, ldc) the covariates; const_idx: a covariate that is constant (the intercept, value
+ *   const_val) or -1 -- it needs no operand; at most nrm_de_sparse_fused_covariates() others; d_ct: nrm_de_sparse_ct_doubles() doubles of scratch. */
+int64_t nrm_de_sparse_fused_covariates(void);
+int64_t nrm_de_sparse_ct_doubles(int64_t n, int64_t nc, int64_t const_idx);
+int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, double* d_common, int64_t nc, const double* d_dci,
 				  const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, const int32_t* d_sig, int64_t ngroups,
 				  const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy,
-				  int32_t* d_flags, void* stream);
+				  int32_t* d_flags, const double* d_c, int64_t ldc, int64_t const_idx, double const_val, double* d_ct, void* stream);
 
 /*
  * The design rows' own statistics from their entries (association.py:224-230 for a sparse design row): d_row_ptr (nx + 1), d_cells (int32),

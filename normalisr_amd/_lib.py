@@ -78,7 +78,9 @@ _SIGNATURES = {
 	'nrm_single1_sweep': ([_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_de_sparse_chunk': ([], _i64),
 	'nrm_de_sparse_max_covariates': ([], _i64),
-	'nrm_de_sparse': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp], _i32),
+	'nrm_de_sparse_fused_covariates': ([], _i64),
+	'nrm_de_sparse_ct_doubles': ([_i64, _i64, _i64], _i64),
+	'nrm_de_sparse': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_design_count': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp], _i32),
 	'nrm_design_plan': ([_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
 	'nrm_design_fill': ([_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),

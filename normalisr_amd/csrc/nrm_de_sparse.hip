@@ -11,17 +11,37 @@
 // sums in registers) and gathers, for each, the records of the cells where that row is not zero -- one ds_read_b128 per entry serves R
 // pairs.  The entries come in ELL form per (chunk, 64 slots of a wave): entries 8 j .. 8 j + 7 of the 64 lanes side by side (one coalesced
 // 1 KB load gives every lane its next 8), lists padded to the longest of the 64 (a multiple of 8) with the offset of a record of zeros.
-// The next chunk's HBM loads are in flight (in registers) while the current one is gathered.  The products with the covariates y C^T and
-// |y|^2 come from nrm_single1.hip's stream kernel (sums only: a second pass over the rows at HBM rate, 0.6 ms at configs[3] size; taken
-// inside THIS kernel they cost more both ways it was tried: covariate values fetched between the barriers of a chunk, every wave in the same
-// phase: +1.1 ms; a dense phase after the gathers -- consecutive lanes on consecutive records and covariate values, two cells at a time to stay
-// inside the registers: +2.0 ms, each batch waiting for its loads at two waves per SIMD; the covariate values travelling with the rows, requested a
-// chunk ahead: +1.0 ms -- a workgroup of 4 rows re-reads the covariates once per 4 rows, 7.5 GB through L2 beside the 3 GB of rows, where the
-// stream kernel's 8 rows per workgroup and its own pass cost 0.64).
+// The next chunk's HBM loads are in flight (in registers) while the current one is gathered.
+//
+// Round 5: the products with the covariates a = y C^T and |y|^2 are taken INSIDE this kernel, on the fp64 matrix cores, from the chunk of
+// records already in LDS (NG >= 0) -- one pass over the expression rows instead of two (rounds 3-4 ran nrm_single1.hip's stream kernel first:
+// a second read of the matrix, 0.64 ms of the 2.6 ms step at configs[3] size; still the path for more than DS_FUSED_NC covariates).  Three
+// ways to take them on the vector ALU had failed in round 4 (covariate values fetched between the barriers of a chunk: +1.1 ms; a dense phase
+// after the gathers: +2.0 ms; values travelling with the rows: +1.0 ms -- 20 doubles per thread and chunk through the registers, 16 x 5 fp64
+// FMAs per thread).  v_mfma_f64_4x4x4_4b_f64 does four independent 4 x 4 x 4 products per instruction: block b = the cells = b mod 4 of a group
+// of 16, A = 4 covariates x 4 cells, B = 4 cells x the workgroup's 4 rows -- 256 multiply-adds, fully used, 16 cycles of a matrix pipe that is
+// otherwise idle here.  Its lane maps (tools/mfma444_probe.hip, measured on gfx950: A[b][i][k] at lane i + 4 b + 16 k, B[b][k][j] at lane
+// j + 4 b + 16 k, D[b][i][j] at lane j + 4 b + 16 i) make both operands LANE-LINEAR reads: lane l takes row l & 3 of cell l >> 2 of the group --
+// for B the float at byte 4 l of the group's 16 records (one conflict-free ds_read_b32), for A the double at index l of the group's block
+// of the covariates stored cell by cell in fours (d_ct: [group of 4 covariates][cell][4], written by k_ds_ct; one coalesced 512-byte load from
+// L2).  |y|^2 and the plain sum (a constant covariate: the intercept needs no operand at all) are two vector instructions per lane and cell
+// group on the same value.  A wave takes 16 of a chunk's 128 cell groups: 16 loads, 16 LDS reads, 16 conversions, 16 matrix instructions per
+// group of 4 covariates.  The fp64 matrix rate of this chip IS its fp64 vector rate -- the matrix instructions take their 16 cycles from the
+// units the gathers' conversions and additions run on: what they save is instruction issue and registers, not arithmetic time.
 #include "nrm_common.h"
 #include "nrm_design.h"  // DS_CH (cells per chunk), DS_T (threads per workgroup), DS_G (design rows per thread)
 
-#define DS_NCMAX 32  // (the sums over the covariates come from nrm_single1_stream: its limit)
+#define DS_NCMAX 32  // (beyond DS_FUSED_NC the sums over the covariates come from nrm_single1_stream: its limit)
+#ifndef DS_UB
+#define DS_UB 4  // cell groups per batch of covariate operands (see the matrix-core section of k_de_sparse)
+#endif
+#ifndef DS_MFMA_AFTER
+#define DS_MFMA_AFTER 0  // the matrix-core section after the gathers of a chunk (1) or before them (0)
+#endif
+#ifndef DS_NT
+#define DS_NT 1  // the expression rows loaded non-temporally when the covariate operands are read beside them (those then stay in L2: 2.00 -> 1.93 ms)
+#endif
+#define DS_FUSED_NC 8  // covariates besides a constant one whose products with the rows are taken inside k_de_sparse (two groups of 4)
 #define DS_WGS 6     // waves per SIMD the register budget is set for (68 registers; three workgroups of 512 threads per CU; 8 waves per SIMD spill and gain nothing)
 
 namespace {
@@ -37,12 +57,15 @@ struct DsVec<double> {
 	static constexpr int V = 2, R = 2;
 };
 
-template <typename T, bool ALIGNED, bool BINARY>
-__global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict__ Y, int64_t ldy, int64_t n, int64_t ny, const double* __restrict__ common, int nc,
+// NG >= 0: the rows' products with the covariates are taken here (NG groups of 4 covariates from ct, plus a constant one when cidx >= 0) and
+// written to `common` for later passes; NG = -1: they are read from `common` (nrm_single1_stream, or an earlier pass)
+template <typename T, bool ALIGNED, bool BINARY, int NG>
+__global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict__ Y, int64_t ldy, int64_t n, int64_t ny, double* __restrict__ common, int nc,
 															   const double* __restrict__ dci, const int16_t* __restrict__ ell, const double* __restrict__ ellv,
 															   const int64_t* __restrict__ ellbase, const int32_t* __restrict__ ellw, const int32_t* __restrict__ sig, int ngroups, int group0,
 															   const int32_t* __restrict__ slot2x, const double* __restrict__ bx, int64_t ldb,
-															   double* __restrict__ dot, int64_t ldd, int by_gene, double* __restrict__ ssy, double* __restrict__ coefy, int32_t* __restrict__ flags, int first) {
+															   double* __restrict__ dot, int64_t ldd, int by_gene, double* __restrict__ ssy, double* __restrict__ coefy, int32_t* __restrict__ flags, int first,
+															   const double* __restrict__ ct, int64_t ctstride, int cidx, double cval) {
 	constexpr int V = DsVec<T>::V, R = DsVec<T>::R;
 	constexpr int NJ = DS_CH / (DS_T * V);  // groups of V consecutive cells a thread stages per chunk
 	typedef T rec_t __attribute__((ext_vector_type(R)));
@@ -79,7 +102,7 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 				const int64_t kc = k < n ? k : 0;
 #pragma unroll
 				for (int r = 0; r < R; r++) {
-					const vec_t t = *reinterpret_cast<const vec_t*>(row[r] + kc);
+					const vec_t t = (DS_NT && NG >= 0) ? __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(row[r] + kc)) : *reinterpret_cast<const vec_t*>(row[r] + kc);
 #pragma unroll
 					for (int v = 0; v < V; v++) st[j][r][v] = t[v];
 				}
@@ -101,6 +124,51 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 		sl_cur[g] = p < nslots ? sig[p] - pos0 : -1;
 		sl_nxt[g] = -1;
 	}
+	// sums of this wave over its cell groups: da[g] = covariates 4 g .. 4 g + 3 against the rows on the matrix cores (every lane one entry of four
+	// 4 x 4 blocks: cells = b mod 4); dq = |y|^2 and dk = the plain sum (the constant covariate) of the lane's row (lane & 3) over the lane's cells
+	double da[NG > 0 ? NG : 1], dq = 0.0, dk = 0.0;
+#pragma unroll
+	for (int g = 0; g < (NG > 0 ? NG : 1); g++) da[g] = 0.0;
+	auto matrix_sums = [&](int c) {
+			// The wave's 16 cell groups in batches of DS_UB: the covariate operands of a batch are requested (from L2: every workgroup reads all of
+			// d_ct once), the rows' operands read from LDS meanwhile.  BEFORE the next chunk's rows are requested: those loads must stay in flight
+			// through the gathers, and the memory counter is in order -- a covariate load behind them could only be waited for together with them.
+			// (All 16 operands at once cost 32 registers: 80 + 108 bytes of scratch at the six waves per SIMD this kernel lives on.)
+			constexpr int U = DS_CH / 16 / (DS_T / 64);
+			// (one base per operand and constant offsets from it: with an address per cell group the compiler kept 16 of each across the chunk loop -- in scratch)
+			const double* ctw = ct + ((int64_t)c * DS_CH + wave * U * 16) * 4 + lane;
+			const T* lw = reinterpret_cast<const T*>(lds) + (sizeof(T) == 4 ? wave * U * 64 + lane : (wave * U * 16 + (lane >> 2)) * 2 + (lane & 1));
+#pragma unroll
+			for (int h = 0; h < U; h += DS_UB) {
+				__builtin_amdgcn_sched_barrier(0);  // (the batches one after the other: hoisted together their operands spill)
+				double cv[NG > 0 ? NG : 1][DS_UB];
+				if constexpr (NG > 0) {
+#pragma unroll
+					for (int g = 0; g < NG; g++)
+#pragma unroll
+						for (int u = 0; u < DS_UB; u++) cv[g][u] = ctw[(int64_t)g * ctstride + (h + u) * 64];
+				}
+#pragma unroll
+				for (int u = 0; u < DS_UB; u++) {
+					double yd;
+					if constexpr (sizeof(T) == 4)
+						yd = (double)lw[(h + u) * 64];  // row lane & 3 of cell 16 (wave U + h + u) + (lane >> 2)
+					else
+						yd = (lane & 2) ? 0.0 : (double)lw[(h + u) * 32];  // (two rows per workgroup)
+					// |y|^2 and the plain sum (the constant covariate) on the vector ALU: two fp64 operations per lane and cell group.  As matrix
+					// instructions (A = the rows themselves, of which only the diagonal is wanted; A = a constant row) they cost 16 cycles each of
+					// the SAME fp64 units the gathers' conversions and additions run on -- the fp64 matrix rate of this chip is its vector rate --:
+					// k_de_sparse 1.61 -> 2.00 ms with them, against 8 cycles for these two
+					dq = fma(yd, yd, dq);
+					dk += yd;
+					asm volatile("" : "+v"(dq), "+v"(dk));  // here, not later: left to the scheduler the two sums were taken after the section, all 16 converted values kept
+					                                        // until then -- and the next chunk's rows, just requested, waited for and spilled to make room
+#pragma unroll
+					for (int g = 0; g < NG; g++) da[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv[g][u], yd, da[g], 0, 0, 0);
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+	};
 	for (int c = 0; c < nchunks; c++) {
 		__syncthreads();  // the gathers of the previous chunk are done with LDS
 		if (c > 0) {
@@ -140,6 +208,7 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 			}
 		}
 		__syncthreads();
+		if constexpr (NG >= 0 && !DS_MFMA_AFTER) matrix_sums(c);
 		if (c + 1 < nchunks) {
 			request(c + 1);
 #pragma unroll
@@ -175,15 +244,63 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 				cur = nxt;
 			}
 		}
+		if constexpr (NG >= 0 && DS_MFMA_AFTER) matrix_sums(c);
 	}
-	// the rows' products with the covariates a = y C^T and |y|^2 were summed by the stream kernel of nrm_single1.hip (common[c * ny + y], row nc: |y|^2)
+	// the rows' products with the covariates a = y C^T and |y|^2: from the matrix cores above, or as the stream kernel of nrm_single1.hip / an earlier
+	// pass left them (common[c * ny + y], row nc: |y|^2)
 	__shared__ double as[R][DS_NCMAX];
+	__shared__ double yraw[R];
 	__syncthreads();
+	if constexpr (NG >= 0) {
+		// the four blocks of an instruction hold the cells = 0, 1, 2, 3 mod 4: added up across the lanes that differ in bits 2 and 3, then the
+		// eight waves in order (through LDS, which the gathers are done with): wsum[wave][which][4 i + j], which = groups, |y|^2, constant
+		double* wsum = reinterpret_cast<double*>(lds);
+		auto fold = [&](double v, int which) {
+			v += __shfl_xor(v, 4, 64);
+			v += __shfl_xor(v, 8, 64);
+			if ((lane & 12) == 0) wsum[(wave * (NG + 2) + which) * 16 + (lane >> 4) * 4 + (lane & 3)] = v;
+		};
+#pragma unroll
+		for (int g = 0; g < NG; g++) fold(da[g], g);
+		// |y|^2 and the plain sums: per lane over its cells; all lanes of a row (lane & 3) together, kept where a product with covariate 0 would sit
+		auto fold_rows = [&](double v, int which) {
+#pragma unroll
+			for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+			if (lane < 4) wsum[(wave * (NG + 2) + which) * 16 + lane] = v;
+		};
+		fold_rows(dq, NG);
+		fold_rows(dk, NG + 1);
+		__syncthreads();
+		if (tid < R) {
+			const int r = tid;
+			auto total = [&](int which, int i) {
+				double t = 0.0;
+				for (int w = 0; w < DS_T / 64; w++) t += wsum[(w * (NG + 2) + which) * 16 + i * 4 + r];
+				return t;
+			};
+			int m = 0;  // covariates other than the constant one, in their order: 4 per group
+			for (int c = 0; c < nc; c++) {
+				if (c == cidx)
+					as[r][c] = cval * total(NG + 1, 0);
+				else {
+					as[r][c] = total(m >> 2, m & 3);
+					m++;
+				}
+			}
+			yraw[r] = total(NG, 0);
+			if (y0 + r < ny) {  // for the kernel's later passes (more than DS_PASS design rows)
+				for (int c = 0; c < nc; c++) common[(int64_t)c * ny + y0 + r] = as[r][c];
+				common[(int64_t)nc * ny + y0 + r] = yraw[r];
+			}
+		}
+	} else if (tid < R && y0 + tid < ny) {
+		for (int c = 0; c < nc; c++) as[tid][c] = common[(int64_t)c * ny + y0 + tid];
+		yraw[tid] = common[(int64_t)nc * ny + y0 + tid];
+	}
 	if (tid < R && y0 + tid < ny) {
 		const int r = tid;
 		const int64_t y = y0 + r;
-		double yy = common[(int64_t)nc * ny + y];
-		for (int c = 0; c < nc; c++) as[r][c] = common[(int64_t)c * ny + y];
+		double yy = yraw[r];
 		if (first) {
 			// b_y = a (C C^T)^+ (association.py:227-229), |y~|^2 = |y|^2 - a . b_y
 			for (int c = 0; c < nc; c++) {
@@ -196,7 +313,7 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 			// |y~|^2 as a difference: a row whose residual is less than a hundredth of the row itself (|y~|^2 < 1e-4 |y|^2) has lost four of
 			// fp64's sixteen digits here, and its products with the design rows likewise -- counted like a pair the integer engine
 			// cannot certify (flags[2]): the caller redoes such a call on K1's two sweeps and the fp64 Gram kernel
-			if (flags && !(yy >= 1e-4 * common[(int64_t)nc * ny + y]) && common[(int64_t)nc * ny + y] > 0.0) atomicAdd(&flags[2], 1);
+			if (flags && !(yy >= 1e-4 * yraw[r]) && yraw[r] > 0.0) atomicAdd(&flags[2], 1);
 		}
 	}
 	__syncthreads();
@@ -216,21 +333,48 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 	}
 }
 
+// the covariates cell by cell in fours, as the A operand of v_mfma_f64_4x4x4_4b_f64 reads them: ct[g][cell][i] = C[map(4 g + i)][cell], map = the
+// covariates in their order without the constant one (cidx); zero for cells >= n (up to whole chunks) and for the last group's empty places
+__global__ void __launch_bounds__(256) k_ds_ct(const double* __restrict__ C, int64_t ldc, int nc, int cidx, int64_t n, int64_t ncells, int ng, double* __restrict__ ct) {
+	const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (group, cell, i)
+	if (e >= (int64_t)ng * ncells * 4) return;
+	const int i = (int)(e & 3);
+	const int64_t cell = (e >> 2) % ncells;
+	const int g = (int)((e >> 2) / ncells);
+	int m = g * 4 + i;  // the m-th covariate that is not the constant one
+	if (cidx >= 0 && m >= cidx) m++;
+	ct[e] = (m < nc && cell < n) ? C[(int64_t)m * ldc + cell] : 0.0;
+}
+
 template <typename T, bool BINARY>
-int ds_go(const void* d_y, int64_t ldy, int64_t n, int64_t ny, const double* d_common, int nc, const double* d_dci, const int16_t* d_ell, const double* d_ellv,
+int ds_go(const void* d_y, int64_t ldy, int64_t n, int64_t ny, double* d_common, int nc, const double* d_dci, const int16_t* d_ell, const double* d_ellv,
 		  const int64_t* d_base, const int32_t* d_w, const int32_t* d_sig, int ngroups, const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd,
-		  int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, hipStream_t st) {
+		  int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, const double* d_ct, int64_t ctstride, int ng, int cidx, double cval, hipStream_t st) {
 	constexpr int R = DsVec<T>::R;
 	const bool aligned = ((uintptr_t)d_y % 16 == 0) && (ldy * sizeof(T)) % 16 == 0 && n % DsVec<T>::V == 0;
 	const dim3 grid((unsigned)((ny + R - 1) / R));
-	for (int g0 = 0; g0 < ngroups; g0 += (DS_T / 64) * DS_G) {  // 1024 design rows per pass
-		if (aligned)
-			hipLaunchKernelGGL((k_de_sparse<T, true, BINARY>), grid, dim3(DS_T), 0, st, (const T*)d_y, ldy, n, ny, d_common, nc, d_dci, d_ell, d_ellv, d_base, d_w,
-							   d_sig, ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
-		else
-			hipLaunchKernelGGL((k_de_sparse<T, false, BINARY>), grid, dim3(DS_T), 0, st, (const T*)d_y, ldy, n, ny, d_common, nc, d_dci, d_ell, d_ellv, d_base, d_w,
-							   d_sig, ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0);
+#define DS_LAUNCH(AL, NGV)                                                                                                                                         \
+	hipLaunchKernelGGL((k_de_sparse<T, AL, BINARY, NGV>), grid, dim3(DS_T), 0, st, (const T*)d_y, ldy, n, ny, d_common, nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, \
+					   ngroups, g0, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, g0 == 0 ? 1 : 0, d_ct, ctstride, cidx, cval)
+	for (int g0 = 0; g0 < ngroups; g0 += (DS_T / 64) * DS_G) {  // 1024 design rows per pass; the first takes the sums with the covariates (ng >= 0)
+		const int ngv = g0 == 0 ? ng : -1;
+		if (aligned) {
+			switch (ngv) {
+				case 0: DS_LAUNCH(true, 0); break;
+				case 1: DS_LAUNCH(true, 1); break;
+				case 2: DS_LAUNCH(true, 2); break;
+				default: DS_LAUNCH(true, -1); break;
+			}
+		} else {
+			switch (ngv) {
+				case 0: DS_LAUNCH(false, 0); break;
+				case 1: DS_LAUNCH(false, 1); break;
+				case 2: DS_LAUNCH(false, 2); break;
+				default: DS_LAUNCH(false, -1); break;
+			}
+		}
 	}
+#undef DS_LAUNCH
 	return nrm_check_launch("k_de_sparse");
 }
 
@@ -238,20 +382,41 @@ int ds_go(const void* d_y, int64_t ldy, int64_t n, int64_t ny, const double* d_c
 
 extern "C" int64_t nrm_de_sparse_chunk(void) { return DS_CH; }
 extern "C" int64_t nrm_de_sparse_max_covariates(void) { return DS_NCMAX; }
+// covariates (besides a constant one) up to which nrm_de_sparse takes the rows' products with them itself (d_ct given)
+extern "C" int64_t nrm_de_sparse_fused_covariates(void) { return DS_FUSED_NC; }
+// doubles of the d_ct scratch of nrm_de_sparse for n cells and nc covariates of which one is constant (const_idx >= 0) or none
+extern "C" int64_t nrm_de_sparse_ct_doubles(int64_t n, int64_t nc, int64_t const_idx) {
+	const int64_t m = nc - (const_idx >= 0 ? 1 : 0), ng = (m + 3) / 4, ncells = (n + DS_CH - 1) / DS_CH * DS_CH;
+	return ng * ncells * 4 > 0 ? ng * ncells * 4 : 1;
+}
 
-extern "C" int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, const double* d_common, int64_t nc, const double* d_dci,
+extern "C" int nrm_de_sparse(const void* d_y, int y_dtype, int64_t ny, int64_t n, int64_t ldy, double* d_common, int64_t nc, const double* d_dci,
 							 const int16_t* d_ell, const double* d_ellv, const int64_t* d_base, const int32_t* d_w, const int32_t* d_sig, int64_t ngroups,
-							 const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags, void* stream) {
+							 const int32_t* d_slot2x, const double* d_bx, int64_t ldb, double* d_dot, int64_t ldd, int by_gene, double* d_ssy, double* d_coefy, int32_t* d_flags,
+							 const double* d_c, int64_t ldc, int64_t const_idx, double const_val, double* d_ct, void* stream) {
 	NRM_REQUIRE(ny > 0 && n > 0 && nc >= 0 && nc <= DS_NCMAX && ngroups > 0 && ngroups < (1 << 24), "nrm_de_sparse: bad sizes (at most %d covariates)", DS_NCMAX);
 	NRM_REQUIRE(y_dtype == NRM_F32 || y_dtype == NRM_F64, "nrm_de_sparse: bad dtype");
 	NRM_REQUIRE(ldy >= n && (nc == 0 || ldb >= nc) && (by_gene || ldd >= ny), "nrm_de_sparse: pitch too small");
 	NRM_REQUIRE(d_y && d_common && d_ell && d_base && d_w && d_sig && d_slot2x && d_dot && d_ssy && (nc == 0 || (d_dci && d_bx)), "nrm_de_sparse: null pointer");
 	hipStream_t st = (hipStream_t)stream;
-	if (y_dtype == NRM_F64)
-		return d_ellv ? ds_go<double, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
-					  : ds_go<double, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
-	return d_ellv ? ds_go<float, false>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st)
-				  : ds_go<float, true>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, d_flags, st);
+	// d_ct given: the rows' products with the covariates and their sums of squares are taken inside the kernel (and left in d_common)
+	int ng = -1, cidx = -1;
+	int64_t ctstride = 0;
+	if (d_ct) {
+		cidx = (const_idx >= 0 && const_idx < nc) ? (int)const_idx : -1;
+		const int64_t m = nc - (cidx >= 0 ? 1 : 0);
+		NRM_REQUIRE(m <= DS_FUSED_NC && (nc == 0 || (d_c && ldc >= n)), "nrm_de_sparse: at most %d covariates besides a constant one with d_ct (run nrm_single1_stream first otherwise)", DS_FUSED_NC);
+		ng = (int)((m + 3) / 4);
+		const int64_t ncells = (n + DS_CH - 1) / DS_CH * DS_CH;
+		ctstride = ncells * 4;
+		if (ng > 0)
+			hipLaunchKernelGGL(k_ds_ct, dim3((unsigned)((ng * ncells * 4 + 255) / 256)), dim3(256), 0, st, d_c, ldc, (int)nc, cidx, n, ncells, ng, d_ct);
+	}
+#define DS_GO(T, BIN) ds_go<T, BIN>(d_y, ldy, n, ny, d_common, (int)nc, d_dci, d_ell, d_ellv, d_base, d_w, d_sig, (int)ngroups, d_slot2x, d_bx, ldb, d_dot, ldd, by_gene, d_ssy, d_coefy, \
+									 d_flags, d_ct, ctstride, ng, cidx, const_val, st)
+	if (y_dtype == NRM_F64) return d_ellv ? DS_GO(double, false) : DS_GO(double, true);
+	return d_ellv ? DS_GO(float, false) : DS_GO(float, true);
+#undef DS_GO
 }
 
 // ---- the design rows' own statistics from their entries ---------------------------------------------------------------------------------

@@ -138,20 +138,29 @@ def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_
 	ncu = nc if active else 0  # (covariates of rank 0 -- all zero -- leave the rows as they are: association.py:899-903)
 	coefy = eng.zeros((ny, nc), torch.float64) if want_coef else None
 	ycode = _lib.NRM_F64 if d_y.dtype == torch.float64 else _lib.NRM_F32
-	# the rows' products with the covariates and their sums of squares: the stream kernel of single=1, every cell "common"
 	common = torch.empty((ncu + 1, ny), dtype=torch.float64, device=eng.device)
-	code = getattr(eng, '_all_common', None)
-	if code is None or code.numel() < n:
-		code = eng._all_common = torch.empty((n, ), dtype=torch.int32, device=eng.device)
-		_lib.check(eng.lib.nrm_fill_i32(code.data_ptr(), _lib.NRM_S1_COMMON, n, eng._stream()))
-	with _engine._Span(eng, 'row_sums'):
-		_lib.check(eng.lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), d_c.data_ptr() if ncu else 0, d_c.stride(0) if ncu else n, ncu, code.data_ptr(), n, ny,
-											  common.data_ptr(), common.data_ptr(), _round_up(ny, 8), eng._stream()))  # (no cell keeps its values: the last buffer is not written)
+	# The rows' products with the covariates and their sums of squares: inside the gather kernel, on the fp64 matrix cores, from the chunk of rows
+	# it holds in LDS anyway -- one pass over the expression matrix -- for up to 8 covariates besides a constant one (csrc/nrm_de_sparse.hip);
+	# beyond that (or NRM_DE_SPARSE_SUMS=stream) the stream kernel of single=1 takes them first, every cell "common": a second pass.
+	ci, cval = eng.constant_row(d_c) if ncu else (-1, 0.0)
+	fused = ncu - (1 if ci >= 0 else 0) <= int(eng.lib.nrm_de_sparse_fused_covariates()) and os.environ.get('NRM_DE_SPARSE_SUMS', 'inside') != 'stream'
+	ct = None
+	if fused:
+		ct = torch.empty((int(eng.lib.nrm_de_sparse_ct_doubles(n, ncu, ci)), ), dtype=torch.float64, device=eng.device)
+	else:
+		code = getattr(eng, '_all_common', None)
+		if code is None or code.numel() < n:
+			code = eng._all_common = torch.empty((n, ), dtype=torch.int32, device=eng.device)
+			_lib.check(eng.lib.nrm_fill_i32(code.data_ptr(), _lib.NRM_S1_COMMON, n, eng._stream()))
+		with _engine._Span(eng, 'row_sums'):
+			_lib.check(eng.lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), d_c.data_ptr() if ncu else 0, d_c.stride(0) if ncu else n, ncu, code.data_ptr(), n, ny,
+												  common.data_ptr(), common.data_ptr(), _round_up(ny, 8), eng._stream()))  # (no cell keeps its values: the last buffer is not written)
 	with _engine._Span(eng, 'de_sparse'):
 		_lib.check(eng.lib.nrm_de_sparse(d_y.data_ptr(), ycode, ny, n, d_y.stride(0), common.data_ptr(), ncu, d_dci.data_ptr() if ncu else 0, lists.ell.data_ptr(),
 										 0 if lists.vals is None else lists.vals.data_ptr(), lists.base.data_ptr(), lists.w.data_ptr(), lists.sig.data_ptr(), lists.ngroups,
 										 lists.slot2x.data_ptr(), bx.data_ptr() if ncu else 0, max(nc, 1), dot.data_ptr(), dot.stride(0), 1 if by_gene else 0, ssy.data_ptr(),
-										 coefy.data_ptr() if (coefy is not None and ncu) else 0, 0 if flags is None else flags.data_ptr(), eng._stream()))
+										 coefy.data_ptr() if (coefy is not None and ncu) else 0, 0 if flags is None else flags.data_ptr(),
+										 d_c.data_ptr() if ncu else 0, d_c.stride(0) if ncu else n, ci, float(cval), 0 if ct is None else ct.data_ptr(), eng._stream()))
 	return dot, ssy, coefy
 
 
