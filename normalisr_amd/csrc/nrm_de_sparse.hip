@@ -35,6 +35,9 @@
 #ifndef DS_UB
 #define DS_UB 4  // cell groups per batch of covariate operands (see the matrix-core section of k_de_sparse)
 #endif
+#ifndef DS_SNAKE
+#define DS_SNAKE 1
+#endif
 #ifndef DS_MFMA_AFTER
 #define DS_MFMA_AFTER 0  // the matrix-core section after the gathers of a chunk (1) or before them (0)
 #endif
@@ -117,10 +120,14 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 	request(0);
 	const int64_t nslots = (int64_t)ngroups * 64;
 	const int pos0 = group0 * 64;  // first position of this pass (positions pos0 .. pos0 + DS_G * DS_T - 1)
+	// The 16 groups of 64 positions of a pass are sorted by the length of their lists (the design rows are: nrm_design_plan); a wave takes two of
+	// them -- group `wave` and, counted from the other end, group 15 - wave: the longest with the shortest (DS_SNAKE; taken in order, wave 0 walked
+	// the two longest of each half and every chunk's barrier waited for it)
+	auto group_of = [&](int g) { return (DS_SNAKE && (g & 1)) ? (g + 1) * (DS_T / 64) - 1 - wave : g * (DS_T / 64) + wave; };
 	int sl_cur[DS_G], sl_nxt[DS_G];  // the design row (within the pass) this thread's position g gathers for in the current / next chunk, -1: none
 #pragma unroll
 	for (int g = 0; g < DS_G; g++) {
-		const int p = pos0 + g * DS_T + tid;
+		const int p = pos0 + group_of(g) * 64 + lane;
 		sl_cur[g] = p < nslots ? sig[p] - pos0 : -1;
 		sl_nxt[g] = -1;
 	}
@@ -213,15 +220,15 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 			request(c + 1);
 #pragma unroll
 			for (int g = 0; g < DS_G; g++) {
-				const int p = pos0 + g * DS_T + tid;
+				const int p = pos0 + group_of(g) * 64 + lane;
 				sl_nxt[g] = p < nslots ? sig[(int64_t)(c + 1) * nslots + p] - pos0 : -1;
 			}
 		}
 		// the design rows' cells of this chunk: 8 entries per lane and load (ix_t), the next 8 requested before these are gathered
 #pragma unroll
 		for (int g = 0; g < DS_G; g++) {
-			const int grp = group0 + g * (DS_T / 64) + wave;
-			if (grp >= ngroups) break;
+			const int grp = group0 + group_of(g);
+			if (grp >= ngroups) continue;
 			const int nb = ellw[(int64_t)c * ngroups + grp] >> 3;  // blocks of 8 entries (widths are multiples of 8)
 			if (nb == 0) continue;
 			const int64_t base = ellbase[(int64_t)c * ngroups + grp] + lane * 8;
@@ -320,8 +327,7 @@ __global__ void __launch_bounds__(DS_T, DS_WGS) k_de_sparse(const T* __restrict_
 	// y~ . x~ for this thread's design rows
 #pragma unroll
 	for (int g = 0; g < DS_G; g++) {
-		const int p = (group0 + g * (DS_T / 64)) * 64 + tid;
-		if ((group0 + g * (DS_T / 64) + wave) >= ngroups) break;
+		if (group0 + group_of(g) >= ngroups) continue;
 		const int x = sl_cur[g] >= 0 ? slot2x[pos0 + sl_cur[g]] : -1;  // (the design row this position gathered for in the last chunk)
 		if (x < 0) continue;
 #pragma unroll
