@@ -31,6 +31,7 @@ extern "C" {
 #define NRM_E_ARG -1      /* bad shape/argument  -> ValueError   (association.py:199-216)  */
 #define NRM_E_DEVICE -2   /* HIP runtime failure -> RuntimeError                           */
 #define NRM_E_NUMERIC -3  /* non-finite / out-of-range result -> AssertionError (association.py:248-259) */
+#define NRM_E_UNSUPPORTED -4  /* the call is outside what a whole-problem host entry covers (nrm_last_error says why): use another path -> NotImplementedError */
 
 /* Tile geometry the padded device buffers must honour (rows multiple of NRM_ROW_TILE, pitch and
  * cell count multiple of NRM_K_TILE). */
@@ -444,6 +445,30 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
 							   const double* h_dci, int rank, int dimreduce, int return_dot,
 							   void* h_p, void* h_stat, void* h_alpha, void* h_varx, void* h_vary,
 							   void* h_r, void* h_t, int out_dtype);
+
+/* (Round 5) nrm_association_tests_host takes the sparse-design path below by itself when dy is given and the design matrix qualifies -- at most
+ * 1/16 of its entries set, >= 32 design rows, >= 64 expression rows, >= 2048 cells, nx n >= 2^22, <= 32 covariates; NRM_DE_SPARSE=0 switches that
+ * off, =force takes it whatever the size -- and hands calls whose rows are too close to the span of the covariates back to its dense fp64 path.
+ *
+ * The other two CLI methods of `normalisr de` at the same seam (association_tests(..., single=1 | 4), association.py:911-980), numpy buffers in
+ * and out, no torch.  Outputs as the reference returns them: h_p, h_stat (gamma, or gamma * varx when return_dot), h_vary (nx, ny), h_varx (nx),
+ * h_alpha (nx, ny, nc) or NULL -- all of out_dtype.  NRM_E_UNSUPPORTED (nrm_last_error says why) for calls outside what the entry covers:
+ *   nrm_association_tests_single1_host (`-m single`, association.py:263-390,911-925): design entries >= 0 of which at most a quarter are set,
+ *     at most 32 covariates (the gRNA incidence of a screen; the package's masked-Gram path takes the rest);
+ *   nrm_association_tests_single4_host (`-m covariate`, association.py:421-576,926-980): the closed form for full-rank designs -- rank == nc
+ *     (h_dci, rank from the host's inv_rank of C C^T) and A A^T certified full rank at `tol` (association.py:77) from norms at hand; a sparse design
+ *     goes through the sparse-design kernels, any other through nrm_residualize + nrm_gram_f64.
+ * nrm_binnet_host (binnet.py:134-173): h_p (ng, ng) -> h_net (ng, ng) bytes 0 / 1, *total = selected entries (0: the reference raises).
+ */
+int nrm_association_tests_single1_host(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny, const void* h_dc, int c_dtype,
+									   int64_t nc, int64_t n_cells, int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
+									   void* h_vary, int out_dtype);
+int nrm_association_tests_single4_host(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny, const void* h_dc, int c_dtype,
+									   int64_t nc, int64_t n_cells, const double* h_dci, int rank, int dimreduce, int return_dot, double tol, void* h_p,
+									   void* h_stat, void* h_alpha, void* h_varx, void* h_vary, int out_dtype);
+int nrm_binnet_host(const void* h_p, int p_dtype, int64_t ng, double qcut, unsigned char* h_net, int64_t* total);
+/* eigenvalues (ascending) of a small symmetric matrix, n <= 32 (host only) */
+int nrm_small_eigvals(const double* m, int64_t n, double* w);
 
 /*
  * de with a SPARSE design matrix (a CRISPR screen's gRNA incidence), association.py:224-235 without the dense contraction: a residual is

@@ -10,7 +10,7 @@ NRM_F32, NRM_F64 = 0, 1
 NRM_TSV_I64, NRM_TSV_I32, NRM_TSV_U8 = 16, 17, 18  # integer dtypes of nrm_tsv_format
 NRM_S1_COMMON, NRM_S1_SKIP = -2, -1  # cell codes of nrm_single1_stream (include/normalisr_hip.h)
 DESIGN_NOTONE, DESIGN_NEG, DESIGN_GT1, DESIGN_HAS1, DESIGN_NAN = 1, 2, 4, 8, 16  # bits of nrm_design_count's d_info[2]
-NRM_E_ARG, NRM_E_DEVICE, NRM_E_NUMERIC = -1, -2, -3
+NRM_E_ARG, NRM_E_DEVICE, NRM_E_NUMERIC, NRM_E_UNSUPPORTED = -1, -2, -3, -4
 ROW_TILE, K_TILE, PCOEF, FIX_STRIDE = 128, 16, 20, 8
 
 _i64, _i32, _vp, _dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
@@ -104,6 +104,10 @@ _SIGNATURES = {
 	'nrm_normvar_apply': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp], _i32),
 	'nrm_normvar_apply_w2': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _vp], _i32),
 	'nrm_alpha': ([_vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp], _i32),
+	'nrm_association_tests_single1_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32], _i32),
+	'nrm_association_tests_single4_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _vp, _vp, _i32], _i32),
+	'nrm_binnet_host': ([_vp, _i32, _i64, _dbl, _vp, _vp], _i32),
+	'nrm_small_eigvals': ([_vp, _i64, _vp], _i32),
 	'nrm_association_tests_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32,
 									_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32], _i32),
 }
@@ -152,4 +156,6 @@ def check(rc):
 		raise ValueError(msg)
 	if rc == NRM_E_NUMERIC:
 		raise AssertionError(msg)
+	if rc == NRM_E_UNSUPPORTED:
+		raise NotImplementedError(msg)
 	raise RuntimeError(msg)

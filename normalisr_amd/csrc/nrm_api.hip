@@ -12,6 +12,7 @@
 #include <vector>
 #include "nrm_common.h"
 #include "nrm_host_logic.h"
+#include "nrm_host_entry.h"
 
 static thread_local char g_err[512] = "";
 
@@ -172,52 +173,14 @@ extern "C" int nrm_copy_rows(void* d_dst, int64_t dst_pitch, const void* d_src, 
 	return NRM_OK;
 }
 
+static NrmDevPool g_pool;
+static std::mutex g_host_entry;
+NrmDevPool& nrm_host_pool() { return g_pool; }
+std::mutex& nrm_host_entry_mutex() { return g_host_entry; }
 namespace {
-struct HipAlloc {
-	void* alloc(size_t bytes) {
-		void* p = nullptr;
-		if (hipMalloc(&p, bytes) != hipSuccess) {
-			(void)hipGetLastError();
-			return nullptr;
-		}
-		return p;
-	}
-	void free(void* p) { (void)hipFree(p); }
-};
-typedef DevPoolT<HipAlloc> DevPool;
-DevPool g_pool;
-std::mutex g_host_entry;  // one whole-problem call at a time per process (the pool and the default stream are shared)
-
-struct DevBuf {
-	void* p = nullptr;
-	~DevBuf() {
-		if (p) {
-			(void)hipDeviceSynchronize();
-			g_pool.give(p);
-		}
-	}
-	int alloc(size_t bytes) {
-		p = g_pool.take(bytes ? bytes : 16);
-		if (!p) {
-			nrm_set_error("hipMalloc of %zu bytes failed", bytes);
-			return NRM_E_DEVICE;
-		}
-		return NRM_OK;
-	}
-	template <typename T>
-	T* as() {
-		return reinterpret_cast<T*>(p);
-	}
-};
-inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-inline size_t esize(int dtype) { return dtype == NRM_F64 ? 8 : 4; }
+inline int64_t round_up(int64_t v, int64_t m) { return nrm_round_up(v, m); }
+inline size_t esize(int dtype) { return nrm_esize(dtype); }
 }  // namespace
-
-#define NRM_TRY(call)        \
-	do {                     \
-		int rc_ = (call);    \
-		if (rc_) return rc_; \
-	} while (0)
 
 namespace {
 // Page-lock of a caller-owned result array for the duration of one call; a range that cannot be locked (already
@@ -275,7 +238,7 @@ static double guard_tolerance() {
 static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
 										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
 										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
-										  void* h_vary, void* h_r, void* h_t, int out_dtype, int nslices, int64_t* guard_hits);
+										  void* h_vary, void* h_r, void* h_t, int out_dtype, int nslices, int64_t* guard_hits, bool allow_sparse);
 
 extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
 										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
@@ -297,11 +260,11 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 	g_guard_worst = 0.0;
 	int64_t hits = 0;
 	int rc = association_tests_host_impl(h_dx, x_dtype, nx, h_dy, y_dtype, ny, h_dc, c_dtype, nc, n, h_dci, rank, dimreduce, return_dot, h_p, h_stat,
-										 h_alpha, h_varx, h_vary, h_r, h_t, out_dtype, nslices, &hits);
-	if (rc == NRM_OK && hits > 0) {  // pairs the guard could not certify: the whole call again on the fp64 matrix cores
+										 h_alpha, h_varx, h_vary, h_r, h_t, out_dtype, nslices, &hits, true);
+	if (rc == NRM_OK && hits > 0) {  // pairs the guard could not certify (or rows the sparse-design kernels handed back): the whole call again on the fp64 matrix cores
 		g_guard_hits = hits;
 		rc = association_tests_host_impl(h_dx, x_dtype, nx, h_dy, y_dtype, ny, h_dc, c_dtype, nc, n, h_dci, rank, dimreduce, return_dot, h_p, h_stat,
-										 h_alpha, h_varx, h_vary, h_r, h_t, out_dtype, 0, nullptr);
+										 h_alpha, h_varx, h_vary, h_r, h_t, out_dtype, 0, nullptr, false);
 	}
 	return rc;
 }
@@ -309,7 +272,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny,
 										  const void* h_dc, int c_dtype, int64_t nc, int64_t n, const double* h_dci, int rank,
 										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
-										  void* h_vary, void* h_r, void* h_t, int out_dtype, int nslices, int64_t* guard_hits) {
+										  void* h_vary, void* h_r, void* h_t, int out_dtype, int nslices, int64_t* guard_hits, bool allow_sparse) {
 	const bool samexy = (h_dy == nullptr);
 	if (samexy) {
 		ny = nx;
@@ -371,6 +334,27 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 	const double guard_tol = guard_tolerance();
 	NRM_TRY(dx.alloc((size_t)nx * n * esize(x_dtype)));
 	NRM_TRY_RC(nrm_upload(h_dx, dx.p, (int64_t)nx * n * esize(x_dtype), 0, (void*)st));  // (from half a GB up: host threads fill page-locked blocks beside the DMA, nrm_upload.hip)
+	// A design matrix with few entries (a CRISPR screen's gRNA incidence): the sparse-design kernels -- the expression rows read once, raw, the
+	// contraction replaced by gathers at the design's entries (nrm_host_entries.hip; what normalisr_amd.engine does for the Python host).
+	// Same size rule as there; NRM_DE_SPARSE=0 switches it off, =force takes it whatever the size.
+	bool dy_up = false;
+	if (allow_sparse && !samexy && nc <= nrm_de_sparse_max_covariates()) {
+		const char* mode = getenv("NRM_DE_SPARSE");
+		const bool off = mode && !strcmp(mode, "0"), force = mode && !strcmp(mode, "force");
+		if (!off && (force || (nx >= 32 && ny >= 64 && n >= 2048 && nx * n >= (1ll << 22)))) {
+			NRM_TRY(dy.alloc((size_t)ny * n * esize(y_dtype)));
+			NRM_TRY_RC(nrm_upload(h_dy, dy.p, (int64_t)ny * n * esize(y_dtype), 0, (void*)st));
+			dy_up = true;
+			int taken = 0;
+			int64_t back = 0;
+			NRM_TRY(nrm_host_de_sparse(dx.p, x_dtype, nx, dy.p, y_dtype, ny, dc.as<double>(), c64.data(), nc, n, dci.as<double>(), rank, dof, (return_dot ? 0 : 1), h_p, h_stat,
+									   want_alpha ? h_alpha : nullptr, h_varx, h_vary, h_r, h_t, out_dtype, &taken, &back));
+			if (taken) {
+				if (back > 0 && guard_hits) *guard_hits = back;
+				return NRM_OK;
+			}
+		}
+	}
 	NRM_TRY(ssx.alloc((size_t)mp * 8));
 	if (want_alpha) NRM_TRY(bx.alloc((size_t)nx * nc * 8));
 	if (want_alpha) NRM_HIP(hipMemsetAsync(bx.p, 0, (size_t)nx * nc * 8, st));
@@ -387,8 +371,10 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 								ssx.as<double>(), want_alpha ? bx.as<double>() : nullptr, st));
 	}
 	if (!samexy) {
-		NRM_TRY(dy.alloc((size_t)ny * n * esize(y_dtype)));
-		NRM_TRY_RC(nrm_upload(h_dy, dy.p, (int64_t)ny * n * esize(y_dtype), 0, (void*)st));
+		if (!dy_up) {
+			NRM_TRY(dy.alloc((size_t)ny * n * esize(y_dtype)));
+			NRM_TRY_RC(nrm_upload(h_dy, dy.p, (int64_t)ny * n * esize(y_dtype), 0, (void*)st));
+		}
 		NRM_TRY(ssy.alloc((size_t)np_ * 8));
 		if (want_alpha) NRM_TRY(by.alloc((size_t)ny * nc * 8));
 		if (want_alpha) NRM_HIP(hipMemsetAsync(by.p, 0, (size_t)ny * nc * 8, st));

@@ -5,6 +5,7 @@
 // handful of sweeps and delivers every eigenvalue to full relative accuracy; the stack is dealt to host threads.  The rule is the
 // reference's (association.py:77-80): singular values (= |eigenvalues| of a symmetric matrix) below tol x the largest count as zero, the
 // rank is the number kept, M^+ = V_kept diag(1 / s_kept) V_kept^T.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -147,5 +148,17 @@ extern "C" int nrm_host_minmax(const void* p, int dtype, int64_t count, int thre
 		out[1] = part[3 * id + 1] > out[1] ? part[3 * id + 1] : out[1];
 		out[2] += part[3 * id + 2];
 	}
+	return NRM_OK;
+}
+
+// eigenvalues (ascending) of one small symmetric matrix (n <= 32): the covariate block of single=4's rank certificate (nrm_host_entries.hip)
+extern "C" int nrm_small_eigvals(const double* m, int64_t n, double* w) {
+	NRM_REQUIRE(m && w && n > 0 && n <= SP_NMAX, "nrm_small_eigvals: bad arguments (matrices up to %d x %d)", SP_NMAX, SP_NMAX);
+	double a[SP_NMAX * SP_NMAX], v[SP_NMAX * SP_NMAX];
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) a[i * n + j] = 0.5 * (m[i * n + j] + m[j * n + i]);
+	jacobi(a, v, w, (int)n);
+	for (int i = 1; i < n; i++)  // insertion sort: n <= 32
+		for (int j = i; j > 0 && w[j] < w[j - 1]; j--) std::swap(w[j], w[j - 1]);
 	return NRM_OK;
 }
