@@ -20,7 +20,7 @@ fp64; at N=8 that is the full 30k x 30k problem, residual blocks exchanged by al
 CRISPR screen of configs[3] as the reference's example runs it besides the naive test (`de -m covariate` / `-m single`,
 examples/GSE120861/code/cmd_highmoi.sh:19-22), coex_c2_f64 = configs[1] on the fp64 matrix cores (NRM_GRAM=f64: the dtype the
 north star names literally), binnet_c5 = binnet on a 30 000 x 30 000 fp64 P-value matrix (the consumer of configs[4]'s output), normvar_c2 = norm.normvar on a
-configs[1]-sized matrix, numpy in -> numpy out (the step in front of the hot path).
+configs[1]-sized matrix resident in HBM (the step in front of the hot path), chain_c2 = normvar -> coex -> binnet as one resident chain.
 `--workload X` makes X the headline instead; `--no-extras` skips them.
 
 Launch: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1) when it is
@@ -642,28 +642,87 @@ def bench_binnet(rk, steps, warmup):
 
 def bench_normvar(rk, steps, warmup):
 	"""norm.normvar (norm.py:166-289) on a configs[1]-sized matrix, the step in front of the hot path: 5000 genes x 10 000 cells fp32,
-	5 covariates, numpy in -> numpy out (the function has no resident form: its results are a new expression matrix and new covariates
-	for the next command)."""
+	5 covariates, the matrix resident in HBM and the result left there (device_out=True: what coex / de take next) -- per-gene moments in one
+	pass, a thread per gene solves its small OLS, one pass writes the result (csrc/nrm_normvar.hip).  The numpy -> numpy call (0.2 GB up,
+	0.4 GB down over PCIe) is timed beside it."""
 	torch = rk.torch
 	import normalisr_amd.normalisr as norm
+	from normalisr_amd.engine import get_engine
+	eng = get_engine(rk.device.index)
 	ng, n, nc = 5000, 10000, 5
 	rng = np.random.default_rng(1)
 	dt = rng.standard_normal((ng, n), dtype=np.float32) - 9
 	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
 	w, wt = np.exp(0.25 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
+	d_dt = torch.from_numpy(dt).to(rk.device)
 
 	class Plan:
 		def step(self, timed=False):
-			self.out = norm.normvar(dt, dc, w, wt)
+			self.out = None
+			self.out = norm.normvar(d_dt, dc, w, wt, device_out=True)
 	plan = Plan()
 	plan.step()
 	elapsed = timed_steps(rk, plan, steps, warmup, False)
 	ms = 1e3 * elapsed / steps
-	byts = float(ng) * n * (4 + 8)  # the fp32 matrix in, the fp64 matrix out: over PCIe here, and that is what bounds the call
-	return dict(metric='normvar values/sec (numpy in -> numpy out)', value=float(ng) * n * steps / elapsed, unit='values/s', steps=steps, warmup=warmup, ms_per_step=ms,
-				scaling='single GPU', dtype='f64', config=dict(workload='norm.normvar {} genes x {} cells fp32, {} covariates, numpy -> numpy'.format(ng, n, nc)),
-				roofline=dict(bound='hbm', kernel='whole call (PCIe-inclusive: 0.2 GB up, 0.4 GB down into pageable memory; two K2 launches, 5000 host SVDs, two element-wise passes)',
-							  achieved=byts / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=byts, traffic=None, kernel_ms=ms))
+	eng.trace = []
+	plan.step()
+	torch.cuda.synchronize()
+	split = {}
+	for name, e0, e1 in eng.trace:
+		split[name] = round(split.get(name, 0.0) + e0.elapsed_time(e1), 4)
+	eng.trace = None
+	t0 = time.perf_counter()
+	norm.normvar(dt, dc, w, wt)
+	host_ms = 1e3 * (time.perf_counter() - t0)
+	byts = float(ng) * n * (4 + 8)  # algorithmic: the fp32 matrix read once, the fp64 result written once
+	kms = sum(split.values()) or ms
+	return dict(metric='normvar values/sec (resident)', value=float(ng) * n * steps / elapsed, unit='values/s', steps=steps, warmup=warmup, ms_per_step=ms,
+				scaling='single GPU', dtype='f64', config=dict(workload='norm.normvar {} genes x {} cells fp32, {} covariates, matrix resident in HBM, result left there'.format(ng, n, nc)),
+				kernels_ms=split, numpy_in_out_ms=host_ms,
+				roofline=dict(bound='hbm', kernel='k_nv_moments + k_nv_solve + k_nv_apply', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+							  algorithmic_bytes=byts, traffic=None, kernel_ms=kms, step_ms=ms, pmc_kernels=['k_nv_moments', 'k_nv_apply'],
+							  note='the matrix is read twice (moments, then the result); a step also uploads the covariates and weights (0.5 MB) and reads one word of flags back'))
+
+
+def bench_chain(rk, steps, warmup):
+	"""The reference's pipeline normvar -> coex -> binnet (examples/GSE123139/code/cmd_coex.sh:38-46; norm.py:166-289 feeds coex.py:46-48 feeds
+	binnet.py:134-173) at configs[1] size as ONE resident chain: the expression matrix, the normalised matrix, the P-values and the network stay in
+	HBM between the three steps (the reference passes them through files)."""
+	torch = rk.torch
+	import normalisr_amd.normalisr as norm
+	from normalisr_amd.binnet import binnet
+	from normalisr_amd.engine import get_engine
+	eng = get_engine(rk.device.index)
+	ng, n = 5000, 10000
+	d_dt, dc = synth_c2(ng, n, 2, rk.device, torch)
+	d_dt -= 9
+	dc = dc.cpu().numpy().astype(np.float64)
+	rng = np.random.default_rng(1)
+	w, wt = np.exp(0.25 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
+
+	class Plan:
+		def step(self, timed=False):
+			self.net = None
+			dtn, dcn = norm.normvar(d_dt, dc, w, wt, device_out=True)
+			p, dot, var = norm.coex(dtn, dcn, device_out=True)
+			self.net = binnet(p, 0.05)
+	plan = Plan()
+	plan.step()
+	elapsed = timed_steps(rk, plan, steps, warmup, False)
+	ms = 1e3 * elapsed / steps
+	eng.trace = []
+	plan.step()
+	torch.cuda.synchronize()
+	split = {}
+	for name, e0, e1 in eng.trace:
+		split[name] = round(split.get(name, 0.0) + e0.elapsed_time(e1), 4)
+	eng.trace = None
+	tests = ng * (ng - 1) // 2
+	roof = gram_roofline(n, 2.0 * n * (tests + ng), split.get('gram', ms), 5120, n)
+	roof['step_ms'] = ms
+	return dict(metric='association tests/sec (normvar -> coex -> binnet, resident)', value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=ms,
+				scaling='single GPU', dtype=ARITH(n), config=dict(workload='norm.normvar -> norm.coex -> binnet, {} genes x {} cells fp32, 3 covariates, nothing leaves HBM between the steps'.format(ng, n),
+																 edges_kept=int(plan.net.sum())), kernels_ms=split, roofline=roof)
 
 
 def bench_c5_full(rk):
@@ -747,7 +806,7 @@ def main():
 	ap.add_argument('--cells', type=int, default=10000)
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
 	ap.add_argument('--cpu-worker', nargs=6, default=None, help=argparse.SUPPRESS)
-	ap.add_argument('--workload', default=None, choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'binnet_c5', 'normvar_c2'],
+	ap.add_argument('--workload', default=None, choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'chain_c2'],
 					help='headline workload.  Default: coex_c2 = BASELINE configs[1] at N=1; coex_c5 = configs[4] (3750 gene rows per rank x 500k cells) at N>1, '
 					'the configuration the 8-GPU target is quoted on.  de_c3 / de_c4 = configs[2] / [3]')
 	ap.add_argument('--c5-rows', type=int, default=C5_ROWS_PER_RANK, help='gene rows per rank of the coex_c5 workload (smaller: functional runs)')
@@ -832,7 +891,11 @@ def main():
 				pmc_traffic(which + ('_dense' if out['roofline']['kernel'].startswith('k_gram') else ''), out['roofline'], kernels=kern)
 			return out
 		if which == 'normvar_c2':
-			return bench_normvar(rk, steps, warmup)
+			out = bench_normvar(rk, steps, warmup)
+			pmc_traffic(which, out['roofline'], kernels=out['roofline'].pop('pmc_kernels', None))
+			return out
+		if which == 'chain_c2':
+			return bench_chain(rk, steps, warmup)
 		if which == 'binnet_c5':
 			out = bench_binnet(rk, steps, warmup)
 			if out is not None:
@@ -928,7 +991,7 @@ def main():
 		dog.daemon = True
 		dog.start()
 		names = [w for w in ('coex_c5', 'coex_c2', 'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64') if w != args.workload and not (w == 'coex_c2' and world == 1)] + (
-			['binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
+			['binnet_c5', 'normvar_c2', 'chain_c2', 'coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
 		if world > 1:
 			names = [w for w in names if w != 'coex_c2_f64']
 		if args.extras:

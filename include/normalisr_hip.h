@@ -416,7 +416,15 @@ int nrm_normvar_weights(const void* d_y, int y_dtype, int64_t rows, int64_t n, i
 						double* d_u, double* d_v, int64_t ldo, int64_t rows_pad, double* d_s1, double* d_s2, void* stream);
 int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_b, const double* d_scale, void* d_out, int out_dtype,
-					  int64_t ldo, void* stream);
+					  int64_t ldo, int32_t* d_flags /* int32[4] or NULL: [1] += waves that wrote a non-finite value (norm.py:286) */, void* stream);
+/* Round 5: b_g, scale_g and the integer rank of every gene WITHOUT leaving the device, for 1 .. nrm_normvar_device_covariates() covariates: one pass
+ * over d_y sums the per-gene moments (M_g = sum_k e_gk^2 C_k C_k^T, a_g = sum_k e_gk^2 y_gk C_k, sum y e, sum (y e)^2) in registers -- no U, V, no Gram
+ * launches --, a thread per gene takes M_g^+ by the rank rule of inv_rank (association.py:77-80; the Jacobi iteration of nrm_small_pinv: same integer
+ * ranks) and the variance-keeping scale (norm.py:248-259; keepvar = 0: 1).  d_mom: rows (nc (nc + 1) / 2 + nc + 2) doubles of scratch; d_flags[0] +=
+ * genes of rank 0 (norm.py:158-159 raises for them).  Then nrm_normvar_apply. */
+int64_t nrm_normvar_device_covariates(void);
+int nrm_normvar_solve(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt, const double* d_c, int64_t nc,
+					  int64_t ldc, double tol, int keepvar, double* d_mom, double* d_b, double* d_scale, int64_t* d_rank, int32_t* d_flags, void* stream);
 /* normvar1 with explicit per-gene cell weights w2 (rows, ldw) (norm.py:150-153: row g is residualised against dc * w2[g]):
  * out_gk = y_gk - w2_gk * sum_c b_gc C_ck, with b_g = (sum_k w2_gk^2 C_k C_k^T)^+ (sum_k w2_gk y_gk C_k) from the host. */
 int nrm_normvar_apply_w2(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_w2, int64_t ldw,

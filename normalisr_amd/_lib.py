@@ -101,7 +101,9 @@ _SIGNATURES = {
 	'nrm_binnet': ([_vp, _i32, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_binnet_rows': ([_vp, _i32, _i64, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_normvar_weights': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
-	'nrm_normvar_apply': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp], _i32),
+	'nrm_normvar_apply': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+	'nrm_normvar_device_covariates': ([], _i64),
+	'nrm_normvar_solve': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
 	'nrm_normvar_apply_w2': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _vp], _i32),
 	'nrm_alpha': ([_vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp], _i32),
 	'nrm_association_tests_single1_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32], _i32),

@@ -272,10 +272,13 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 			raise ValueError('Batch sizes must be non-negative integers.')
 	if single not in {0, 1, 4, 5}:
 		raise ValueError('Unknown value single={}'.format(single))
-	dx = np.asarray(dx)
+	# dx / dy may be torch CUDA tensors already in HBM (what normvar(..., device_out=True) returns; a resident pipeline normvar -> coex -> binnet)
+	is_dev = lambda a: hasattr(a, 'is_cuda') and a.is_cuda
+	if not is_dev(dx):
+		dx = np.asarray(dx)
 	dc = np.asarray(dc)
 	samexy = dy is None
-	if not samexy:
+	if not samexy and not is_dev(dy):
 		dy = np.asarray(dy)
 	if dx.ndim != 2 or dc.ndim != 2 or (not samexy and dy.ndim != 2):
 		raise ValueError('Incorrect dx/dy/dc size.')
@@ -299,7 +302,10 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		raise ValueError('Unmatching dx/dy/dc dimensions.')
 	if dx.shape[0] == 0 or ref_y.shape[0] == 0:
 		raise AssertionError('No association test to perform.')  # assert len(ans0) > 0, association.py:998
-	out_dtype = ref_y.dtype if ref_y.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	if is_dev(ref_y):
+		out_dtype = np.dtype(np.float32 if 'float32' in str(ref_y.dtype) else np.float64)
+	else:
+		out_dtype = ref_y.dtype if ref_y.dtype in (np.float32, np.float64) else np.dtype(np.float64)
 	nc = dc.shape[0]
 	if nc == 0:
 		logging.warning('No covariate dc input.')
@@ -315,7 +321,8 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		res = _single0_host_entry(_engine.as_input(dx), None if samexy else _engine.as_input(dy), dc64, dci, dcr, dimreduce, return_dot,
 								  not lowmem, out_dtype, return_stats)
 	else:
-		res = _engine.get_engine().association_single0(_engine.as_input(dx), None if samexy else _engine.as_input(dy), dc64, dci, dcr,
+		prep = lambda a: a if is_dev(a) else _engine.as_input(a)
+		res = _engine.get_engine().association_single0(prep(dx), None if samexy else prep(dy), dc64, dci, dcr,
 								  dimreduce, return_dot=return_dot, want_alpha=not lowmem, out_dtype=out_dtype,
 								  want_rt=return_stats, device_out=device_out and not return_stats)
 	stat = res['stat']

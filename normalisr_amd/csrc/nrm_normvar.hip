@@ -5,6 +5,7 @@
 // are rows of two Gram contractions on the fp64 matrix cores (K2): U P^T and V C^T with U = e^2, V = e^2 y and
 // P = the nc(nc+1)/2 products C_c * C_c'.  This file holds the two HBM-bound element-wise passes around them.
 #include "nrm_common.h"
+#include "nrm_jacobi.h"
 
 #define NV_R 4
 
@@ -68,8 +69,9 @@ template <typename T, typename OutT>
 __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy, const double* __restrict__ lnw,
 												  const double* __restrict__ wt, const double* __restrict__ c, int nc, int64_t ldc,
 												  const double* __restrict__ b, const double* __restrict__ scale, OutT* __restrict__ out,
-												  int64_t ldo) {
+												  int64_t ldo, int32_t* __restrict__ flags) {
 	__shared__ double s_b[NV_R][64];
+	bool bad = false;
 	const int tid = threadIdx.x;
 	const int64_t row0 = (int64_t)blockIdx.x * NV_R;
 	for (int i = tid; i < NV_R * nc; i += 256) {
@@ -98,10 +100,14 @@ __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64
 		for (int r = 0; r < NV_R; r++) {
 			if (row0 + r < rows) {
 				const double e = ex[r] == 0.0 ? 1.0 : exp(ex[r] * lw);
-				out[(row0 + r) * ldo + k] = (OutT)(sc[r] * e * ((double)y[(row0 + r) * ldy + k] - fit[r]));
+				const OutT o = (OutT)(sc[r] * e * ((double)y[(row0 + r) * ldy + k] - fit[r]));
+				bad |= !(fabs((double)o) <= 1.7976931348623157e308);
+				out[(row0 + r) * ldo + k] = o;
 			}
 		}
 	}
+	// the reference asserts that its result is finite (norm.py:286): counted here, where the values are at hand (flags[1] += waves with one that is not)
+	if (flags && __ballot(bad) && (tid & 63) == 0) atomicAdd(&flags[1], 1);
 }
 
 // normvar1 with explicit per-gene cell weights (norm.py:150-153: row g is residualised against dc * w2[g]):
@@ -164,13 +170,13 @@ extern "C" int nrm_normvar_weights(const void* d_y, int y_dtype, int64_t rows, i
 
 extern "C" int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
 								 const double* d_c, int64_t nc, int64_t ldc, const double* d_b, const double* d_scale, void* d_out, int out_dtype,
-								 int64_t ldo, void* stream) {
+								 int64_t ldo, int32_t* d_flags, void* stream) {
 	NRM_REQUIRE((y_dtype == NRM_F32 || y_dtype == NRM_F64) && (out_dtype == NRM_F32 || out_dtype == NRM_F64), "nrm_normvar_apply: bad dtype");
 	NRM_REQUIRE(rows > 0 && n > 0 && ldy >= n && ldo >= n && nc > 0 && nc <= 64 && ldc >= n, "Unmatched gene or cell counts.");
 	NRM_REQUIRE(d_y && d_lnw && d_wt && d_c && d_b && d_scale && d_out, "nrm_normvar_apply: null pointer");
 	dim3 grid((unsigned)((rows + NV_R - 1) / NV_R));
 	hipStream_t st = (hipStream_t)stream;
-#define NV_LAUNCH(TY, TO) hipLaunchKernelGGL((k_nv_apply<TY, TO>), grid, dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, (int)nc, ldc, d_b, d_scale, (TO*)d_out, ldo)
+#define NV_LAUNCH(TY, TO) hipLaunchKernelGGL((k_nv_apply<TY, TO>), grid, dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, (int)nc, ldc, d_b, d_scale, (TO*)d_out, ldo, d_flags)
 	if (y_dtype == NRM_F64 && out_dtype == NRM_F64) NV_LAUNCH(double, double);
 	else if (y_dtype == NRM_F64) NV_LAUNCH(double, float);
 	else if (out_dtype == NRM_F64) NV_LAUNCH(float, double);
@@ -178,3 +184,113 @@ extern "C" int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int
 #undef NV_LAUNCH
 	return nrm_check_launch("k_nv_apply");
 }
+
+// ---- round 5: the whole of normvar on the device, for up to NV_NC covariates ------------------------------------------------------------------
+// The form above materialises U = e^2 and V = e^2 y (1.6 GB of fp64 at 5000 x 10 000) for two Gram launches, brings the per-gene moments to the
+// host for 5000 pseudo-inverses and sends coefficients back: 16.9 ms per call at configs[1] size, 0.004 of the HBM rate (round-4 verdict).  Here:
+//   k_nv_moments  a workgroup per gene reads the row ONCE and sums, per cell, e^2 C_c C_d (c <= d), e^2 y C_c, y e and (y e)^2 in registers;
+//   k_nv_solve    a thread per gene: M_g^+ by the Jacobi iteration of nrm_jacobi.h (the host's code: the same integer ranks), b_g = M_g^+ a_g,
+//                 the variance-keeping scale (norm.py:248-259);
+//   k_nv_apply    (above) the second read of the row writes the result.
+// Two reads of the matrix and one write: HBM-bound; nothing crosses PCIe.
+#define NV_NC 8
+
+template <typename T, int NC>
+__global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy, const double* __restrict__ lnw,
+													 const double* __restrict__ wt, const double* __restrict__ c, int64_t ldc, double* __restrict__ mom) {
+	constexpr int NP = NC * (NC + 1) / 2, NM = NP + NC + 2;
+	__shared__ double sm[4][NM];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	const int64_t g = blockIdx.x;
+	const double ex = wt[g];
+	double acc[NM];
+#pragma unroll
+	for (int j = 0; j < NM; j++) acc[j] = 0.0;
+	const T* row = y + g * ldy;
+	for (int64_t k = tid; k < n; k += 256) {
+		const double e = ex == 0.0 ? 1.0 : exp(ex * lnw[k]);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
+		const double yv = (double)row[k], e2 = e * e, yp = yv * e;
+		double cv[NC];
+#pragma unroll
+		for (int q = 0; q < NC; q++) cv[q] = c[(int64_t)q * ldc + k];
+		int j = 0;
+#pragma unroll
+		for (int q = 0; q < NC; q++) {
+			const double t = e2 * cv[q];
+#pragma unroll
+			for (int d = q; d < NC; d++, j++) acc[j] = fma(t, cv[d], acc[j]);
+		}
+#pragma unroll
+		for (int q = 0; q < NC; q++, j++) acc[j] = fma(e2 * yv, cv[q], acc[j]);
+		acc[j] += yp;
+		acc[j + 1] = fma(yp, yp, acc[j + 1]);
+	}
+#pragma unroll
+	for (int j = 0; j < NM; j++) {
+		const double t = nv_wave_sum(acc[j]);
+		if (lane == 0) sm[wid][j] = t;
+	}
+	__syncthreads();
+	if (tid < NM) mom[g * NM + tid] = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
+}
+
+// mom (rows, NP + NC + 2) -> b (rows, NC), scale (rows), rank (rows); flags[0] += genes of rank 0
+template <int NC>
+__global__ void __launch_bounds__(64) k_nv_solve(const double* __restrict__ mom, int64_t rows, int64_t n, const double* __restrict__ wt, double tol, int keepvar,
+												  double* __restrict__ b, double* __restrict__ scale, int64_t* __restrict__ rank, int32_t* __restrict__ flags) {
+	constexpr int NP = NC * (NC + 1) / 2, NM = NP + NC + 2;
+	const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
+	if (g >= rows) return;
+	const double* mo = mom + g * NM;
+	double m[NC * NC], inv[NC * NC];
+	int j = 0;
+	for (int q = 0; q < NC; q++)
+		for (int d = q; d < NC; d++, j++) m[q * NC + d] = m[d * NC + q] = mo[j];
+	int64_t rk = 0;
+	nrm_small_pinv_one<NC>(m, NC, tol, inv, &rk);
+	rank[g] = rk;
+	if (rk <= 0) atomicAdd(&flags[0], 1);
+	const double* a = mo + NP;
+	double ab = 0.0;
+	for (int q = 0; q < NC; q++) {
+		double t = 0.0;
+		for (int d = 0; d < NC; d++) t += inv[q * NC + d] * a[d];
+		b[g * NC + q] = t;
+		ab += a[q] * t;
+	}
+	double sc = 1.0;
+	if (keepvar) {
+		const double s1 = mo[NP + NC], s2 = mo[NP + NC + 1];
+		const double mean = s1 / (double)n;
+		const double dv = sqrt(fmax(s2 / (double)n - mean * mean, 0.0));  // norm.py:248-249
+		const double dv2 = sqrt(fmax(s2 - ab, 0.0) / (double)n);          // |y' - P y'|^2 = |y'|^2 - a . b
+		sc = pow(dv / dv2, wt[g]);                                          // norm.py:259
+	}
+	scale[g] = sc;
+}
+
+extern "C" int64_t nrm_normvar_device_covariates(void) { return NV_NC; }
+
+// d_mom: rows x (nc (nc + 1) / 2 + nc + 2) doubles of scratch; d_b (rows, nc), d_scale (rows), d_rank (rows) int64; d_flags int32[4]: [0] += genes whose
+// weighted covariates have rank 0 (norm.py:158-159 raises).  1 <= nc <= nrm_normvar_device_covariates().
+extern "C" int nrm_normvar_solve(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt, const double* d_c, int64_t nc,
+								 int64_t ldc, double tol, int keepvar, double* d_mom, double* d_b, double* d_scale, int64_t* d_rank, int32_t* d_flags, void* stream) {
+	NRM_REQUIRE(y_dtype == NRM_F32 || y_dtype == NRM_F64, "nrm_normvar_solve: bad dtype");
+	NRM_REQUIRE(rows > 0 && n > 0 && ldy >= n && nc >= 1 && nc <= NV_NC && ldc >= n && tol > 0, "nrm_normvar_solve: bad sizes (1 to %d covariates)", NV_NC);
+	NRM_REQUIRE(d_y && d_lnw && d_wt && d_c && d_mom && d_b && d_scale && d_rank && d_flags, "nrm_normvar_solve: null pointer");
+	hipStream_t st = (hipStream_t)stream;
+#define NV_GO(NCV)                                                                                                                                   \
+	case NCV:                                                                                                                                        \
+		if (y_dtype == NRM_F64)                                                                                                                      \
+			hipLaunchKernelGGL((k_nv_moments<double, NCV>), dim3((unsigned)rows), dim3(256), 0, st, (const double*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, ldc, d_mom); \
+		else                                                                                                                                         \
+			hipLaunchKernelGGL((k_nv_moments<float, NCV>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, ldc, d_mom);   \
+		hipLaunchKernelGGL((k_nv_solve<NCV>), dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, d_mom, rows, n, d_wt, tol, keepvar, d_b, d_scale, d_rank, d_flags); \
+		break;
+	switch ((int)nc) {
+		NV_GO(1) NV_GO(2) NV_GO(3) NV_GO(4) NV_GO(5) NV_GO(6) NV_GO(7) NV_GO(8)
+	}
+#undef NV_GO
+	return nrm_check_launch("nrm_normvar_solve");
+}
+

@@ -7,6 +7,8 @@ Gram matrices and moment vectors are rows of two Gram contractions on the fp64 m
 with U = e^2, V = e^2 y, P = the pairwise products of covariate rows; the pseudo-inverses (integer ranks) are a
 batched SVD on the host, and two HBM-bound element-wise kernels (csrc/nrm_normvar.hip) do the rest.
 Only normvar / normvar1 are provided from the reference's norm module (normcov, compute_var are out of scope)."""
+import os
+
 import numpy as np
 
 from . import _lib
@@ -89,10 +91,21 @@ def _normvar1_weighted(dt, dc, w2, tol=1E-8):
 		return dtn
 
 
-def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, normmean=False, tol=1E-8):
+def _is_dev(a):
+	return hasattr(a, 'is_cuda') and a.is_cuda
+
+
+def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, normmean=False, tol=1E-8, device_out=False):
 	"""Mean and variance normalisation, same contract as reference norm.py:166-289: returns [dtn, dcn] (+ [dextran]).
-	nth and bs are accepted for compatibility and ignored."""
-	dt, dc, w, wt = np.asarray(dt), np.asarray(dc), np.asarray(w), np.asarray(wt)
+	nth and bs are accepted for compatibility and ignored.
+	dt may be a torch CUDA tensor already in HBM; device_out=True leaves dtn there (a torch tensor) -- what coex / de / binnet take next
+	(examples/GSE123139/code/cmd_coex.sh:38-46 chains the three through files): nothing of the expression matrix crosses PCIe.  With up to 8
+	covariates the whole computation stays on the device (csrc/nrm_normvar.hip: per-gene moments in one pass, pseudo-inverses by a thread per
+	gene with the host's Jacobi code, one more pass writes the result); more covariates take the Gram-launch form with the host's batched
+	pseudo-inverses."""
+	if not _is_dev(dt):
+		dt = np.asarray(dt)
+	dc, w, wt = np.asarray(dc), np.asarray(w), np.asarray(wt)
 	if any(x.ndim != 2 for x in (dt, dc)):
 		raise ValueError('dt and dc should have 2 dimensions.')
 	if any(x.ndim != 1 for x in (w, wt)):
@@ -115,7 +128,8 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 		raise ValueError('Invalid cat value.')
 	if nc > 63:
 		raise NotImplementedError('normvar on the device supports at most 63 covariates.')
-	out_dtype = np.result_type(dt.dtype, dc.dtype, w.dtype, wt.dtype, np.float32)
+	dt_dtype = np.dtype(str(dt.dtype).replace('torch.', '')) if _is_dev(dt) else dt.dtype
+	out_dtype = np.result_type(dt_dtype, dc.dtype, w.dtype, wt.dtype, np.float32)
 	out_dtype = np.dtype(np.float32) if out_dtype == np.float32 else np.dtype(np.float64)
 	eng = _engine.get_engine()
 	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
@@ -124,48 +138,70 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 		npair = nc * (nc + 1) // 2
 		iu = np.triu_indices(nc)
 		with torch.cuda.device(eng.device):
-			y = eng.upload(_engine.as_input(dt))
+			y = dt if _is_dev(dt) else eng.upload(_engine.as_input(dt))
+			if y.dtype not in (torch.float32, torch.float64):
+				y = y.to(torch.float64)
+			if y.stride(1) != 1:
+				y = y.contiguous()
 			ycode = _lib.NRM_F64 if y.dtype == torch.float64 else _lib.NRM_F32
 			d_lnw = eng.upload(np.log(np.asarray(w, dtype=np.float64)))
 			d_wt = eng.upload(np.asarray(wt, dtype=np.float64))
 			d_c = eng.upload(c64)
-			rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
-			u = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
-			v = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
-			s1 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
-			s2 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
-			_lib.check(eng.lib.nrm_normvar_weights(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), u.data_ptr(),
-												   v.data_ptr(), kp, rp, s1.data_ptr(), s2.data_ptr(), eng._stream()))
-			# operands of the two Gram contractions: P = pairwise products of covariate rows, C itself
-			pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
-			pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
-			cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
-			cp[:nc, :ns] = d_c
-			R = _engine.Residualized
-			gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
-			ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
-			# per-gene pseudo-inverse on the host: batched SVD, rank rule of inv_rank (association.py:77)
-			m = np.zeros((nt, nc, nc))
-			m[:, iu[0], iu[1]] = gm
-			m[:, iu[1], iu[0]] = gm
-			from .association import small_pinv
-			mi, rk = small_pinv(m, tol)  # per-gene pseudo-inverse by the rank rule of inv_rank (association.py:77), threaded in the library
-			if (np.asarray(rk) <= 0).any():
-				raise RuntimeError('Zero-rank covariates found.')
-			b = np.einsum('gcd,gd->gc', mi, ga)  # b_g = M_g^+ a_g
-			scale = np.ones(nt)
-			if keepvar:
-				mean = s1[:nt].cpu().numpy() / ns
-				dv = np.sqrt(np.maximum(s2[:nt].cpu().numpy() / ns - mean * mean, 0.0))  # norm.py:248-249
-				dv2 = np.sqrt(np.maximum(s2[:nt].cpu().numpy() - np.einsum('gc,gc->g', ga, b), 0.0) / ns)  # |y' - P y'|^2 = |y'|^2 - a.b
-				with np.errstate(divide='ignore', invalid='ignore'):
-					scale = (dv / dv2)**np.asarray(wt, dtype=np.float64)  # norm.py:259
 			tdt = torch.float64 if out_dtype == np.float64 else torch.float32
-			out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
-			d_b, d_scale = eng.upload(b), eng.upload(scale)
-			_lib.check(eng.lib.nrm_normvar_apply(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), d_c.data_ptr(), nc,
-												 d_c.stride(0), d_b.data_ptr(), d_scale.data_ptr(), out.data_ptr(),
-												 _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, eng._stream()))
+			flags = eng.zeros((4, ), torch.int32)
+			on_device = nc <= int(eng.lib.nrm_normvar_device_covariates()) and os.environ.get('NRM_NORMVAR', 'device') != 'host'
+			if on_device:
+				# everything on the device: one pass sums the per-gene moments, a thread per gene solves its small OLS, one pass writes the result
+				mom = torch.empty((nt, npair + nc + 2), dtype=torch.float64, device=eng.device)
+				d_b = torch.empty((nt, nc), dtype=torch.float64, device=eng.device)
+				d_scale = torch.empty((nt, ), dtype=torch.float64, device=eng.device)
+				d_rank = torch.empty((nt, ), dtype=torch.int64, device=eng.device)
+				with _engine._Span(eng, 'normvar_solve'):
+					_lib.check(eng.lib.nrm_normvar_solve(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), d_c.data_ptr(), nc, d_c.stride(0), float(tol),
+														 1 if keepvar else 0, mom.data_ptr(), d_b.data_ptr(), d_scale.data_ptr(), d_rank.data_ptr(), flags.data_ptr(), eng._stream()))
+				out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
+				with _engine._Span(eng, 'normvar_apply'):
+					_lib.check(eng.lib.nrm_normvar_apply(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), d_c.data_ptr(), nc, d_c.stride(0),
+														 d_b.data_ptr(), d_scale.data_ptr(), out.data_ptr(), _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns,
+														 flags.data_ptr(), eng._stream()))
+				eng._normvar_ranks = d_rank  # (tests: the integer ranks of the last call)
+			if not on_device:
+				rp, kp = _round_up(nt, ROW_TILE), _round_up(ns, K_TILE)
+				u = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
+				v = torch.empty((rp, kp), dtype=torch.float64, device=eng.device)
+				s1 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
+				s2 = torch.empty((rp, ), dtype=torch.float64, device=eng.device)
+				_lib.check(eng.lib.nrm_normvar_weights(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), u.data_ptr(),
+													   v.data_ptr(), kp, rp, s1.data_ptr(), s2.data_ptr(), eng._stream()))
+				# operands of the two Gram contractions: P = pairwise products of covariate rows, C itself
+				pr = torch.zeros((_round_up(npair, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+				pr[:npair, :ns] = d_c[torch.as_tensor(iu[0], device=eng.device)] * d_c[torch.as_tensor(iu[1], device=eng.device)]
+				cp = torch.zeros((_round_up(nc, ROW_TILE), kp), dtype=torch.float64, device=eng.device)
+				cp[:nc, :ns] = d_c
+				R = _engine.Residualized
+				gm = eng.gram(R(nt, ns, u, None, None), R(npair, ns, pr, None, None), False)[:nt, :npair].cpu().numpy()
+				ga = eng.gram(R(nt, ns, v, None, None), R(nc, ns, cp, None, None), False)[:nt, :nc].cpu().numpy()
+				# per-gene pseudo-inverse on the host: batched SVD, rank rule of inv_rank (association.py:77)
+				m = np.zeros((nt, nc, nc))
+				m[:, iu[0], iu[1]] = gm
+				m[:, iu[1], iu[0]] = gm
+				from .association import small_pinv
+				mi, rk = small_pinv(m, tol)  # per-gene pseudo-inverse by the rank rule of inv_rank (association.py:77), threaded in the library
+				if (np.asarray(rk) <= 0).any():
+					raise RuntimeError('Zero-rank covariates found.')
+				b = np.einsum('gcd,gd->gc', mi, ga)  # b_g = M_g^+ a_g
+				scale = np.ones(nt)
+				if keepvar:
+					mean = s1[:nt].cpu().numpy() / ns
+					dv = np.sqrt(np.maximum(s2[:nt].cpu().numpy() / ns - mean * mean, 0.0))  # norm.py:248-249
+					dv2 = np.sqrt(np.maximum(s2[:nt].cpu().numpy() - np.einsum('gc,gc->g', ga, b), 0.0) / ns)  # |y' - P y'|^2 = |y'|^2 - a.b
+					with np.errstate(divide='ignore', invalid='ignore'):
+						scale = (dv / dv2)**np.asarray(wt, dtype=np.float64)  # norm.py:259
+				out = torch.empty((nt, ns), dtype=tdt, device=eng.device)
+				d_b, d_scale = eng.upload(b), eng.upload(scale)
+				_lib.check(eng.lib.nrm_normvar_apply(y.data_ptr(), ycode, nt, ns, y.stride(0), d_lnw.data_ptr(), d_wt.data_ptr(), d_c.data_ptr(), nc,
+													 d_c.stride(0), d_b.data_ptr(), d_scale.data_ptr(), out.data_ptr(),
+													 _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, flags.data_ptr(), eng._stream()))
 			# covariates: continuous rows (and the intercept for cat=1) are scaled by w (norm.py:261-273)
 			w64 = np.asarray(w, dtype=np.float64)
 			if cat == 2:
@@ -185,8 +221,12 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 				cov = eng.covariates(dcn64, mi)
 				res = eng.residualize(out, cov[0], cov[1], r)
 				out = res.data[:nt, :ns].to(tdt).contiguous()
-			dtn = eng.download(out)
-		assert _finite_within(dtn) and _finite_within(dcn)
+			f = flags.cpu().numpy()
+			if f[0]:
+				raise RuntimeError('Zero-rank covariates found.')
+			assert not f[1]  # np.isfinite(dtn).all() (norm.py:286): counted by the kernel that wrote the values
+			dtn = out if device_out else eng.download(out)
+		assert (device_out or _finite_within(dtn)) and _finite_within(dcn)
 		ans = [dtn, dcn]
 		if dextra is not None:
 			dextran = dextra * w

@@ -314,7 +314,7 @@ def test_bench_default_line_carries_the_other_configs():
 	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
 	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
 	ex = out['_detail']
-	names = {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'coex_c5_full_1gpu'}
+	names = {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'chain_c2', 'coex_c5_full_1gpu'}
 	assert set(ex) == names | {'coex_c2'} and set(out['extra_workloads']) == names, (sorted(ex), sorted(out['extra_workloads']))
 	for w in names:  # the summary rows are the records' numbers
 		row, rec = out['extra_workloads'][w], ex[w]
@@ -336,6 +336,9 @@ def test_bench_default_line_carries_the_other_configs():
 	assert roof['traffic'] is None or ('k_de_sparse' in roof['traffic_source'] and 'k_gram_i8' not in roof['traffic_source'] and roof['traffic'] < 4 * roof['algorithmic_bytes'])
 	# a cold call (a design tensor the engine has not seen: lists built inside the call) beside the resident step
 	assert ex['de_c4']['ms_per_step'] < ex['de_c4']['cold_ms'] < ex['de_c4']['ms_per_step'] + 1.0 and out['extra_workloads']['de_c4']['cold_ms'] == round(ex['de_c4']['cold_ms'], 3)
+	# normvar without the host: resident step under 1.5 ms (round 4: 16.9 ms numpy -> numpy); the chain normvar -> coex -> binnet costs about its parts
+	assert ex['normvar_c2']['ms_per_step'] < 1.5 and ex['normvar_c2']['roofline']['frac'] > 0.05 and ex['chain_c2']['ms_per_step'] < ex['normvar_c2']['ms_per_step'] + out['ms_per_step'] + 2.0
+	assert ex['chain_c2']['config']['edges_kept'] > 0
 	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'hbm' and ex['coex_c5']['roofline']['bound'] == 'mfma'
 	for k, v in ex.items():
 		assert 'error' not in v, (k, v)
