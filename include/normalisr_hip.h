@@ -105,21 +105,9 @@ int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64
 int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
 					  double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
-					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax, double* d_fix,
-					  void* d_work, int64_t work_bytes, void* stream);
-/* d_work / work_bytes (nrm_residualize_q, nrm_residualize_q_chunked): a device scratch of at least nrm_residualize_workspace_bytes()
- * bytes, 16-byte aligned, ZEROED by the caller when it is allocated (the kernel leaves its counters at zero again; they are the first
- * 16 + 4 * rows_pad bytes, the partials follow: a scratch reused for a launch with MORE rows must have that many leading bytes zeroed again) and
- * not shared by launches that may run at the same time.  With it -- and d_out == NULL, at most 48 covariates, n % 4 == 0 -- K1 keeps every row ON CHIP between its two
- * phases (csrc/nrm_residualize_res.hip): one HBM read per input row instead of two; a row longer than 6144 fp32 / 3072 fp64 cells
- * is shared by the workgroups that hold its segments, which exchange their partial products through the scratch (summed in a
- * fixed order: results are bitwise reproducible).  NULL: the two-sweep kernel.  Returns 0 for shapes the resident kernel does not
- * take. */
-int64_t nrm_residualize_workspace_bytes(int x_dtype, int64_t rows_pad, int64_t n, int64_t nc, int64_t chunk_ksteps);
-/* Profiling aid, not part of the product path: d_stamps = a device buffer of 8 int64 per work item of the resident kernel (see
- * csrc/nrm_residualize_res.hip) that later launches fill with time stamps of its phases; NULL switches it off (tools/k1_phases.py). */
-int nrm_k1_debug_buffer(void* d_stamps);
-/* The same for nrm_binnet*: 6 int64 per row (time stamps: start, row loaded, threshold found, mask written; counting passes; spare). */
+					  int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax, double* d_fix, void* stream);
+/* Profiling aid, not part of the product path: d_stamps = a device buffer of 6 int64 per row of nrm_binnet* (time stamps: start, row loaded,
+ * threshold found, mask written; counting passes; spare) that later launches fill; NULL switches it off (tools/time_binnet.py). */
 int nrm_binnet_debug_buffer(void* d_stamps);
 /* The same with the digit planes cut along the cells into chunks of 32 * chunk_ksteps cells: chunk c is a dense quantised operand
  * of its own (nslices planes of rows_pad / 32 * chunk_ksteps KB) at d_q + c * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices);
@@ -128,7 +116,7 @@ int nrm_binnet_debug_buffer(void* d_stamps);
 int nrm_residualize_q_chunked(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx,
 							  const double* d_c, int64_t nc, int64_t ldc, const double* d_dci, int rank,
 							  int64_t rows_pad, double* d_ss, int nslices, void* d_q, int32_t* d_exp,
-							  int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* d_work, int64_t work_bytes, void* stream);
+							  int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* stream);
 
 /*
  * K2 -- Gram contraction dot[i,j] = sum_k A[i,k] B[j,k] on the fp64 matrix cores
@@ -287,24 +275,7 @@ int64_t nrm_gram_skinny_workspace_bytes(void);  /* scratch for d_work (determini
 int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
 					   int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,
 					   void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags,
-					   int const_last /* as above: covariate nc-1 in column 31, the design rows from column nc-1 on */,
-					   /* d_g from nrm_skinny_i8 (all NULL / 0 otherwise): its digit sums and shifts, the records and shifts of the Z rows
-					    * (nrm_quantize_rows), the sums of squares the shifts were taken with (or NULL) and the guard's tolerance: every column
-					    * gets the exact mean-product correction, every pair the accuracy guard (d_flags[2], [3] as in nrm_assoc_sweep;
-					    * a row whose sum of squares differs from d_ss_ref counts as uncertified) */
-					   const double* d_dig, const int32_t* d_ysh, const double* d_zfix, const int32_t* d_zsh, const double* d_ss_ref, double guard_tol,
-					   void* stream);
-/*
- * The streaming pass on the int8 matrix cores (csrc/nrm_skinny_i8.hip): same contract as nrm_gram_skinny, the products exact for
- * 46-bit fixed-point operands.  d_ysh (rows): shifts of the expression rows from nrm_row_scales -- the rows must be the ones the
- * shifts were taken from (nrm_row_scales also returns their sums of squares; pass them to nrm_de_small_sweep as d_ss_ref).
- * d_zq / d_zsh: the 32 Z rows as nrm_quantize_rows(d_z, 32, k_pad, ...) wrote them (6 digit planes); Z row 31 must hold a non-zero
- * constant (its column returns the digit sums of the expression rows): at most 31 rows of Z carry data.  d_dig (rows_pad, 8).
- */
-int nrm_row_scales(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, int32_t* d_ysh, double* d_ss, void* stream);
-int nrm_skinny_i8(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const int32_t* d_ysh, const void* d_zq,
-				  const int32_t* d_zsh, int64_t k_pad, double* d_g, double* d_ss, double* d_dig, int64_t rows_pad, void* d_work, void* stream);
-int64_t nrm_skinny_i8_workspace_bytes(void);
+					   int const_last /* as above: covariate nc-1 in column 31, the design rows from column nc-1 on */, void* stream);
 
 /*
  * single=4 sweep (competition-aware DE, association.py:421-576 in closed form).

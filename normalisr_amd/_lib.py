@@ -36,11 +36,9 @@ _SIGNATURES = {
 	'nrm_fill_i32': ([_vp, _i32, _i64, _vp], _i32),
 	'nrm_copy_rows': ([_vp, _i64, _vp, _i64, _i64, _i64, _vp], _i32),
 	'nrm_residualize': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
-	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
-	'nrm_residualize_workspace_bytes': ([_i32, _i64, _i64, _i64, _i64], _i64),
-	'nrm_k1_debug_buffer': ([_vp], _i32),
+	'nrm_residualize_q': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_binnet_debug_buffer': ([_vp], _i32),
-	'nrm_residualize_q_chunked': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp], _i32),
+	'nrm_residualize_q_chunked': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_gram_f64': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_f64_band': ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp], _i32),
 	'nrm_gram_workspace_bytes': ([], _i64),
@@ -70,11 +68,7 @@ _SIGNATURES = {
 	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp], _i32),
 	'nrm_gram_skinny': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_gram_skinny_workspace_bytes': ([], _i64),
-	'nrm_de_small_sweep': ([_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32,
-							_vp, _vp, _vp, _vp, _vp, _dbl, _vp], _i32),
-	'nrm_row_scales': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp], _i32),
-	'nrm_skinny_i8': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp], _i32),
-	'nrm_skinny_i8_workspace_bytes': ([], _i64),
+	'nrm_de_small_sweep': ([_vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp], _i32),
 	'nrm_single1_sweep': ([_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_de_sparse_chunk': ([], _i64),
 	'nrm_de_sparse_max_covariates': ([], _i64),

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _opts
 from . import engine as _engine
 
 
@@ -127,7 +127,7 @@ def small_pinv(m, tol=1E-8):
 	if m.ndim != 3 or m.shape[1] != m.shape[2]:
 		raise ValueError('Wrong shape for m.')
 	count, n = m.shape[0], m.shape[1]
-	if os.environ.get('NRM_SMALL_SVD', 'native') == 'lapack' or n > 12 or count < 64 or n == 0:
+	if _opts.debug('small_svd', 'native') == 'lapack' or n > 12 or count < 64 or n == 0:
 		return inv_rank(m, tol=tol)
 	if not np.isfinite(m).all():
 		raise ValueError('array must not contain infs or NaNs')

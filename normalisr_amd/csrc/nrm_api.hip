@@ -317,20 +317,7 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 	}
 	const bool want_alpha = h_alpha != nullptr && nc > 0;
 	NRM_REQUIRE(!(want_alpha && samexy), "alpha is not provided for dy == NULL (meaningless in the reference, association.py:1066-1068)");
-	DevBuf qx, qy, ex, ey, fx, fy, k1w;
-	int64_t k1_bytes = 0;  // K1's scratch (rows resident on chip, nrm_residualize_res.hip): the larger of the two operands' needs, zeroed once
-	const char* k1_mode = getenv("NRM_K1");
-	if (nslices && k1_mode && !strcmp(k1_mode, "res")) {
-		k1_bytes = nrm_residualize_workspace_bytes(x_dtype, mp, n, nc, 0);
-		if (!samexy) {
-			const int64_t b = nrm_residualize_workspace_bytes(y_dtype, np_, n, nc, 0);
-			k1_bytes = b > k1_bytes ? b : k1_bytes;
-		}
-		if (k1_bytes) {
-			NRM_TRY(k1w.alloc((size_t)k1_bytes));
-			NRM_HIP(hipMemsetAsync(k1w.p, 0, (size_t)k1_bytes, st));
-		}
-	}
+	DevBuf qx, qy, ex, ey, fx, fy;
 	const double guard_tol = guard_tolerance();
 	NRM_TRY(dx.alloc((size_t)nx * n * esize(x_dtype)));
 	NRM_TRY_RC(nrm_upload(h_dx, dx.p, (int64_t)nx * n * esize(x_dtype), 0, (void*)st));  // (from half a GB up: host threads fill page-locked blocks beside the DMA, nrm_upload.hip)
@@ -364,7 +351,7 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 		NRM_TRY(fx.alloc((size_t)mp * 8 * 8));
 		NRM_TRY(nrm_residualize_q(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, mp, ssx.as<double>(),
 								  want_alpha ? bx.as<double>() : nullptr, nslices, qx.p, ex.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr,
-								  fx.as<double>(), k1w.p, k1_bytes, st));
+								  fx.as<double>(), st));
 	} else {
 		NRM_TRY(rx.alloc((size_t)mp * kp * 8));
 		NRM_TRY(nrm_residualize(dx.p, x_dtype, nx, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, rx.as<double>(), kp, mp,
@@ -379,13 +366,12 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 		if (want_alpha) NRM_TRY(by.alloc((size_t)ny * nc * 8));
 		if (want_alpha) NRM_HIP(hipMemsetAsync(by.p, 0, (size_t)ny * nc * 8, st));
 		if (nslices) {
-			if (k1_bytes) NRM_HIP(hipMemsetAsync(k1w.p, 0, (size_t)(16 + 4 * np_), st));  // (the x rows' partials lie where this launch's counters must be zero)
 			NRM_TRY(qy.alloc((size_t)nrm_quant_bytes(np_, kp, nslices)));
 			NRM_TRY(ey.alloc((size_t)np_ * 4));
 			NRM_TRY(fy.alloc((size_t)np_ * 8 * 8));
 			NRM_TRY(nrm_residualize_q(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, nullptr, kp, np_, ssy.as<double>(),
 									  want_alpha ? by.as<double>() : nullptr, nslices, qy.p, ey.as<int32_t>(), 0, nc ? cmax.as<double>() : nullptr,
-									  fy.as<double>(), k1w.p, k1_bytes, st));
+									  fy.as<double>(), st));
 		} else {
 			NRM_TRY(ry.alloc((size_t)np_ * kp * 8));
 			NRM_TRY(nrm_residualize(dy.p, y_dtype, ny, n, n, dc.as<double>(), nc, n, dci.as<double>(), rank, ry.as<double>(), kp, np_,

@@ -1,4 +1,4 @@
-// Pieces shared by the K1 kernels (nrm_residualize.hip: k_residualize, k_residualize_v4; nrm_residualize_res.hip: k_residualize_res).
+// Pieces shared by the K1 kernels (nrm_residualize.hip: k_residualize, k_residualize_v4; tools/experiments/nrm_residualize_res.hip: k_residualize_res).
 #pragma once
 #include "nrm_common.h"
 #include "nrm_digits.h"
@@ -139,10 +139,3 @@ struct QuantOut {
 // covariates with large opposite coefficients -- the residuals are swept for their true maximum, so that no more than log2 of
 // this / (true max / rms) of the 8 NS - 2 bits are lost to the overestimate.
 #define RES_LOOSE 12.0
-
-
-// nrm_residualize_res.hip: K1 with the rows resident on chip (one HBM read per row)
-bool nrm_k1_res_applies(int x_dtype, int64_t n, int64_t nc, int64_t chunk_ksteps);
-int nrm_k1_res_launch(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int nc, int64_t ldc, const double* d_dci,
-					  int active, int64_t rows_pad, double* d_ss, double* d_coef, int nslices, const QuantOut& qo, void* d_work, int64_t work_bytes,
-					  int64_t chunk_ksteps, hipStream_t st);

@@ -4,7 +4,7 @@
 // the second sweep is served from L2 only for short rows (configs[1]: 10 000 cells); from 50 000 cells up the rows a chip-full of
 // workgroups holds between its sweeps (512 x 4 x 200 KB .. 4 MB) exceed L2 and the 256 MB Infinity Cache and every row is fetched from
 // HBM twice (round-3 counters: 1.6 - 1.8x the algorithmic traffic).  Round 4 built the alternative -- rows resident in registers
-// between the two phases, nrm_residualize_res.hip -- and measured why it does not win yet.
+// between the two phases (tools/experiments/nrm_residualize_res.hip) -- and measured why it does not win.
 //
 //   b_i  = (x_i C^T) dci          (association.py:226-227)
 //   x~_i = x_i - b_i C            (association.py:228-229)
@@ -500,7 +500,7 @@ static void launch_residualize(bool vec, const T* x, int64_t rows, int64_t n, in
 static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc, int64_t ldc,
 							const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss, double* d_coef,
 							int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch, int64_t chunk_ksteps, const double* d_cmax, double* d_fix,
-							void* d_work, int64_t work_bytes, void* stream) {
+							void* stream) {
 	NRM_REQUIRE(x_dtype == NRM_F32 || x_dtype == NRM_F64, "nrm_residualize: bad dtype");
 	NRM_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "Incorrect dx/dy/dc size.");
 	NRM_REQUIRE(nc >= 0 && nc <= RES_NC_MAX, "nrm_residualize: at most %d covariates supported", RES_NC_MAX);
@@ -537,13 +537,6 @@ static int residualize_impl(const void* d_x, int x_dtype, int64_t rows, int64_t 
 		}
 		qo.q = (char*)d_q;
 		qo.exps = d_exp;
-		// rows resident on chip between the two phases (nrm_residualize_res.hip) when the caller lends a workspace.  The callers in this
-		// tree do so only under NRM_K1=res: the kernel reads every row from HBM once, but an item's chain of phases (load, products,
-		// meeting, digits, records: tools/k1_phases.py) keeps its registers for 45 - 90 us at two workgroups per CU, so the two-sweep
-		// kernel below is still faster on every BASELINE shape
-		if (d_work && !d_out && nrm_k1_res_applies(x_dtype, n, nc, chunk_ksteps))
-			return nrm_k1_res_launch(d_x, x_dtype, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, rows_pad, d_ss, d_coef, nslices, qo, d_work, work_bytes,
-									 chunk_ksteps, (hipStream_t)stream);
 	}
 	if (x_dtype == NRM_F64)
 		launch_residualize<double>(vec, (const double*)d_x, rows, n, ldx, d_c, (int)nc, ldc, d_dci, active, d_out, ldo, rows_pad, d_ss, d_coef,
@@ -559,15 +552,15 @@ extern "C" int nrm_residualize(const void* d_x, int x_dtype, int64_t rows, int64
 							   int64_t rows_pad, double* d_ss, double* d_coef, void* stream) {
 	NRM_REQUIRE(d_out != nullptr, "nrm_residualize: null output");
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, 0, nullptr, nullptr, 0, 0, nullptr,
-							nullptr, nullptr, 0, stream);
+							nullptr, stream);
 }
 
 extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 								 int64_t ldc, const double* d_dci, int rank, double* d_out, int64_t ldo, int64_t rows_pad, double* d_ss,
 								 double* d_coef, int nslices, void* d_q, int32_t* d_exp, int64_t plane_pitch_bytes, const double* d_cmax,
-								 double* d_fix, void* d_work, int64_t work_bytes, void* stream) {
+								 double* d_fix, void* stream) {
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, d_out, ldo, rows_pad, d_ss, d_coef, nslices, d_q, d_exp,
-							plane_pitch_bytes, 0, d_cmax, d_fix, d_work, work_bytes, stream);
+							plane_pitch_bytes, 0, d_cmax, d_fix, stream);
 }
 
 // The same with the digit planes cut along the cells into chunks of chunk_ksteps * 32 cells: chunk c is a dense quantised
@@ -576,11 +569,10 @@ extern "C" int nrm_residualize_q(const void* d_x, int x_dtype, int64_t rows, int
 // (nrm_gram_i8_chunk).  d_q: ceil(ceil(k_pad / 32) / chunk_ksteps) * nrm_quant_bytes(rows_pad, 32 * chunk_ksteps, nslices) bytes.
 extern "C" int nrm_residualize_q_chunked(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 										 int64_t ldc, const double* d_dci, int rank, int64_t rows_pad, double* d_ss, int nslices, void* d_q,
-										 int32_t* d_exp, int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* d_work, int64_t work_bytes,
-										 void* stream) {
+										 int32_t* d_exp, int64_t chunk_ksteps, const double* d_cmax, double* d_fix, void* stream) {
 	NRM_REQUIRE(chunk_ksteps > 0 && chunk_ksteps < (1 << 24), "nrm_residualize_q_chunked: bad chunk size");
 	return residualize_impl(d_x, x_dtype, rows, n, ldx, d_c, nc, ldc, d_dci, rank, nullptr, 0, rows_pad, d_ss, nullptr, nslices, d_q, d_exp, 0,
-							chunk_ksteps, d_cmax, d_fix, d_work, work_bytes, stream);
+							chunk_ksteps, d_cmax, d_fix, stream);
 }
 
 // Few design rows (streaming de path): the work is spread along the CELLS instead of the rows.  The OLS

@@ -435,15 +435,6 @@ __global__ void __launch_bounds__(256, sizeof(OutT) == 8 ? 2 : 3) k_assoc_sweep_
 // Sweep for the streaming de path (nrm_gram_skinny): one thread per gene.  G[y] = [y C^T (nc) | y X~^T (nx) | 0...],
 // ssraw[y] = |y|^2.  |y~|^2 = |y|^2 - a dci a^T with a = y C^T (association.py:226-230 expanded), y~.x~ = y.x~.
 #define DS_NZ 32
-// what the sweep needs when G came from the streaming kernel on the int8 matrix cores (all null / 0 otherwise)
-struct SkinnyFix {
-	const double* dig;     // (ny, 8) digit sums of the expression rows (planes 0..4)
-	const int* ysh;        // (ny) their fixed-point shifts
-	const double* zfix;    // (32, NRM_FIX_STRIDE) records of the Z rows (nrm_quantize_rows), in the column order of G
-	const int* zsh;        // (32) their shifts
-	const double* ss_ref;  // (ny) sums of squares of the rows the shifts were taken from, or null
-	double inv_n, kconst, budget;
-};
 template <typename OutT>
 __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict__ G, const double* __restrict__ ssraw,
 														 const double* __restrict__ dci, int nc, int rank_pos,
@@ -451,7 +442,7 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 														 int stat_kind, PvalPlan pl, OutT* __restrict__ p_out, OutT* __restrict__ stat_out,
 														 OutT* __restrict__ r_out, OutT* __restrict__ t_out, int64_t ldo,
 														 double* __restrict__ ssy_out, double* __restrict__ by_out,
-														 int32_t* __restrict__ flags, int const_last, SkinnyFix sf) {
+														 int32_t* __restrict__ flags, int const_last) {
 	const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (y >= ny) return;
 	double g[DS_NZ];
@@ -473,32 +464,7 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 			g[c] = v;
 		}
 	}
-	// G from the streaming kernel on the int8 matrix cores (nrm_skinny_i8.hip): the exact correction for the digit products it leaves
-	// out -- the product of the digit means, from this gene's digit sums and the records of the Z rows (nrm_fix.h) -- on every column
-	double ynorm = 0.0, epsy_c = 0.0, epsy_g = 0.0;
-	if (sf.zfix) {
-		double uy[5];
-		const int sh = sf.ysh[y];
-#pragma unroll
-		for (int s2 = 0; s2 < 5; s2++) uy[s2] = ldexp(sf.dig[y * 8 + s2], sh + 8 * s2);
-#pragma unroll
-		for (int c = 0; c < DS_NZ; c++) {
-			if (c < nc + nx) {
-				const FixCol zc = nrm_fix_col(sf.zfix + c * NRM_FIX_STRIDE);
-				g[c] += nrm_fix_corr(uy, zc, 4, sf.inv_n);
-			}
-		}
-		// this gene's side of the guard, relative to the norm of the RAW row (which is what was cut into digits): every digit
-		// variance is at most 128^2 n, the rounding of the conversion at most half a unit
-		ynorm = sqrt(ssraw[y]);
-		const double unit = ynorm > 0.0 ? ldexp(sqrt(ncells), sh) / ynorm : 0.0;
-		epsy_c = 128.0 * unit;
-		epsy_g = 0.5 * unit;
-		// not the rows the scales were taken from (the two sums are taken in different orders: equal to rounding when the rows are
-		// the same): counted as uncertified, the caller redoes the step on the fp64 kernel
-		if (sf.ss_ref && !(fabs(sf.ss_ref[y] - ssraw[y]) <= 1e-9 * ssraw[y])) nrm_guard_count(flags, 1);
-	}
-	double q = 0.0, ty = 0.0;  // ty: sum_c |b_c| |C_c| eps(y, c), the covariates' share of the error of |y~|^2
+	double q = 0.0;
 	if (rank_pos) {
 #pragma unroll
 		for (int c = 0; c < DS_NZ; c++) {
@@ -509,11 +475,6 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 					if (e < nc) b = fma(dci[c * nc + e], g[e], b);
 				q = fma(g[c], b, q);
 				if (by_out) by_out[y * nc + c] = b;
-				if (sf.zfix) {
-					const double* zr = sf.zfix + c * NRM_FIX_STRIDE;
-					const double znorm = zr[6] > 0.0 ? ldexp(0.5 * sqrt(ncells), sf.zsh[c]) / zr[6] : 0.0;  // |C_c| from g = sqrt(n) 2^sh / (2 |C_c|)
-					ty = fma(fabs(b) * znorm, fma(sf.kconst * epsy_c, zr[5], epsy_g + zr[6]), ty);
-				}
 			}
 		}
 	}
@@ -521,9 +482,7 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 	if (sy < 0.0) sy = 0.0;
 	ssy_out[y] = sy;
 	const double vy = (sy == 0.0) ? ncells : sy;  // variance 0 -> 1 (association.py:233)
-	int bad_nf = 0, bad_rng = 0, bad_fix = 0;
-	float worst = 0.f;
-	const double sqrt_dof = sqrt(dof);
+	int bad_nf = 0, bad_rng = 0;
 #pragma unroll
 	for (int c = 0; c < DS_NZ; c++) {
 		const int x = c - nc;
@@ -536,24 +495,6 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 			if (r2 > 1.0 + 1e-8) bad_rng = 1;
 			const int64_t o = (int64_t)x * ldo + y;
 			const double pval = nrm_pvalue(r2, pl);
-			// (a gene whose residual sum of squares is cancellation noise -- a constant row -- has nothing to certify: its statistics are
-			// rounding noise in the reference too)
-			if (sf.zfix && sf.budget > 0.0 && sy > 1e-11 * ssraw[y]) {
-				// |delta(y . x~)| <= eps(y, x) |y| |x~| and |delta |y~|^2| <= 2 |y| ty: in units of Pearson r
-				const double* zr = sf.zfix + c * NRM_FIX_STRIDE;
-				const double ar = (double)(sqrtf((float)r2) * 1.0000002f);
-				const double eps = fma(sf.kconst * epsy_c, zr[5], epsy_g + zr[6]);
-				const double dr = (eps * ynorm + ar * ynorm * ty / sqrt(vy)) / sqrt(vy);
-				const double om = fmax(1.0 - r2, 1e-150);
-				const double num = dr * fma(dof, ar, sqrt_dof), den = om * om;
-				bool over = num > sf.budget * den || !(num == num);
-				if (over && pval == 0.0) {
-					const double lo = fmax(ar - dr, 0.0);
-					over = nrm_pvalue(lo * lo, pl) != 0.0;
-				}
-				if (over) bad_fix++;
-				if (pval != 0.0 || over) worst = fmaxf(worst, __fdividef((float)num, (float)den));
-			}
 			p_out[o] = (OutT)pval;
 			stat_out[o] = (OutT)(stat_kind ? d / vx : d / ncells);
 			if (r_out) r_out[o] = (OutT)(d / sqrt(vx * vy));
@@ -566,10 +507,6 @@ __global__ void __launch_bounds__(256) k_de_small_sweep(const double* __restrict
 	if (flags) {
 		if (bad_nf) atomicAdd(&flags[0], 1);
 		if (bad_rng) atomicAdd(&flags[1], 1);
-		if (sf.zfix) {
-			nrm_guard_count(flags, bad_fix);
-			if (worst > 0.f && __float_as_int(worst) > __hip_atomic_load(&flags[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[3], __float_as_int(worst));
-		}
 	}
 }
 
@@ -700,16 +637,8 @@ extern "C" int nrm_alpha(const void* d_stat, int stat_dtype, int64_t ldg, int st
 
 extern "C" int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, const double* d_dci, int64_t nc, int rank, const double* d_ssx,
 								  int64_t nx, int64_t ny, int64_t n_cells, double dof, int stat_kind, void* d_p, void* d_stat, void* d_r,
-								  void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags, int const_last,
-								  const double* d_dig, const int32_t* d_ysh, const double* d_zfix, const int32_t* d_zsh, const double* d_ss_ref, double guard_tol,
-								  void* stream) {
+								  void* d_t, int out_dtype, int64_t ldo, double* d_ssy, double* d_by, int32_t* d_flags, int const_last, void* stream) {
 	NRM_REQUIRE(nx > 0 && ny > 0 && nc >= 0 && nx + nc <= DS_NZ, "nrm_de_small_sweep: needs nx + nc <= %d", DS_NZ);
-	SkinnyFix sf = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0};
-	if (d_zfix) {
-		NRM_REQUIRE(d_dig && d_ysh && d_zsh && d_flags && !const_last && nx + nc < DS_NZ, "nrm_de_small_sweep: integer streaming input needs digit sums, shifts, flags, no constant-row column and nx + nc <= 31");
-		const FixArgs fa = nrm_fix_args(d_zfix, d_zfix, 6, n_cells, dof, guard_tol);
-		sf = SkinnyFix{d_dig, d_ysh, d_zfix, d_zsh, d_ss_ref, fa.inv_n, fa.kconst, guard_tol};
-	}
 	NRM_REQUIRE(!const_last || nc >= 1, "nrm_de_small_sweep: const_last needs a covariate");
 	NRM_REQUIRE(out_dtype == NRM_F32 || out_dtype == NRM_F64, "nrm_de_small_sweep: bad out_dtype");
 	NRM_REQUIRE(d_g && d_ssraw && d_ssx && d_p && d_stat && d_ssy && ldo >= ny, "nrm_de_small_sweep: null pointer or small pitch");
@@ -722,10 +651,10 @@ extern "C" int nrm_de_small_sweep(const double* d_g, const double* d_ssraw, cons
 	if (out_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_de_small_sweep<double>, grid, dim3(256), 0, (hipStream_t)stream, d_g, d_ssraw, d_dci, (int)nc, rank_pos, d_ssx,
 						   (int)nx, ny, (double)n_cells, dof, stat_kind, to_dev(plan), (double*)d_p, (double*)d_stat, (double*)d_r,
-						   (double*)d_t, ldo, d_ssy, d_by, d_flags, const_last, sf);
+						   (double*)d_t, ldo, d_ssy, d_by, d_flags, const_last);
 	else
 		hipLaunchKernelGGL(k_de_small_sweep<float>, grid, dim3(256), 0, (hipStream_t)stream, d_g, d_ssraw, d_dci, (int)nc, rank_pos, d_ssx,
 						   (int)nx, ny, (double)n_cells, dof, stat_kind, to_dev(plan), (float*)d_p, (float*)d_stat, (float*)d_r,
-						   (float*)d_t, ldo, d_ssy, d_by, d_flags, const_last, sf);
+						   (float*)d_t, ldo, d_ssy, d_by, d_flags, const_last);
 	return nrm_check_launch("k_de_small_sweep");
 }

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _opts
 from ._lib import ROW_TILE
 
 MAX_DENSITY = 1.0 / 16  # (break-even against K1 + the integer Gram engine is near one entry in ten)
@@ -143,7 +143,7 @@ def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_
 	# it holds in LDS anyway -- one pass over the expression matrix -- for up to 8 covariates besides a constant one (csrc/nrm_de_sparse.hip);
 	# beyond that (or NRM_DE_SPARSE_SUMS=stream) the stream kernel of single=1 takes them first, every cell "common": a second pass.
 	ci, cval = eng.constant_row(d_c) if ncu else (-1, 0.0)
-	fused = ncu - (1 if ci >= 0 else 0) <= int(eng.lib.nrm_de_sparse_fused_covariates()) and os.environ.get('NRM_DE_SPARSE_SUMS', 'inside') != 'stream'
+	fused = ncu - (1 if ci >= 0 else 0) <= int(eng.lib.nrm_de_sparse_fused_covariates()) and _opts.debug('de_sparse_sums', 'inside') != 'stream'
 	ct = None
 	if fused:
 		ct = torch.empty((int(eng.lib.nrm_de_sparse_ct_doubles(n, ncu, ci)), ), dtype=torch.float64, device=eng.device)

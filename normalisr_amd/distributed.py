@@ -17,6 +17,8 @@ import os
 
 import numpy as np
 
+from . import _opts
+
 from ._lib import ROW_TILE, K_TILE
 
 
@@ -179,7 +181,7 @@ class StepGraph:
 		self.calls = 0
 		self.graph = None
 		self.result = None
-		self.enabled = os.environ.get('NRM_GRAPH', '1') != '0'
+		self.enabled = _opts.debug('graph', '1') != '0'
 
 	def run(self, fn):
 		self.calls += 1
@@ -373,7 +375,7 @@ class CoexPlan:
 		# NRM_FORCE_EXCHANGE = chunks | blocks | raw: take the N > 1 code path of that exchange form on ONE rank -- the collectives run
 		# (a group of one: RCCL on the one GPU of a development box), and the rank's own block pair is contracted from the GATHER
 		# BUFFERS after the waits instead of from the local block, so what the collective delivered is what is computed on
-		forced = os.environ.get('NRM_FORCE_EXCHANGE', '')
+		forced = _opts.debug('force_exchange', '')
 		if forced and forced not in ('chunks', 'blocks', 'raw'):
 			raise ValueError('NRM_FORCE_EXCHANGE must be chunks, blocks or raw')
 		self.forced = bool(forced) and world == 1 and group is not None and backend is None
@@ -388,8 +390,8 @@ class CoexPlan:
 		if multi and mode in ('auto', 'chunks') and not few_links and hasattr(self.be, 'gram_chunk') and self.be.chunkable(dt_local, self.cov):
 			# chunk launches of fewer than ~128 k-steps (4096 cells) cost more than they hide (tools/time_chunks.py: a 1792 x 1792
 			# block pair over 10 000 cells takes 1.04x in 2 chunks, 1.33x in 4, 2.0x in 8; at 100 000 cells 4 chunks are free)
-			min_ks = int(os.environ.get('NRM_EXCHANGE_MIN_KSTEPS', '128'))
-			self.chunks = max(1, min(int(os.environ.get('NRM_EXCHANGE_CHUNKS', '8')), ((self.k_pad + 31) // 32) // max(1, min_ks)))
+			min_ks = int(_opts.debug('exchange_min_ksteps', '128'))
+			self.chunks = max(1, min(int(_opts.debug('exchange_chunks', '8')), ((self.k_pad + 31) // 32) // max(1, min_ks)))
 		elif multi and mode == 'chunks':
 			raise ValueError('NRM_EXCHANGE=chunks needs the integer Gram engine and 16-byte aligned rows')
 		self.exchange_raw = multi and backend is None and not self.chunks and mode != 'blocks' and 'float32' in str(dt_local.dtype)
@@ -561,7 +563,7 @@ class CoexPlan:
 		# half-split pair of an even world -- goes pair by pair
 		full = [e for e in rest if e[0] == self.rank and e[2] == 0 and e[3] == self.rows_pad and not e[4]]
 		K = len(full)
-		merged = K >= 2 and hasattr(be, 'gram_chunk_blocks') and os.environ.get('NRM_MERGE_PARTNERS', '1') != '0' and [
+		merged = K >= 2 and hasattr(be, 'gram_chunk_blocks') and _opts.debug('merge_partners', '1') != '0' and [
 			e[1] for e in full] == [(self.rank + 1 + j) % self.world for j in range(K)]
 		if merged:
 			rest = [e for e in rest if e not in full]
@@ -600,7 +602,7 @@ class CoexPlan:
 		if self.multi and not self.exchange_raw:
 			self._pending = self._exchange(blk, ss)
 		outs = []
-		merged = self.exchange_raw and self.n_partners >= 1 and os.environ.get('NRM_MERGE_PARTNERS', '1') != '0'
+		merged = self.exchange_raw and self.n_partners >= 1 and _opts.debug('merge_partners', '1') != '0'
 		merged_done = False
 		for bi, bj, lo, hi, sym in self.sched:
 			if self._pending and (self.forced or not (bi == self.rank and bj == self.rank)):
@@ -854,7 +856,6 @@ class DePlan:
 				except GuardHit as g2:
 					g = g2
 			if g is not None:  # the integer engine could not certify every P-value: this step again, eagerly, on the fp64 Gram kernel
-				st.pop('yscale', None)  # (streaming path: no more integer passes for this plan -- stale row scales count as a hit)
 				st['keep'] = False
 				self._graph.enabled, self._graph.graph = False, None
 				with self.eng.forced_f64():

@@ -14,7 +14,7 @@ import threading
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _opts
 from ._lib import NRM_F32, NRM_F64, ROW_TILE, K_TILE, FIX_STRIDE
 
 
@@ -167,7 +167,6 @@ class Engine:
 		self._tls = threading.local()
 		self._gram_work = None
 		self._skinny_ws = None
-		self._k1_ws = {}
 		self._copy = None
 		self.pool = PinnedPool(self.lib)
 		self._cmax = {}
@@ -195,7 +194,7 @@ class Engine:
 		fill page-locked blocks beside the DMA: 38 -> 54 GB/s for the 3 GB expression matrix of BASELINE configs[3]; at 200 MB the runtime's
 		own pageable copy already runs at 56 GB/s and stays); NRM_UPLOAD=torch: torch's copy whatever the size."""
 		a = np.ascontiguousarray(a)
-		if dtype is None and a.nbytes >= (512 << 20) and str(a.dtype) in self._NPT and os.environ.get('NRM_UPLOAD', 'staged') != 'torch':
+		if dtype is None and a.nbytes >= (512 << 20) and str(a.dtype) in self._NPT and _opts.debug('upload', 'staged') != 'torch':
 			torch = self.torch
 			with torch.cuda.device(self.device):
 				t = torch.empty(a.shape, dtype=getattr(torch, self._NPT[str(a.dtype)]), device=self.device)
@@ -310,27 +309,6 @@ class Engine:
 		e = None if d_c is None else self._cmax.get(d_c.data_ptr())
 		return e[1].data_ptr() if e is not None and e[0]() is d_c else 0
 
-	def k1_work(self, dtype_code, rows_pad, n, nc, chunk_ksteps=0):
-		"""(pointer, bytes) of the scratch through which K1 keeps its rows on chip (csrc/nrm_residualize_res.hip): one buffer per
-		launch stream, zeroed when it is allocated (the kernel leaves its counters at zero), grown on demand.  (0, 0): the shape is
-		outside that kernel, or it was not asked for (NRM_K1=res: opt-in, the two-sweep kernel is faster on the BASELINE shapes)."""
-		if os.environ.get('NRM_K1', '') != 'res':
-			return 0, 0
-		need = int(self.lib.nrm_residualize_workspace_bytes(dtype_code, rows_pad, n, nc, chunk_ksteps))
-		if need == 0:
-			return 0, 0
-		key = self._stream()
-		w, groups_last = self._k1_ws.get(key, (None, 0))
-		groups = rows_pad // 4
-		if w is None or w.numel() < need:
-			w = self.zeros((need + (need >> 2), ), self.torch.uint8)
-		elif groups > groups_last:
-			# the counters sit at the start of the scratch, the partials behind them: a launch on more rows than the last one finds that
-			# one's partials where its counters must be zero
-			_lib.check(self.lib.nrm_fill_zero(w.data_ptr(), 16 + 16 * groups, self._stream()))
-		self._k1_ws[key] = (w, groups)
-		return w.data_ptr(), int(w.numel())
-
 	@serialised
 	def residualize(self, x, d_c, d_dci, rank, want_coef=False, rows_pad=None, nslices=0, keep_fp64=True, into=None):
 		"""K1 on a host (numpy) or device (torch) matrix of shape (rows, n).  nslices = 5 / 6: also (keep_fp64=False: only) the
@@ -381,8 +359,7 @@ class Engine:
 					x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 					0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 					0 if d_dci is None else d_dci.data_ptr(), int(rank), 0 if out is None else out.data_ptr(), kp, rp, ss.data_ptr(),
-					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self.cmax_ptr(d_c), fix.data_ptr(),
-					*self.k1_work(NRM_F64 if x.dtype == torch.float64 else NRM_F32, rp, n, nc), self._stream()))
+					0 if coef is None else coef.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(), 0, self.cmax_ptr(d_c), fix.data_ptr(), self._stream()))
 				r = Residualized(rows, n, out, ss, coef, shape=(rp, kp))
 				r._quant = (planes, exps, nslices)
 				r.fix = fix
@@ -428,8 +405,7 @@ class Engine:
 				x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows, n, x.stride(0),
 				0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0),
 				0 if d_dci is None else d_dci.data_ptr(), int(rank), rows_pad, ss.data_ptr(), nslices, planes.data_ptr(), exps.data_ptr(),
-				cks, self.cmax_ptr(d_c), fix.data_ptr(), *self.k1_work(NRM_F64 if x.dtype == torch.float64 else NRM_F32, rows_pad, n, nc, cks),
-				self._stream()))
+				cks, self.cmax_ptr(d_c), fix.data_ptr(), self._stream()))
 		r = Residualized(rows, n, None, ss, None, shape=(rows_pad, kp))
 		r._quant = ([planes[c * cb:(c + 1) * cb] for c in range(nchunks)], exps, nslices)
 		r._planes = planes  # (the one buffer the chunk operands are views of)
@@ -493,7 +469,7 @@ class Engine:
 		"""(digit planes, row records of the x rows, of the y rows, guard tolerance) for the sweep of a dot product the integer engine
 		made from rx and ry; zeros for the fp64 Gram kernels."""
 		fx, fy = getattr(rx, 'fix', None), getattr(ry, 'fix', None)
-		if fx is None or fy is None or os.environ.get('NRM_I8_FIX', '1') == '0':  # (the switch exists for the tests that show what the records are for)
+		if fx is None or fy is None or _opts.debug('i8_fix', '1') == '0':  # (the switch exists for the tests that show what the records are for)
 			return 0, 0, 0, 0.0
 		return int(rx._quant[2]), fx.data_ptr(), fy.data_ptr(), float(self.guard_tol)
 
@@ -570,7 +546,7 @@ class Engine:
 	def banded_ok(self, nx, ny, out_dtype):
 		"""Pipeline K2 -> K3 -> copy-out by row bands when there is more than one band and the results are large enough
 		for the PCIe leg to matter (NRM_PIPELINE=0 switches it off)."""
-		if os.environ.get('NRM_PIPELINE', '1') == '0':
+		if _opts.debug('pipeline', '1') == '0':
 			return False
 		return nx > self.BAND and 2 * nx * ny * np.dtype(out_dtype).itemsize >= (16 << 20)
 
@@ -579,7 +555,7 @@ class Engine:
 	def chunked_ok(self, dy):
 		"""de whose expression matrix still sits on the host and is large: upload it in row chunks on a second stream
 		so that K1/K2/K3 of chunk c run while chunk c+1 crosses PCIe (NRM_PIPELINE=0 switches it off)."""
-		return (isinstance(dy, np.ndarray) and dy.nbytes >= 2 * self.CHUNK_BYTES and os.environ.get('NRM_PIPELINE', '1') != '0')
+		return (isinstance(dy, np.ndarray) and dy.nbytes >= 2 * self.CHUNK_BYTES and _opts.debug('pipeline', '1') != '0')
 
 	@serialised
 	def association_de_chunked(self, dx, dy, dc, dci, rank, dof, stat_kind, out_dtype, cov=None):
@@ -704,7 +680,7 @@ class Engine:
 	def coex_pipelined_ok(self, dx, dc, n):
 		"""coex whose expression matrix still sits on the host, large enough for PCIe to matter, on the integer engine with rows K1
 		can quantise itself (16-byte aligned): upload, kernels and copy-out overlap chunk by chunk (NRM_PIPELINE=0 switches it off)."""
-		return (isinstance(dx, np.ndarray) and os.environ.get('NRM_PIPELINE', '1') != '0' and self.gram_slices(n) > 0 and dx.shape[0] > self.BAND
+		return (isinstance(dx, np.ndarray) and _opts.debug('pipeline', '1') != '0' and self.gram_slices(n) > 0 and dx.shape[0] > self.BAND
 				and dx.nbytes >= (32 << 20) and (dx.shape[1] * dx.itemsize) % 16 == 0 and (dc.shape[0] == 0 or (dc.shape[1] * 8) % 16 == 0))
 
 	@serialised
@@ -728,7 +704,7 @@ class Engine:
 		plane = (mp // 32) * nks * 1024
 		cuts = list(range(0, ng, self.BAND)) + [ng]
 		import time
-		trace = [] if os.environ.get('NRM_TRACE') else None
+		trace = [] if _opts.debug('trace') else None
 		mark = (lambda what: trace.append((what, time.perf_counter()))) if trace is not None else (lambda what: None)
 		mark('start')
 		with torch.cuda.device(self.device):
@@ -758,7 +734,7 @@ class Engine:
 			# SLOWER on the MI355X box (configs[1]: 11.6 ms against 7.7): the copies of all chunks but the last are hidden behind the uploads
 			# anyway, so halving them shortens the tail by 0.5 ms only (copied out at 6.9 instead of 7.4 ms), while 32 host threads transpose
 			# the 100 MB at ~16 GB/s -- below the 27 GB/s of the rectangular copy-out they replace.
-			host_mirror = os.environ.get('NRM_HOST_MIRROR', '0') == '1'
+			host_mirror = _opts.debug('host_mirror', '0') == '1'
 			import queue
 			mirror_q, mirror_err = queue.Queue(), []
 
@@ -820,7 +796,7 @@ class Engine:
 						xc.data_ptr(), NRM_F64 if xc.dtype == torch.float64 else NRM_F32, b - a, n, xc.stride(0),
 						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
 						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
-						fixt.data_ptr() + a * FIX_STRIDE * 8, *self.k1_work(NRM_F64 if xc.dtype == torch.float64 else NRM_F32, rpc, n, nc), self._stream()))
+						fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
 					blk = self.row_block(whole, a, a + rpc, rows=b - a)
 					dot = self.gram(blk, blk, True, nslices=ns)
 					_lib.check(self.lib.nrm_assoc_sweep(dot.data_ptr(), dot.stride(0), blk.ss.data_ptr(), blk.ss.data_ptr(), b - a, b - a, int(n), float(dof), 1, 0,
@@ -904,7 +880,7 @@ class Engine:
 						x.data_ptr(), NRM_F64 if x.dtype == torch.float64 else NRM_F32, b - a, n, x.stride(0),
 						0 if d_c is None else d_c.data_ptr(), nc, 0 if d_c is None else d_c.stride(0), 0 if d_dci is None else d_dci.data_ptr(), int(rank),
 						0, kp, rpc, ss.data_ptr() + a * 8, 0, ns, planes.data_ptr() + (a // 32) * nks * 1024, exps.data_ptr() + a * 4, plane, self.cmax_ptr(d_c),
-						fixt.data_ptr() + a * FIX_STRIDE * 8, *self.k1_work(NRM_F64 if x.dtype == torch.float64 else NRM_F32, rpc, n, nc), self._stream()))
+						fixt.data_ptr() + a * FIX_STRIDE * 8, self._stream()))
 				torch.cuda.current_stream(self.device).synchronize()  # the block is released before the next one is made
 				del x
 			mark('residualised')
@@ -1007,7 +983,7 @@ class Engine:
 
 	def de_streaming_ok(self, dx, dy, dc):
 		"""The streaming path (K2s) applies to de with few design rows and 16-byte aligned expression rows."""
-		mode = os.environ.get('NRM_DE_PATH', 'auto')
+		mode = _opts.debug('de_path', 'auto')
 		if dy is None or mode == 'general':
 			return False
 		ok = dx.shape[0] + dc.shape[0] <= 32
@@ -1034,16 +1010,9 @@ class Engine:
 			# A constant covariate row (the intercept) leaves Z: its product with every expression row is a plain sum, taken on the
 			# vector ALU by the streaming kernel (column 31 of G) instead of occupying a matrix-core row group.  The covariates are
 			# reordered so that it comes last; dci is permuted with them (b' = P b: no rank assumption), alpha is put back in order.
-			# Streaming on the int8 matrix cores (csrc/nrm_skinny_i8.hip; opt-in with NRM_DE_I8=1: correct, not yet faster than the fp64
-			# kernel): needs the fixed-point scale of every expression row before the row is streamed, i.e. rows that were seen
-			# before -- a caller that keeps `state` (a DePlan) gets them from nrm_row_scales at the end of its first step and streams on
-			# the integer engine from the second step on
-			ysc = state.get('yscale')
-			use_i8 = (ysc is not None and not isinstance(dy, np.ndarray) and ysc[0] is dy and self.gram_slices(n) == 6 and nc + nx <= 31
-					  and not (want_alpha or want_rt) and os.environ.get('NRM_DE_I8', '0') == '1')
 			ci, cval = self.constant_row(d_c)
-			if use_i8 or os.environ.get('NRM_CONST_ROW', '1') == '0' or nc + nx > 31 + (ci >= 0):
-				ci, cval = -1, 0.0  # (the integer kernel takes the intercept like any other row: its 32-row tile has room)
+			if _opts.debug('const_row', '1') == '0' or nc + nx > 31 + (ci >= 0):
+				ci, cval = -1, 0.0
 			perm = None
 			if ci >= 0:
 				perm = [c for c in range(nc) if c != ci] + [ci]
@@ -1066,7 +1035,6 @@ class Engine:
 				_lib.check(self.lib.nrm_fill_zero(z[ncz:].data_ptr(), (31 - ncz) * k32 * 8, self._stream()))
 			else:
 				z = self.zeros((32, k32), torch.float64)
-				z[31].fill_(1.0)  # (row 31: a constant; the integer kernel reads the expression rows' digit sums off its column, the fp64 one ignores it)
 				if ncz:
 					self.copy_rows(z, d_cz[:ncz])
 				if nc:
@@ -1093,33 +1061,9 @@ class Engine:
 			ny_pad = _round_up(ny, 256)
 			g = torch.empty((ny_pad, 32), dtype=torch.float64, device=self.device)
 			ssraw = torch.empty((ny_pad, ), dtype=torch.float64, device=self.device)
-			i8 = (0, 0, 0, 0, 0, 0.0)  # the sweep's extra arguments when G comes from the integer kernel
-			use_i8 = use_i8 and y is dy  # (a padded copy of the rows is not what the scales were taken from)
-			if use_i8:
-				with _Span(self, 'gram'):
-					nks = k32 // 32
-					planes = torch.empty((6 * nks * 1024, ), dtype=torch.uint8, device=self.device)
-					zsh = torch.empty((32, ), dtype=torch.int32, device=self.device)
-					zfix = torch.empty((32, FIX_STRIDE), dtype=torch.float64, device=self.device)
-					_lib.check(self.lib.nrm_quantize_rows(z.data_ptr(), 32, k32, k32, 6, planes.data_ptr(), zsh.data_ptr(), zfix.data_ptr(), int(n), self._stream()))
-					dig = torch.empty((ny_pad, 8), dtype=torch.float64, device=self.device)
-					if getattr(self, '_skinny_i8_ws', None) is None:
-						self._skinny_i8_ws = torch.empty((int(self.lib.nrm_skinny_i8_workspace_bytes()) // 8, ), dtype=torch.float64, device=self.device)
-					_lib.check(self.lib.nrm_skinny_i8(y.data_ptr(), ycode, ny, n, y.stride(0), ysc[1].data_ptr(), planes.data_ptr(), zsh.data_ptr(), k32,
-													  g.data_ptr(), ssraw.data_ptr(), dig.data_ptr(), ny_pad, self._skinny_i8_ws.data_ptr(), self._stream()))
-				i8 = (dig.data_ptr(), ysc[1].data_ptr(), zfix.data_ptr(), zsh.data_ptr(), ysc[2].data_ptr(), float(self.guard_tol))
-			else:
-				with _Span(self, 'gram'):
-					_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), ycode, ny, n, y.stride(0), z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(),
-														ny_pad, ncz + nx, float(cval), self._skinny_work().data_ptr(), self._stream()))
-				if (state.get('keep', False) and (ysc is None or ysc[0] is not dy) and y is dy and self.gram_slices(n) == 6 and nc + nx <= 31
-						and not (want_alpha or want_rt) and os.environ.get('NRM_DE_I8', '0') == '1'):
-					# a resident caller: take the row scales now, for the next steps
-					ysh = torch.empty((ny, ), dtype=torch.int32, device=self.device)
-					ss0 = torch.empty((ny, ), dtype=torch.float64, device=self.device)
-					with _Span(self, 'row scales'):
-						_lib.check(self.lib.nrm_row_scales(y.data_ptr(), ycode, ny, n, y.stride(0), ysh.data_ptr(), ss0.data_ptr(), self._stream()))
-					state['yscale'] = (dy, ysh, ss0)
+			with _Span(self, 'gram'):
+				_lib.check(self.lib.nrm_gram_skinny(y.data_ptr(), ycode, ny, n, y.stride(0), z.data_ptr(), k32, k32, g.data_ptr(), ssraw.data_ptr(),
+													ny_pad, ncz + nx, float(cval), self._skinny_work().data_ptr(), self._stream()))
 			p = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			stat = torch.empty((nx, ny), dtype=tdt, device=self.device)
 			r = torch.empty((nx, ny), dtype=tdt, device=self.device) if want_rt else None
@@ -1131,7 +1075,7 @@ class Engine:
 			_lib.check(self.lib.nrm_de_small_sweep(g.data_ptr(), ssraw.data_ptr(), 0 if d_dciz is None else d_dciz.data_ptr(), nc, int(rank),
 												   rx.ss.data_ptr(), nx, ny, n, float(dof), stat_kind, p.data_ptr(), stat.data_ptr(),
 												   0 if r is None else r.data_ptr(), 0 if t is None else t.data_ptr(), _code(out_dtype),
-												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), 1 if ci >= 0 else 0, *i8, self._stream()))
+												   ny, ssy.data_ptr(), 0 if by is None else by.data_ptr(), flags.data_ptr(), 1 if ci >= 0 else 0, self._stream()))
 			alpha = None
 			if want_alpha:
 				if nc > 0:

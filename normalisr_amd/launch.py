@@ -17,6 +17,8 @@ import subprocess
 import sys
 import time
 
+from . import _opts
+
 SHARDED = ('coex', 'de')
 
 
@@ -48,8 +50,8 @@ def run_sharded(cmd, args):
 		procs.append(subprocess.Popen([sys.executable, '-m', 'normalisr_amd.shard_worker', payload], env=env))
 	status = 0
 	live = list(procs)
-	grace = float(os.environ.get('NRM_RANK_GRACE_S', '20'))  # what the survivors get to exit by themselves after the first failure
-	limit = float(os.environ.get('NRM_JOB_TIMEOUT_S', '0'))  # overall watchdog, 0 = none
+	grace = float(_opts.debug('rank_grace_s', '20'))  # what the survivors get to exit by themselves after the first failure
+	limit = float(_opts.debug('job_timeout_s', '0'))  # overall watchdog, 0 = none
 	t0 = time.time()
 	failed_at = None
 	while live:

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _opts
 from . import engine as _engine
 from ._lib import ROW_TILE, K_TILE
 from .association import inv_rank
@@ -149,7 +149,7 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 			d_c = eng.upload(c64)
 			tdt = torch.float64 if out_dtype == np.float64 else torch.float32
 			flags = eng.zeros((4, ), torch.int32)
-			on_device = nc <= int(eng.lib.nrm_normvar_device_covariates()) and os.environ.get('NRM_NORMVAR', 'device') != 'host'
+			on_device = nc <= int(eng.lib.nrm_normvar_device_covariates()) and _opts.debug('normvar', 'device') != 'host'
 			if on_device:
 				# everything on the device: one pass sums the per-gene moments, a thread per gene solves its small OLS, one pass writes the result
 				mom = torch.empty((nt, npair + nc + 2), dtype=torch.float64, device=eng.device)

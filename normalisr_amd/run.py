@@ -12,6 +12,8 @@ import logging
 
 import numpy as np
 
+from . import _opts
+
 fmt_float = '%.8G'
 fmt_int = '%i'
 
@@ -23,7 +25,7 @@ def _is_binary(name):
 def _native_text():
 	"""The library's text reader / writer unless NRM_TSV=numpy asks for numpy.loadtxt / numpy.savetxt (the reference's own calls)."""
 	import os
-	return os.environ.get('NRM_TSV', 'native') != 'numpy'
+	return _opts.debug('tsv', 'native') != 'numpy'
 
 
 def _open_bytes(f):

@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _opts
 from . import engine as _engine
 from ._lib import ROW_TILE
 from .association import inv_rank, small_pinv
@@ -68,7 +68,7 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			# cell selection on the device (association.py:914-918): the design matrix travels once, in its own dtype
 			d_dx = dx if _is_dev(dx) else eng.upload(_engine.as_input(dx))
 			lists = None
-			if nc <= 32 and os.environ.get('NRM_SINGLE1', 'sparse') != 'dense':
+			if nc <= 32 and _opts.debug('single1', 'sparse') != 'dense':
 				# the design's entries listed by the library (csrc/nrm_design_lists.hip: one pass counts them and says what they are like, a
 				# second writes them row by row) -- unless more than a quarter of the matrix is set, which no design of this method is
 				from . import de_sparse
@@ -166,7 +166,7 @@ def _sparse(eng, lists, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, o
 	groupings themselves (M_i = C_S C_S^T, C_S x_S, |x_S|^2: association.py:350-364) are finished on the host WHILE the stream kernel runs."""
 	torch = eng.torch
 	from .single4 import _Marks
-	mark = _Marks(eng, 'NRM_S1_TRACE', 'single=1')
+	mark = _Marks(eng, 's1_trace', 'single=1')
 	mark('entry lists')
 	dev = eng.device
 	nnz = lists.nnz

@@ -23,7 +23,7 @@ import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _opts
 from . import engine as _engine
 
 
@@ -194,11 +194,11 @@ def _is_dev(a):
 
 
 class _Marks:
-	"""NRM_S4_TRACE=1 (NRM_S1_TRACE=1 from single1.py): wall-clock of the phases of a call, each closed by a device synchronisation (profiling aid)."""
+	"""NRM_DEBUG=s4_trace=1 (s1_trace=1 from single1.py): wall-clock of the phases of a call, each closed by a device synchronisation (profiling aid)."""
 
-	def __init__(self, eng, env='NRM_S4_TRACE', label='single=4'):
+	def __init__(self, eng, key='s4_trace', label='single=4'):
 		import time
-		self.on = os.environ.get(env, '') == '1'
+		self.on = _opts.debug(key, '') == '1'
 		self.label = label
 		self.eng, self.clock, self.rows = eng, time.perf_counter, []
 		self.t = self.clock()
@@ -244,7 +244,7 @@ def _spd_inverse_device(eng, m_d, nx, ss):
 		# is looked at after two steps and, unless it is falling, the iteration starts over from X = I / ||M||_1, which always converges
 		# (log2(cond) + ~6 steps: 8 for the same matrices).  NRM_S4_START=norm: the second start only.
 		done = False
-		for start in (('diagonal', 'norm') if os.environ.get('NRM_S4_START', 'diagonal') != 'norm' else ('norm', )):
+		for start in (('diagonal', 'norm') if _opts.debug('s4_start', 'diagonal') != 'norm' else ('norm', )):
 			_lib.check(lib.nrm_spd_start(mp.data_ptr(), nxp, 1 if start == 'diagonal' else 0, scal.data_ptr(), x.data_ptr(), st))
 			look_from = 2 if start == 'diagonal' else 4
 			diverged = False
@@ -438,7 +438,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 				lists = lists if lists.ok else None
 		if lists is not None:
 			ns = 0
-		if lists is not None and os.environ.get('NRM_S4_SPARSE_M', '1') != '0':
+		if lists is not None and _opts.debug('s4_sparse_m', '1') != '0':
 			# M~ = X~ X~^T is the same product with the design rows in the place of the expression rows: x~_i . x~_j = x_i . x_j - (x_j C^T) . b_i
 			# -- the design's own statistics from its entries and one more run of the sparse-design kernels over the 200 MB design matrix,
 			# instead of K1's fp64 residuals of it (400 MB) and a 1e11-flop product of them
@@ -454,7 +454,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 			mark('K1 design')
 			mt_d = eng.gram(rx, rx, True)  # M~ = X~ X~^T (fp64 kernel, tiles on / above the diagonal)
 		# N~ = M~^-1 on the device (Newton-Schulz on the fp64 matrix cores); the host's LAPACK only if that does not converge
-		inv = _spd_inverse_device(eng, mt_d, nx, rx.ss) if os.environ.get('NRM_S4_INVERSE', 'device') != 'host' else None
+		inv = _spd_inverse_device(eng, mt_d, nx, rx.ss) if _opts.debug('s4_inverse', 'device') != 'host' else None
 		if inv is None:
 			mt = mt_d[:nx, :nx].cpu().numpy()
 			mt = np.triu(mt) + np.triu(mt, 1).T
@@ -478,7 +478,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 		# the genes: K1 and the large contraction
 		if lists is not None:
 			from . import de_sparse
-			if os.environ.get('NRM_S4_SPARSE_M', '1') == '0':
+			if _opts.debug('s4_sparse_m', '1') == '0':
 				sp_flags = eng.new_flags()
 			g_d, ssy, coefy = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, not lowmem, True, sp_flags)
 			if int(sp_flags[2]) > 0:  # rows all but inside the span of the covariates: K1's two sweeps and the fp64 Gram kernel for this call
