@@ -99,6 +99,10 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			varx = np.empty(nx)
 			pitch = 26 + nc + nc * nc
 			kp = ry.k_pad
+			if nc:
+				cp = eng.zeros((_round_up(nc, ROW_TILE), kp), torch.float64)
+				eng.copy_rows(cp, d_c)
+				cpad = _engine.Residualized(nc, n, cp, None, None)
 			for i0 in range(0, nx, chunk):
 				i1 = min(nx, i0 + chunk)
 				m = i1 - i0
@@ -122,8 +126,9 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 				info = np.zeros((m, pitch))
 				rk = np.zeros(m, dtype=np.int64)
 				if nc:
-					mc = torch.einsum('icn,dn->icd', wv[:, :nc, :n], d_c).cpu().numpy()       # (m, nc, nc)
-					xc = torch.einsum('in,dn->id', wv[:, nc, :n], d_c).cpu().numpy()          # (m, nc)
+					# W against the covariate rows on the fp64 Gram kernel (rounds 3-4: two torch.einsum calls -- rocBLAS behind torch on a product path)
+					gc = eng.gram(W, cpad, False)[:m * nw, :nc].cpu().numpy().reshape(m, nw, nc)
+					mc, xc = np.ascontiguousarray(gc[:, :nc, :]), np.ascontiguousarray(gc[:, nc, :])  # (m, nc, nc), (m, nc)
 					mi, rk = small_pinv(mc)  # association.py:350-351, all groupings of the chunk
 					mi[rk == 0] = 0
 					ccx = np.einsum('icd,id->ic', mi, xc)
