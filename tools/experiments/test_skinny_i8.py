@@ -55,27 +55,3 @@ def test_streaming_de_on_the_int8_matrix_cores(eng, dtype, n, ny, nc, monkeypatc
 	ok2 = po2[0] >= tiny
 	ok2[0, 4] = False
 	assert relerr(changed[0][ok2], po2[0][ok2]) < tol
-
-
-_TORCH_FREE = r'''
-import sys
-sys.modules['torch'] = None  # any `import torch` in this process now raises ImportError
-import ctypes, numpy as np
-lib = ctypes.CDLL(sys.argv[1])
-lib.nrm_last_error.restype = ctypes.c_char_p
-d = np.load(sys.argv[2])
-dt, dc, dci = d['dt'], d['dc'], d['dci']
-ng, n = dt.shape
-p, dot, var = np.empty((ng, ng)), np.empty((ng, ng)), np.empty(ng)
-vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-i64 = ctypes.c_int64
-rc = lib.nrm_association_tests_host(vp(dt), 1, i64(ng), None, 0, i64(0), vp(dc), 1, i64(dc.shape[0]), i64(n), vp(dci), int(d['rank']), 0, 1,
-	vp(p), vp(dot), None, None, vp(var), None, None, 1)
-assert rc == 0, lib.nrm_last_error()
-hits, worst = i64(-1), ctypes.c_double(-1)
-assert lib.nrm_last_guard(ctypes.byref(hits), ctypes.byref(worst)) == 0
-assert 'torch' not in [m for m, v in sys.modules.items() if v is not None]
-np.savez(sys.argv[3], p=p, dot=dot, var=var, hits=hits.value, worst=worst.value)
-'''
-
-
