@@ -80,12 +80,20 @@ std::vector<Piece> cut(const char* buf, int64_t len, int threads, char delim) {
 }
 
 // one field -> double, as Python's float(): blanks around it, an optional '+', inf / nan in any case, out-of-range -> +-inf / 0
+// (Only what float() takes: a NaN spelled with a payload, "nan(abc)", parses for from_chars / strtod and raises for numpy.loadtxt; a '\r' inside a
+// line is a line break for numpy's text reader -- neither is a blank here, so such text fails to parse and the caller hands the file to
+// numpy.loadtxt itself, whose answer or exception then is the reference's: run.py, _read_text.)
+inline bool inner_blank(char ch) { return ch == ' ' || ch == '\t' || ch == '\v' || ch == '\f'; }
+inline bool plain_nan(const char* a, const char* e) {
+	if (a < e && (*a == '+' || *a == '-')) a++;
+	return e - a == 3 && (a[0] | 32) == 'n' && (a[1] | 32) == 'a' && (a[2] | 32) == 'n';
+}
 inline bool field(const char* a, const char* e, double& v) {
-	while (a < e && blank(*a)) a++;
-	while (e > a && blank(e[-1])) e--;
+	while (a < e && inner_blank(*a)) a++;
+	while (e > a && inner_blank(e[-1])) e--;
 	if (a == e) return false;
 	auto r = std::from_chars(a, e, v);
-	if (r.ec == std::errc() && r.ptr == e) return true;
+	if (r.ec == std::errc() && r.ptr == e) return v == v || plain_nan(a, e);
 	if (e - a > 400) return false;
 	char tmp[408];
 	memcpy(tmp, a, (size_t)(e - a));
@@ -96,7 +104,7 @@ inline bool field(const char* a, const char* e, double& v) {
 	if ((s[0] == '0' && (s[1] == 'x' || s[1] == 'X')) || (s[0] == '-' && s[1] == '0' && (s[2] == 'x' || s[2] == 'X'))) return false;  // float() takes no hex
 	char* stop = nullptr;
 	v = strtod(s, &stop);
-	return stop && *stop == 0 && stop != s;
+	return stop && *stop == 0 && stop != s && (v == v || plain_nan(a, e));
 }
 
 struct Fail {

@@ -61,7 +61,10 @@ def _read_text(f, delimiter, dtype):
 	buf = _open_bytes(f)
 	if buf is None:
 		return None
-	out = parse_text(buf, delimiter, dtype)
+	try:
+		out = parse_text(buf, delimiter, dtype)
+	except ValueError:
+		return None  # text the library's parser does not take: numpy.loadtxt answers -- its matrix or its exception are the reference's (run.py:20-27)
 	return None if out is None else out.squeeze()  # loadtxt's own squeeze (a single row or column comes back 1-D)
 
 
