@@ -253,8 +253,8 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 	"""All-pairs association tests between rows of dx and dy (or dx with itself when dy is None).
 
 	Same contract as association.py:761-1093: returns (P-values, dot|gamma, alpha|None, varx|None, vary).
-	single=0 runs on the device; single=1 (per-grouping cell subsets) and single=4 (other X as covariates) run the
-	closed-form device paths in normalisr_amd.single1 / .single4.  bsx, bsy, nth, bs4 are accepted and ignored (see module docstring).
+	single=0 runs on the device; single=1 (per-grouping cell subsets), single=4 (other X as covariates) and single=5 (single=4 under a mask of
+	allowed pairs, mask=...) run the closed-form device paths in normalisr_amd.single1 / .single4 / .single5.  bsx, bsy, nth, bs4 are accepted and ignored (see module docstring).
 	With return_stats=True a sixth element {'r':..., 't':..., 'dof':...} is appended.  With device_out=True (single=0 only)
 	the two (n_x, n_y) matrices are returned as torch tensors resident in HBM (e.g. to feed binnet without crossing PCIe).
 	device=<index> runs the call on that GPU instead of the current one (also engine.use_device, NORMALISR_DEVICE).
@@ -288,7 +288,12 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		from .single1 import association_tests_single1
 		return association_tests_single1(dx, dy, dc, lowmem=lowmem, return_dot=return_dot, return_stats=return_stats, **ka)
 	if single == 5:
-		raise NotImplementedError('single=5 is under development in the reference and not provided.')
+		from .single5 import association_tests_single5
+		if return_stats:
+			raise NotImplementedError('return_stats is only available for single=0.')
+		if 'mask' not in ka:
+			raise KeyError('mask')  # association.py:969: ka0.pop('mask')
+		return association_tests_single5(dx, dy, dc, ka.pop('mask'), bsx=bsx, bsy=bsy, lowmem=lowmem, return_dot=return_dot, **ka)
 	if single == 4:
 		from .single4 import association_tests_single4
 		return association_tests_single4(dx, dy, dc, lowmem=lowmem, return_dot=return_dot, return_stats=return_stats, **ka)

@@ -217,6 +217,54 @@ def _test4_block(vx, vy, prod, prody, prodyy, na, dimreduce=0, lowmem=False, **k
 	return [vx, vy, p, gam, alpha, None if samexy else vxo, vyo]
 
 
+def _test5_block(vx, vy, prod, prody, prodyy, na, mask, dimreduce=0, lowmem=False, **ka):
+	"""association.py:579-728 ("under development" upstream): like association_test_4, but only the pairs (x, y) the mask allows are tested, and
+	the covariates of a pair are the OTHER x's the mask allows for this y plus the real covariates (:671-676).  Restated with the reference's
+	quirk: the variance of x is written to its whole ROW of the (lenx, ny) block (:699), so after the loop a row holds the value of the
+	last allowed pair of that row in the block."""
+	nx, ny, nc, n, lenx = na
+	p = np.zeros((lenx, ny))
+	vxo = np.zeros((lenx, ny))
+	vyo = np.zeros((lenx, ny))
+	gam = np.zeros((lenx, ny))
+	alpha = None if lowmem else np.zeros((lenx, ny, nc))
+	rank = np.zeros((lenx, ny), dtype=int)
+	it = np.array(np.nonzero(mask)).T  # row by row (:664-666)
+	it = it[(it[:, 0] >= vx) & (it[:, 0] < vx + lenx)]
+	it[:, 0] -= vx
+	for i, j in it:
+		t0 = [k for k in list(np.nonzero(mask[:, j])[0]) + list(np.arange(nc) + nx) if k != vx + i]  # :669-676
+		if len(t0) > 0:
+			t1i, r = inv_rank(prod[np.ix_(t0, t0)], **ka)
+		else:
+			r = 0
+		rank[i, j] = r
+		if r == 0:
+			dxx, dyy, dxy = prod[vx + i, vx + i] / n, prodyy[j] / n, prody[vx + i, j] / n
+		else:
+			ccx = np.matmul(prod[[vx + i], t0], t1i)
+			dxx = (prod[vx + i, vx + i] - float(np.matmul(ccx, prod[t0, [vx + i]]))) / n
+			ccy = np.matmul(prody[t0, j], t1i)
+			dyy = (prodyy[j] - np.matmul(ccy, prody[t0, j])) / n
+			dxy = (prody[vx + i, j] - np.matmul(ccy, prod[t0, vx + i])) / n
+		if dxx == 0:
+			dxx = 1
+		vxo[i] = dxx  # (the whole row: :699)
+		vyo[i, j] = dyy
+		gam[i, j] = dxy / dxx
+		if (not lowmem) and r > 0:
+			alpha[i, j] = (ccy[-nc:] - gam[i, j] * ccx.ravel()[-nc:]) if nc > 0 else 0
+		p[i, j] = (dxy**2) / (dxx * dyy)
+	assert (p >= 0).all() and (p <= 1 + 1E-8).all()
+	dof = n - 1 - rank - dimreduce
+	if (dof <= 0).any():
+		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+	for d in np.unique(dof):
+		sel = dof == d
+		p[sel] = pvalues(p[sel], d)
+	return [vx, vy, p, gam, alpha, vxo, vyo]
+
+
 def _test2_block(vx, vy, dx, dy, dc, sselectx, dimreduce=0, lowmem=False):
 	"""association.py:263-390: like association_test_1 but every x uses its own subset of cells."""
 	nx, n = dx.shape
@@ -263,7 +311,8 @@ def _test2_block(vx, vy, dx, dy, dc, sselectx, dimreduce=0, lowmem=False):
 
 
 def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, **ka):
-	"""association.py:761-1093 for single=0 (any dy), single=1 and single=4 (dy is not None)."""
+	"""association.py:761-1093 for single=0 (any dy), single=1, single=4 and single=5 (mask=...: the targets are the first ny rows of [dx; dc], as the
+	reference takes them from its Gram matrix whatever dy holds, :969-980)."""
 	samexy = dy is None
 	if samexy:
 		dy = dx
@@ -274,11 +323,13 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		bsx, bsy = _auto_batchsize(bsx, bsy, dx.dtype.itemsize, dy.dtype.itemsize, dc.dtype.itemsize, nc, ns, samexy)
 	elif single == 4:
 		bsx, bsy = _auto_batchsize(bsx, bsy, dx.dtype.itemsize, dy.dtype.itemsize, dc.dtype.itemsize, nc, ns, samexy, maxx=10, maxy=500000)
+	elif single == 5:
+		bsx, bsy = _auto_batchsize(bsx, bsy, dx.dtype.itemsize, dy.dtype.itemsize, dc.dtype.itemsize, nc, ns, samexy, maxx=500000, maxy=10)
 	else:
 		raise ValueError('Unknown value single={}'.format(single))
 	tiles = itertools.product([(a, min(a + bsx, nx)) for a in range(0, nx, bsx)],
 							  [(b, min(b + bsy, ny)) for b in range(0, ny, bsy)])
-	if samexy:
+	if samexy and single != 5:
 		tiles = [t for t in tiles if t[0][0] <= t[1][0]]  # :893-894
 	ka0 = dict(ka, lowmem=lowmem)
 	if single == 0:
@@ -300,7 +351,13 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		prod = np.matmul(t1, t1.T)
 		dr = ka0.pop('dimreduce', 0)
 		drs = (lambda y: dr[y[0]:y[1]]) if np.ndim(dr) else (lambda y: dr)
-		if samexy:  # :974-980: the Gram matrix alone; association_test_4 takes its y products from it
+		if single == 5:  # :969-980
+			mask = np.asarray(ka0.pop('mask'))
+			assert mask.shape == (nx, ny)
+			dg = np.diag(prod)
+			tasks = [(_test5_block, (x[0], y[0], prod, prod[:, y[0]:y[1]], dg[y[0]:y[1]], [nx, y[1] - y[0], nc, ns, x[1] - x[0]], mask[:, y[0]:y[1]]),
+					  dict(ka0, dimreduce=drs(y))) for x, y in tiles]
+		elif samexy:  # :974-980: the Gram matrix alone; association_test_4 takes its y products from it
 			tasks = [(_test4_block, (x[0], y[0], prod, None, None, [nx, y[1] - y[0], nc, ns, x[1] - x[0]]), dict(ka0, dimreduce=drs(y)))
 					 for x, y in tiles]
 		else:
@@ -313,7 +370,7 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 	p = np.ones((nx, ny), dtype=dy.dtype)  # :1005
 	dot = np.zeros((nx, ny), dtype=dy.dtype)
 	alpha = None if lowmem else np.zeros((nx, ny, nc), dtype=dy.dtype)
-	varx = None if samexy else np.zeros((nx, ), dtype=dy.dtype)
+	varx = np.zeros((nx, ny), dtype=dy.dtype) if single == 5 else (None if samexy else np.zeros((nx, ), dtype=dy.dtype))
 	vary = np.zeros((ny, ) if single == 0 else (nx, ny), dtype=dy.dtype)
 	for r in res:
 		i, j = r[0], r[1]
@@ -321,13 +378,18 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		dot[i:i + r[3].shape[0], j:j + r[3].shape[1]] = r[3]
 		if not lowmem:
 			alpha[i:i + r[4].shape[0], j:j + r[4].shape[1]] = r[4]
-		if not samexy:
+		if single == 5:
+			varx[i:i + r[5].shape[0], j:j + r[5].shape[1]] = r[5]
+		elif not samexy:
 			varx[i:i + r[5].shape[0]] = r[5]
 		if single == 0:
 			vary[j:j + r[6].shape[0]] = r[6]
 		else:
 			vary[i:i + r[6].shape[0], j:j + r[6].shape[1]] = r[6]
-	if samexy:
+	if single == 5:
+		if return_dot:
+			dot = dot * varx  # :1045-1046
+	elif samexy:
 		dot = (dot.T * vary).T if single == 0 else dot * vary  # :1039-1042  coefficient -> covariance x~_i.x~_j/n
 		p = np.triu(p, 1)
 		p = p + p.T  # :1050-1051  diagonals exactly 0

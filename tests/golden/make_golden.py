@@ -400,6 +400,28 @@ def g14():
 	save('G14_c2', seed=14, rows=rows, check=np.array([float(dt.astype(np.float64).sum()), dc.sum()]), p=p[rows], dot=d[rows], var=v)
 
 
+def g15():
+	"""single=5 (association.py:579-728,969-980; "under development" upstream): every row of dx as a target, only the pairs a mask allows are tested,
+	the other allowed rows of the same target join the covariates.  Default tiles (targets in blocks of 10) and small ones (the variance of x is
+	written per block: a quirk that makes it depend on the tiling), lowmem on / off, return_dot on / off, a repeated covariate row (rank-deficient sets)."""
+	rng = np.random.default_rng(15)
+	nx, n = 23, 400
+	dx = rng.normal(size=(nx, n))
+	dx[2] += 0.5 * dx[0]
+	dx[5] += 0.7 * dx[2] - 0.3 * dx[1]
+	r1 = rng.normal(size=(1, n))
+	dc = np.vstack([r1, r1, np.ones((1, n))])  # a repeated covariate row: every covariate set is rank deficient (the truncated pseudo-inverse, :677-678)
+	mask = rng.random((nx, nx)) < 0.3
+	np.fill_diagonal(mask, False)
+	out = dict(dx=dx, dc=dc, mask=mask)
+	for name, kw in (('a', dict(lowmem=False)), ('b', dict(return_dot=False)), ('c', dict(bsx=5, bsy=4, lowmem=False)), ('d', dict(dimreduce=2))):
+		p, d, a, vx, vy = association_tests(dx, None, dc, single=5, mask=mask, **kw)
+		out.update({name + '_p': p, name + '_dot': d, name + '_vx': vx, name + '_vy': vy})
+		if a is not None:
+			out[name + '_alpha'] = a
+	save('G15_single5', **out)
+
+
 def main():
 	if len(sys.argv) > 1:  # selected fixtures only, e.g. `make_golden.py g11`
 		for name in sys.argv[1:]:
@@ -418,6 +440,7 @@ def main():
 	g11()
 	g13()
 	g14()
+	g15()
 	meta = dict(sklearn=skl, reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:

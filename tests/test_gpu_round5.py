@@ -399,3 +399,36 @@ def test_normvar_on_the_device_and_the_resident_chain(golden, norm, eng, monkeyp
 	assert np.array_equal(p.cpu().numpy(), hp) and np.array_equal(net.cpu().numpy(), binnet(hp, 0.05)) and net.any()
 	po = oracle.coex(oracle.normvar(dt.astype(np.float64), dc, w, wt)[0], h_dcn)[0]
 	assert p_close(hp, po, 1e-5)
+
+
+def test_single5_with_a_mask(golden):
+	"""association_tests(dx, None, dc, single=5, mask=...) (association.py:579-728,969-980, "under development" upstream: the one function of the
+	reference's association module without a counterpart until round 5): the Gram matrix of [dx; dc] on the device, one regression per target in
+	closed form (the reference: one pseudo-inverse per allowed pair), the per-pair algorithm where a target's set is rank deficient.  Golden G15 --
+	the reference's own outputs, incl. its per-block variance of x and a repeated covariate row -- and a larger seeded case against the oracle."""
+	from normalisr_amd.association import association_tests
+	g = golden('G15_single5')
+	for name, kw in (('a', dict(lowmem=False)), ('b', dict(return_dot=False)), ('c', dict(bsx=5, bsy=4, lowmem=False)), ('d', dict(dimreduce=2))):
+		p, d, a, vx, vy = association_tests(g['dx'], None, g['dc'], single=5, mask=g['mask'], **kw)
+		assert p_close(p, g[name + '_p']) and close(d, g[name + '_dot'], 1e-6, 1e-12) and close(vx, g[name + '_vx'], 1e-9, 1e-12) and close(vy, g[name + '_vy'], 1e-9, 1e-12)
+		assert (p[~g['mask']] == 1).all() and (d[~g['mask']] == 0).all() and (vy[~g['mask']] == 0).all()
+		if name + '_alpha' in g.files:
+			assert close(a, g[name + '_alpha'], 1e-6, 1e-9)
+		else:
+			assert a is None
+	# a sparse prior network over 300 variables, full-rank sets (closed form for every target), fp32 rows
+	rng = np.random.default_rng(150)
+	nx, n = 300, 3000
+	f = rng.normal(size=(6, n))
+	dx = (rng.normal(size=(nx, n)) + 0.6 * rng.normal(size=(nx, 6)) @ f).astype(np.float32)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	mask = rng.random((nx, nx)) < 0.03
+	np.fill_diagonal(mask, False)
+	got = association_tests(dx, None, dc, single=5, mask=mask, lowmem=False, return_dot=False)
+	ref = oracle.association_tests(dx.astype(np.float64), None, dc, single=5, mask=mask, lowmem=False, return_dot=False)
+	assert got[0].dtype == np.float32 and got[3].shape == (nx, nx)
+	ok = mask & (ref[0] > 1e-30)
+	assert relerr(got[0][ok], ref[0][ok]) < 2e-5 and close(got[1], ref[1], 2e-5, 1e-6) and close(got[3], ref[3], 2e-6, 1e-9) and close(got[4], ref[4], 2e-6, 1e-9)
+	assert close(got[2], ref[2], 2e-4, 1e-5) and (got[0][~mask] == 1).all()
+	with pytest.raises(KeyError):
+		association_tests(dx, None, dc, single=5)

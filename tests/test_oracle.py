@@ -177,6 +177,23 @@ def test_single4_variants_golden(golden):
 	assert relerr(p, g['s1c_p']) < 1e-8 and relerr(gam, g['s1c_gamma'], 1e-12) < 1e-8 and relerr(a, g['s1c_alpha'], 1e-10) < 1e-8
 
 
+G15_CASES = (('a', dict(lowmem=False)), ('b', dict(return_dot=False)), ('c', dict(bsx=5, bsy=4, lowmem=False)), ('d', dict(dimreduce=2)))
+
+
+def test_single5_masked_golden(golden):
+	"""G15: single=5 with a mask (association.py:579-728,969-980) -- the oracle's restatement on the reference's own outputs: default and small
+	tiles (the per-block variance of x), alpha, both forms of the statistic, a repeated covariate row (truncated pseudo-inverses)."""
+	g = golden('G15_single5')
+	for name, kw in G15_CASES:
+		p, d, a, vx, vy = oracle.association_tests(g['dx'], None, g['dc'], single=5, mask=g['mask'], **kw)
+		assert relerr(p, g[name + '_p'], 1e-300) < 1e-8 and relerr(d, g[name + '_dot'], 1e-12) < 1e-8 and relerr(vx, g[name + '_vx'], 1e-12) < 1e-10
+		assert relerr(vy, g[name + '_vy'], 1e-12) < 1e-10 and (p[~g['mask']] == 1).all() and (d[~g['mask']] == 0).all()
+		if name + '_alpha' in g.files:
+			assert relerr(a, g[name + '_alpha'], 1e-10) < 1e-8
+		else:
+			assert a is None
+
+
 def test_g11_rows_that_are_hard_for_fixed_point(golden):
 	"""G11 (4096 cells, reference-generated): sparse log1p-count rows, 0/1 rows, rows with a huge mean, heavy tails and single
 	spikes under intercept-only, one-hot-batch, near-collinear and no covariates.  The oracle is fp64 like the reference, so it
