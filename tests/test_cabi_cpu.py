@@ -67,8 +67,10 @@ def test_argument_validation_before_device():
 		association_tests(x[:, :2], None, c[:, :2])  # n <= rank + 1
 	with pytest.raises(NotImplementedError):
 		association_tests(x, None, c, single=1)  # dy=None with single=1 (association.py:912)
-	with pytest.raises(NotImplementedError):
-		association_tests(x, None, c, single=5)
+	with pytest.raises(KeyError):
+		association_tests(x, None, c, single=5)  # single=5 needs mask= (association.py:969: ka0.pop('mask'))
+	with pytest.raises(AssertionError):
+		association_tests(x, None, c, single=5, mask=np.ones((2, 2), dtype=bool))  # mask.shape == (n_x, n_y) (association.py:970)
 	with pytest.raises(TypeError):
 		association_tests(x, None, c, bogus=1)
 	with pytest.raises(ValueError):
