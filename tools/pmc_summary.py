@@ -13,7 +13,7 @@ import sys
 
 import pandas as pd
 
-WIDE = {'k_de_sparse': True, 'k_s1_stream': True, 'k_s1_cells': False, 'k_binnet_rows': True, 'k_residualize_res': True, 'k_s4_sweep': False, 'k_fix_dot': False, 'k_gram_skinny': True, 'k_gram_f64': True, 'k_gram_i8': True, 'k_quantize_rows': True, 'k_residualize_v4': True, 'k_assoc_sweep_sym': False, 'k_assoc_sweep': False, 'k_residualize': False}
+WIDE = {'k_dl_count': True, 'k_dl_fill': True, 'k_ds_ct': False, 'k_nv_moments': False, 'k_nv_apply': False, 'k_nv_weights': False, 'k_de_sparse': True, 'k_s1_stream': True, 'k_s1_cells': False, 'k_binnet_rows': True, 'k_residualize_res': True, 'k_s4_sweep': False, 'k_fix_dot': False, 'k_gram_skinny': True, 'k_gram_f64': True, 'k_gram_i8': True, 'k_quantize_rows': True, 'k_residualize_v4': True, 'k_assoc_sweep_sym': False, 'k_assoc_sweep': False, 'k_residualize': False}
 
 
 def main(dirs):
