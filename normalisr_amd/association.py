@@ -248,6 +248,56 @@ def _single0_host_entry(dx, dy, dc64, dci, dcr, dimreduce, return_dot, want_alph
 	return dict(p=p, stat=stat, alpha=alpha, varx=varx, vary=vary, r=r, t=t, dof=n - 1 - dcr - dimreduce)
 
 
+def _use_host_entry():
+	return os.environ.get('NRM_HOST_ENTRY', '') == '1' or not _have_torch()
+
+
+def _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka):
+	"""single=1 / single=4 through nrm_association_tests_single1_host / _single4_host (include/normalisr_hip.h): host buffers in and out, no torch --
+	what `normalisr de -m single|covariate` needs in a process that has numpy and the library only.  NotImplementedError (NRM_E_UNSUPPORTED) for the
+	calls the entries do not cover (per-gene dimreduce, mpc / method / qr, rank-deficient designs, negative entries, dy=None): with torch present the
+	caller then takes the package's device paths."""
+	import ctypes
+	ka = dict(ka)
+	dimreduce = ka.pop('dimreduce', 0)
+	tol = ka.pop('tol', 1E-8)
+	if single == 4 and (ka.pop('method', 'auto') != 'auto' or ka.pop('mpc', 0) != 0 or ka.pop('qr', 0) != 0):
+		raise NotImplementedError('single=4 host entry: inv_rank options other than tol follow the per-grouping algorithm (needs the package\'s device path)')
+	if ka:
+		raise TypeError("association_test_{}() got an unexpected keyword argument '{}'".format(2 if single == 1 else 4, next(iter(ka))))
+	if dy is None or np.ndim(dimreduce) != 0:
+		raise NotImplementedError('single={} host entry: dy=None and per-gene dimreduce need the package\'s device path'.format(single))
+	if int(dimreduce) != dimreduce or dimreduce < 0:
+		raise ValueError('dimreduce must be a non-negative integer.')
+	nx, n = dx.shape
+	ny, nc = dy.shape[0], dc.shape[0]
+	if dc.shape[1] != n or dy.shape[1] != n:
+		raise ValueError('Unmatching dx/dy/dc dimensions.')
+	if nx == 0 or ny == 0 or n == 0:
+		raise ValueError('Dimensions in na==0 detected.')
+	if nc == 0:
+		logging.warning('No covariate dc input.')
+	odt = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	dx, dy = _engine.as_input(dx), _engine.as_input(dy)
+	dc64, dci, dcr = _prepare_covariates(dc)
+	dc64 = np.ascontiguousarray(dc64)
+	dci = np.ascontiguousarray(dci, dtype=np.float64)
+	lib = _lib.load()
+	code = lambda a: _lib.NRM_F64 if a.dtype == np.float64 else _lib.NRM_F32
+	vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+	p, stat, vary = (np.empty((nx, ny), dtype=odt) for _ in range(3))
+	varx = np.empty(nx, dtype=odt)
+	alpha = None if lowmem else np.empty((nx, ny, nc), dtype=odt)
+	ocode = _lib.NRM_F64 if odt == np.float64 else _lib.NRM_F32
+	if single == 1:
+		_lib.check(lib.nrm_association_tests_single1_host(vp(dx), code(dx), nx, vp(dy), code(dy), ny, vp(dc64), _lib.NRM_F64, nc, n, int(dimreduce), 1 if return_dot else 0,
+														  vp(p), vp(stat), vp(alpha), vp(varx), vp(vary), ocode))
+	else:
+		_lib.check(lib.nrm_association_tests_single4_host(vp(dx), code(dx), nx, vp(dy), code(dy), ny, vp(dc64), _lib.NRM_F64, nc, n, vp(dci), int(dcr), int(dimreduce),
+														  1 if return_dot else 0, float(tol), vp(p), vp(stat), vp(alpha), vp(varx), vp(vary), ocode))
+	return (p, stat, alpha, varx, vary)
+
+
 def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, bs4=500,
 					  return_stats=False, device_out=False, **ka):
 	"""All-pairs association tests between rows of dx and dy (or dx with itself when dy is None).
@@ -282,6 +332,13 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		dy = np.asarray(dy)
 	if dx.ndim != 2 or dc.ndim != 2 or (not samexy and dy.ndim != 2):
 		raise ValueError('Incorrect dx/dy/dc size.')
+	if single in (1, 4) and _use_host_entry() and not return_stats and not device_out and not is_dev(dx) and not (dy is not None and is_dev(dy)):
+		# no torch in this process (or asked for): the library's whole-problem entries for `de -m single|covariate`
+		try:
+			return _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka)
+		except NotImplementedError:
+			if not _have_torch():
+				raise
 	if single == 1:
 		if samexy:
 			raise NotImplementedError('dy=None with single=1')
@@ -319,7 +376,7 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 		raise ValueError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
 	if samexy and not lowmem:
 		raise NotImplementedError('alpha for dy=None is not meaningful in the reference (symmetrised) and is not provided.')
-	if os.environ.get('NRM_HOST_ENTRY', '') == '1' or not _have_torch():
+	if _use_host_entry():
 		# no torch in this process (or asked for): the library's own whole-problem entry, numpy buffers in and out
 		if device_out:
 			raise RuntimeError('device_out=True returns torch tensors: torch is needed for it.')

@@ -71,6 +71,18 @@ def binnet(net, qcut):
 		raise ValueError('Wrong shape of net or namet.')
 	if qcut <= 0 or qcut >= 1:
 		raise ValueError('Q-value cutoff must be between 0 and 1.')
+	from .association import _use_host_entry
+	if not on_device and _use_host_entry():
+		# no torch in this process (or NRM_HOST_ENTRY=1): the library's whole-problem entry, numpy buffers in and out
+		import ctypes
+		hp = _engine.as_input(net)
+		out = np.empty((nt, nt), dtype=np.uint8)
+		total = ctypes.c_int64(-1)
+		_lib.check(_lib.load().nrm_binnet_host(hp.ctypes.data_as(ctypes.c_void_p), _lib.NRM_F64 if hp.dtype == np.float64 else _lib.NRM_F32, nt, float(qcut),
+											   out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)))
+		if total.value == 0:
+			raise RuntimeError('Empty binary network.')
+		return out.view(np.bool_)
 	eng = _engine.get_engine()
 	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
 		torch = eng.torch

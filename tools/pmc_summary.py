@@ -5,7 +5,9 @@
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
 on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced stream, so it is doubled for kernels
-whose loads are that wide (K2, vectorised K1, K3's 8 B/lane tile reads are left uncorrected and flagged)."""
+whose loads are that wide (K2, vectorised K1).  Round 5 calibrated two narrower patterns on known byte counts, as the guide asks for other widths: the
+normvar kernels' 4 B/lane coalesced row reads (200 MB read, 102.6 MB reported) and K3's 8 B/lane reads of the product matrix (120 MB read, 61.1 MB
+reported) are halved in the same way -- a wave's contiguous 256 / 512 B are 128-byte requests tallied at 64 -- and doubled here as well."""
 import glob
 import json
 import os
@@ -13,7 +15,7 @@ import sys
 
 import pandas as pd
 
-WIDE = {'k_dl_count': True, 'k_dl_fill': True, 'k_ds_ct': False, 'k_nv_moments': False, 'k_nv_apply': False, 'k_nv_weights': False, 'k_de_sparse': True, 'k_s1_stream': True, 'k_s1_cells': False, 'k_binnet_rows': True, 'k_residualize_res': True, 'k_s4_sweep': False, 'k_fix_dot': False, 'k_gram_skinny': True, 'k_gram_f64': True, 'k_gram_i8': True, 'k_quantize_rows': True, 'k_residualize_v4': True, 'k_assoc_sweep_sym': False, 'k_assoc_sweep': False, 'k_residualize': False}
+WIDE = {'k_dl_count': True, 'k_dl_fill': True, 'k_ds_ct': False, 'k_nv_moments': True, 'k_nv_apply': True, 'k_nv_weights': True, 'k_de_sparse': True, 'k_s1_stream': True, 'k_s1_cells': False, 'k_binnet_rows': True, 'k_residualize_res': True, 'k_s4_sweep': False, 'k_fix_dot': False, 'k_gram_skinny': True, 'k_gram_f64': True, 'k_gram_i8': True, 'k_quantize_rows': True, 'k_residualize_v4': True, 'k_assoc_sweep_sym': True, 'k_assoc_sweep': True, 'k_residualize': False}
 
 
 def main(dirs):
