@@ -118,10 +118,19 @@ def design_stats(eng, lists, d_c, d_dci, rank, nx, nc, flags=None):
 
 def run(eng, d_x, lists, dy, d_c, d_dci, rank, nx, ny, n, nc, want_coef, flags=None):
 	"""The design rows' statistics from their entries, the one-pass kernels on the expression rows.
-	Returns (dot (nx_pad, ny_pad) fp64 with dot[i, y] = x~_i . y~_y, rx, ssy, coefy)."""
+	Returns (dot (nx_pad, ny_pad) fp64 with dot[i, y] = x~_i . y~_y, rx, ssy, coefy); rx.yraw = the raw rows' |y|^2."""
 	rx = design_stats(eng, lists, d_c, d_dci, rank, nx, nc, flags)
-	dot, ssy, coefy = products(eng, lists, dy, d_c, d_dci, rank, rx.coef, nx, ny, n, nc, want_coef, False, flags)
+	dot, ssy, coefy, common = products(eng, lists, dy, d_c, d_dci, rank, rx.coef, nx, ny, n, nc, want_coef, False, flags)
+	rx.yraw = common[-1]  # |y|^2 of the raw rows (flagged_rows)
 	return dot, rx, ssy, coefy
+
+
+def flagged_rows(eng, ssy, yraw, ny):
+	"""Indices (device, int64) of the expression rows k_de_sparse counted into flags[2]: |y~|^2 < 1e-4 |y|^2 (the kernel's own test, on what it
+	stored).  Only looked at after the counter came back non-zero -- the exceptional path, a few torch launches."""
+	torch = eng.torch
+	s, q = ssy[:ny], yraw[:ny]
+	return torch.nonzero(~(s >= 1e-4 * q) & (q > 0)).reshape(-1)
 
 
 def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_gene, flags=None):
@@ -161,7 +170,7 @@ def products(eng, lists, dy, d_c, d_dci, rank, bx, nx, ny, n, nc, want_coef, by_
 										 lists.slot2x.data_ptr(), bx.data_ptr() if ncu else 0, max(nc, 1), dot.data_ptr(), dot.stride(0), 1 if by_gene else 0, ssy.data_ptr(),
 										 coefy.data_ptr() if (coefy is not None and ncu) else 0, 0 if flags is None else flags.data_ptr(),
 										 d_c.data_ptr() if ncu else 0, d_c.stride(0) if ncu else n, ci, float(cval), 0 if ct is None else ct.data_ptr(), eng._stream()))
-	return dot, ssy, coefy
+	return dot, ssy, coefy, common
 
 
 assert __name__ != "__main__"

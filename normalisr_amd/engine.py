@@ -1232,13 +1232,48 @@ class Engine:
 			self.last_guard = dict(hits=0, worst=0.0, fallback=False)  # (fp64 sums of a few hundred terms: nothing to certify)
 			if resident and not (want_alpha or want_rt):
 				return dict(p=p, stat=stat, alpha=alpha, ssx=rx.ss, ssy=ssy, flags=flags, dof=dof)
-			self.check_flags(flags)
+			redo = self._sparse_flagged_rows(flags, ssy, rx.yraw, ny)
+			if redo is None:
+				self.check_flags(flags)  # (raises GuardHit for what the rows below do not cover: the whole call is then redone on the dense path)
 			keep = (lambda v: v) if device_out else self.download
-			res = dict(p=keep(p), stat=keep(stat), alpha=alpha, varx=self.variances(rx.ss, nx, n, out_dtype), vary=self.variances(ssy, ny, n, out_dtype), dof=dof)
+			vary = self.variances(ssy, ny, n, out_dtype)
+			r_h, t_h = (self.download(r), self.download(t)) if want_rt else (None, None)
+			if redo is not None:
+				# A few expression rows too close to the span of the covariates for the differences the kernel takes (csrc/nrm_de_sparse.hip): only THOSE
+				# rows are redone on K1's two sweeps and the fp64 Gram kernel and their columns replaced -- one high-mean, low-variance gene in
+				# 15 000 costs a 1000 x 1 problem, not the whole call on the dense path
+				import logging
+				logging.info('normalisr_amd: %d of %d expression rows too close to the span of the covariates for the sparse-design kernel: those rows redone on the fp64 matrix cores.',
+							 redo.numel(), ny)
+				rows_h = redo.cpu().numpy()
+				sub = dy[rows_h] if isinstance(dy, np.ndarray) else dy.index_select(0, redo)
+				with self.forced_f64():
+					part = self._association_single0(d_x, sub, dc, dci, rank, dimreduce, return_dot, want_alpha, out_dtype, want_rt, (d_c, d_dci), True, False)
+				as_dev = lambda v: v if hasattr(v, 'is_cuda') else self.torch.from_numpy(np.ascontiguousarray(v)).to(self.device)  # (the streaming de kernel answers in numpy)
+				p[:, redo] = as_dev(part['p'])
+				stat[:, redo] = as_dev(part['stat'])
+				vary[rows_h] = part['vary']
+				if alpha is not None:
+					alpha[:, rows_h] = part['alpha']
+				if want_rt:
+					r_h[:, rows_h], t_h[:, rows_h] = part['r'], part['t']
+				self.last_guard = dict(hits=int(redo.numel()), worst=0.0, fallback=True)
+			res = dict(p=keep(p), stat=keep(stat), alpha=alpha, varx=self.variances(rx.ss, nx, n, out_dtype), vary=vary, dof=dof)
 			if want_rt:
-				res['r'] = self.download(r)
-				res['t'] = self.download(t)
+				res['r'], res['t'] = r_h, t_h
 			return res
+
+	def _sparse_flagged_rows(self, flags, ssy, yraw, ny):
+		"""After a sparse-design call: the expression rows to redo on the dense path (device indices), or None -- nothing flagged, or a verdict the rows
+		do not explain (a design row flagged, the reference's assertions hit, more than an eighth of the rows): check_flags then speaks for the whole call."""
+		from . import de_sparse
+		f = flags.cpu().numpy()
+		if f[2] <= 0 or f[0] or f[1]:
+			return None
+		rows = de_sparse.flagged_rows(self, ssy, yraw, ny)
+		if rows.numel() != int(f[2]) or rows.numel() > max(1, ny // 8):
+			return None
+		return rows
 
 
 _engines = {}

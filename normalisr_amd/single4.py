@@ -447,7 +447,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 			rx = de_sparse.design_stats(eng, lists, d_c, d_dci, dcr, nx, nc, sp_flags)
 			nxp = _engine._round_up(nx, _lib.ROW_TILE)
 			mark('design rows')
-			mt_d, _, _ = de_sparse.products(eng, lists, d_x, d_c, d_dci, dcr, rx.coef, nx, nx, n, nc, False, False, sp_flags)  # (rows i, columns j; its upper triangle is used)
+			mt_d, _, _, _ = de_sparse.products(eng, lists, d_x, d_c, d_dci, dcr, rx.coef, nx, nx, n, nc, False, False, sp_flags)  # (rows i, columns j; its upper triangle is used)
 		else:
 			rx = eng.residualize(d_x, d_c, d_dci, dcr, want_coef=bool(nc), nslices=ns, keep_fp64=True)
 			nxp = rx.rows_pad
@@ -480,7 +480,7 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 			from . import de_sparse
 			if _opts.debug('s4_sparse_m', '1') == '0':
 				sp_flags = eng.new_flags()
-			g_d, ssy, coefy = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, not lowmem, True, sp_flags)
+			g_d, ssy, coefy, _ = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, not lowmem, True, sp_flags)
 			if int(sp_flags[2]) > 0:  # rows all but inside the span of the covariates: K1's two sweeps and the fp64 Gram kernel for this call
 				logging.info('single=4: %d rows (design or expression) too close to the span of the covariates for the sparse-design products; fp64 Gram kernel', int(sp_flags[2]))
 				return _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=True, device_out=device_out)

@@ -229,7 +229,43 @@ def test_sparse_design_path_hands_design_rows_near_the_covariate_span_back(monke
 	assert 'too close to the span of the covariates' in caplog.text and p_close(p4, ref4[0])
 
 
+@pytest.mark.parametrize('resident_rows', [False, True])
+def test_sparse_design_path_redoes_only_the_rows_near_the_covariate_span(monkeypatch, caplog, resident_rows):
+	"""One high-mean, low-variance gene among hundreds (|y~|^2 < 1e-4 |y|^2: the differences the sparse-design kernel takes lose their digits) used to send
+	the WHOLE call to K1 + the fp64 Gram kernel (round-4 advice).  Only the flagged rows are redone now and their columns replaced: results as the
+	oracle's for every row, P-values, statistic, alpha, variances, r and t; the log says how many rows."""
+	import logging
+	import torch
+	from normalisr_amd.association import association_tests
+	rng = np.random.default_rng(77)
+	nx, ny, n = 48, 300, 6000
+	dx = (rng.random((nx, n)) < 0.02).astype(np.float64)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dy = rng.normal(size=(ny, n)) + 9.0
+	bad = [17, 205]
+	dy[bad] = 1e3 + 1e-3 * rng.normal(size=(2, n))
+	dy[17] += 4e-4 * dx[3]
+	dy[40] += 0.6 * dx[5]
+	ref = oracle.association_tests(dx, dy, dc, return_dot=False, lowmem=False)
+	assert ref[0][3, 17] < 1e-4 and ref[0][5, 40] < 1e-6
+	monkeypatch.setenv('NRM_DE_SPARSE', 'force')
+	arg = torch.from_numpy(dy).cuda() if resident_rows else dy
+	with caplog.at_level(logging.INFO):
+		got = association_tests(dx, arg, dc, return_dot=False, lowmem=False, return_stats=True)
+	assert '2 of 300 expression rows too close to the span of the covariates' in caplog.text and 'redoing the call' not in caplog.text
+	assert p_close(got[0], ref[0]) and close(got[1], ref[1], 1e-6, 1e-12) and close(got[2], ref[2], 1e-6, 1e-9) and close(got[3], ref[3], 1e-9) and close(got[4], ref[4], 1e-7)
+	ro, to = oracle.pearson_r_t((ref[1].T * ref[3]).T, ref[3], ref[4], got[5]['dof'])  # dot = gamma varx
+	assert close(got[5]['r'], ro, 1e-6, 1e-9) and close(got[5]['t'], to, 1e-6, 1e-6)
+	# without the two rows: no redo at all
+	keep = np.setdiff1d(np.arange(ny), bad)
+	caplog.clear()
+	with caplog.at_level(logging.INFO):
+		p2 = association_tests(dx, dy[keep], dc, return_dot=False)[0]
+	assert 'too close to the span' not in caplog.text and p_close(p2, ref[0][:, keep])
+
+
 _TORCH_FREE_ENTRIES = r'''
+
 import ctypes, sys
 import numpy as np
 lib = ctypes.CDLL(sys.argv[1])
