@@ -1,0 +1,108 @@
+"""Seeded random shapes through the device paths built in round 5, against the oracle: de on sparse designs (the library's list kernels and the
+one-pass gather kernel), single=1 (the library's cell selection), single=4 on sparse designs, normvar on the device.  Each case is small enough
+for the oracle's loops; the shapes wander over what the fixed parity tests pin at a few points -- cell counts off every grid, one to several
+passes of design rows, 0 .. 9 covariates with and without an intercept, 0/1 and valued entries, fp32 and fp64 rows, empty design rows."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import relerr
+from test_gpu_parity import close, p_close
+
+pytestmark = pytest.mark.gpu
+_MORE = int(os.environ.get('NRM_TEST_SEEDS', '0'))  # a longer one-off sweep: NRM_TEST_SEEDS=300 python -m pytest tests/test_gpu_random_shapes.py
+
+
+def _case(seed, single=False):
+	"""single: a design the reference's single=1 / single=4 take (entries 0 / 1, single=1 asserts it at association.py:914; every grouping with cells; enough cells)."""
+	rng = np.random.default_rng(seed)
+	nx = int(rng.choice([1, 2, 7, 33, 64, 65, 130]))
+	ny = int(rng.integers(1, 70))
+	n = int(rng.choice([rng.integers(60, 300), rng.integers(2040, 2060), rng.integers(2100, 7000)]))
+	nc = int(rng.choice([0, 1, 2, 3, 5, 9]))
+	f32 = bool(rng.integers(0, 2))
+	valued = bool(rng.integers(0, 2)) and not single
+	if single:
+		n = max(n, 6 * (nx + nc))
+	dens = float(rng.choice([0.002, 0.01, 0.05]))
+	dx = (rng.random((nx, n)) < dens).astype(np.float64)
+	if valued:
+		dx *= rng.uniform(0.5, 2.0, dx.shape)
+	if nx > 2 and not single:
+		dx[int(rng.integers(0, nx))] = 0  # a design row without entries
+	if single:
+		for i in range(nx):  # every grouping has cells
+			dx[i, rng.integers(0, n, 4)] = 1
+	dx[0, :max(3, n // 50)] = 1.5 if valued else 1.0  # every case has entries; one list much longer than its neighbours'
+	dc = rng.normal(size=(nc, n))
+	if nc and rng.integers(0, 2):
+		dc[int(rng.integers(0, nc))] = rng.uniform(0.5, 2.0)  # an intercept (any constant)
+	dy = rng.normal(size=(ny, n)) + rng.uniform(0, 9)
+	dy[: min(ny, 3)] += 0.5 * dx[0]
+	if f32:
+		dx, dy = dx.astype(np.float32), dy.astype(np.float32)
+	return dx, dy, dc, f32
+
+
+def _tols(f32):
+	return (3e-4, 3e-5, 1e-6) if f32 else (1e-6, 1e-7, 1e-12)
+
+
+@pytest.mark.parametrize('seed', range(24 + _MORE))
+def test_de_on_random_sparse_designs(seed, monkeypatch):
+	from normalisr_amd.association import association_tests
+	dx, dy, dc, f32 = _case(seed)
+	monkeypatch.setenv('NRM_DE_SPARSE', 'force')
+	lowmem = bool(seed % 2)
+	got = association_tests(dx, dy, dc, return_dot=bool(seed % 3), lowmem=lowmem)
+	ref = oracle.association_tests(dx.astype(np.float64), dy.astype(np.float64), dc, return_dot=bool(seed % 3), lowmem=lowmem)
+	ptol, stol, floor = _tols(f32)
+	ok = ref[0] > (1e-30 if f32 else 1e-290)
+	assert got[0].shape == ref[0].shape and got[0].dtype == (np.float32 if f32 else np.float64)
+	assert relerr(got[0][ok], ref[0][ok]) < ptol, (seed, dx.shape, dy.shape, dc.shape)
+	assert close(got[1], ref[1], stol, floor * 1e3) and close(got[3], ref[3], stol, 1e-15) and close(got[4], ref[4], stol, 1e-15)
+	if not lowmem:
+		assert close(got[2], ref[2], 10 * stol, 1e-6 if f32 else 1e-9)
+
+
+@pytest.mark.parametrize('seed', range(1000, 1016 + _MORE))
+def test_single1_and_single4_on_random_sparse_designs(seed, monkeypatch):
+	from normalisr_amd.association import association_tests
+	dx, dy, dc, f32 = _case(seed, single=True)
+	monkeypatch.setenv('NRM_DE_SPARSE', 'force')
+	ptol, stol, floor = _tols(f32)
+	for single in (1, 4):
+		try:
+			ref = oracle.association_tests(dx.astype(np.float64), dy.astype(np.float64), dc, single=single, return_dot=False)
+		except Exception as e:  # the reference's own assertions on this draw (e.g. R^2 of a degenerate grouping): the device must raise as well
+			with pytest.raises(type(e)):
+				association_tests(dx, dy, dc, single=single, return_dot=False)
+			continue
+		got = association_tests(dx, dy, dc, single=single, return_dot=False)
+		ok = ref[0] > (1e-30 if f32 else 1e-290)
+		assert relerr(got[0][ok], ref[0][ok]) < ptol, (seed, single, dx.shape, dy.shape, dc.shape)
+		assert close(got[1], ref[1], stol, floor * 1e3) and close(got[3], ref[3], stol, 1e-15) and close(got[4], ref[4], stol, 1e-15)
+
+
+@pytest.mark.parametrize('seed', range(5000, 5012 + _MORE))
+def test_normvar_on_random_shapes(seed):
+	import normalisr_amd.normalisr as norm
+	rng = np.random.default_rng(seed)
+	ng, n, nc = int(rng.integers(1, 90)), int(rng.choice([rng.integers(30, 200), rng.integers(1000, 5000)])), int(rng.integers(1, 9))
+	f32 = bool(rng.integers(0, 2))
+	dt = rng.normal(size=(ng, n)) - 9
+	dc = rng.normal(size=(nc, n))
+	if rng.integers(0, 2):
+		dc[-1] = 1.0
+	if nc > 2 and rng.integers(0, 2):
+		dc[1] = 2.0 * dc[0]  # rank-deficient covariates: the integer ranks must follow inv_rank's rule
+	w, wt = np.exp(0.3 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
+	wt[rng.integers(0, ng)] = 0.0
+	if f32:
+		dt = dt.astype(np.float32)
+	got = norm.normvar(dt, dc, w, wt)
+	ref = oracle.normvar(dt.astype(np.float64), dc, w, wt)
+	scale = np.abs(ref[0]).max()
+	assert np.abs(got[0] - ref[0]).max() < (2e-5 if f32 else 1e-9) * scale and close(got[1], ref[1], 1e-12, 1e-15)
