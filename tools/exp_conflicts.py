@@ -39,7 +39,7 @@ for name in ('random offsets', 'bank quads distinct within every 16 lanes'):
 		if it == 2:
 			ev[0].record()
 		_lib.check(lib.nrm_de_sparse(dy.data_ptr(), 0, ny, n, n, common.data_ptr(), 0, 0, ell.data_ptr(), 0, base.data_ptr(), wt.data_ptr(), sig.data_ptr(), ng, slot2x.data_ptr(),
-									 0, 1, dot.data_ptr(), dot.stride(0), 0, ssy.data_ptr(), 0, 0, eng._stream()))
+									 0, 1, dot.data_ptr(), dot.stride(0), 0, ssy.data_ptr(), 0, 0, 0, n, -1, 0.0, 0, eng._stream()))  # (no covariates: the gathers alone, sums from `common`)
 	ev[1].record()
 	torch.cuda.synchronize()
 	print('%-45s %d entries per pass: %.3f ms' % (name, nch * ng * w * 64, ev[0].elapsed_time(ev[1]) / 5), flush=True)
