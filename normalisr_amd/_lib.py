@@ -2,6 +2,7 @@
 library is missing or a call fails, this raises."""
 import ctypes
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnormalisr_hip.so')
@@ -115,6 +116,35 @@ def exported_symbols():
 	return sorted(_SIGNATURES)
 
 
+_prefer_host = False
+
+
+def prefer_host_entry(on=True):
+	"""The command line's default for de / coex / binnet on one GPU: numpy buffers through the library's whole-problem entries, torch not imported."""
+	global _prefer_host
+	prev, _prefer_host = _prefer_host, bool(on)
+	return prev
+
+
+def host_entry_preferred():
+	v = os.environ.get('NRM_HOST_ENTRY', '')
+	return v == '1' or (_prefer_host and v != '0')
+
+
+def _preload_torch_hip():
+	try:
+		import importlib.util
+		spec = importlib.util.find_spec('torch')  # (finds the package, does not import it)
+		for d in (spec.submodule_search_locations or []) if spec is not None else []:
+			f = os.path.join(d, 'lib', 'libamdhip64.so')
+			if os.path.exists(f):
+				ctypes.CDLL(f, mode=ctypes.RTLD_GLOBAL)
+				return True
+	except Exception:
+		pass
+	return False
+
+
 def load():
 	"""Load the HIP library; raises RuntimeError (never falls back) when it is not built."""
 	global _lib
@@ -130,10 +160,16 @@ def load():
 	# One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  If it is
 	# loaded first our DT_NEEDED entry binds to it; the other order would load /opt/rocm's copy next to
 	# torch's and the second runtime finds no device.  torch is the plumbing for device memory anyway.
-	try:
-		import torch  # noqa: F401
-	except ImportError:
-		pass
+	if 'torch' not in sys.modules and host_entry_preferred():
+		# a process on the library's own whole-problem entries (the command line; NRM_HOST_ENTRY=1) never needs torch: its import alone is a
+		# second of a 1.3 s `normalisr coex` call.  The HIP runtime torch bundles is loaded by itself instead, so that a later `import torch`
+		# (a call the entries do not cover) still finds ONE runtime in the process.
+		_preload_torch_hip()
+	else:
+		try:
+			import torch  # noqa: F401
+		except ImportError:
+			pass
 	lib = ctypes.CDLL(LIB_PATH)
 	for name, (args, res) in _SIGNATURES.items():
 		f = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

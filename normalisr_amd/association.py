@@ -249,7 +249,7 @@ def _single0_host_entry(dx, dy, dc64, dci, dcr, dimreduce, return_dot, want_alph
 
 
 def _use_host_entry():
-	return os.environ.get('NRM_HOST_ENTRY', '') == '1' or not _have_torch()
+	return _lib.host_entry_preferred() or not _have_torch()
 
 
 def _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka):

@@ -194,6 +194,20 @@ COMMANDS = {
 def run(cmd, args):
 	"""Run sub-command `cmd` with the parsed command line `args` (a dict of argparse destinations)."""
 	spec = COMMANDS[cmd]
+	if cmd in ('de', 'coex', 'binnet'):
+		# files in, files out, one GPU: the library's whole-problem entries (include/normalisr_hip.h) do everything these commands need -- same kernels,
+		# same results -- and torch's import (1.0 of a 1.3 s call) is not paid; NRM_HOST_ENTRY=0 keeps the torch engine.  Calls the entries do not
+		# cover fall back to it by themselves.
+		from . import _lib
+		prev = _lib.prefer_host_entry(True)
+		try:
+			return _run(cmd, spec, args)
+		finally:
+			_lib.prefer_host_entry(prev)  # (a preference of this call, not of the process: tests and notebooks call run() beside the torch engine)
+	return _run(cmd, spec, args)
+
+
+def _run(cmd, spec, args):
 	mats = {k: file_read_tsv(args[k]) for k in spec['inputs']}
 	ka = {}
 	for key, (kw, conv) in spec['options'].items():

@@ -428,6 +428,49 @@ def test_de_methods_and_binnet_of_the_package_without_torch(tmp_path, golden):
 	assert np.array_equal(o['net'], g8['net_q5']) and int(o['unsupported']) == 1
 
 
+_CLI_NO_TORCH = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+tmp = sys.argv[2]
+from normalisr_amd.__main__ import main
+f = lambda name: os.path.join(tmp, name)
+main(['coex', f('exp.npy'), f('cov.npy'), f('pv.npy'), '--dot_out', f('dot.npy'), '--var_out', f('var.npy')])
+main(['binnet', f('pv.npy'), f('net.npy'), '0.05'])
+for m in ('ignore', 'single', 'covariate'):
+	main(['de', f('dg1.npy' if m == 'single' else 'dg.npy'), f('exp.npy'), f('cov.npy'), f('de_pv_%s.npy' % m), f('de_lfc_%s.npy' % m), '-m', m, '--vart_out', f('de_vt_%s.npy' % m)])
+assert not any(m == 'torch' or m.startswith('torch.') for m in sys.modules), 'the command line imported torch'
+import torch  # the runtime torch bundles was loaded first: torch still finds its GPU in this process
+assert torch.cuda.is_available() and float(torch.ones(3, device='cuda').sum()) == 3.0
+'''
+
+
+def test_command_line_runs_on_the_library_entries_without_importing_torch(tmp_path, norm):
+	"""`normalisr coex | binnet | de -m ignore|single|covariate` from files on one GPU: through the library's whole-problem entries -- torch is not imported
+	(1.0 of the 1.3 s of a small call; tools/cli_startup.sh) -- with the results of the torch engine; the HIP runtime torch bundles is loaded by itself
+	first, so a later `import torch` in the same process still works (one runtime per process)."""
+	import subprocess
+	rng = np.random.default_rng(12)
+	ng, nx, n = 150, 12, 3000
+	dt = np.log1p(rng.poisson(2.0, (ng, n))).astype(np.float64)
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones(n)])
+	dg = (rng.random((nx, n)) < 0.05).astype(np.float64)
+	dg1 = (rng.random((nx, n)) < 1.0 / nx).astype(np.float64)
+	dt[:5] += 0.5 * dg[0] + 0.5 * dg1[1]
+	for name, a in (('exp', dt), ('cov', dc), ('dg', dg), ('dg1', dg1)):
+		np.save(tmp_path / (name + '.npy'), a)
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	env = {k: v for k, v in os.environ.items() if k != 'NRM_HOST_ENTRY'}
+	r = subprocess.run([sys.executable, '-c', _CLI_NO_TORCH, root, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+	assert r.returncode == 0, r.stderr[-3000:]
+	ld = lambda name: np.load(tmp_path / name)
+	p, dot, var = norm.coex(dt, dc)
+	assert p_close(ld('pv.npy'), p) and close(ld('dot.npy'), dot, 1e-9, 1e-12) and close(ld('var.npy'), var, 1e-12)
+	assert np.array_equal(ld('net.npy').astype(bool), norm.binnet(p, 0.05))
+	for m, single, d in (('ignore', 0, dg), ('single', 1, dg1), ('covariate', 4, dg)):
+		ref = oracle.de(d, dt, dc, single=single)
+		assert p_close(ld('de_pv_%s.npy' % m), ref[0]) and close(ld('de_lfc_%s.npy' % m), ref[1], 1e-8, 1e-12) and close(ld('de_vt_%s.npy' % m), ref[4], 1e-9, 1e-15)
+
+
 def test_normvar_on_the_device_and_the_resident_chain(golden, norm, eng, monkeypatch):
 	"""normvar without the host (round-4 verdict, missing item 3 / weak item 7): per-gene moments in one pass, a thread per gene solves its small OLS
 	with the host's Jacobi code (norm.py:131-163 per gene), one pass writes the result.  Golden G9 and a larger case against the oracle's
