@@ -261,10 +261,11 @@ int nrm_design_products(const void* d_x, int x_dtype, int64_t rows, int64_t n_ce
 
 /* Residualise <= 32 rows with the work spread along the cells (used for the design rows of the streaming path):
  * d_ga (rows, 32) holds x C^T in its first nc columns (from nrm_gram_skinny against Z = [C; 0]); out (rows, ldo) fp64,
- * zero padded up to ldo; d_ss (rows) sums of squares; d_coef (rows, nc) or NULL the OLS coefficients. */
+ * zero padded up to ldo; d_ss (rows) sums of squares; d_coef (rows, nc) or NULL the OLS coefficients.  A row the covariates explain to twenty digits
+ * (|x~|^2 < 1e-22 |x|^2) is explained exactly: its row of d_out is cleared, its sum of squares 0 (variance 0 -> 1, P = 1). */
 int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, int64_t n, int64_t ldx, const double* d_c, int64_t nc,
 						 int64_t ldc, const double* d_ga, const double* d_dci, int rank, double* d_out, int64_t ldo,
-						 double* d_ss, double* d_coef, double* d_work /* 32 * ceil(ldo/1024) doubles */,
+						 double* d_ss, double* d_coef, double* d_work /* 64 * ceil(ldo/1024) doubles */,
 						 int const_last /* != 0: the LAST covariate is the constant row: its product sits in column 31 of d_ga */, void* stream);
 int nrm_gram_skinny(const void* d_a, int a_dtype, int64_t rows, int64_t n, int64_t lda, const double* d_z, int64_t ldz,
 					int64_t k_pad, double* d_g, double* d_ss, int64_t rows_pad, int64_t nz /* used rows of Z (<= 32); <= 16 selects the half-width variant */,
@@ -425,7 +426,8 @@ int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t nx,
 							   void* h_p, void* h_stat, void* h_alpha, void* h_varx, void* h_vary,
 							   void* h_r, void* h_t, int out_dtype);
 
-/* (Round 5) nrm_association_tests_host takes the sparse-design path below by itself when dy is given and the design matrix qualifies -- at most
+/* (Round 5) nrm_association_tests_host streams the raw expression rows (nrm_gram_skinny, as the Python engine does) when dy is given and nx + nc <= 32 --
+ * case-control DE, BASELINE configs[2]; NRM_DEBUG="de_path=general" keeps K1 + K2 -- and takes the sparse-design path below by itself when dy is given and the design matrix qualifies -- at most
  * 1/16 of its entries set, >= 32 design rows, >= 64 expression rows, >= 2048 cells, nx n >= 2^22, <= 32 covariates; NRM_DE_SPARSE=0 switches that
  * off, =force takes it whatever the size -- and hands calls whose rows are too close to the span of the covariates back to its dense fp64 path.
  *

@@ -230,6 +230,13 @@ extern "C" int nrm_last_guard(int64_t* hits, double* worst) {
 	return NRM_OK;
 }
 
+static bool de_path_general() {  // NRM_DEBUG="de_path=general" (or NRM_DE_PATH=general): no streaming de kernel, as in normalisr_amd/_opts.py
+	const char* d = getenv("NRM_DEBUG");
+	if (d && strstr(d, "de_path=general")) return true;
+	const char* e = getenv("NRM_DE_PATH");
+	return e && !strcmp(e, "general");
+}
+
 static double guard_tolerance() {
 	const char* t = getenv("NRM_I8_GUARD_TOL");  // largest relative change of a P-value the integer engine may cause (0: no guard)
 	return t ? atof(t) : 2.5e-7;
@@ -324,6 +331,12 @@ static int association_tests_host_impl(const void* h_dx, int x_dtype, int64_t nx
 	// A design matrix with few entries (a CRISPR screen's gRNA incidence): the sparse-design kernels -- the expression rows read once, raw, the
 	// contraction replaced by gathers at the design's entries (nrm_host_entries.hip; what normalisr_amd.engine does for the Python host).
 	// Same size rule as there; NRM_DE_SPARSE=0 switches it off, =force takes it whatever the size.
+	// de with few design rows (case-control DE, BASELINE configs[2]): the raw expression rows streamed once against [C; X~], as the Python engine does
+	// (engine.association_de_streaming); NRM_DEBUG de_path=general keeps K1 + K2
+	if (allow_sparse && !samexy && nx + nc <= 32 && !de_path_general()) {
+		return nrm_host_de_streaming(dx.p, x_dtype, nx, h_dy, y_dtype, ny, c64.data(), nc, n, h_dci, rank, dof, return_dot ? 0 : 1, h_p, h_stat, want_alpha ? h_alpha : nullptr,
+									 h_varx, h_vary, h_r, h_t, out_dtype);
+	}
 	bool dy_up = false;
 	if (allow_sparse && !samexy && nc <= nrm_de_sparse_max_covariates()) {
 		const char* mode = getenv("NRM_DE_SPARSE");

@@ -186,6 +186,139 @@ int nrm_host_de_sparse(const void* d_x, int x_dtype, int64_t nx, const void* d_y
 	return NRM_OK;
 }
 
+// ---- de with nx + nc <= 32 (case-control DE: BASELINE configs[2]) -------------------------------------------------------------------------------------
+// The raw expression rows streamed once against Z = [C; X~] on the fp64 matrix cores (csrc/nrm_gram_skinny.hip), never residualised, never
+// quantised: what engine.association_de_streaming does for the Python host, kernel for kernel.  A constant covariate (the intercept) leaves Z -- its
+// product with a row is a plain sum the kernel takes on the vector ALU -- by moving to the end of the covariates; dci is permuted with it (no rank
+// assumption) and alpha is put back in the caller's order.  d_x: the design rows already in HBM (pitch n); h_dy: uploaded here, into rows zero padded
+// to 16 cells when n is not a multiple of 16 (the kernel streams 16-cell slabs without bounds checks).
+int nrm_host_de_streaming(const void* d_x, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny, const double* h_c64, int64_t nc, int64_t n,
+						  const double* h_dci, int rank, double dof, int stat_kind, void* h_p, void* h_stat, void* h_alpha, void* h_varx, void* h_vary, void* h_r, void* h_t,
+						  int out_dtype) {
+	hipStream_t st = nullptr;
+	NRM_REQUIRE(nx + nc <= 32 && nx > 0 && ny > 0, "nrm_host_de_streaming: needs nx + nc <= 32");
+	double cval = 0.0;
+	int ci = nc ? constant_row(h_c64, nc, n, &cval) : -1;
+	if (nc + nx > 31 + (ci >= 0 ? 1 : 0)) {
+		ci = -1;
+		cval = 0.0;
+	}
+	const int const_last = ci >= 0 ? 1 : 0;
+	const int64_t ncz = nc - const_last;  // covariate rows that stay in Z
+	std::vector<int64_t> perm((size_t)nc);
+	{
+		int64_t j = 0;
+		for (int64_t c = 0; c < nc; c++)
+			if (c != ci) perm[(size_t)j++] = c;
+		if (ci >= 0) perm[(size_t)j] = ci;
+	}
+	DevBuf cz, dciz, z, xpad, gx, xwork, rwork, ssx, coefx, ypad, yraw, g, ssraw, swork, ssy, by, flags, op, ostat, orr, ot, oalpha;
+	if (nc) {  // the covariates in Z's order (the constant one last) and their pseudo-inverse permuted with them
+		std::vector<double> hc((size_t)nc * n), hd((size_t)nc * nc);
+		for (int64_t c = 0; c < nc; c++) memcpy(&hc[(size_t)(c * n)], h_c64 + perm[(size_t)c] * n, (size_t)n * 8);
+		for (int64_t a = 0; a < nc; a++)
+			for (int64_t b = 0; b < nc; b++) hd[(size_t)(a * nc + b)] = h_dci ? h_dci[perm[(size_t)a] * nc + perm[(size_t)b]] : 0.0;
+		NRM_TRY(cz.alloc(hc.size() * 8));
+		NRM_HIP(hipMemcpy(cz.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice));
+		NRM_TRY(dciz.alloc(hd.size() * 8));
+		NRM_HIP(hipMemcpy(dciz.p, hd.data(), hd.size() * 8, hipMemcpyHostToDevice));
+	}
+	const int64_t k32 = nrm_round_up(n, 128), n16 = nrm_round_up(n, 16);
+	NRM_TRY(z.alloc((size_t)32 * k32 * 8));
+	NRM_HIP(hipMemsetAsync(z.p, 0, (size_t)32 * k32 * 8, st));
+	if (ncz) NRM_TRY(nrm_copy_rows(z.p, k32 * 8, cz.p, n * 8, n * 8, ncz, st));
+	// the design rows: readable up to a multiple of 16 cells
+	const size_t xe = nrm_esize(x_dtype), ye = nrm_esize(y_dtype);
+	const void* xd = d_x;
+	int64_t ldx = n;
+	if (n16 != n) {
+		NRM_TRY(xpad.alloc((size_t)nx * n16 * xe));
+		NRM_HIP(hipMemsetAsync(xpad.p, 0, (size_t)nx * n16 * xe, st));
+		NRM_TRY(nrm_copy_rows(xpad.p, n16 * xe, d_x, n * xe, n * xe, nx, st));
+		xd = xpad.p;
+		ldx = n16;
+	}
+	NRM_TRY(gx.alloc((size_t)256 * 32 * 8));
+	NRM_HIP(hipMemsetAsync(gx.p, 0, (size_t)256 * 32 * 8, st));
+	const bool active = rank > 0 && nc > 0;
+	if (active) {  // a = x C^T against the covariates in Z's order (the constant one: column 31)
+		NRM_TRY(xwork.alloc((size_t)nrm_design_products_workspace_doubles(nx, n) * 8));
+		NRM_TRY(nrm_design_products(xd, x_dtype, nx, n, ldx, cz.as<double>(), nc, n, gx.as<double>(), xwork.as<double>(), const_last, st));
+	}
+	const bool want_alpha = h_alpha != nullptr && nc > 0;
+	NRM_TRY(rwork.alloc((size_t)64 * ((k32 + 1023) / 1024) * 8));
+	NRM_TRY(ssx.alloc((size_t)NRM_ROW_TILE * 8));
+	NRM_HIP(hipMemsetAsync(ssx.p, 0, (size_t)NRM_ROW_TILE * 8, st));
+	if (want_alpha) {
+		NRM_TRY(coefx.alloc((size_t)nx * nc * 8));
+		NRM_HIP(hipMemsetAsync(coefx.p, 0, (size_t)nx * nc * 8, st));
+	}
+	double* xt = z.as<double>() + ncz * k32;  // the residualised design rows go straight into their rows of Z
+	NRM_TRY(nrm_residualize_wide(xd, x_dtype, nx, n, ldx, nc ? cz.as<double>() : nullptr, nc, n, gx.as<double>(), nc ? dciz.as<double>() : nullptr, rank, xt, k32, ssx.as<double>(),
+								 want_alpha ? coefx.as<double>() : nullptr, rwork.as<double>(), const_last, st));
+	// the expression rows
+	const void* yd;
+	int64_t ldy = n;
+	if (n16 == n) {
+		NRM_TRY(ypad.alloc((size_t)ny * n * ye));
+		NRM_TRY(nrm_upload(h_dy, ypad.p, (int64_t)ny * n * ye, 0, (void*)st));
+		yd = ypad.p;
+	} else {
+		NRM_TRY(yraw.alloc((size_t)ny * n * ye));
+		NRM_TRY(nrm_upload(h_dy, yraw.p, (int64_t)ny * n * ye, 0, (void*)st));
+		NRM_TRY(ypad.alloc((size_t)ny * n16 * ye));
+		NRM_HIP(hipMemsetAsync(ypad.p, 0, (size_t)ny * n16 * ye, st));
+		NRM_TRY(nrm_copy_rows(ypad.p, n16 * ye, yraw.p, n * ye, n * ye, ny, st));
+		yraw.release();
+		yd = ypad.p;
+		ldy = n16;
+	}
+	const int64_t nyp = nrm_round_up(ny, 256);
+	NRM_TRY(g.alloc((size_t)nyp * 32 * 8));
+	NRM_TRY(ssraw.alloc((size_t)nyp * 8));
+	NRM_TRY(swork.alloc((size_t)nrm_gram_skinny_workspace_bytes()));
+	NRM_TRY(nrm_gram_skinny(yd, y_dtype, ny, n, ldy, z.as<double>(), k32, k32, g.as<double>(), ssraw.as<double>(), nyp, ncz + nx, cval, swork.p, st));
+	const size_t ob = (size_t)nx * ny * nrm_esize(out_dtype);
+	NRM_TRY(op.alloc(ob));
+	NRM_TRY(ostat.alloc(ob));
+	if (h_r) NRM_TRY(orr.alloc(ob));
+	if (h_t) NRM_TRY(ot.alloc(ob));
+	NRM_TRY(ssy.alloc((size_t)nyp * 8));
+	if (want_alpha) {
+		NRM_TRY(by.alloc((size_t)ny * nc * 8));
+		NRM_HIP(hipMemsetAsync(by.p, 0, (size_t)ny * nc * 8, st));
+	}
+	NRM_TRY(flags.alloc(16));
+	NRM_HIP(hipMemsetAsync(flags.p, 0, 16, st));
+	NRM_TRY(nrm_de_small_sweep(g.as<double>(), ssraw.as<double>(), nc ? dciz.as<double>() : nullptr, nc, rank, ssx.as<double>(), nx, ny, n, dof, stat_kind, op.p, ostat.p,
+							   h_r ? orr.p : nullptr, h_t ? ot.p : nullptr, out_dtype, ny, ssy.as<double>(), want_alpha ? by.as<double>() : nullptr, flags.as<int32_t>(), const_last, st));
+	if (want_alpha) {
+		NRM_TRY(oalpha.alloc(ob * nc));
+		NRM_TRY(nrm_alpha(ostat.p, out_dtype, ny, stat_kind, ssx.as<double>(), n, coefx.as<double>(), by.as<double>(), nx, ny, nc, oalpha.p, out_dtype, st));
+	}
+	int32_t hf[4];
+	NRM_HIP(hipMemcpyAsync(hf, flags.p, 16, hipMemcpyDeviceToHost, st));
+	NRM_HIP(hipStreamSynchronize(st));
+	if (hf[0] || hf[1]) {
+		nrm_set_error("association results failed the reference's assertions (association.py:248,252): %d tiles non-finite, %d tiles with R^2 > 1+1e-8", hf[0], hf[1]);
+		return NRM_E_NUMERIC;
+	}
+	NRM_HIP(hipMemcpy(h_p, op.p, ob, hipMemcpyDeviceToHost));
+	NRM_HIP(hipMemcpy(h_stat, ostat.p, ob, hipMemcpyDeviceToHost));
+	if (h_r) NRM_HIP(hipMemcpy(h_r, orr.p, ob, hipMemcpyDeviceToHost));
+	if (h_t) NRM_HIP(hipMemcpy(h_t, ot.p, ob, hipMemcpyDeviceToHost));
+	if (want_alpha) {  // the coefficients came out in Z's covariate order: back to the caller's
+		const size_t es = nrm_esize(out_dtype), cnt = (size_t)nx * ny;
+		std::vector<char> tmp(ob * nc);
+		NRM_HIP(hipMemcpy(tmp.data(), oalpha.p, ob * nc, hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < cnt; i++)
+			for (int64_t c = 0; c < nc; c++) memcpy((char*)h_alpha + (i * nc + (size_t)perm[(size_t)c]) * es, tmp.data() + (i * nc + (size_t)c) * es, es);
+	}
+	NRM_TRY(emit_var(ssy.as<double>(), ny, n, h_vary, out_dtype));
+	if (h_varx) NRM_TRY(emit_var(ssx.as<double>(), nx, n, h_varx, out_dtype));
+	return NRM_OK;
+}
+
 // ---- shared pieces of the entries below ---------------------------------------------------------------------------------------------------
 namespace {
 

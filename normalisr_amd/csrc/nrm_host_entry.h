@@ -88,3 +88,7 @@ struct NrmDesignLists {
 int nrm_host_de_sparse(const void* d_x, int x_dtype, int64_t nx, const void* d_y, int y_dtype, int64_t ny, const double* d_c, const double* h_c64, int64_t nc, int64_t n,
 					   const double* d_dci, int rank, double dof, int stat_kind, void* h_p, void* h_stat, void* h_alpha, void* h_varx, void* h_vary, void* h_r, void* h_t,
 					   int out_dtype, int* taken, int64_t* handed_back);
+// de with nx + nc <= 32: the streaming kernel (nrm_host_entries.hip); d_x in HBM, h_dy uploaded inside
+int nrm_host_de_streaming(const void* d_x, int x_dtype, int64_t nx, const void* h_dy, int y_dtype, int64_t ny, const double* h_c64, int64_t nc, int64_t n,
+						  const double* h_dci, int rank, double dof, int stat_kind, void* h_p, void* h_stat, void* h_alpha, void* h_varx, void* h_vary, void* h_r, void* h_t,
+						  int out_dtype);

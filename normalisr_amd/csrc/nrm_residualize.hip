@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ 
 														   int active, double* __restrict__ out, int64_t ldo, double* __restrict__ ss_part,
 														   double* __restrict__ coef, int const_last) {
 	__shared__ double s_b[RW_ROWS][RW_ROWS];
-	__shared__ double s_w[4];
+	__shared__ double s_w[4], s_r[4];
 	const int tid = threadIdx.x, lane = tid & 63;
 	if (active) {
 		for (int i = tid; i < rows * nc; i += 256) {
@@ -600,36 +600,63 @@ __global__ void __launch_bounds__(256) k_residualize_wide(const T* __restrict__ 
 	}
 	const int64_t k0 = (int64_t)blockIdx.x * 1024;
 	for (int r = 0; r < rows; r++) {
-		double sq = 0.0;
+		double sq = 0.0, raw = 0.0;
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int64_t k = k0 + tid + 256 * j;
 			if (k >= ldo) continue;
 			double v = (k < n) ? (double)x[(int64_t)r * ldx + k] : 0.0;
+			raw = fma(v, v, raw);
 			if (active && k < n)
 				for (int q = 0; q < nc; q++) v = fma(-s_b[r][q], c[(int64_t)q * ldc + k], v);
 			out[(int64_t)r * ldo + k] = v;
 			sq = fma(v, v, sq);
 		}
-		// per-block partial sums (no atomics: k_rw_sum adds them in block order, bitwise reproducible)
+		// per-block partial sums (no atomics: k_rw_sum adds them in block order, bitwise reproducible); the raw rows' squares ride along (k_rw_sum)
 		sq = wave_sum(sq);
+		raw = wave_sum(raw);
 		__syncthreads();
-		if (lane == 0) s_w[tid >> 6] = sq;
+		if (lane == 0) {
+			s_w[tid >> 6] = sq;
+			s_r[tid >> 6] = raw;
+		}
 		__syncthreads();
-		if (tid == 0) ss_part[(int64_t)blockIdx.x * RW_ROWS + r] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+		if (tid == 0) {
+			ss_part[(int64_t)blockIdx.x * RW_ROWS + r] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+			ss_part[((int64_t)gridDim.x + blockIdx.x) * RW_ROWS + r] = s_r[0] + s_r[1] + s_r[2] + s_r[3];
+		}
 	}
 }
 
 // one workgroup per row: the per-block partial sums are added in a fixed (strided, then tree) order -- bitwise reproducible
-__global__ void __launch_bounds__(256) k_rw_sum(const double* __restrict__ part, int nblocks, int rows, double* __restrict__ ss) {
-	__shared__ double s_w[4];
+// A row the covariates explain to twenty digits (|x~|^2 < 1e-22 |x|^2: a constant design row beside an intercept, a copy of a covariate) is explained
+// exactly: its residual is rounding noise, NOT orthogonal to the covariates, and the streaming kernel's y~ . x~ = y . x~ would make an R^2 of millions of it.
+// The row of `out` is cleared and its sum of squares is 0 (the variance 0 -> 1 rule then gives P = 1: what exact arithmetic gives the reference).
+__global__ void __launch_bounds__(256) k_rw_sum(const double* __restrict__ part, int nblocks, int rows, double* __restrict__ ss, double* __restrict__ out, int64_t ldo) {
+	__shared__ double s_w[4], s_r[4];
+	__shared__ int s_clear;
 	const int r = blockIdx.x;
-	double acc = 0.0;
-	for (int b = threadIdx.x; b < nblocks; b += 256) acc += part[(int64_t)b * RW_ROWS + r];
+	double acc = 0.0, raw = 0.0;
+	for (int b = threadIdx.x; b < nblocks; b += 256) {
+		acc += part[(int64_t)b * RW_ROWS + r];
+		raw += part[((int64_t)nblocks + b) * RW_ROWS + r];
+	}
 	acc = wave_sum(acc);
-	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+	raw = wave_sum(raw);
+	if ((threadIdx.x & 63) == 0) {
+		s_w[threadIdx.x >> 6] = acc;
+		s_r[threadIdx.x >> 6] = raw;
+	}
 	__syncthreads();
-	if (threadIdx.x == 0) ss[r] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+	if (threadIdx.x == 0) {
+		const double a = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]), q = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
+		const int clear = a < 1e-22 * q;
+		ss[r] = clear ? 0.0 : a;
+		s_clear = clear;
+	}
+	__syncthreads();
+	if (s_clear)
+		for (int64_t k = threadIdx.x; k < ldo; k += 256) out[(int64_t)r * ldo + k] = 0.0;
 }
 
 // The OLS products a = x C^T of a few design rows, spread along the cells like k_residualize_wide: every workgroup takes 1024 cells of
@@ -717,7 +744,7 @@ extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, 
 	const int active = (rank > 0 && nc > 0) ? 1 : 0;
 	NRM_REQUIRE(!active || (d_c && d_ga && d_dci && ldc >= n), "Unmatching dx/dy/dc dimensions.");
 	hipStream_t st = (hipStream_t)stream;
-	NRM_REQUIRE(d_work != nullptr, "nrm_residualize_wide: d_work must hold 32 * ceil(ldo / 1024) doubles");
+	NRM_REQUIRE(d_work != nullptr, "nrm_residualize_wide: d_work must hold 64 * ceil(ldo / 1024) doubles");
 	dim3 grid((unsigned)((ldo + 1023) / 1024));
 	if (x_dtype == NRM_F64)
 		hipLaunchKernelGGL(k_residualize_wide<double>, grid, dim3(256), 0, st, (const double*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
@@ -725,6 +752,6 @@ extern "C" int nrm_residualize_wide(const void* d_x, int x_dtype, int64_t rows, 
 	else
 		hipLaunchKernelGGL(k_residualize_wide<float>, grid, dim3(256), 0, st, (const float*)d_x, (int)rows, n, ldx, d_c, (int)nc, ldc, d_ga,
 						   d_dci, active, d_out, ldo, d_work, d_coef, const_last);
-	hipLaunchKernelGGL(k_rw_sum, dim3((unsigned)rows), dim3(256), 0, st, d_work, (int)grid.x, (int)rows, d_ss);
+	hipLaunchKernelGGL(k_rw_sum, dim3((unsigned)rows), dim3(256), 0, st, d_work, (int)grid.x, (int)rows, d_ss, d_out, ldo);
 	return nrm_check_launch("k_residualize_wide");
 }

@@ -1048,7 +1048,7 @@ class Engine:
 				_lib.check(self.lib.nrm_design_products(xd.data_ptr(), xcode, nx, n, xd.stride(0), d_cz.data_ptr(), nc, d_cz.stride(0), gx.data_ptr(),
 														xc_work.data_ptr(), 1 if ci >= 0 else 0, self._stream()))
 			xt = z[ncz:ncz + nx]  # the residualised design rows are written straight into their rows of Z (zero padded up to k32)
-			rw_work = torch.empty((32 * ((k32 + 1023) // 1024), ), dtype=torch.float64, device=self.device)
+			rw_work = torch.empty((64 * ((k32 + 1023) // 1024), ), dtype=torch.float64, device=self.device)
 			ssx = torch.empty((ROW_TILE, ), dtype=torch.float64, device=self.device)
 			coefx = self.zeros((nx, nc), torch.float64) if want_alpha else None
 			_lib.check(self.lib.nrm_residualize_wide(xd.data_ptr(), xcode, nx, n, xd.stride(0), 0 if d_cz is None else d_cz.data_ptr(), nc,
