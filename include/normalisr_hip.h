@@ -448,6 +448,13 @@ int nrm_association_tests_single4_host(const void* h_dx, int x_dtype, int64_t nx
 									   int64_t nc, int64_t n_cells, const double* h_dci, int rank, int dimreduce, int return_dot, double tol, void* h_p,
 									   void* h_stat, void* h_alpha, void* h_varx, void* h_vary, int out_dtype);
 int nrm_binnet_host(const void* h_p, int p_dtype, int64_t ng, double qcut, unsigned char* h_net, int64_t* total);
+/* (Round 5) normvar's expression side at the same kind of seam (norm.py:166-289; `normalisr normvar`): h_y (rows, n) fp32 / fp64, h_lnw (n) = ln w, h_wt (rows), h_c (nc, n)
+ * fp64 -> h_out (rows, n) of out_dtype = gene g times w^wt_g, the covariates C w^wt_g removed, the variance kept (keepvar != 0, norm.py:248-259); tol: the rank rule of
+ * inv_rank (association.py:77).  1 .. nrm_normvar_device_covariates() covariates (NRM_E_UNSUPPORTED beyond).  *zero_rank = genes whose covariates have rank 0 (the
+ * reference raises RuntimeError, norm.py:158-159; h_out is not written then); NRM_E_NUMERIC for non-finite results (norm.py:286).  The covariates' own scaling
+ * (norm.py:261-273) is element-wise on (nc, n) and stays with the caller. */
+int nrm_normvar_host(const void* h_y, int y_dtype, int64_t rows, int64_t n, const double* h_lnw, const double* h_wt, const double* h_c, int64_t nc, double tol,
+					 int keepvar, void* h_out, int out_dtype, int64_t* zero_rank);
 /* eigenvalues (ascending) of a small symmetric matrix, n <= 32 (host only) */
 int nrm_small_eigvals(const double* m, int64_t n, double* w);
 

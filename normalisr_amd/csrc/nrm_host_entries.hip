@@ -588,6 +588,51 @@ extern "C" int nrm_binnet_host(const void* h_p, int p_dtype, int64_t ng, double 
 	return copy_out(h_net, dn.p, (size_t)ng * ng);
 }
 
+// ---- normvar (norm.py:166-289): the expression side, whole problem ------------------------------------------------------------------------------
+// h_y (rows, n) fp32 / fp64 -> h_out (rows, n): gene g multiplied by e_gk = w_k^wt_g, the covariates C e_g removed, the variance put back (keepvar).  The
+// three kernels of csrc/nrm_normvar.hip as normalisr_amd.norm.normvar launches them: per-gene moments in one pass, a lane per gene solving its small OLS with the
+// reference's rank rule, one pass writing the result.  1 .. nrm_normvar_device_covariates() covariates (NRM_E_UNSUPPORTED beyond: the package's Gram-launch form);
+// *zero_rank = genes whose covariates have rank 0 (norm.py:158-159 raises for them: the caller does); non-finite results: NRM_E_NUMERIC (norm.py:286).
+// The covariates' own scaling (norm.py:261-273) is a few numpy lines on (nc, n) and stays with the caller.
+extern "C" int nrm_normvar_host(const void* h_y, int y_dtype, int64_t rows, int64_t n, const double* h_lnw, const double* h_wt, const double* h_c, int64_t nc, double tol,
+								int keepvar, void* h_out, int out_dtype, int64_t* zero_rank) {
+	std::lock_guard<std::mutex> serial(nrm_host_entry_mutex());
+	NRM_REQUIRE(h_y && h_lnw && h_wt && h_c && h_out && zero_rank && rows > 0 && n > 0 && nc > 0, "nrm_normvar_host: bad arguments");
+	NRM_REQUIRE((y_dtype == NRM_F32 || y_dtype == NRM_F64) && (out_dtype == NRM_F32 || out_dtype == NRM_F64), "nrm_normvar_host: bad dtype");
+	if (nc > nrm_normvar_device_covariates()) {
+		nrm_set_error("nrm_normvar_host: at most %d covariates (the package's Gram-launch form takes more)", (int)nrm_normvar_device_covariates());
+		return NRM_E_UNSUPPORTED;
+	}
+	hipStream_t st = nullptr;
+	DevBuf y, lnw, wt, c, mom, b, scale, rank, flags, out;
+	NRM_TRY(upload_matrix(h_y, y_dtype, rows, n, y, st));
+	NRM_TRY(upload_matrix(h_lnw, NRM_F64, 1, n, lnw, st));
+	NRM_TRY(upload_matrix(h_wt, NRM_F64, 1, rows, wt, st));
+	NRM_TRY(upload_matrix(h_c, NRM_F64, nc, n, c, st));
+	NRM_TRY(mom.alloc((size_t)rows * (size_t)(nc * (nc + 1) / 2 + nc + 2) * 8));
+	NRM_TRY(b.alloc((size_t)rows * nc * 8));
+	NRM_TRY(scale.alloc((size_t)rows * 8));
+	NRM_TRY(rank.alloc((size_t)rows * 8));
+	NRM_TRY(flags.alloc(16));
+	NRM_HIP(hipMemsetAsync(flags.p, 0, 16, st));
+	NRM_TRY(nrm_normvar_solve(y.p, y_dtype, rows, n, n, lnw.as<double>(), wt.as<double>(), c.as<double>(), nc, n, tol, keepvar ? 1 : 0, mom.as<double>(), b.as<double>(),
+							  scale.as<double>(), rank.as<int64_t>(), flags.as<int32_t>(), st));
+	const size_t ob = (size_t)rows * n * nrm_esize(out_dtype);
+	NRM_TRY(out.alloc(ob));
+	NRM_TRY(nrm_normvar_apply(y.p, y_dtype, rows, n, n, lnw.as<double>(), wt.as<double>(), c.as<double>(), nc, n, b.as<double>(), scale.as<double>(), out.p, out_dtype, n,
+							  flags.as<int32_t>(), st));
+	int32_t hf[4];
+	NRM_HIP(hipMemcpyAsync(hf, flags.p, 16, hipMemcpyDeviceToHost, st));
+	NRM_HIP(hipStreamSynchronize(st));
+	*zero_rank = hf[0];
+	if (hf[0]) return NRM_OK;
+	if (hf[1]) {
+		nrm_set_error("normvar: non-finite results (norm.py:286)");
+		return NRM_E_NUMERIC;
+	}
+	return copy_out(h_out, out.p, ob);
+}
+
 // ---- single=4 (association.py:421-576,926-980) in closed form, for full-rank designs --------------------------------------------------------
 namespace {
 

@@ -95,6 +95,47 @@ def _is_dev(a):
 	return hasattr(a, 'is_cuda') and a.is_cuda
 
 
+def _scaled_covariates(dc, w, cat):
+	"""Continuous covariate rows (and, cat=1, the intercept; cat=2: every row) are scaled by w (norm.py:261-273)."""
+	if cat == 2:
+		return dc * w
+	dcn = dc.copy()
+	t0 = ((dc != 0) & (dc != 1)).any(axis=1)
+	if cat == 1:
+		t0 |= (dc == 1).all(axis=1)
+	dcn = dcn.astype(np.result_type(dc.dtype, w.dtype), copy=False)
+	dcn[t0] = dc[t0] * w
+	return dcn
+
+
+def _normvar_host_entry(dt, dc, w, wt, dextra, cat, keepvar, tol, out_dtype):
+	"""normvar through nrm_normvar_host (include/normalisr_hip.h): host buffers in and out, no torch -- what `normalisr normvar` needs in a process that
+	has numpy and the library only.  NotImplementedError beyond the entry's covariate count (the caller then takes the package's Gram-launch form)."""
+	import ctypes
+	lib = _lib.load()
+	y = _engine.as_input(dt)
+	nt, ns = y.shape
+	nc = dc.shape[0]
+	c64 = np.ascontiguousarray(dc, dtype=np.float64)
+	lnw = np.log(np.asarray(w, dtype=np.float64))
+	wt64 = np.ascontiguousarray(wt, dtype=np.float64)
+	out = np.empty((nt, ns), dtype=out_dtype)
+	zero = ctypes.c_int64(0)
+	vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+	code = lambda a: _lib.NRM_F64 if a.dtype == np.float64 else _lib.NRM_F32
+	_lib.check(lib.nrm_normvar_host(vp(y), code(y), nt, ns, vp(lnw), vp(wt64), vp(c64), nc, float(tol), 1 if keepvar else 0, vp(out), code(out), ctypes.byref(zero)))
+	if zero.value:
+		raise RuntimeError('Zero-rank covariates found.')
+	dcn = _scaled_covariates(dc, w, cat)
+	assert _finite_within(out) and _finite_within(dcn)
+	ans = [out, dcn]
+	if dextra is not None:
+		dextran = dextra * w
+		assert _finite_within(dextran)
+		ans.append(dextran)
+	return ans
+
+
 def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, normmean=False, tol=1E-8, device_out=False):
 	"""Mean and variance normalisation, same contract as reference norm.py:166-289: returns [dtn, dcn] (+ [dextran]).
 	nth and bs are accepted for compatibility and ignored.
@@ -131,6 +172,15 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 	dt_dtype = np.dtype(str(dt.dtype).replace('torch.', '')) if _is_dev(dt) else dt.dtype
 	out_dtype = np.result_type(dt_dtype, dc.dtype, w.dtype, wt.dtype, np.float32)
 	out_dtype = np.dtype(np.float32) if out_dtype == np.float32 else np.dtype(np.float64)
+	from .association import _use_host_entry
+	if not _is_dev(dt) and not device_out and not normmean and _use_host_entry():
+		# no torch in this process (or the command line / NRM_HOST_ENTRY=1): the library's whole-problem entry, numpy buffers in and out
+		try:
+			return _normvar_host_entry(dt, dc, w, wt, dextra, cat, keepvar, tol, out_dtype)
+		except NotImplementedError:
+			from .association import _have_torch
+			if not _have_torch():
+				raise
 	eng = _engine.get_engine()
 	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)
 		torch = eng.torch
@@ -203,16 +253,7 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 													 d_c.stride(0), d_b.data_ptr(), d_scale.data_ptr(), out.data_ptr(),
 													 _lib.NRM_F64 if out_dtype == np.float64 else _lib.NRM_F32, ns, flags.data_ptr(), eng._stream()))
 			# covariates: continuous rows (and the intercept for cat=1) are scaled by w (norm.py:261-273)
-			w64 = np.asarray(w, dtype=np.float64)
-			if cat == 2:
-				dcn = dc * w
-			else:
-				dcn = dc.copy()
-				t0 = ((dc != 0) & (dc != 1)).any(axis=1)
-				if cat == 1:
-					t0 |= (dc == 1).all(axis=1)
-				dcn = dcn.astype(np.result_type(dc.dtype, w.dtype), copy=False)
-				dcn[t0] = dc[t0] * w
+			dcn = _scaled_covariates(dc, w, cat)
 			if normmean:
 				dcn64 = np.asarray(dcn, dtype=np.float64)
 				mi, r = inv_rank(np.matmul(dcn64, dcn64.T))
@@ -232,7 +273,6 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 			dextran = dextra * w
 			assert _finite_within(dextran)
 			ans.append(dextran)
-		del w64
 		return ans
 
 

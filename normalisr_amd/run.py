@@ -194,7 +194,7 @@ COMMANDS = {
 def run(cmd, args):
 	"""Run sub-command `cmd` with the parsed command line `args` (a dict of argparse destinations)."""
 	spec = COMMANDS[cmd]
-	if cmd in ('de', 'coex', 'binnet'):
+	if cmd in ('de', 'coex', 'binnet', 'normvar'):
 		# files in, files out, one GPU: the library's whole-problem entries (include/normalisr_hip.h) do everything these commands need -- same kernels,
 		# same results -- and torch's import (1.0 of a 1.3 s call) is not paid; NRM_HOST_ENTRY=0 keeps the torch engine.  Calls the entries do not
 		# cover fall back to it by themselves.

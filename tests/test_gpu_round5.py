@@ -392,6 +392,13 @@ for name, dg, single in (('s1', dg1, 1), ('s4', dg4, 4)):
 	p, lfc, a, vg, vt = norm.de(dg, dt, dc, single=single, lowmem=False)
 	out.update({'p_' + name: p, 'lfc_' + name: lfc, 'a_' + name: a, 'vg_' + name: vg, 'vt_' + name: vt})
 out['net'] = norm.binnet(d['pc'], 0.05)
+nv = norm.normvar(d['lcpm'], dc, d['w'], d['wt'])
+out['nv_t'], out['nv_c'] = nv[0], nv[1]
+try:
+	norm.normvar(d['lcpm'], np.vstack([dc] * 4), d['w'], d['wt'])  # 12 covariates: beyond the entry, needs the package's Gram-launch form, i.e. torch
+	out['nv_unsupported'] = 0
+except NotImplementedError:
+	out['nv_unsupported'] = 1
 try:
 	norm.de(dg4, dt, dc, single=4, mpc=2)  # outside the entry: needs the package's device path, i.e. torch
 	out['unsupported'] = 0
@@ -415,7 +422,9 @@ def test_de_methods_and_binnet_of_the_package_without_torch(tmp_path, golden):
 	dg1[7] = 0  # a grouping without cells: de drops and re-inflates it
 	dt = rng.normal(size=(ny, n)) + 0.5 * dg4[0] + 0.5 * dg1[1]
 	g8 = golden('G8_binnet')
-	np.savez(tmp_path / 'in.npz', dg1=dg1, dg4=dg4, dt=dt, dc=dc, pc=g8['p'])
+	lcpm = (rng.normal(size=(ny, n)) - 9).astype(np.float32)
+	w, wt = np.exp(0.3 * rng.normal(size=n)), rng.uniform(0, 1.5, ny)
+	np.savez(tmp_path / 'in.npz', dg1=dg1, dg4=dg4, dt=dt, dc=dc, pc=g8['p'], lcpm=lcpm, w=w, wt=wt)
 	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 	r = subprocess.run([sys.executable, '-c', _NO_TORCH_CRISPR, root, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], capture_output=True, text=True, timeout=900)
 	assert r.returncode == 0, r.stderr[-3000:]
@@ -426,6 +435,8 @@ def test_de_methods_and_binnet_of_the_package_without_torch(tmp_path, golden):
 		assert close(o['vg_' + name], ref[3], 1e-9, 1e-15) and close(o['vt_' + name], ref[4], 1e-9, 1e-15)  # (the grouping without cells: variance 0 on both sides)
 	assert (o['p_s1'][7] == 1).all() and (o['lfc_s1'][7] == 0).all()
 	assert np.array_equal(o['net'], g8['net_q5']) and int(o['unsupported']) == 1
+	refn = oracle.normvar(lcpm.astype(np.float64), dc, w, wt)
+	assert np.abs(o['nv_t'] - refn[0]).max() < 2e-5 * np.abs(refn[0]).max() and close(o['nv_c'], refn[1], 1e-12, 1e-15) and int(o['nv_unsupported']) == 1
 
 
 _CLI_NO_TORCH = r'''
@@ -438,6 +449,7 @@ main(['coex', f('exp.npy'), f('cov.npy'), f('pv.npy'), '--dot_out', f('dot.npy')
 main(['binnet', f('pv.npy'), f('net.npy'), '0.05'])
 for m in ('ignore', 'single', 'covariate'):
 	main(['de', f('dg1.npy' if m == 'single' else 'dg.npy'), f('exp.npy'), f('cov.npy'), f('de_pv_%s.npy' % m), f('de_lfc_%s.npy' % m), '-m', m, '--vart_out', f('de_vt_%s.npy' % m)])
+main(['normvar', f('lcpm.npy'), f('w.npy'), f('cov.npy'), f('wt.npy'), f('nv_exp.npy'), f('nv_cov.npy')])
 assert not any(m == 'torch' or m.startswith('torch.') for m in sys.modules), 'the command line imported torch'
 import torch  # the runtime torch bundles was loaded first: torch still finds its GPU in this process
 assert torch.cuda.is_available() and float(torch.ones(3, device='cuda').sum()) == 3.0
@@ -456,7 +468,8 @@ def test_command_line_runs_on_the_library_entries_without_importing_torch(tmp_pa
 	dg = (rng.random((nx, n)) < 0.05).astype(np.float64)
 	dg1 = (rng.random((nx, n)) < 1.0 / nx).astype(np.float64)
 	dt[:5] += 0.5 * dg[0] + 0.5 * dg1[1]
-	for name, a in (('exp', dt), ('cov', dc), ('dg', dg), ('dg1', dg1)):
+	lcpm, w, wt = rng.normal(size=(ng, n)) - 9, np.exp(0.3 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
+	for name, a in (('exp', dt), ('cov', dc), ('dg', dg), ('dg1', dg1), ('lcpm', lcpm), ('w', w), ('wt', wt)):
 		np.save(tmp_path / (name + '.npy'), a)
 	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 	env = {k: v for k, v in os.environ.items() if k != 'NRM_HOST_ENTRY'}
@@ -466,6 +479,8 @@ def test_command_line_runs_on_the_library_entries_without_importing_torch(tmp_pa
 	p, dot, var = norm.coex(dt, dc)
 	assert p_close(ld('pv.npy'), p) and close(ld('dot.npy'), dot, 1e-9, 1e-12) and close(ld('var.npy'), var, 1e-12)
 	assert np.array_equal(ld('net.npy').astype(bool), norm.binnet(p, 0.05))
+	refn = oracle.normvar(lcpm, dc, w, wt)
+	assert np.abs(ld('nv_exp.npy') - refn[0]).max() < 1e-9 * np.abs(refn[0]).max() and close(ld('nv_cov.npy'), refn[1], 1e-12, 1e-15)
 	for m, single, d in (('ignore', 0, dg), ('single', 1, dg1), ('covariate', 4, dg)):
 		ref = oracle.de(d, dt, dc, single=single)
 		assert p_close(ld('de_pv_%s.npy' % m), ref[0]) and close(ld('de_lfc_%s.npy' % m), ref[1], 1e-8, 1e-12) and close(ld('de_vt_%s.npy' % m), ref[4], 1e-9, 1e-15)
