@@ -260,7 +260,9 @@ def _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka):
 	import ctypes
 	ka = dict(ka)
 	dimreduce = ka.pop('dimreduce', 0)
-	tol = ka.pop('tol', 1E-8)
+	tol = ka.pop('tol', 1E-8) if single == 4 else 1E-8
+	if single == 1:
+		ka.pop('chunk', None)  # (the package's grouping chunk: no meaning here)
 	if single == 4 and (ka.pop('method', 'auto') != 'auto' or ka.pop('mpc', 0) != 0 or ka.pop('qr', 0) != 0):
 		raise NotImplementedError('single=4 host entry: inv_rank options other than tol follow the per-grouping algorithm (needs the package\'s device path)')
 	if ka:
