@@ -191,8 +191,54 @@ def _sparse(eng, lists, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, o
 	_lib.check(eng.lib.nrm_single1_select(lists.row_ptr.data_ptr(), lists.cells.data_ptr(), ptr(lists.row_vals), nx, n, nnz, ptr(d_c), n, nc, cnt.data_ptr(),
 										  code.data_ptr(), d_seg.data_ptr(), idx_e.data_ptr(), xe_d.data_ptr(), ptr(d_ce), rowinfo.data_ptr(), ptr(gpart), info.data_ptr(),
 										  eng._stream()))
-	# what the host needs of the cell order (before the stream kernel is queued: a download behind it would wait for it)
-	h_info, h_rows = info.cpu().numpy(), rowinfo.cpu().numpy()
+	# The groupings' own sums by a wave each (k_s1_group_stats, <= 8 covariates) are queued at once, and so is the stream kernel when its output can be
+	# sized without the host (at most one row of YE per design entry; beyond 4 GB of that the kept count is waited for): what the host needs of the
+	# selection then comes down on the copy stream BESIDE the stream kernel -- downloaded in front of it (round 4) the GPU sat idle for three read-backs.
+	on_device = nc <= 8
+	gs_d = None
+	if on_device:
+		npair = nc * (nc + 1) // 2
+		gs_d = torch.empty((nx, npair + nc + 1), dtype=torch.float64, device=dev)
+		_lib.check(eng.lib.nrm_single1_group_stats(d_seg.data_ptr(), idx_e.data_ptr(), xe_d.data_ptr(), ptr(d_c), n, nc, nx, gs_d.data_ptr(), eng._stream()))
+	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
+	ldye = _round_up(ny, 8)
+	ycode = _lib.NRM_F64 if d_y.dtype == torch.float64 else _lib.NRM_F32
+	common = torch.empty((nc + 1, ny), dtype=torch.float64, device=eng.device)
+	early = on_device and nnz * ldye * d_y.element_size() <= (4 << 30)
+
+	def stream_kernel(rows_ye):
+		ye_ = torch.empty((max(rows_ye, 1), ldye), dtype=d_y.dtype, device=eng.device)
+		with _engine._Span(eng, 's1_stream'):
+			_lib.check(eng.lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), 0 if d_c is None else d_c.data_ptr(), n, nc, code.data_ptr(), n, ny,
+												  common.data_ptr(), ye_.data_ptr(), ldye, eng._stream()))
+		return ye_
+	ye = None
+	if early:
+		main = torch.cuda.current_stream(dev)
+		ready = torch.cuda.Event()
+		ready.record(main)
+		if eng._copy is None:
+			eng._copy = torch.cuda.Stream(device=dev)
+		ye = stream_kernel(nnz)
+		with torch.cuda.stream(eng._copy):
+			eng._copy.wait_event(ready)
+			hosts = []
+			for t in (info, rowinfo, gpart, gs_d):
+				if t is None:
+					hosts.append(None)
+					continue
+				h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+				h.copy_(t, non_blocking=True)
+				t.record_stream(eng._copy)
+				hosts.append(h)
+			arrived = torch.cuda.Event()
+			arrived.record(eng._copy)
+		arrived.synchronize()
+		h_info, h_rows = hosts[0].numpy(), hosts[1].numpy()
+		hp_early, gs_early = (None if hosts[2] is None else hosts[2].numpy()), hosts[3].numpy()
+	else:
+		# what the host needs of the cell order (before the stream kernel is queued: a download behind it would wait for it)
+		h_info, h_rows = info.cpu().numpy(), rowinfo.cpu().numpy()
 	n_common, n_e = int(h_info[3]), int(h_info[4])
 	ns = n_common + h_rows[:, 0]
 	# > 1 distinct value among a grouping's selected cells (:917-918): 0 on the shared cells, if there are any, and its values on its own
@@ -202,7 +248,7 @@ def _sparse(eng, lists, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, o
 	assert bool((vhi > vlo).all())
 	mark('cell order')
 	if nc:  # covariate Gram of the shared cells: the kernel's partial sums added up in a fixed order (no BLAS, on either side)
-		hp = gpart.cpu().numpy()
+		hp = hp_early if early else gpart.cpu().numpy()
 		mcc = np.zeros((nb * 8, nb * 8))
 		q = 0
 		for bi in range(nb):
@@ -214,26 +260,16 @@ def _sparse(eng, lists, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, o
 				mcc[bj * 8:bj * 8 + 8, bi * 8:bi * 8 + 8] = blk.reshape(8, 8).T
 				q += 1
 		mcc = np.ascontiguousarray(mcc[:nc, :nc])
-	on_device = nc <= 8  # the groupings' own sums by a wave each (k_s1_group_stats); more covariates: numpy segment sums on the host
-	if on_device:
-		npair = nc * (nc + 1) // 2
-		gs_d = torch.empty((nx, npair + nc + 1), dtype=torch.float64, device=dev)
-		_lib.check(eng.lib.nrm_single1_group_stats(d_seg.data_ptr(), idx_e.data_ptr(), xe_d.data_ptr(), ptr(d_c), n, nc, nx, gs_d.data_ptr(), eng._stream()))
-		gs = gs_d.cpu().numpy()
+	if on_device:  # (more covariates: numpy segment sums on the host)
+		gs = gs_early if early else gs_d.cpu().numpy()
 	else:
 		counts = h_rows[:, 0].astype(np.int64)
 		seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
 		idx_h = idx_e.cpu().numpy()[:n_e]
 		xe = xe_d.cpu().numpy()[:n_e]
 	# the device's share: it needs nothing of the host's statistics and runs while they are taken
-	d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(dy))
-	ldye = _round_up(ny, 8)
-	ye = torch.empty((max(n_e, 1), ldye), dtype=d_y.dtype, device=eng.device)
-	common = torch.empty((nc + 1, ny), dtype=torch.float64, device=eng.device)
-	ycode = _lib.NRM_F64 if d_y.dtype == torch.float64 else _lib.NRM_F32
-	with _engine._Span(eng, 's1_stream'):
-		_lib.check(eng.lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), 0 if d_c is None else d_c.data_ptr(), n, nc, code.data_ptr(), n, ny,
-											  common.data_ptr(), ye.data_ptr(), ldye, eng._stream()))
+	if ye is None:
+		ye = stream_kernel(n_e)
 	eng.s1_cells_kept = n_e  # (bench.py: the bytes the stream kernel writes)
 	# grouping-side statistics on the host
 	pitch = 26 + nc + nc * nc
