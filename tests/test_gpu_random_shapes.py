@@ -64,7 +64,7 @@ def test_de_on_random_sparse_designs(seed, monkeypatch):
 	assert relerr(got[0][ok], ref[0][ok]) < ptol, (seed, dx.shape, dy.shape, dc.shape)
 	assert close(got[1], ref[1], stol, floor * 1e3) and close(got[3], ref[3], stol, 1e-15) and close(got[4], ref[4], stol, 1e-15)
 	if not lowmem:
-		assert close(got[2], ref[2], 10 * stol, 1e-6 if f32 else 1e-9)
+		assert close(got[2], ref[2], 10 * stol, (1e-6 if f32 else 1e-9) * max(1.0, float(np.abs(ref[2]).max()) if ref[2].size else 1.0, float(np.abs(ref[1]).max())))  # (fp32 outputs: alpha = b_y - gamma b_x is formed from the ROUNDED gamma, as the reference's fp32 path does: its error is that of its largest part)
 
 
 @pytest.mark.parametrize('seed', range(1000, 1016 + _MORE))
