@@ -106,3 +106,42 @@ def test_normvar_on_random_shapes(seed):
 	ref = oracle.normvar(dt.astype(np.float64), dc, w, wt)
 	scale = np.abs(ref[0]).max()
 	assert np.abs(got[0] - ref[0]).max() < (2e-5 if f32 else 1e-9) * scale and close(got[1], ref[1], 1e-12, 1e-15)
+
+
+@pytest.mark.parametrize('seed', range(9000, 9016 + _MORE))
+def test_coex_and_de_on_random_dense_shapes(seed):
+	"""The paths of the earlier rounds under this round's refactors (K1 without its workspace arguments, the streaming sweep without the int8 variant, the
+	degenerate-row rule of nrm_residualize_wide): coex and de on dense rows -- fp64 Gram kernel below 2048 cells, integer engine above, streaming de when
+	nx + nc <= 32, K1 + K2 otherwise -- against the oracle."""
+	import normalisr_amd.normalisr as norm
+	rng = np.random.default_rng(seed)
+	ng = int(rng.integers(2, 150))
+	n = int(rng.choice([rng.integers(40, 400), rng.integers(2048, 2100), rng.integers(2200, 6000)]))
+	nc = int(rng.choice([0, 1, 3, 6, 9]))
+	nx = int(rng.choice([1, 3, 20, 40]))
+	f32 = bool(rng.integers(0, 2))
+	dt = np.log1p(rng.poisson(rng.uniform(0.2, 3.0), (ng, n))).astype(np.float64) + 1e-3 * rng.normal(size=(ng, n))
+	dc = rng.normal(size=(nc, n))
+	if nc and rng.integers(0, 2):
+		dc[-1] = 1.0
+	dg = (rng.random((nx, n)) < rng.uniform(0.1, 0.6)).astype(np.float64)
+	dg[:, :3] = [1, 0, 1]  # (no constant grouping)
+	if n <= nc + 3:
+		pytest.skip('too few cells')
+	if f32:
+		dt = dt.astype(np.float32)
+	ptol, stol = (3e-4, 3e-5) if f32 else (1e-6, 1e-7)
+	d64 = dt.astype(np.float64)
+	p, dot, var = norm.coex(dt, dc)
+	po, do, vo = oracle.coex(d64, dc)
+	off = ~np.eye(ng, dtype=bool)
+	ok = off & (po > (1e-30 if f32 else 1e-290))
+	assert relerr(p[ok], po[ok]) < ptol, (seed, ng, n, nc, f32)
+	assert close(dot[off], do[off], stol, (1e-6 if f32 else 1e-11) * float(np.abs(do[off]).max() if off.any() else 1.0)) and close(var, vo, stol, 1e-15)
+	assert (p == p.T).all() and (np.diag(p) == 0).all()
+	got = norm.de(dg, dt, dc)
+	ref = oracle.de(dg, d64, dc)
+	ok = ref[0] > (1e-30 if f32 else 1e-290)
+	assert relerr(got[0][ok], ref[0][ok]) < ptol, (seed, 'de', nx, ng, n, nc, f32)
+	assert close(got[1], ref[1], stol, (1e-6 if f32 else 1e-11) * float(np.abs(ref[1]).max())) and close(got[3], ref[3], stol, 1e-15) and close(got[4], ref[4], stol, 1e-15)
+
