@@ -137,11 +137,13 @@ def test_coex_and_de_on_random_dense_shapes(seed):
 	off = ~np.eye(ng, dtype=bool)
 	ok = off & (po > (1e-30 if f32 else 1e-290))
 	assert relerr(p[ok], po[ok]) < ptol, (seed, ng, n, nc, f32)
-	assert close(dot[off], do[off], stol, (1e-6 if f32 else 1e-11) * float(np.abs(do[off]).max() if off.any() else 1.0)) and close(var, vo, stol, 1e-15)
+	# (covariances near zero: the integer engine is exact to ~1e-13 of sqrt(var_i var_j) at 2048 cells, DESIGN 4 -- i.e. |delta r| < 1e-12; fp32 outputs round at 6e-8 of the value)
+	assert (np.abs(dot - do)[off] <= stol * np.abs(do[off]) + (1e-7 if f32 else 1e-12) * float(vo.max())).all() and close(var, vo, stol, 1e-15)
 	assert (p == p.T).all() and (np.diag(p) == 0).all()
 	got = norm.de(dg, dt, dc)
 	ref = oracle.de(dg, d64, dc)
 	ok = ref[0] > (1e-30 if f32 else 1e-290)
 	assert relerr(got[0][ok], ref[0][ok]) < ptol, (seed, 'de', nx, ng, n, nc, f32)
-	assert close(got[1], ref[1], stol, (1e-6 if f32 else 1e-11) * float(np.abs(ref[1]).max())) and close(got[3], ref[3], stol, 1e-15) and close(got[4], ref[4], stol, 1e-15)
+	assert (np.abs(got[1] - ref[1]) <= stol * np.abs(ref[1]) + (1e-7 if f32 else 1e-12) * np.sqrt(ref[3][:, None] * ref[4][None, :].max())).all()
+	assert close(got[3], ref[3], stol, 1e-15) and close(got[4], ref[4], stol, 1e-15)
 
