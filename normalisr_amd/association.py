@@ -221,6 +221,20 @@ def _have_torch():
 		return False
 
 
+_pool = None
+
+
+def _result(shape, dtype):
+	"""A result array of the host-entry route: from the recycled page-locked pool the torch engine uses (engine.PinnedPool: ctypes and the library only) --
+	a fresh numpy array of 100 MB costs its page faults and a page-lock on EVERY call (configs[1] through the entry: 24 ms per call against 11) --, or plain
+	numpy memory when the pool is exhausted or disabled (NRM_PINNED_POOL_MB)."""
+	global _pool
+	if _pool is None:
+		_pool = _engine.PinnedPool(_lib.load())
+	a = _pool.empty(shape, dtype)
+	return np.empty(shape, dtype=dtype) if a is None else a
+
+
 def _single0_host_entry(dx, dy, dc64, dci, dcr, dimreduce, return_dot, want_alpha, out_dtype, want_rt):
 	"""single=0 through nrm_association_tests_host (include/normalisr_hip.h): the C entry a maintainer of the reference would bind --
 	host buffers in, host buffers out, uploads, kernels, the integer engine's guard and its fp64 rerun inside the library.  Used
@@ -234,12 +248,12 @@ def _single0_host_entry(dx, dy, dc64, dci, dcr, dimreduce, return_dot, want_alph
 	odt = np.dtype(out_dtype)
 	code = lambda a: _lib.NRM_F64 if a.dtype == np.float64 else _lib.NRM_F32
 	vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-	p, stat = np.empty((nx, ny), dtype=odt), np.empty((nx, ny), dtype=odt)
-	alpha = np.empty((nx, ny, nc), dtype=odt) if (want_alpha and not samexy) else None
+	p, stat = _result((nx, ny), odt), _result((nx, ny), odt)
+	alpha = _result((nx, ny, nc), odt) if (want_alpha and not samexy) else None
 	varx = None if samexy else np.empty(nx, dtype=odt)
 	vary = np.empty(ny, dtype=odt)
-	r = np.empty((nx, ny), dtype=odt) if want_rt else None
-	t = np.empty((nx, ny), dtype=odt) if want_rt else None
+	r = _result((nx, ny), odt) if want_rt else None
+	t = _result((nx, ny), odt) if want_rt else None
 	dc64 = np.ascontiguousarray(dc64)
 	dci = np.ascontiguousarray(dci, dtype=np.float64)
 	_lib.check(lib.nrm_association_tests_host(vp(dx), code(dx), nx, vp(dy), 0 if samexy else code(dy), 0 if samexy else ny, vp(dc64), _lib.NRM_F64, nc, n,
@@ -287,9 +301,9 @@ def _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka):
 	lib = _lib.load()
 	code = lambda a: _lib.NRM_F64 if a.dtype == np.float64 else _lib.NRM_F32
 	vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-	p, stat, vary = (np.empty((nx, ny), dtype=odt) for _ in range(3))
+	p, stat, vary = (_result((nx, ny), odt) for _ in range(3))
 	varx = np.empty(nx, dtype=odt)
-	alpha = None if lowmem else np.empty((nx, ny, nc), dtype=odt)
+	alpha = None if lowmem else _result((nx, ny, nc), odt)
 	ocode = _lib.NRM_F64 if odt == np.float64 else _lib.NRM_F32
 	if single == 1:
 		_lib.check(lib.nrm_association_tests_single1_host(vp(dx), code(dx), nx, vp(dy), code(dy), ny, vp(dc64), _lib.NRM_F64, nc, n, int(dimreduce), 1 if return_dot else 0,

@@ -17,6 +17,7 @@ for route in ('package', 'c_entry'):
 		t0 = time.perf_counter()
 		out = norm.coex(dt, dc)
 		ts.append(time.perf_counter() - t0)
+	print(route, ' '.join('%.1f' % (t * 1e3) for t in ts))
 	res[route] = (min(ts), out)
 	out = None
 a, b = res['package'][1][0].astype(np.float64), res['c_entry'][1][0].astype(np.float64)
