@@ -76,7 +76,8 @@ def binnet(net, qcut):
 		# no torch in this process (or NRM_HOST_ENTRY=1): the library's whole-problem entry, numpy buffers in and out
 		import ctypes
 		hp = _engine.as_input(net)
-		out = np.empty((nt, nt), dtype=np.uint8)
+		from .association import _result
+		out = _result((nt, nt), np.uint8)
 		total = ctypes.c_int64(-1)
 		_lib.check(_lib.load().nrm_binnet_host(hp.ctypes.data_as(ctypes.c_void_p), _lib.NRM_F64 if hp.dtype == np.float64 else _lib.NRM_F32, nt, float(qcut),
 											   out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(total)))

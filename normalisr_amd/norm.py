@@ -119,7 +119,8 @@ def _normvar_host_entry(dt, dc, w, wt, dextra, cat, keepvar, tol, out_dtype):
 	c64 = np.ascontiguousarray(dc, dtype=np.float64)
 	lnw = np.log(np.asarray(w, dtype=np.float64))
 	wt64 = np.ascontiguousarray(wt, dtype=np.float64)
-	out = np.empty((nt, ns), dtype=out_dtype)
+	from .association import _result
+	out = _result((nt, ns), out_dtype)  # (page-locked, recycled: 400 MB of fresh numpy memory per call cost more than the kernels)
 	zero = ctypes.c_int64(0)
 	vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
 	code = lambda a: _lib.NRM_F64 if a.dtype == np.float64 else _lib.NRM_F32
