@@ -261,3 +261,25 @@ def test_host_minmax_in_one_threaded_pass(dtype):
 				assert out[1] == np.inf
 	lib.nrm_host_minmax(a.ctypes.data, code, 0, 0, out.ctypes.data)
 	assert out[0] == np.inf and out[1] == -np.inf and out[2] == 0
+
+
+def test_host_entry_routing_and_result_arrays_without_a_gpu(monkeypatch):
+	"""The pieces of the torch-free route that are host logic: NRM_HOST_ENTRY / the command line's preference (and =0 overriding it), and result arrays that
+	fall back to plain numpy memory when no page-locked block can be had (no GPU here: hipHostMalloc fails)."""
+	from normalisr_amd import _lib, association
+	monkeypatch.delenv('NRM_HOST_ENTRY', raising=False)
+	assert not _lib.host_entry_preferred()
+	prev = _lib.prefer_host_entry(True)
+	try:
+		assert _lib.host_entry_preferred()
+		monkeypatch.setenv('NRM_HOST_ENTRY', '0')
+		assert not _lib.host_entry_preferred()
+	finally:
+		_lib.prefer_host_entry(prev)
+	monkeypatch.setenv('NRM_HOST_ENTRY', '1')
+	assert _lib.host_entry_preferred()
+	a = association._result((700, 800), np.float32)
+	assert a.shape == (700, 800) and a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+	a[:] = 1.0
+	assert float(a.sum()) == 700 * 800
+
