@@ -284,12 +284,15 @@ __global__ void __launch_bounds__(256) k_s1_cells(const T* __restrict__ YE, int6
 	for (int c = 0; c < NA; c++) a[c] = c < nc ? common[(int64_t)c * ny + y] : 0.0;
 	int64_t k = seg[i];
 	const int64_t k1 = seg[i + 1];
-	for (; k + 4 <= k1; k += 4) {  // four cells per step: their loads are in flight together
-		double v[4];
+#ifndef S1_CU
+#define S1_CU 8  // (4: 0.347 ms, 8: 0.333, 16: 0.359 for the configs[3]-shaped screen)
+#endif
+	for (; k + S1_CU <= k1; k += S1_CU) {  // S1_CU cells per step: their loads are in flight together
+		double v[S1_CU];
 #pragma unroll
-		for (int u = 0; u < 4; u++) v[u] = (double)YE[(k + u) * ldye + y];
+		for (int u = 0; u < S1_CU; u++) v[u] = (double)YE[(k + u) * ldye + y];
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
+		for (int u = 0; u < S1_CU; u++) {
 			const double* ck = CE + (k + u) * nc;
 #pragma unroll
 			for (int c = 0; c < NA; c++)
