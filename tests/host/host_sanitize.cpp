@@ -3,13 +3,16 @@
 //  * the persistent Gram schedule: for many shapes, every k-unit of every tile of a launch is covered exactly once by the pieces
 //    of the workgroups, split tiles get a slab each inside the workspace, band launches tile the whole problem;
 //  * the scratch pool of the whole-problem entry (best-fit reuse, out-of-memory retry, release) on a counting allocator;
-//  * the P-value plan constants (finite, monotone in dof).
+//  * the P-value plan constants (finite, monotone in dof);
+//  * the Jacobi pseudo-inverse the host stack and normvar's device solve share (csrc/nrm_jacobi.h): M M^+ M = M, integer ranks of full-rank, rank-deficient,
+//    tiny- and huge-scaled matrices up to the 32 x 32 the stack allows.
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <set>
 #include "../../normalisr_amd/csrc/nrm_host_logic.h"
+#include "../../normalisr_amd/csrc/nrm_jacobi.h"
 
 static char g_err[512];
 void nrm_set_error(const char* fmt, ...) {
@@ -127,6 +130,47 @@ int main() {
 	}
 	nrm_pvalue_plan pl;
 	CHECK(nrm_pvalue_plan_init_host(&pl, 0.0) == NRM_E_ARG && nrm_pvalue_plan_init_host(nullptr, 3.0) == NRM_E_ARG);
+	// the shared Jacobi pseudo-inverse: Moore-Penrose identity and ranks (association.py:77-80)
+	{
+		unsigned long long st = 88172645463325252ull;
+		auto rnd = [&]() {
+			st ^= st << 13;
+			st ^= st >> 7;
+			st ^= st << 17;
+			return (double)(st >> 11) / 9007199254740992.0 - 0.5;
+		};
+		for (int n : {1, 2, 5, 8, 17, 32})
+			for (int deficient = 0; deficient < 3; deficient++)
+				for (double scale : {1.0, 1e-150, 1e150}) {
+					const int r = deficient == 0 ? n : (deficient == 1 ? (n + 1) / 2 : 1);  // rank of the factor
+					std::vector<double> f((size_t)n * r), m((size_t)n * n), inv((size_t)n * n), t((size_t)n * n);
+					for (auto& x : f) x = rnd();
+					for (int i = 0; i < n; i++)
+						for (int j = 0; j < n; j++) {
+							double acc = 0;
+							for (int k = 0; k < r; k++) acc += f[(size_t)i * r + k] * f[(size_t)j * r + k];
+							m[(size_t)i * n + j] = acc * scale;
+						}
+					int64_t rank = -1;
+					nrm_small_pinv_one<32>(m.data(), n, 1e-8, inv.data(), &rank);
+					CHECK(rank == r);
+					double err = 0, nrm = 0;  // M M^+ M = M
+					for (int i = 0; i < n; i++)
+						for (int j = 0; j < n; j++) {
+							double acc = 0;
+							for (int k = 0; k < n; k++) acc += m[(size_t)i * n + k] * inv[(size_t)k * n + j];
+							t[(size_t)i * n + j] = acc;
+						}
+					for (int i = 0; i < n; i++)
+						for (int j = 0; j < n; j++) {
+							double acc = 0;
+							for (int k = 0; k < n; k++) acc += t[(size_t)i * n + k] * m[(size_t)k * n + j];
+							err = std::max(err, std::fabs(acc - m[(size_t)i * n + j]));
+							nrm = std::max(nrm, std::fabs(m[(size_t)i * n + j]));
+						}
+					CHECK(err <= 1e-9 * nrm);
+				}
+	}
 	printf("host logic ok\n");
 	return 0;
 }
