@@ -154,6 +154,30 @@ def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
 	assert r.returncode == 0 and 'host logic ok' in r.stdout, r.stdout[-2000:]
 
 
+def _sanitize_build_and_run(tmp_path, hip_source, harness, token):
+	import shutil
+	import subprocess
+	gxx = shutil.which('g++')
+	hip_inc = '/opt/rocm/include'
+	if gxx is None or not os.path.exists(os.path.join(hip_inc, 'hip', 'hip_runtime.h')):
+		pytest.skip('no g++ / HIP headers')
+	exe = str(tmp_path / 'sanitize_exe')
+	r = subprocess.run([gxx, '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=all', '-D__HIP_PLATFORM_AMD__', '-I' + hip_inc, '-pthread', '-w',
+						'-x', 'c++', os.path.join(ROOT, 'normalisr_amd', 'csrc', hip_source), os.path.join(ROOT, 'tests', 'host', harness), '-o', exe],
+					   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+	if r.returncode != 0 and ('asan' in r.stdout or 'ubsan' in r.stdout or 'sanitize' in r.stdout):
+		pytest.skip('sanitizer runtimes not installed: ' + r.stdout[-200:])
+	assert r.returncode == 0, r.stdout[-3000:]
+	r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+	assert r.returncode == 0 and token in r.stdout, r.stdout[-3000:]
+
+
+def test_small_numerics_under_address_and_ub_sanitizers(tmp_path):
+	"""csrc/nrm_small_pinv.hip (host code): the threaded stack of small pseudo-inverses, the one-pass minimum / maximum / NaN count behind the reference's result
+	assertions, the small eigenvalue routine -- odd counts, every thread count, exact-size buffers, under ASan + UBSan (tests/host/pinv_sanitize.cpp)."""
+	_sanitize_build_and_run(tmp_path, 'nrm_small_pinv.hip', 'pinv_sanitize.cpp', 'small numerics ok')
+
+
 def test_text_parser_and_printer_under_address_and_ub_sanitizers(tmp_path):
 	"""The command line's text parser / printer (csrc/nrm_tsv.hip: host code) reads what users hand it: built by g++ with -fsanitize=address,undefined beside a
 	harness (tests/host/tsv_sanitize.cpp) that round-trips random matrices of every magnitude through '%.8G' / '%i' text in 1 .. 7 threads and feeds it hostile text
