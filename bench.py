@@ -18,8 +18,8 @@ HBM-bound streaming kernel), de_c4 = configs[3] (1k gRNAs x 15k genes x 50k cell
 ranks, no collective), coex_c5 = the per-rank shape of configs[4] (3750 gene rows per rank x 500k cells,
 fp64; at N=8 that is the full 30k x 30k problem, residual blocks exchanged by all-gather), de_c4_single4 / de_c4_single1 = the
 CRISPR screen of configs[3] as the reference's example runs it besides the naive test (`de -m covariate` / `-m single`,
-examples/GSE120861/code/cmd_highmoi.sh:19-22), coex_c2_f64 = configs[1] on the fp64 matrix cores (NRM_GRAM=f64: the dtype the
-north star names literally), binnet_c5 = binnet on a 30 000 x 30 000 fp64 P-value matrix (the consumer of configs[4]'s output), normvar_c2 = norm.normvar on a
+examples/GSE120861/code/cmd_highmoi.sh:19-22), coex_c2_f64 / coex_c5_f64 = configs[1] / the configs[4] per-rank slice on the fp64 matrix cores
+(NRM_GRAM=f64: the dtype the north star names literally), binnet_c5 = binnet on a 30 000 x 30 000 fp64 P-value matrix (the consumer of configs[4]'s output), normvar_c2 = norm.normvar on a
 configs[1]-sized matrix resident in HBM (the step in front of the hot path), chain_c2 = normvar -> coex -> binnet as one resident chain.
 `--workload X` makes X the headline instead; `--no-extras` skips them.
 
@@ -806,7 +806,7 @@ def main():
 	ap.add_argument('--cells', type=int, default=10000)
 	ap.add_argument('--cpu-seconds', type=float, default=10.0, help='minimum CPU-baseline time (0 = skip)')
 	ap.add_argument('--cpu-worker', nargs=6, default=None, help=argparse.SUPPRESS)
-	ap.add_argument('--workload', default=None, choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_full_1gpu', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'chain_c2'],
+	ap.add_argument('--workload', default=None, choices=['coex_c2', 'de_c3', 'de_c4', 'coex_c5', 'coex_c5_f64', 'coex_c5_full_1gpu', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'chain_c2'],
 					help='headline workload.  Default: coex_c2 = BASELINE configs[1] at N=1; coex_c5 = configs[4] (3750 gene rows per rank x 500k cells) at N>1, '
 					'the configuration the 8-GPU target is quoted on.  de_c3 / de_c4 = configs[2] / [3]')
 	ap.add_argument('--c5-rows', type=int, default=C5_ROWS_PER_RANK, help='gene rows per rank of the coex_c5 workload (smaller: functional runs)')
@@ -901,11 +901,11 @@ def main():
 			if out is not None:
 				pmc_traffic(which, out['roofline'], kernels=['k_binnet_rows'])
 			return out
-		if which == 'coex_c2_f64':  # configs[1] on the fp64 matrix cores: the dtype the north star names literally
+		if which in ('coex_c2_f64', 'coex_c5_f64'):  # configs[1] / the configs[4] slice on the fp64 matrix cores: the dtype the north star names literally
 			prev = os.environ.get('NRM_GRAM')
 			os.environ['NRM_GRAM'] = 'f64'
 			try:
-				out = run('coex_c2', steps, warmup)
+				out = run(which[:-4], steps, warmup)
 			finally:
 				if prev is None:
 					del os.environ['NRM_GRAM']
@@ -990,10 +990,10 @@ def main():
 		dog = threading.Timer(args.extras_timeout, give_up)
 		dog.daemon = True
 		dog.start()
-		names = [w for w in ('coex_c5', 'coex_c2', 'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64') if w != args.workload and not (w == 'coex_c2' and world == 1)] + (
+		names = [w for w in ('coex_c5', 'coex_c2', 'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c2_f64', 'coex_c5_f64') if w != args.workload and not (w == 'coex_c2' and world == 1)] + (
 			['binnet_c5', 'normvar_c2', 'chain_c2', 'coex_c5_full_1gpu'] if world == 1 and not rk.forced else [])
 		if world > 1:
-			names = [w for w in names if w != 'coex_c2_f64']
+			names = [w for w in names if w not in ('coex_c2_f64', 'coex_c5_f64')]
 		if args.extras:
 			names = [w for w in names if w in args.extras.split(',')]
 		for w in names:

@@ -26,3 +26,63 @@ def relerr(a, b, atol=0.):
 	a = np.asarray(a, dtype=np.float64)
 	b = np.asarray(b, dtype=np.float64)
 	return float(np.max(np.abs(a - b) / (np.abs(b) + atol))) if a.size else 0.
+
+
+# ---- collection order of the GPU suite ---------------------------------------------------------------------------------------
+# The driver runs `pytest tests -x -q -m gpu`: one failure ends the run.  What proves parity runs first -- the reference-held
+# fixtures (every test that takes the `golden` fixture, G1-G15) and the kernels' exactness tests --, then the C-ABI entries, then
+# the rest of the parity tests, then everything that starts other processes (bench.py, the sharded command line), and LAST the
+# timing bounds (tests/test_zz_perf_gpu.py).  Inside a tier the order of the files is kept.
+_FIRST = ('golden', 'g11_', 'g13_', 'g14_', 'integer_gram', 'gram_engines', 'gram_kernel_layout', 'pvalue_kernel_table', 'pvalue_function_against_mpmath',
+		  'block_g7', 'k1_row_records', 'single5_with_a_mask', 'full_size_c2_properties')
+_ENTRIES = ('host_entry', 'c_entry', 'c_entries', 'without_torch', 'without_importing_torch')
+_PROCESSES = ('bench_', 'sharded', 'two_ranks', 'rccl_', 'cli_')
+
+
+def _tier(item):
+	name = item.name.lower()
+	if 'test_zz_perf' in item.nodeid:
+		return 9
+	if 'golden' in getattr(item, 'fixturenames', ()) or any(k in name for k in _FIRST):
+		return 0
+	if any(k in name for k in _ENTRIES):
+		return 1
+	if any(k in name for k in _PROCESSES) or 'bench_default' in getattr(item, 'fixturenames', ()):
+		return 3
+	return 2
+
+
+def pytest_collection_modifyitems(config, items):
+	gpu = [i for i, it in enumerate(items) if it.get_closest_marker('gpu') is not None]
+	ordered = sorted((items[i] for i in gpu), key=_tier)  # stable: file order inside a tier
+	for i, it in zip(gpu, ordered):
+		items[i] = it
+
+
+def run_bench(extra_args, env_extra, timeout=900):
+	"""`python bench.py ...` as the driver runs it (a child process); returns the contract line (the LAST line of stdout, under 4 KB) with the
+	full record of every workload, printed on the lines before it, under '_detail'."""
+	import json
+	import subprocess
+	env = dict(os.environ)
+	env.update(env_extra)
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+					   timeout=timeout)
+	assert r.returncode == 0, r.stderr[-3000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+	assert lines and r.stdout.rstrip().splitlines()[-1] == lines[-1], r.stdout[-2000:]  # the contract line is the LAST line
+	assert len(lines[-1]) < 4096, len(lines[-1])  # (the driver keeps the tail of stdout: round 4's 14 KB line lost its first extras there)
+	out = json.loads(lines[-1])
+	detail = {}
+	for ln in lines[:-1]:  # the full record of every workload, printed before it
+		d = json.loads(ln)
+		detail[d.pop('workload_detail')] = d
+	out['_detail'] = detail
+	return out
+
+
+@pytest.fixture(scope='session')
+def bench_default():
+	"""One default N=1 run of bench.py (short: 3 steps, no CPU baseline, no PCIe leg), shared by the test of the line's CONTENT
+	(tests/test_gpu_round2.py) and the timing bounds (tests/test_zz_perf_gpu.py)."""
+	return run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})

@@ -228,10 +228,12 @@ def test_pvalue_plans_of_a_screen_are_cheap():
 	dof = np.ascontiguousarray(np.arange(30, 30 + 4000, dtype=np.float64))
 	out = np.zeros((dof.size, 24))
 	lib.nrm_pvalue_plan_init_many(dof.ctypes.data, 1, out.ctypes.data, 24)
-	t0 = time.perf_counter()
-	assert lib.nrm_pvalue_plan_init_many(dof.ctypes.data, dof.size, out.ctypes.data, 24) == 0
-	dt = time.perf_counter() - t0
-	assert dt < 0.02, dt  # 5 us per plan at most
+	dt = []
+	for _ in range(5):  # (the best of five in this thread's CPU time: a busy box must not fail a parity suite)
+		t0 = time.thread_time()
+		assert lib.nrm_pvalue_plan_init_many(dof.ctypes.data, dof.size, out.ctypes.data, 24) == 0
+		dt.append(time.thread_time() - t0)
+	assert min(dt) < 0.05, dt  # 12 us per plan at most (25 us each with powl() in the loops)
 	again = np.zeros((1, 24))
 	lib.nrm_pvalue_plan_init_many(dof[1234:].ctypes.data, 1, again.ctypes.data, 24)
 	assert np.array_equal(again[0], out[1234])

@@ -258,22 +258,7 @@ def test_config4_rank_shape_fp64_500k_cells(eng):
 	assert (np.diag(res['p']) == 0).all() and (res['p'] == res['p'].T).all() and (res['stat'] == res['stat'].T).all()
 
 
-def _run_bench(extra_args, env_extra, timeout=900):
-	env = dict(os.environ)
-	env.update(env_extra)
-	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-					   timeout=timeout)
-	assert r.returncode == 0, r.stderr[-3000:]
-	lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-	assert lines and r.stdout.rstrip().splitlines()[-1] == lines[-1], r.stdout[-2000:]  # the contract line is the LAST line
-	assert len(lines[-1]) < 4096, len(lines[-1])  # (the driver keeps the tail of stdout: round 4's 14 KB line lost its first extras there)
-	out = json.loads(lines[-1])
-	detail = {}
-	for ln in lines[:-1]:  # the full record of every workload, printed before it
-		d = json.loads(ln)
-		detail[d.pop('workload_detail')] = d
-	out['_detail'] = detail
-	return out
+from conftest import run_bench as _run_bench  # noqa: E402
 
 
 def test_bench_self_launches_two_ranks_on_one_gpu():
@@ -307,14 +292,16 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 	assert one['scaling_series']['ms_per_step'] == one['_detail']['coex_c5']['ms_per_step'] and one['scaling_series']['tests_per_step'] == 384 * 383 // 2
 
 
-def test_bench_default_line_carries_the_other_configs():
+def test_bench_default_line_carries_the_other_configs(bench_default):
 	"""The default N=1 run: configs[1] as `value` on a contract line under 4 KB that is the LAST line of stdout, with one summary row per
 	extra workload (de_c3 / de_c4 / coex_c5 = the per-rank slice / configs[4] whole on this one GPU / ...) and the scaling series; the full
-	record of every workload -- roofline, kernel split, the guard's verdict -- on the lines before it."""
-	out = _run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
+	record of every workload -- roofline, kernel split, the guard's verdict -- on the lines before it.  CONTENT only: which kernels ran, which
+	keys are there, what the guard said.  No bound on a time here (round 5's driver run lost 101 tests behind `ms_per_step < 12` on a box
+	whose host was slow); the timing bounds are tests/test_zz_perf_gpu.py, collected last."""
+	out = bench_default
 	assert out['n_gpus'] == 1 and out['config']['genes'] == 5000 and out['dtype'].startswith('i8 digits') and out['roofline']['kernel'] == 'k_gram_i8'
 	ex = out['_detail']
-	names = {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'chain_c2', 'coex_c5_full_1gpu'}
+	names = {'de_c3', 'de_c4', 'de_c4_single4', 'de_c4_single1', 'coex_c5', 'coex_c5_f64', 'coex_c2_f64', 'binnet_c5', 'normvar_c2', 'chain_c2', 'coex_c5_full_1gpu'}
 	assert set(ex) == names | {'coex_c2'} and set(out['extra_workloads']) == names, (sorted(ex), sorted(out['extra_workloads']))
 	for w in names:  # the summary rows are the records' numbers
 		row, rec = out['extra_workloads'][w], ex[w]
@@ -322,27 +309,27 @@ def test_bench_default_line_carries_the_other_configs():
 	# (b) one workload at every N: the per-rank slice of configs[4], here from the coex_c5 extra
 	ser = out['scaling_series']
 	assert ser['ranks'] == 1 and ser['value'] == ex['coex_c5']['value'] and ser['ms_per_step'] == ex['coex_c5']['ms_per_step'] and ser['tests_per_step'] == 3750 * 3749 // 2
-	assert ex['de_c4_single1']['roofline']['kernel'] == 'k_s1_stream' and ex['de_c4_single1']['ms_per_step'] < 12
+	assert ex['de_c4_single1']['roofline']['kernel'] == 'k_s1_stream'
 	assert ex['coex_c2_f64']['roofline']['kernel'] == 'k_gram_f64' and ex['coex_c2_f64']['dtype'] == 'f64' and ex['coex_c2_f64']['roofline']['traffic'] is None
 	assert 'traffic_source' not in ex['coex_c2_f64']['roofline']
+	# configs[4]'s literal-fp64 companion: the per-rank slice on the fp64 matrix cores, priced against their peak
+	assert ex['coex_c5_f64']['roofline']['kernel'] == 'k_gram_f64' and ex['coex_c5_f64']['dtype'] == 'f64' and ex['coex_c5_f64']['roofline']['peak'] == 78.6
+	assert ex['coex_c5_f64']['config']['tests_per_step'] == ex['coex_c5']['config']['tests_per_step']
 	assert ex['de_c4_single4']['roofline']['kernel'] == 'k_de_sparse' and ex['de_c4_single4']['guard']['uncertified_pairs'] == 0 and not ex['de_c4_single4']['guard']['fp64_rerun']
-	assert ex['de_c4_single4']['ms_per_step'] < 4 * ex['de_c4']['ms_per_step']
 	assert out['guard']['uncertified_pairs'] == 0 and 0 < out['guard']['largest_relative_p_error_bound'] < out['guard']['tolerance']
 	assert ex['coex_c5_full_1gpu']['config']['tests_per_step'] == 30000 * 29999 // 2 and ex['coex_c5_full_1gpu']['guard']['uncertified_pairs'] == 0
 	# configs[3]'s design is gRNA incidence (1 % of the entries set): the sparse-design kernels, not K1 + K2 (tests/test_gpu_round4.py holds both to the oracle)
-	assert ex['de_c4']['roofline']['kernel'] == 'k_de_sparse' and ex['de_c4']['kernels_ms']['de_sparse'] < ex['de_c4']['ms_per_step'] < 8
+	assert ex['de_c4']['roofline']['kernel'] == 'k_de_sparse' and ex['de_c4']['kernels_ms']['de_sparse'] > 0
 	# (a) its traffic is that of the kernels the step ran (or null) -- never the dense path's k_gram_i8
 	roof = ex['de_c4']['roofline']
 	assert roof['traffic'] is None or ('k_de_sparse' in roof['traffic_source'] and 'k_gram_i8' not in roof['traffic_source'] and roof['traffic'] < 4 * roof['algorithmic_bytes'])
-	# a cold call (a design tensor the engine has not seen: lists built inside the call) beside the resident step
-	assert 0.7 * ex['de_c4']['ms_per_step'] < ex['de_c4']['cold_ms'] < ex['de_c4']['ms_per_step'] + 1.0 and out['extra_workloads']['de_c4']['cold_ms'] == round(ex['de_c4']['cold_ms'], 3)
-	# normvar without the host: resident step under 1.5 ms (round 4: 16.9 ms numpy -> numpy); the chain normvar -> coex -> binnet costs about its parts
-	assert ex['normvar_c2']['ms_per_step'] < 1.5 and ex['normvar_c2']['roofline']['frac'] > 0.05 and ex['chain_c2']['ms_per_step'] < ex['normvar_c2']['ms_per_step'] + out['ms_per_step'] + 2.0
+	# a cold call (a design tensor the engine has not seen: lists built inside the call) is reported beside the resident step
+	assert ex['de_c4']['cold_ms'] > 0 and out['extra_workloads']['de_c4']['cold_ms'] == round(ex['de_c4']['cold_ms'], 3)
 	assert ex['chain_c2']['config']['edges_kept'] > 0
 	assert ex['de_c3']['roofline']['bound'] == 'hbm' and ex['de_c4']['roofline']['bound'] == 'hbm' and ex['coex_c5']['roofline']['bound'] == 'mfma'
 	for k, v in ex.items():
 		assert 'error' not in v, (k, v)
-		assert v['value'] > 0 and v['ms_per_step'] > 0 and 0 < v['roofline']['frac'] < 1.2, (k, v['roofline'])
+		assert v['value'] > 0 and v['ms_per_step'] > 0 and v['roofline']['frac'] > 0, (k, v['roofline'])
 
 
 def test_single4_variants_golden_and_oracle(golden, norm):

@@ -1,4 +1,4 @@
-"""GPU tests added in round 4 (K1 with the rows resident on chip left the library in round 5: tools/experiments/test_k1_res.py): the engine called from several
+"""GPU tests added in round 4 (K1 with the rows resident on chip left the library in round 5: tools/experiments/k1_res_parity.py): the engine called from several
 threads, single=4 / single=1 on the integer engine, one-pass binnet.  Same tolerances as test_gpu_parity.py (BASELINE.json
 north_star: 1e-6 relative on Pearson r, t and p; integers, shapes and zeros bit-exact)."""
 import os

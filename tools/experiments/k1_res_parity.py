@@ -2,6 +2,13 @@
 the kernel was part of the shipped library (round 4, opt-in NRM_K1=res).  Parity-green and slower than the two-sweep kernel (4.19 against 3.55 ms
 on configs[3] rows: Little's law on the register file, profiles/r04_k1res_phases.txt); it left the library in round 5 with its entry points (the
 d_work / work_bytes arguments of nrm_residualize_q*, nrm_residualize_workspace_bytes, nrm_k1_debug_buffer, Engine.k1_work).  """
+import numpy as np
+import pytest
+
+# archived with its kernel: the entry points it drives are no longer exported by the library (see the header); not collected (the file name
+# does not match test_*.py, and the repo-root conftest.py ignores tools/)
+pytestmark = pytest.mark.skip(reason="archived experiment: needs the entry points of the kernel restored")
+
 def decode_planes(planes, rows_pad, nks, ns, cks=None):
 	"""Fixed-point integers q (rows_pad, 32 nks) from the digit planes of the integer Gram engine: plane s is
 	[rows_pad / 32][k-steps][32 rows x 32 bytes], the two 16-byte halves of a row swapped when (row >> 3) & 1 (nrm_gram_i8.hip)."""

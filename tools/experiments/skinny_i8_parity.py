@@ -3,6 +3,13 @@ while the kernel was part of the shipped library (rounds 3-4, opt-in NRM_DE_I8=1
 kernel on every BASELINE shape (2.48 against 1.87 ms on configs[2]) and left the library in round 5 with its entry
 points (nrm_skinny_i8, nrm_row_scales, the integer arguments of nrm_de_small_sweep).  Kept for whoever picks the formulation up again: it needs
 those entry points restored (git show 91ead47:normalisr_amd/csrc/nrm_sweep.hip, :include/normalisr_hip.h, :normalisr_amd/engine.py)."""
+import numpy as np
+import pytest
+
+# archived with its kernel: the entry points it drives are no longer exported by the library (see the header); not collected (the file name
+# does not match test_*.py, and the repo-root conftest.py ignores tools/)
+pytestmark = pytest.mark.skip(reason="archived experiment: needs the entry points of the kernel restored")
+
 @pytest.mark.parametrize('dtype,n,ny,nc', [(np.float32, 4096 + 48, 1000, 20), (np.float64, 8192, 530, 3), (np.float32, 20000, 700, 30)])
 def test_streaming_de_on_the_int8_matrix_cores(eng, dtype, n, ny, nc, monkeypatch):
 	"""A resident DePlan on the streaming path (n_x + n_cov <= 31): the first step runs the fp64 kernel and takes the fixed-point scale
