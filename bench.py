@@ -388,6 +388,51 @@ def timed_steps(rk, plan, steps, warmup, events_inside):
 	return rk.max_over_ranks(time.perf_counter() - t0)
 
 
+def self_check(rk, plan, dt_local, dc, n_rows=12):
+	"""The N > 1 line checks itself (round-5 verdict, item 5): after the timed region, untimed, every rank completes the rows of its gene block
+	(CoexPlan.complete_rows: the point-to-point exchange of the blocks other ranks computed), the ranks pool a few RAW gene rows each (>= n_rows in
+	all) and their P-values against each other as the N ranks computed them; then the SAME device computes those pairs as one rank would -- one
+	coex call on the pooled rows, no exchange -- and the two must agree to 1e-6 relative (the north star's bar).  A pair's P-value depends on its two
+	rows and the covariates alone, so the sub-problem's values are the full problem's.  The oracle is not involved (tests/ hold the device to it)."""
+	import numpy as np
+	import torch.distributed as dist
+	from normalisr_amd.association import inv_rank
+	torch, world, rank = rk.torch, rk.world, rk.rank
+	R = plan.rows
+	m = max(1, -(-n_rows // world))
+	idx = torch.tensor(sorted(set(int(v) for v in np.linspace(0, R - 1, m).round())), device=dt_local.device)
+	m = int(idx.numel())
+	P, _ = plan.complete_rows()
+	cols = torch.cat([idx + b * R for b in range(world)])
+	mine_rows = dt_local.index_select(0, idx).contiguous()
+	mine_p = P.index_select(0, idx.to(P.device)).index_select(1, cols.to(P.device)).to(torch.float64).contiguous()  # (m, world m)
+	if os.environ.get('NRM_BENCH_FAULT') == 'p' and rank == world - 1:
+		mine_p[0, 0] *= 1.001  # (tests: one P-value of the last rank off by 1e-3 -- the run must fail)
+	on_host = rk.backend != 'nccl'
+	send = lambda t: t.cpu() if on_host else t
+	rows_all = [torch.empty_like(send(mine_rows)) for _ in range(world)]
+	p_all = [torch.empty_like(send(mine_p)) for _ in range(world)]
+	dist.all_gather(rows_all, send(mine_rows))
+	dist.all_gather(p_all, send(mine_p))
+	xs = torch.cat([t.to(dt_local.device) for t in rows_all])  # (world m, n)
+	p_dist = torch.cat([t.to(dt_local.device) for t in p_all]).cpu().numpy()  # (world m, world m)
+	dc_h = dc.cpu().numpy().astype(np.float64)
+	dci, dcr = inv_rank(dc_h @ dc_h.T)
+	res = plan.be.eng.association_single0(xs, None, dc_h, dci, dcr, 0, True, False, np.float64 if dt_local.dtype == torch.float64 else np.float32)
+	p_one = np.asarray(res['p'], dtype=np.float64)
+	off = ~np.eye(world * m, dtype=bool)
+	big = off & (p_one > 1e-290)
+	rel = float(np.max(np.abs(p_dist[big] - p_one[big]) / p_one[big])) if big.any() else 0.0
+	tiny_ok = bool((np.abs(p_dist[off & ~big] - p_one[off & ~big]) <= 1e-290).all())
+	ok = bool(rel <= 1e-6 and tiny_ok and rk.ranks_seen == world and np.isfinite(p_dist[off]).all())
+	# one decision of all ranks
+	t = torch.tensor([0.0 if ok else 1.0], device=rk.device if rk.backend == 'nccl' else 'cpu', dtype=torch.float64)
+	dist.all_reduce(t)
+	return dict(ok=bool(t.item() == 0), ranks_seen_by_collective=rk.ranks_seen, ranks=world, gene_rows_checked=world * m, pairs_checked=int(off.sum()) // 2,
+				max_relative_p_difference=rel, tolerance=1e-6,
+				against='the same device as ONE rank: coex on the pooled raw rows, no exchange (a pair\'s P-value depends on its two rows and the covariates alone)')
+
+
 def guard_verdict(flags, eng):
 	"""The integer engine's accuracy guard over every step that accumulated into `flags` (engine.new_flags): pairs whose P-value
 	it could not certify to the tolerance (a user call would have been redone on the fp64 kernel) and the largest error estimate."""
@@ -431,6 +476,8 @@ def bench_coex(rk, nd, steps, warmup, rows_local, n, seed, dtype, label, loading
 			   kernels_ms=plan.kernel_breakdown(), kernels_ms_from='timed region' if events_inside else '3 extra steps after the timed region',
 			   guard=guard_verdict(plan.flags, plan.be.eng))
 	out['kernels_roofline'] = side_rooflines(out['kernels_ms'], rows_local, n, esz, SLICES(n), plan.local_pair_count(), esz)
+	if world > 1:
+		out['self_check'] = self_check(rk, plan, dt_local, dc)
 	return out, plan
 
 
@@ -553,10 +600,22 @@ def bench_de_method(rk, steps, warmup, single):
 		def step(self, timed=False):
 			self.out = None  # (the previous step's results go back to the allocator first: no second set of GB-sized buffers)
 			self.out = fn(dx, dy, dc_h, return_dot=False, device_out=True)
-	plan = Plan()
+
+		def check(self):
+			pass
+	# a resident screen: the plan replays a step as one HIP graph; nothing of a step runs on the host (round 6)
+	if single == 1:
+		from normalisr_amd.single1 import Single1Plan
+		plan = Single1Plan(dx, dy, dc_h, return_dot=False)
+	elif os.environ.get('NRM_BENCH_S4', 'plan') == 'plan':
+		from normalisr_amd.single4 import Single4Plan
+		plan = Single4Plan(dx, dy, dc_h, return_dot=False)
+	else:
+		plan = Plan()
 	for _ in range(3):  # the allocator's pool and the kernels' code objects settle in the first calls
 		plan.step()
 	elapsed = timed_steps(rk, plan, steps, warmup, False)
+	plan.check()  # (the reference's assertions over the timed steps: device counters, looked at once)
 	guard = dict(eng.last_guard)
 	eng.trace = []
 	for _ in range(2):
@@ -569,6 +628,19 @@ def bench_de_method(rk, steps, warmup, single):
 	tests = nx * ny_local * world
 	ms = 1e3 * elapsed / steps
 	cold = {}
+	if single == 1:
+		# a COLD call: the public entry on a design tensor the engine has not seen -- entry lists, a plan's buffers, one step, the counters read
+		fresh = [dx.clone() for _ in range(max(2, min(steps, 5)) + 1)]
+		fn(fresh.pop(), dy, dc_h, return_dot=False, device_out=True)
+		rk.barrier()
+		t0 = time.perf_counter()
+		for d in fresh:
+			out = fn(d, dy, dc_h, return_dot=False, device_out=True)
+		torch.cuda.synchronize()
+		rk.barrier()
+		cold_ms = 1e3 * rk.max_over_ranks(time.perf_counter() - t0) / len(fresh)
+		del out, fresh
+		cold = dict(cold_ms=cold_ms, cold_tests_per_s=tests / (cold_ms * 1e-3), cold_note='association_tests(single=1) on a design tensor the engine has not seen: entry lists, buffers, one step, the counters read back; ms_per_step is a resident Single1Plan step (one HIP graph)')
 	if single == 4:
 		# a COLD call: a design tensor the engine has not seen (the timed steps reuse the lists kept for their design tensor; single=1 lists
 		# its design anew in every call).  Fresh copies are made outside the timed region.
@@ -596,17 +668,17 @@ def bench_de_method(rk, steps, warmup, single):
 		roof['step_ms'] = ms
 		dtype = ARITH(n)
 	else:
-		kept = int(getattr(eng, 's1_cells_kept', 0))
+		kept = plan.cells_kept()
 		byts = 4.0 * ny_local * (n + kept)  # every fp32 expression value read once + the values at the cells that carry one gRNA written once (transposed)
 		kms = split.get('s1_stream', ms)
 		roof = dict(bound='hbm', kernel='k_s1_stream', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
 					frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, algorithmic_bytes=byts, kernel_ms=kms, step_ms=ms, cells_with_one_grna=kept,
-					note='the stream kernel runs beside the host\'s 1000 small SVDs (the statistics of the gRNAs themselves: inv_rank, association.py:350-351); a step is bound by those, not by the device')
+					note='a step is seven launches replayed as one HIP graph: cell selection, the gRNAs\' own sums, their pseudo-inverses / ranks / P-value plans (a lane per gRNA: association.py:350-374), the stream kernel, the sweep -- nothing on the host')
 		dtype = 'f64'
 	return dict(cold, value=tests * steps / elapsed, unit='tests/s', steps=steps, warmup=warmup, ms_per_step=ms, scaling='strong', dtype=dtype,
 				config=dict(workload='norm.de(single={}) {} gRNAs x {} genes x {} cells, fp32 input, {} covariates (BASELINE configs[3] as `normalisr de -m {}`, examples/GSE120861/code/cmd_highmoi.sh)'.format(
 					single, nx, ny, n, nc, 'covariate' if single == 4 else 'single') + ('' if single == 4 else '; gRNA incidence 0.1 % (low MOI: single=1 needs cells with one gRNA)'), parallelism='gene rows of Y x{}, no collective'.format(world)),
-				roofline=roof, kernels_ms={k: round(v, 4) for k, v in split.items()}, kernels_ms_from='2 extra steps after the timed region (HIP events around the engine\'s launches; the rest of a step is the host: rank certificate, inverse)',
+				roofline=roof, kernels_ms={k: round(v, 4) for k, v in split.items()}, kernels_ms_from='2 extra steps after the timed region, eager, HIP events around the engine\'s launches (the timed steps are one HIP graph each)',
 				guard=dict(uncertified_pairs=int(guard.get('hits', 0)), largest_relative_p_error_bound=float(guard.get('worst', 0.0)), tolerance=eng.guard_tol,
 						   fp64_rerun=bool(guard.get('fallback', False))), metric='association tests/sec (de)')
 
@@ -780,6 +852,8 @@ def contract_line(head, extras, world, e2e=None):
 				kernels_ms={k: round(v, 4) for k, v in (head.get('kernels_ms') or {}).items()}, ranks_seen_by_collective=head['ranks_seen_by_collective'],
 				dist_backend=head['dist_backend'], frac_of_fp32_mfma_peak=head.get('frac_of_fp32_mfma_peak'),
 				end_to_end_pcie_s=None if not e2e else e2e['seconds'])
+	if head.get('self_check') is not None:
+		line['self_check'] = {k: v for k, v in head['self_check'].items() if k != 'against'}
 	rows = {}
 	for w, r in extras.items():
 		if not isinstance(r, dict) or 'value' not in r:
@@ -1016,8 +1090,12 @@ def main():
 				say(dict(workload_detail=w, **extras[w]))
 		dog.cancel()
 	emit()
+	# N > 1: a line whose ranks did not all take part, or whose N-rank P-values differ from what this device computes as one rank, is a FAILED run
+	bad = world > 1 and (rk.ranks_seen != world or not (head.get('self_check') or {}).get('ok', head.get('self_check') is None))
+	if bad and rank == 0:
+		print('bench.py: the N = {} run failed its own check: ranks seen by the collective {}, self_check {}'.format(world, rk.ranks_seen, head.get('self_check')), file=sys.stderr, flush=True)
 	rk.close()
-	return 0
+	return 3 if bad else 0
 
 
 if __name__ == '__main__':

@@ -187,6 +187,8 @@ int nrm_pvalue_plan_init(nrm_pvalue_plan* plan, double dof);
 /* The same for `count` dofs (single=1: one dof per grouping, association.py:374): record j = the 24 doubles of the plan
  * for dof[j], written at out + j * pitch (pitch in doubles, >= 24). */
 int nrm_pvalue_plan_init_many(const double* dof, int64_t count, double* out, int64_t pitch);
+/* The same records from the double-precision form the device builds its plans with (csrc/nrm_pvalue_plan.h, here compiled for the host). */
+int nrm_pvalue_plan_fill_many(const double* dof, int64_t count, double* out, int64_t pitch);
 
 /* Elementwise p-values from R^2 (device arrays); kernel-level entry for the table tests. */
 int nrm_pvalues_from_r2(const double* d_r2, int64_t count, double dof, double* d_p, void* stream);
@@ -325,6 +327,9 @@ int nrm_spd_start(const double* d_mp, int64_t nxp, int diagonal, const double* d
 int nrm_spd_transpose_residual(const double* d_t, int64_t nxp, double* d_tt, double* d_res, double* d_work, void* stream);
 int nrm_spd_update(double* d_x, const double* d_xt, int64_t count, void* stream);
 int nrm_spd_finish(const double* d_x, int64_t nx, int64_t nxp, const double* d_ss, double* d_n, double* d_small, void* stream);
+/* What the single=4 sweep needs of N~ (d_small (3, nx) of nrm_spd_finish) without the host: d_dxx[i] = 1 / (n_cells N~_ii) (association.py:539-540 in closed form),
+ * d_varx the same with the reference's 0 -> 1 (:546-547); d_flags[5] (int32[8]) += design rows whose N~_ii is not a positive finite number. */
+int nrm_single4_design_scalars(const double* d_small, int64_t nx, int64_t n_cells, double* d_dxx, double* d_varx, int32_t* d_flags, void* stream);
 
 /*
  * single=1 sweep (every grouping tested on its own subset of cells, association.py:263-390).
@@ -361,6 +366,14 @@ int nrm_single1_cells(const void* d_ye, int y_dtype, int64_t ldye, const double*
  * indices, int64) / d_xe (its value there); d_out (nx, nc (nc + 1) / 2 + nc + 1): the sums of C_c C_d (c <= d, row by row), of C_c x, of x x.  nc <= 8. */
 int nrm_single1_group_stats(const int64_t* d_seg, const int64_t* d_cells, const double* d_xe, const double* d_c, int64_t ldc, int64_t nc, int64_t nx,
 							double* d_out, void* stream);
+/* The grouping side of association_test_2's loop body (association.py:350-374) on the device, a lane per grouping: M_i = (the shared cells' covariate
+ * Gram matrix, d_gram_part of nrm_single1_select added up in block order) + (the grouping's own, d_gs of nrm_single1_group_stats); its pseudo-inverse and
+ * INTEGER rank by the rule of inv_rank (association.py:77-80; the Jacobi code the host's nrm_small_pinv runs); ccx_i, vx_i (0 -> 1), dof_i = ns_i - 1 -
+ * rank_i - dimreduce and the P-value plan for it -- written as the records nrm_single1_cells reads (d_info (nx, info_pitch >= 26 + nc + nc nc)) -- and
+ * d_varx (nx) fp64.  What the reference asserts or raises there is counted into d_flags (int32[8], zeroed by the caller; [0], [1] are the sweep's):
+ * [2] groupings with a single value on their selected cells (:917-918), [3] groupings with dof <= 0, [4] groupings whose M_i is not finite.  nc <= 8. */
+int nrm_single1_group_info(const double* d_gs, const double* d_gram_part, const double* d_rowinfo, const int64_t* d_sel_info, int64_t nc, int64_t nx,
+						   int dimreduce, double* d_info, int64_t info_pitch, double* d_varx, int32_t* d_flags, void* stream);
 
 /*
  * binnet -- binarise a (ng, ng) co-expression P-value matrix at a per-row Benjamini-Hochberg q-value cutoff

@@ -49,6 +49,7 @@ _SIGNATURES = {
 	'nrm_gram_i8_chunk': ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _vp, _vp], _i32),
 	'nrm_pvalue_plan_init': ([ctypes.POINTER(PvaluePlan), _dbl], _i32),
 	'nrm_pvalue_plan_init_many': ([_vp, _i64, _vp, _i64], _i32),
+	'nrm_pvalue_plan_fill_many': ([_vp, _i64, _vp, _i64], _i32),
 	'nrm_pvalues_from_r2': ([_vp, _i64, _dbl, _vp, _vp], _i32),
 	'nrm_assoc_sweep': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _dbl, _vp], _i32),
 	'nrm_assoc_sweep_band': ([_vp, _i64, _vp, _vp, _i64, _i64, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _vp], _i32),
@@ -64,6 +65,7 @@ _SIGNATURES = {
 	'nrm_spd_transpose_residual': ([_vp, _i64, _vp, _vp, _vp, _vp], _i32),
 	'nrm_spd_update': ([_vp, _vp, _i64, _vp], _i32),
 	'nrm_spd_finish': ([_vp, _i64, _i64, _vp, _vp, _vp, _vp], _i32),
+	'nrm_single4_design_scalars': ([_vp, _i64, _i64, _vp, _vp, _vp, _vp], _i32),
 	'nrm_design_products_workspace_doubles': ([_i64, _i64], _i64),
 	'nrm_design_products': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp], _i32),
 	'nrm_residualize_wide': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp], _i32),
@@ -91,6 +93,7 @@ _SIGNATURES = {
 	'nrm_tsv_width': ([_i32], _i64),
 	'nrm_tsv_format': ([_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32], _i32),
 	'nrm_single1_group_stats': ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp], _i32),
+	'nrm_single1_group_info': ([_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp], _i32),
 	'nrm_single1_stream': ([_vp, _i32, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp], _i32),
 	'nrm_single1_cells': ([_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_binnet': ([_vp, _i32, _i64, _i64, _dbl, _vp, _i64, _vp, _vp, _vp], _i32),

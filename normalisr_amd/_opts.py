@@ -22,6 +22,8 @@ DEBUG_KEYS = {
 	's4_sparse_m': "0: single=4 on a sparse design takes M~ from K1's residuals and the fp64 Gram kernel",
 	's4_trace': "1: phase times of a single=4 call", 's1_trace': "1: phase times of a single=1 call",
 	'single1': "dense: single=1 through the masked Gram contractions whatever the design",
+	'single1_stats': "host: single=1 finishes the groupings' statistics (pseudo-inverses, ranks, P-value plans) on the host as rounds 3-5 did",
+	's4_plan': "public: a Single4Plan calls the public function every step (no lean device-only replay)",
 	'normvar': "host: normvar through the Gram launches and the host's batched pseudo-inverses",
 	'small_svd': "lapack: numpy's stacked SVD instead of the library's threaded Jacobi iteration",
 	'upload': "torch: host -> device copies of half a GB and more through torch instead of the library's staged copy",

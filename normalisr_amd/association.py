@@ -263,7 +263,20 @@ def _single0_host_entry(dx, dy, dc64, dci, dcr, dimreduce, return_dot, want_alph
 
 
 def _use_host_entry():
-	return _lib.host_entry_preferred() or not _have_torch()
+	"""True when the call goes to the library's whole-problem entries (the command line's default; a process without torch) -- and then the
+	GPU they run on has been chosen as every other route chooses it: `device=` / engine.use_device of this thread, else NORMALISR_DEVICE, else GPU 0.
+	nrm_set_device validates the index (ValueError for a GPU that is not there), binds this thread and the entries' helper threads, and releases
+	what the library cached for another device."""
+	if not (_lib.host_entry_preferred() or not _have_torch()):
+		return False
+	dev = getattr(_engine._selected, 'device', None)
+	if dev is None and os.environ.get('NORMALISR_DEVICE', '') != '':
+		try:
+			dev = int(os.environ['NORMALISR_DEVICE'])
+		except ValueError:
+			raise ValueError('NORMALISR_DEVICE must be a GPU index, not {!r}'.format(os.environ['NORMALISR_DEVICE']))
+	_lib.check(_lib.load().nrm_set_device(0 if dev is None else int(dev)))
+	return True
 
 
 def _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka):

@@ -5,8 +5,11 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
+#include <strings.h>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -32,8 +35,31 @@ extern "C" int nrm_device_count(int* count) {
 	return NRM_OK;
 }
 
+// The GPU the library's whole-problem entries run on.  hipSetDevice is per THREAD: the entry a Python thread calls, the helper threads that page-lock
+// the caller's result arrays beside the kernels, and a second Python thread calling the next entry must all bind to the same device, and the scratch pool
+// and the upload ring hold memory OF a device.  nrm_set_device records the choice for the process (validated: NRM_E_ARG -> ValueError for an index
+// that is not there), releases what was cached for another device, and binds the calling thread; nrm_bind_device() binds any other thread.
+static std::atomic<int> g_device{-1};
+static NrmDevPool g_pool;
+
 extern "C" int nrm_set_device(int device) {
+	int count = 0;
+	NRM_HIP(hipGetDeviceCount(&count));
+	NRM_REQUIRE(device >= 0 && device < count, "GPU %d requested, %d visible", device, count);
+	const int prev = g_device.exchange(device);
+	if (prev != device && prev >= 0) {  // (scratch blocks and page-locked ring slots belong to the device they were made on)
+		(void)hipSetDevice(prev);
+		(void)hipDeviceSynchronize();
+		g_pool.release();
+		(void)nrm_upload_release();
+	}
 	NRM_HIP(hipSetDevice(device));
+	return NRM_OK;
+}
+
+int nrm_bind_device(void) {
+	const int d = g_device.load();
+	if (d >= 0) NRM_HIP(hipSetDevice(d));
 	return NRM_OK;
 }
 
@@ -81,6 +107,7 @@ extern "C" int nrm_host_mirror_rows(void* h, int64_t ld_bytes, int elem_bytes, i
 
 extern "C" int nrm_host_pin(void* ptr, int64_t bytes, int threads) {
 	NRM_REQUIRE(ptr != nullptr && bytes > 0, "nrm_host_pin: empty range");
+	NRM_TRY_RC(nrm_bind_device());  // (called from the entries' helper threads too: a fresh thread's current device is 0)
 	const int64_t page = 4096;
 	if (threads <= 0) {
 		threads = (int)std::min<int64_t>(16, std::max<int64_t>(1, bytes / (8 << 20)));
@@ -173,7 +200,6 @@ extern "C" int nrm_copy_rows(void* d_dst, int64_t dst_pitch, const void* d_src, 
 	return NRM_OK;
 }
 
-static NrmDevPool g_pool;
 static std::mutex g_host_entry;
 NrmDevPool& nrm_host_pool() { return g_pool; }
 std::mutex& nrm_host_entry_mutex() { return g_host_entry; }
@@ -230,9 +256,31 @@ extern "C" int nrm_last_guard(int64_t* hits, double* worst) {
 	return NRM_OK;
 }
 
-static bool de_path_general() {  // NRM_DEBUG="de_path=general" (or NRM_DE_PATH=general): no streaming de kernel, as in normalisr_amd/_opts.py
+// NRM_DEBUG="key=value,key=value" read the way normalisr_amd/_opts.py reads it: split on ',', key and value trimmed, the key compared without case --
+// so that a switch means the same to the package's engine and to the library's own entries.  true: `key` is there with exactly `value`.
+static bool nrm_debug_is(const char* key, const char* value) {
 	const char* d = getenv("NRM_DEBUG");
-	if (d && strstr(d, "de_path=general")) return true;
+	if (!d) return false;
+	const size_t kl = strlen(key), vl = strlen(value);
+	while (*d) {
+		const char* end = strchr(d, ',');
+		if (!end) end = d + strlen(d);
+		const char* eq = (const char*)memchr(d, '=', (size_t)(end - d));
+		if (eq) {
+			const char *k0 = d, *k1 = eq, *v0 = eq + 1, *v1 = end;
+			while (k0 < k1 && isspace((unsigned char)*k0)) k0++;
+			while (k1 > k0 && isspace((unsigned char)k1[-1])) k1--;
+			while (v0 < v1 && isspace((unsigned char)*v0)) v0++;
+			while (v1 > v0 && isspace((unsigned char)v1[-1])) v1--;
+			if ((size_t)(k1 - k0) == kl && (size_t)(v1 - v0) == vl && !strncasecmp(k0, key, kl) && !strncmp(v0, value, vl)) return true;
+		}
+		d = *end ? end + 1 : end;
+	}
+	return false;
+}
+
+static bool de_path_general() {  // NRM_DEBUG="de_path=general" (or NRM_DE_PATH=general): no streaming de kernel, as in normalisr_amd/_opts.py
+	if (nrm_debug_is("de_path", "general")) return true;
 	const char* e = getenv("NRM_DE_PATH");
 	return e && !strcmp(e, "general");
 }
@@ -252,6 +300,7 @@ extern "C" int nrm_association_tests_host(const void* h_dx, int x_dtype, int64_t
 										  int dimreduce, int return_dot, void* h_p, void* h_stat, void* h_alpha, void* h_varx,
 										  void* h_vary, void* h_r, void* h_t, int out_dtype) {
 	std::lock_guard<std::mutex> serial(g_host_entry);
+	NRM_TRY_RC(nrm_bind_device());
 	// K2 engine as in the Python host (NRM_GRAM): exact fixed-point contraction on the int8 matrix cores (6 slices = 46 bits; i8x5: 5
 	// slices = 38 bits), or the fp64 matrix-core kernel (f64).  With the integer engine K1 writes the digit planes itself and the
 	// fp64 residuals are never stored.

@@ -94,7 +94,9 @@ __global__ void __launch_bounds__(256) k_dl_count(const T* __restrict__ X, int64
 // grid (ceil(nslots / DS_PASS), chunks), DS_PASS threads.
 __global__ void __launch_bounds__(DS_PASS) k_dl_plan(const int32_t* __restrict__ cnt, int64_t nslots, int ngroups, int32_t* __restrict__ sig, int32_t* __restrict__ pos,
 													 int32_t* __restrict__ w) {
-	__shared__ int32_t keys[DS_PASS];
+	// the key packs (entries of the slot in this chunk) << 10 | (DS_PASS - 1 - t) into one int32, and the ELL offsets are int16: both hold only for these sizes
+	static_assert(DS_PASS <= 1024 && DS_CH <= 2048 && DS_CH < 32768, "k_dl_plan: key packing (10 bits of position, 21 of count) and int16 ELL offsets");
+	__shared__ alignas(16) int32_t keys[DS_PASS];  // (read back as int4)
 	const int c = blockIdx.y, t = threadIdx.x;
 	const int64_t lo = (int64_t)blockIdx.x * DS_PASS, slot = lo + t;
 	const int my = slot < nslots ? DL_COUNT(cnt[(int64_t)c * nslots + slot]) : -1;

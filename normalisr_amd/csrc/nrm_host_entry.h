@@ -21,6 +21,7 @@ struct NrmHipAlloc {
 typedef DevPoolT<NrmHipAlloc> NrmDevPool;
 NrmDevPool& nrm_host_pool();     // (nrm_api.hip)
 std::mutex& nrm_host_entry_mutex();  // one whole-problem call at a time per process (the pool and the default stream are shared)
+int nrm_bind_device(void);              // the calling thread onto the device nrm_set_device chose for the process (nrm_api.hip); nothing when none was chosen
 
 struct DevBuf {
 	void* p = nullptr;

@@ -530,3 +530,114 @@ extern "C" int nrm_single1_group_stats(const int64_t* d_seg, const int64_t* d_ce
 	hipLaunchKernelGGL(k_s1_group_stats, dim3((unsigned)nx), dim3(64), 0, (hipStream_t)stream, d_seg, d_cells, d_xe, d_c, ldc, (int)nc, nx, d_out);
 	return nrm_check_launch("k_s1_group_stats");
 }
+
+// ---- per grouping: pseudo-inverse, rank, ccx, vx, dof and the P-value plan -- the record k_s1_cells reads -- without the host ------------------
+// Rounds 3-5 finished the groupings' statistics on the host (1000 small pseudo-inverses, two einsum calls, 1000 P-value plans, five read-backs and
+// an upload per call: "a single=1 step is bound by the host", and on a box whose host was slow the 2 ms step took 18).  A lane per grouping does
+// the same here, with the same code where integers are decided (nrm_jacobi.h: the rank rule of association.py:77-80) --
+//     M_i = C_N C_N^T + C_Ei C_Ei^T (the shared cells' partial sums added in block order + the grouping's own, k_s1_group_stats)
+//     M_i^+, r_i;  ccx_i = M_i^+ (C_S x_S);  vx_i = (|x_S|^2 - (C_S x_S) . ccx_i) / ns_i, 0 -> 1        association.py:350-364
+//     dof_i = ns_i - 1 - r_i - dimreduce and its P-value plan (nrm_pvalue_plan.h)                         association.py:372-374
+// and what the reference asserts or raises on the way is COUNTED into flags (the host looks once, when it takes the results):
+//     flags[2] groupings with a single value on their selected cells (association.py:917-918, AssertionError)
+//     flags[3] groupings with dof <= 0 ("Insufficient number of cells")        flags[4] groupings whose M_i is not finite (the SVD's ValueError)
+#include "nrm_jacobi.h"
+#include "nrm_pvalue_plan.h"
+
+template <int NC>
+__global__ void __launch_bounds__(64) k_s1_group_info(const double* __restrict__ gs, const double* __restrict__ gpart, int gb, const double* __restrict__ rowinfo,
+													   const int64_t* __restrict__ sel_info, int64_t nx, int dimreduce, double* __restrict__ info, int64_t pitch,
+													   double* __restrict__ varx, int32_t* __restrict__ flags) {
+	constexpr int NA = NC > 0 ? NC : 1, NP = NC * (NC + 1) / 2;
+	__shared__ double mcc[64];
+	if constexpr (NC > 0) {
+		double t = 0.0;
+		for (int g = 0; g < gb; g++) t += gpart[(int64_t)g * 64 + threadIdx.x];  // (block order: the sum the host took)
+		mcc[threadIdx.x] = t;
+		__syncthreads();
+	}
+	const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+	if (i >= nx) return;
+	const double n_common = (double)sel_info[3];
+	const double ns = n_common + rowinfo[i * 3];
+	double lo = rowinfo[i * 3 + 1], hi = rowinfo[i * 3 + 2];
+	if (n_common > 0) {  // 0 on the shared cells, if there are any, and its own values on its own
+		lo = fmin(lo, 0.0);
+		hi = fmax(hi, 0.0);
+	}
+	if (!(hi > lo)) atomicAdd(&flags[2], 1);
+	const double* o = gs + i * (NP + NC + 1);
+	double* rec = info + i * pitch;
+	double xx = o[NP + NC];
+	int64_t rk = 0;
+	if constexpr (NC > 0) {
+		double m[NA * NA], inv[NA * NA];
+		bool finite = true;
+		int w = 0;
+		for (int c = 0; c < NC; c++)
+			for (int d = c; d < NC; d++, w++) {
+				const double v = o[w] + mcc[c * 8 + d];
+				m[c * NC + d] = m[d * NC + c] = v;
+				finite = finite && isfinite(v);
+			}
+		if (!finite) {
+			atomicAdd(&flags[4], 1);
+			for (int e = 0; e < NC * NC; e++) m[e] = e % (NC + 1) == 0 ? 1.0 : 0.0;
+		}
+		nrm_small_pinv_one<NA>(m, NC, 1e-8, inv, &rk);  // association.py:350-351
+		if (rk == 0)
+			for (int e = 0; e < NC * NC; e++) inv[e] = 0.0;
+		const double* xc = o + NP;
+		double dot = 0.0;
+		for (int c = 0; c < NC; c++) {
+			double t = 0.0;
+			for (int d = 0; d < NC; d++) t += inv[c * NC + d] * xc[d];
+			rec[S1_HEAD + c] = t;  // ccx
+			dot += xc[c] * t;
+		}
+		xx -= dot;
+		for (int e = 0; e < NC * NC; e++) rec[S1_HEAD + NC + e] = inv[e];
+	}
+	double vx = xx / ns;
+	if (vx == 0.0) vx = 1.0;  // association.py:362-364
+	double dof = ns - 1.0 - (double)rk - (double)dimreduce;
+	if (!(dof > 0.0)) {
+		atomicAdd(&flags[3], 1);
+		dof = 1.0;  // (the call raises; the sweep still gets a plan it can evaluate)
+	}
+	rec[0] = ns;
+	rec[1] = vx;
+	nrm_pvalue_plan_fill(dof, rec + 2);
+	varx[i] = vx;
+}
+
+// d_gs (nx, nc (nc + 1) / 2 + nc + 1) from nrm_single1_group_stats; d_gram_part, d_rowinfo, d_sel_info from nrm_single1_select (d_gram_part may be NULL
+// for nc == 0); d_info (nx, info_pitch) <- the records nrm_single1_cells reads; d_varx (nx) fp64; d_flags int32[8] (see above; [0], [1] are the sweep's).
+// nc <= 8.  Reference: association.py:350-374 (the loop body of association_test_2 on the grouping's side).
+extern "C" int nrm_single1_group_info(const double* d_gs, const double* d_gram_part, const double* d_rowinfo, const int64_t* d_sel_info, int64_t nc, int64_t nx,
+									  int dimreduce, double* d_info, int64_t info_pitch, double* d_varx, int32_t* d_flags, void* stream) {
+	NRM_REQUIRE(nx > 0 && nc >= 0 && nc <= S1_GS_NC && info_pitch >= S1_HEAD + nc + nc * nc, "nrm_single1_group_info: bad sizes (at most %d covariates)", S1_GS_NC);
+	NRM_REQUIRE(d_gs && d_rowinfo && d_sel_info && d_info && d_varx && d_flags && (nc == 0 || d_gram_part), "nrm_single1_group_info: null pointer");
+	const dim3 grid((unsigned)((nx + 63) / 64));
+	const int gb = (int)nrm_single1_select_gram_blocks();
+#define S1_GI(NCV)                                                                                                                                                  \
+	case NCV:                                                                                                                                                       \
+		hipLaunchKernelGGL((k_s1_group_info<NCV>), grid, dim3(64), 0, (hipStream_t)stream, d_gs, d_gram_part, gb, d_rowinfo, d_sel_info, nx, dimreduce, d_info, info_pitch, \
+						   d_varx, d_flags);                                                                                                                        \
+		break;
+	switch ((int)nc) {
+		S1_GI(0) S1_GI(1) S1_GI(2) S1_GI(3) S1_GI(4) S1_GI(5) S1_GI(6) S1_GI(7) S1_GI(8)
+	}
+#undef S1_GI
+	return nrm_check_launch("k_s1_group_info");
+}
+
+// The double-precision plans of nrm_pvalue_plan.h on the host (the code the device runs, compiled for the host: tests hold it to nrm_pvalue_plan_init_many)
+extern "C" int nrm_pvalue_plan_fill_many(const double* dof, int64_t count, double* out, int64_t pitch) {
+	NRM_REQUIRE(count >= 0 && pitch >= 4 + NRM_PCOEF && (count == 0 || (dof && out)), "nrm_pvalue_plan_fill_many: bad arguments");
+	for (int64_t j = 0; j < count; j++) {
+		NRM_REQUIRE(dof[j] > 0, "Insufficient number of cells: dof = %g must be positive", dof[j]);
+		nrm_pvalue_plan_fill(dof[j], out + j * pitch);
+	}
+	return NRM_OK;
+}

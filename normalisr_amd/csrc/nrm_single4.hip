@@ -394,3 +394,24 @@ extern "C" int nrm_spd_finish(const double* d_x, int64_t nx, int64_t nxp, const 
 	hipLaunchKernelGGL(k_spd_rows, dim3((unsigned)nx), dim3(256), 0, st, d_n, nxp, nx, d_ss, d_small + 2 * nx, d_small + nx, d_small);
 	return nrm_check_launch("nrm_spd_finish");
 }
+
+// ---- what the sweep needs of N~ = M~^-1, taken on the device (a resident single=4 step has nothing on the host: single4.Single4Plan) --------------
+// d_small (3, nx) of nrm_spd_finish: row 0 = the diagonal d_i of N~.  d_dxx[i] = 1 / (n d_i) = the partial variance of design row i given all other
+// rows and the covariates (association.py:539-540 in the closed form of single4.py); d_varx[i] the same with the reference's 0 -> 1 (:546-547);
+// flags[5] += design rows whose d_i is not a positive finite number (the rows are linearly dependent given the covariates: the host raises LinAlgError).
+__global__ void __launch_bounds__(256) k_s4_design_scalars(const double* __restrict__ small, int64_t nx, double n_cells, double* __restrict__ dxx,
+															double* __restrict__ varx, int32_t* __restrict__ flags) {
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= nx) return;
+	const double d = small[i], ka = small[nx + i], rs = small[2 * nx + i];
+	if (!(isfinite(d) && d > 0.0 && isfinite(ka) && isfinite(rs))) atomicAdd(&flags[5], 1);
+	const double v = 1.0 / (n_cells * d);
+	dxx[i] = v;
+	varx[i] = v == 0.0 ? 1.0 : v;
+}
+
+extern "C" int nrm_single4_design_scalars(const double* d_small, int64_t nx, int64_t n_cells, double* d_dxx, double* d_varx, int32_t* d_flags, void* stream) {
+	NRM_REQUIRE(d_small && d_dxx && d_varx && d_flags && nx > 0 && n_cells > 0, "nrm_single4_design_scalars: bad arguments");
+	hipLaunchKernelGGL(k_s4_design_scalars, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_small, nx, (double)n_cells, d_dxx, d_varx, d_flags);
+	return nrm_check_launch("k_s4_design_scalars");
+}

@@ -41,10 +41,28 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 	if return_stats:
 		raise NotImplementedError('return_stats is only available for single=0.')
 	if np.ndim(dimreduce) != 0:
-		d = np.unique(np.asarray(dimreduce))
-		if d.size != 1:
-			raise NotImplementedError('Per-gene dimreduce arrays are not supported on the device path.')
-		dimreduce = d[0]
+		# One value per row of dy (the reference subtracts it from the degrees of freedom of every (grouping, gene) pair, association.py:374 -- its own
+		# broadcast takes a (n_y, 1) column): gamma and the variances do not depend on it, so the call is repeated per DISTINCT value and every gene keeps
+		# the P-values of its own.
+		per_gene = np.asarray(dimreduce).reshape(-1)
+		if per_gene.size != np.shape(dy)[0]:
+			raise ValueError('dimreduce must be an integer or have one entry per row of dy.')
+		if (per_gene != per_gene.astype(np.int64)).any():
+			raise ValueError('dimreduce must be an integer.')
+		vals = np.unique(per_gene.astype(np.int64))
+		if vals.size > 1:
+			if device_out:
+				raise NotImplementedError('device_out with one dimreduce per gene')
+			out = None
+			for v in vals:
+				r = association_tests_single1(dx, dy, dc, lowmem=lowmem, return_dot=return_dot, dimreduce=int(v), chunk=chunk)
+				if out is None:
+					out = [None if a is None else np.array(a) for a in r]
+				else:
+					cols = per_gene == v
+					out[0][:, cols] = r[0][:, cols]
+			return tuple(out)
+		dimreduce = vals[0]
 	dimreduce = int(dimreduce)
 	dx, dy, dc = (dx if _is_dev(dx) else np.asarray(dx)), (dy if _is_dev(dy) else np.asarray(dy)), np.asarray(dc)
 	nx, n = dx.shape
@@ -78,6 +96,10 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 				if lists.ok and not (b & _lib.DESIGN_NEG):
 					# entries >= 0: the selection follows from the LIST of the design's entries (a cell is selected for grouping i when i is its
 					# only entry, and for every grouping when it has none) -- no (groupings x cells) selection matrix, no passes over one
+					if nc <= int(_S1_DEVICE_NC) and _opts.debug('single1_stats', 'device') != 'host':
+						plan = Single1Plan(d_dx, dy, c64, dimreduce=dimreduce, lowmem=lowmem, return_dot=return_dot, lists=lists, eng=eng)
+						plan.step()
+						return plan.results(device_out=device_out)
 					return _sparse(eng, lists, dy, c64, nx, ny, n, nc, dimreduce, lowmem, return_dot, out_dtype, tdt, device_out)
 			else:
 				assert float(torch.amax(d_dx)) == 1  # association.py:914
@@ -152,6 +174,149 @@ def association_tests_single1(dx, dy, dc, lowmem=True, return_dot=True, return_s
 			eng.check_flags(flags)
 			return (eng.download(p), eng.download(stat), None if alpha is None else eng.download(alpha), varx.astype(out_dtype),
 					eng.download(vary))
+
+
+_S1_DEVICE_NC = 8  # covariates up to which the groupings' statistics are finished on the device (csrc/nrm_single1.hip: S1_GS_NC)
+
+
+def _lists_for(eng, d_dx):
+	"""The design's CSR lists, kept for the next call on the SAME device tensor as long as it has not been written to (as de_sparse.lists_for
+	does for single=0 / single=4: a resident screen pays for its lists once; bench.py reports a cold call beside the resident step)."""
+	import weakref
+	from . import de_sparse
+	hit = getattr(eng, '_s1_lists', None)
+	if hit is not None and hit[0]() is d_dx and hit[1] == d_dx._version:
+		return hit[2]
+	lists = de_sparse.Lists(eng, d_dx, ell=False, max_density=0.25)
+	eng._s1_lists = (weakref.ref(d_dx), d_dx._version, lists)
+	return lists
+
+
+class Single1Plan:
+	"""single=1 for a design with entries >= 0 and at most 8 covariates, with NOTHING of a step on the host (round 6; rounds 3-5 finished the
+	groupings' statistics there: five read-backs, 1000 pseudo-inverses, 1000 P-value plans and an upload per call, and a step took 2 ms on one
+	box and 18 on another).  A step is seven launches on the engine's stream --
+
+	    nrm_single1_select       the cell selection from the design's entry lists (association.py:914-918)
+	    nrm_single1_group_stats  each grouping's sums over its own cells (a wave per grouping)
+	    nrm_single1_stream       the expression matrix read ONCE: sums over the shared cells, the values at the groupings' own cells
+	    nrm_single1_group_info   per grouping: pseudo-inverse + integer rank (Jacobi, the rule of inv_rank), ccx, vx, dof, the P-value plan (:350-374)
+	    nrm_single1_cells        the sweep
+
+	-- into buffers the plan owns (no allocation inside a step), replayed as ONE HIP graph from the third step on; what the reference asserts or
+	raises on the way (:917-918, dof <= 0, non-finite results, R^2 > 1) is counted on the device and looked at once, in results().
+	dx / dy: torch CUDA tensors resident in HBM (numpy arrays are uploaded once); dc: host array."""
+
+	def __init__(self, dx, dy, dc, dimreduce=0, lowmem=True, return_dot=True, lists=None, eng=None):
+		eng = self.eng = eng or _engine.get_engine()
+		torch = eng.torch
+		dev = eng.device
+		c64 = np.ascontiguousarray(np.asarray(dc, dtype=np.float64))
+		with eng.lock, torch.cuda.device(dev):
+			self.d_dx = dx if _is_dev(dx) else eng.upload(_engine.as_input(np.asarray(dx)))
+			self.d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(np.asarray(dy)))
+			nx, n = self.d_dx.shape
+			ny, nc = self.d_y.shape[0], c64.shape[0]
+			if self.d_y.shape[1] != n or c64.shape[1] != n:
+				raise ValueError('Unmatching dx/dy/dc dimensions.')
+			if nc > _S1_DEVICE_NC:
+				raise NotImplementedError('Single1Plan: at most {} covariates (association_tests_single1 takes more)'.format(_S1_DEVICE_NC))
+			self.nx, self.ny, self.n, self.nc = nx, ny, n, nc
+			self.dimreduce, self.lowmem, self.return_dot = int(dimreduce), lowmem, return_dot
+			self.out_dtype = np.dtype(np.float32 if self.d_y.dtype == torch.float32 else np.float64)
+			tdt = torch.float64 if self.out_dtype == np.float64 else torch.float32
+			lists = self.lists = lists if lists is not None else _lists_for(eng, self.d_dx)
+			b = lists.bits
+			assert (b & _lib.DESIGN_HAS1) and not (b & (_lib.DESIGN_GT1 | _lib.DESIGN_NAN))  # dx.max() == 1 (association.py:914)
+			if not lists.ok or (b & _lib.DESIGN_NEG):
+				raise NotImplementedError('Single1Plan: a design with entries >= 0 of which at most a quarter are set (association_tests_single1 takes the others)')
+			nnz = self.nnz = lists.nnz
+			f64 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+			self.d_c = eng.upload(c64) if nc else None
+			self.cnt = torch.empty(n, dtype=torch.int32, device=dev)
+			self.code = torch.empty(n, dtype=torch.int32, device=dev)
+			self.seg = torch.empty(nx + 1, dtype=torch.int64, device=dev)
+			self.idx = torch.empty(nnz, dtype=torch.int64, device=dev)
+			self.xe = f64(nnz)
+			self.ce = f64(nnz, nc) if nc else None
+			self.rowinfo = f64(nx, 3)
+			self.sel_info = torch.empty(8, dtype=torch.int64, device=dev)
+			gb = int(eng.lib.nrm_single1_select_gram_blocks())
+			self.gpart = f64(1, gb, 64) if nc else None
+			self.gs = f64(nx, nc * (nc + 1) // 2 + nc + 1)
+			self.ldye = _round_up(ny, 8)
+			# (at most one row of YE per design entry: sized without waiting for the count of the entries that are alone in their cell)
+			self.ye = torch.empty((max(nnz, 1), self.ldye), dtype=self.d_y.dtype, device=dev)
+			self.common = f64(nc + 1, ny)
+			self.pitch = 26 + nc + nc * nc
+			self.info = f64(nx, self.pitch)
+			self.varx = f64(nx)
+			self.p, self.stat, self.vary = (torch.empty((nx, ny), dtype=tdt, device=dev) for _ in range(3))
+			self.alpha = None if lowmem else eng.zeros((nx, ny, nc), tdt)
+			self.flags = eng.zeros((8, ), torch.int32)
+		from .distributed import StepGraph
+		self._graph = StepGraph(torch)
+
+	def _launch(self):
+		eng, lib, L = self.eng, self.eng.lib, self.lists
+		nx, ny, n, nc = self.nx, self.ny, self.n, self.nc
+		ptr = lambda t: 0 if t is None else t.data_ptr()
+		st = eng._stream()
+		d_y = self.d_y
+		ycode = _lib.NRM_F64 if d_y.dtype == eng.torch.float64 else _lib.NRM_F32
+		with _engine._Span(eng, 's1_select'):
+			_lib.check(lib.nrm_single1_select(L.row_ptr.data_ptr(), L.cells.data_ptr(), ptr(L.row_vals), nx, n, self.nnz, ptr(self.d_c), n, nc, self.cnt.data_ptr(),
+											  self.code.data_ptr(), self.seg.data_ptr(), self.idx.data_ptr(), self.xe.data_ptr(), ptr(self.ce), self.rowinfo.data_ptr(),
+											  ptr(self.gpart), self.sel_info.data_ptr(), st))
+			_lib.check(lib.nrm_single1_group_stats(self.seg.data_ptr(), self.idx.data_ptr(), self.xe.data_ptr(), ptr(self.d_c), n, nc, nx, self.gs.data_ptr(), st))
+			_lib.check(lib.nrm_single1_group_info(self.gs.data_ptr(), ptr(self.gpart), self.rowinfo.data_ptr(), self.sel_info.data_ptr(), nc, nx, self.dimreduce,
+												  self.info.data_ptr(), self.pitch, self.varx.data_ptr(), self.flags.data_ptr(), st))
+		with _engine._Span(eng, 's1_stream'):
+			_lib.check(lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), ptr(self.d_c), n, nc, self.code.data_ptr(), n, ny, self.common.data_ptr(),
+											  self.ye.data_ptr(), self.ldye, st))
+		code_o = _lib.NRM_F64 if self.out_dtype == np.float64 else _lib.NRM_F32
+		with _engine._Span(eng, 's1_cells'):
+			_lib.check(lib.nrm_single1_cells(self.ye.data_ptr(), ycode, self.ldye, ptr(self.ce), self.xe.data_ptr(), self.seg.data_ptr(), self.common.data_ptr(),
+											 self.info.data_ptr(), self.pitch, nc, nx, ny, 1 if self.return_dot else 0, self.p.data_ptr(), self.stat.data_ptr(),
+											 self.vary.data_ptr(), ptr(self.alpha), code_o, ny, self.flags.data_ptr(), st))
+
+	def step(self, timed=False):
+		"""One pass over the screen; results stay in HBM (results() takes them)."""
+		eng = self.eng
+		with eng.lock, eng.torch.cuda.device(eng.device):
+			if eng.trace is not None:  # (bench.py's per-kernel split: events between the launches, not capturable)
+				self._launch()
+			else:
+				self._graph.run(self._launch)
+
+	def cells_kept(self):
+		"""Cells that carry exactly one grouping (the rows of YE the stream kernel writes): one small read-back, outside the steps."""
+		return int(self.sel_info.cpu()[4])
+
+	def check(self):
+		"""The reference's assertions and errors, from the counters of the steps since the last look."""
+		f = self.flags.cpu().numpy()
+		self.flags.zero_()
+		if f[2]:
+			raise AssertionError('{} groupings take a single value on the cells selected for them (association.py:917-918)'.format(int(f[2])))
+		if f[4]:
+			raise ValueError('array must not contain infs or NaNs')
+		if f[3]:
+			raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
+		if f[0] or f[1]:
+			raise AssertionError('association results failed the reference assertions (association.py:248,252): '
+								 '{} tiles with non-finite values, {} tiles with R^2 > 1+1e-8'.format(int(f[0]), int(f[1])))
+
+	def results(self, device_out=False):
+		"""(p, gamma|dot, alpha|None, varx (n_x,), vary (n_x, n_y)) of the last step -- numpy arrays, or with device_out=True the plan's own
+		device tensors (overwritten by the next step)."""
+		eng = self.eng
+		with eng.lock, eng.torch.cuda.device(eng.device):
+			self.check()
+			if device_out:
+				return (self.p, self.stat, self.alpha, self.varx.to(self.p.dtype), self.vary)
+			return (eng.download(self.p), eng.download(self.stat), None if self.alpha is None else eng.download(self.alpha),
+					self.varx.cpu().numpy().astype(self.out_dtype), eng.download(self.vary))
 
 
 def _segment_sums(v, starts, counts):

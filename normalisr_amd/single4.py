@@ -261,6 +261,7 @@ def _spd_inverse_device(eng, m_d, nx, ss):
 				_lib.check(lib.nrm_spd_update(x.data_ptr(), xt.data_ptr(), nxp * nxp, st))
 				if r < 1e-7:  # the step just taken squares it: below the rounding floor
 					done = True
+					eng._s4_inverse = (start, it + 1)  # (Single4Plan: the same steps again without looking at the residual in between)
 					break
 			if done:
 				break
@@ -271,6 +272,164 @@ def _spd_inverse_device(eng, m_d, nx, ss):
 		small = mk(3, nx)
 		_lib.check(lib.nrm_spd_finish(x.data_ptr(), nx, nxp, ss.data_ptr(), t.data_ptr(), small.data_ptr(), st))
 	return t, scale, small.cpu().numpy()
+
+
+def _spd_inverse_fixed(eng, m_d, nx, ss, start, iters):
+	"""_spd_inverse_device without the host: the start and the number of steps the eager call needed on this design, no look at the residual in
+	between (the residual of the iterate that went into the LAST step is left in `res` for the caller to check afterwards: < 1e-7 means the step taken
+	squared it below the rounding floor, exactly the eager criterion).  Returns (N~ padded, scal = [||M~||_1, ...] on the device, small (3, nx), res)."""
+	from .engine import Residualized
+	torch = eng.torch
+	nxp = m_d.shape[0]
+	lib, st = eng.lib, eng._stream()
+	mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=eng.device)
+	mp, t, tt, xt, x = mk(nxp, nxp), mk(nxp, nxp), mk(nxp, nxp), mk(nxp, nxp), mk(nxp, nxp)
+	scal, work, res, small = mk(2), mk(max(2 * nxp, (nxp // 32)**2)), mk(1), mk(3, nx)
+	_lib.check(lib.nrm_spd_prepare(m_d.data_ptr(), m_d.stride(0), nx, nxp, mp.data_ptr(), scal.data_ptr(), work.data_ptr(), st))
+	rm = Residualized(nxp, nxp, mp, None, None)
+	rx_, rtt = Residualized(nxp, nxp, x, None, None), Residualized(nxp, nxp, tt, None, None)
+	_lib.check(lib.nrm_spd_start(mp.data_ptr(), nxp, 1 if start == 'diagonal' else 0, scal.data_ptr(), x.data_ptr(), st))
+	for _ in range(iters):
+		eng.gram(rm, rx_, False, dot=t)
+		_lib.check(lib.nrm_spd_transpose_residual(t.data_ptr(), nxp, tt.data_ptr(), res.data_ptr(), work.data_ptr(), st))
+		eng.gram(rx_, rtt, False, dot=xt)
+		_lib.check(lib.nrm_spd_update(x.data_ptr(), xt.data_ptr(), nxp * nxp, st))
+	_lib.check(lib.nrm_spd_finish(x.data_ptr(), nx, nxp, ss.data_ptr(), t.data_ptr(), small.data_ptr(), st))
+	return t, scal, small, res
+
+
+class Single4Plan:
+	"""A resident single=4 screen (`normalisr de -m covariate` on inputs that stay in HBM) with nothing of a step on the host (round 6).
+
+	The FIRST step is the public call, association_tests_single4(device_out=True): it decides everything that depends on the design and the
+	covariates alone -- whether the closed form applies (the reference's rank test on A A^T through the norm certificate, association.py:77), whether
+	the design is sparse enough for the entry lists, which start the Newton-Schulz inverse of M~ needs and how many steps.  When that call took the
+	sparse-design closed form with a scalar dimreduce and nothing was handed back (no row near the span of the covariates), every later step on the
+	same, unwritten tensors is that call's device work and nothing else --
+
+	    k_design_stats, k_de_sparse on the design rows (M~), nrm_spd_* + 2 K2' products per Newton-Schulz step (the count the first call needed),
+	    k_s4_design_scalars, k_de_sparse on the genes (Y~ X~^T), K2' (B = G N~), k_s4_rss + k_s4_sweep
+
+	-- captured as ONE HIP graph: no read-back, no upload, no allocation, no launch gap.  What the eager call looks at between its kernels is
+	counted on the device instead and checked in results(): rows too close to the span of the covariates, a diagonal of N~ that is not positive, a
+	last Newton-Schulz residual above the eager criterion, non-finite results, R^2 out of range -- any of them and the step is redone by the public
+	call (which has the fallbacks).  Anything else (dense design, guard-carrying integer engine, rank-deficient design, per-gene dimreduce) keeps
+	calling the public function every step."""
+
+	def __init__(self, dx, dy, dc, dimreduce=0, lowmem=True, return_dot=True, eng=None):
+		eng = self.eng = eng or _engine.get_engine()
+		self.dx, self.dy = dx, dy
+		self.dc = np.ascontiguousarray(np.asarray(dc, dtype=np.float64))
+		self.dimreduce, self.lowmem, self.return_dot = dimreduce, lowmem, return_dot
+		self.out = None
+		self.lean = None  # decided by the first step
+		self.fallbacks = 0
+		from .distributed import StepGraph
+		self._graph = StepGraph(eng.torch)
+
+	def _public(self):
+		return association_tests_single4(self.dx, self.dy, self.dc, lowmem=self.lowmem, return_dot=self.return_dot, dimreduce=self.dimreduce, device_out=True)
+
+	def _first(self):
+		eng = self.eng
+		eng._s4_inverse = eng._s4_path = None
+		out = self._public()
+		path, inv = getattr(eng, '_s4_path', None), getattr(eng, '_s4_inverse', None)
+		ok = (path == 'sparse closed form' and inv is not None and _is_dev(self.dx) and _is_dev(self.dy) and np.ndim(self.dimreduce) == 0 and self.lowmem
+			  and _opts.debug('s4_plan', 'lean') != 'public')
+		if ok:
+			from .association import inv_rank
+			from . import de_sparse
+			torch = eng.torch
+			nc = self.dc.shape[0]
+			self.start, self.iters = inv
+			with torch.cuda.device(eng.device):
+				dci, self.dcr = inv_rank(self.dc @ self.dc.T) if nc else (np.zeros((0, 0)), 0)
+				self.d_c, self.d_dci = eng.covariates(self.dc, dci) if nc else (None, None)
+				self.lists = de_sparse.lists_for(eng, self.dx)
+				self.flags = eng.zeros((8, ), torch.int32)
+			self.versions = (self.dx._version, self.dy._version)
+		self.lean = bool(ok)
+		return out
+
+	def _launch(self):
+		from .engine import Residualized
+		from . import de_sparse
+		eng, torch = self.eng, self.eng.torch
+		d_x, d_y, lists, d_c, d_dci, dcr = self.dx, self.dy, self.lists, self.d_c, self.d_dci, self.dcr
+		nx, n = d_x.shape
+		ny, nc = d_y.shape[0], self.dc.shape[0]
+		m = nx + nc
+		flags = self.flags  # [0] non-finite, [1] R^2 out of range (the sweep), [2] rows near the span of the covariates (k_design_stats, k_de_sparse), [5] diagonal of N~
+		rx = de_sparse.design_stats(eng, lists, d_c, d_dci, dcr, nx, nc, flags)
+		nxp = _engine._round_up(nx, _lib.ROW_TILE)
+		mt_d, _, _, _ = de_sparse.products(eng, lists, d_x, d_c, d_dci, dcr, rx.coef, nx, nx, n, nc, False, False, flags)
+		d_n, scal, small, res = _spd_inverse_fixed(eng, mt_d, nx, rx.ss, self.start, self.iters)
+		dxx = torch.empty(nx, dtype=torch.float64, device=eng.device)
+		varx = torch.empty(nx, dtype=torch.float64, device=eng.device)
+		_lib.check(eng.lib.nrm_single4_design_scalars(small.data_ptr(), nx, n, dxx.data_ptr(), varx.data_ptr(), flags.data_ptr(), eng._stream()))
+		g_d, ssy, _, _ = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, False, True, flags)
+		bt_d = eng.gram(Residualized(ny, nxp, g_d, None, None), Residualized(nx, nxp, d_n, None, None), False)  # B^T = (Y~ X~^T) N~
+		tdt = d_y.dtype if d_y.dtype in (torch.float32, torch.float64) else torch.float64
+		p, stat, vary = (torch.empty((nx, ny), dtype=tdt, device=eng.device) for _ in range(3))
+		work = torch.empty((ny, ), dtype=torch.float64, device=eng.device)
+		code = _lib.NRM_F64 if tdt == torch.float64 else _lib.NRM_F32
+		with _engine._Span(eng, 'sweep'):
+			_lib.check(eng.lib.nrm_single4_sweep(bt_d.data_ptr(), g_d.data_ptr(), bt_d.stride(0), ssy.data_ptr(), dxx.data_ptr(), nx, ny, nx, n, float(n - m - int(self.dimreduce)),
+												 1 if self.return_dot else 0, p.data_ptr(), stat.data_ptr(), vary.data_ptr(), code, ny, work.data_ptr(), flags.data_ptr(), eng._stream()))
+		return p, stat, varx, vary, res
+
+	def step(self, timed=False):
+		eng = self.eng
+		with eng.lock, eng.torch.cuda.device(eng.device):
+			if self.lean is None:
+				self.out = self._first()
+				return
+			if not self.lean or (self.dx._version, self.dy._version) != self.versions:
+				self.out = None
+				self.out = self._public()
+				if self.lean:  # (inputs written to since the first step: decided anew)
+					self.lean = None
+				return
+			if eng.trace is not None:
+				p, stat, varx, vary, self.res = self._launch()
+			else:
+				p, stat, varx, vary, self.res = self._graph.run(self._launch)
+			self.out = ((p, stat, None, varx, vary), None)
+			eng.last_guard = dict(hits=0, worst=0.0, fallback=False)
+
+	def check(self):
+		"""True when the lean steps since the last look stand; otherwise the last step has been redone by the public call (self.out replaced)."""
+		if not self.lean:
+			return True
+		eng = self.eng
+		with eng.lock, eng.torch.cuda.device(eng.device):
+			f = self.flags.cpu().numpy()
+			r = float(self.res.cpu()[0]) if getattr(self, 'res', None) is not None else 0.0
+			self.flags.zero_()
+			if not (f[0] or f[1] or f[2] or f[5]) and r < 1e-7:
+				return True
+			logging.info('single=4 plan: a lean step did not stand (flags %s, last Newton-Schulz residual %.3g); redone by the public call', f.tolist(), r)
+			self.fallbacks += 1
+			self.lean = False
+			self.out = None
+			self.out = self._public()
+			return False
+
+	def results(self, device_out=False):
+		"""(p, gamma|dot, alpha|None, varx (n_x,), vary (n_x, n_y)) of the last step."""
+		self.check()
+		out = self.out
+		if isinstance(out, tuple) and len(out) == 2 and isinstance(out[0], tuple):
+			out = out[0]
+		p, stat, alpha, varx, vary = out
+		od = np.dtype(np.float32 if str(p.dtype) in ('torch.float32', 'float32') else np.float64)
+		if device_out:
+			return out
+		eng = self.eng
+		dl = lambda t: eng.download(t) if _is_dev(t) else t
+		vx = varx.cpu().numpy().astype(od) if _is_dev(varx) else varx
+		return (dl(p), dl(stat), alpha, vx, dl(vary))
 
 
 def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, tol=1E-8,
@@ -328,6 +487,7 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		mark = _Marks(eng)
 		from .engine import Residualized
 		mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
+		eng._s4_path = None
 		with torch.cuda.device(eng.device):
 			d_x = dx if _is_dev(dx) else eng.upload(_engine.as_input(dx))
 		may_close = mpc == 0 and method in ('auto', 'scipy')
@@ -370,6 +530,7 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 				raise err
 			return res
 		del res
+		eng._s4_path = None  # (no closed form: nothing for a Single4Plan to replay)
 		if _is_dev(dy):
 			dy = dy.cpu().numpy()
 		logging.info('single=4: no closed form (rank-deficient A A^T or truncated inverse); following the per-grouping algorithm on the host.')
@@ -482,10 +643,12 @@ def _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, ou
 				sp_flags = eng.new_flags()
 			g_d, ssy, coefy, _ = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, not lowmem, True, sp_flags)
 			if int(sp_flags[2]) > 0:  # rows all but inside the span of the covariates: K1's two sweeps and the fp64 Gram kernel for this call
+				eng._s4_path = None
 				logging.info('single=4: %d rows (design or expression) too close to the span of the covariates for the sparse-design products; fp64 Gram kernel', int(sp_flags[2]))
 				return _closed_form(eng, d_x, dy, dc64, dci, dcr, dimreduce, lowmem, return_dot, out_dtype, force_f64=True, device_out=device_out)
 			ry = Residualized(ny, n, None, ssy, coefy, shape=(g_d.shape[0], _engine._round_up(n, _lib.K_TILE)))
 			mark('Y~ X~^T (sparse design: expression rows read once)')
+			eng._s4_path = 'sparse closed form' if _opts.debug('s4_sparse_m', '1') != '0' and inv is not None else None  # (Single4Plan)
 		else:
 			ry = eng.residualize(d_y, d_c, d_dci, dcr, want_coef=not lowmem, nslices=ns, keep_fp64=not ns)
 			mark('K1 genes')

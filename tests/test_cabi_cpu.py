@@ -330,3 +330,23 @@ def test_host_entry_routing_and_result_arrays_without_a_gpu(monkeypatch):
 	a[:] = 1.0
 	assert float(a.sum()) == 700 * 800
 
+
+
+def test_device_pvalue_plans_match_the_host_plans():
+	"""single=1 builds one P-value plan per grouping ON THE DEVICE (k_s1_group_info; round 6: no host inside a resident step) with csrc/nrm_pvalue_plan.h,
+	the long-double plan of nrm_pvalue_plan_init restated in double arithmetic.  The same code compiled for the host against the long-double plans: a, alpha,
+	ln_front, umax identical; the polynomial sum_j coef_j u^j (a correction of ~1e-7 u beside erfcx in the P-value) to 1e-15 of its terms, over dof 1 ... 2e6."""
+	from normalisr_amd import _lib
+	lib = _lib.load()
+	dof = np.ascontiguousarray(np.concatenate([np.arange(1, 60, 0.5), np.geomspace(60, 2e6, 3000)]))
+	a, b = np.zeros((dof.size, 24)), np.zeros((dof.size, 24))
+	assert lib.nrm_pvalue_plan_init_many(dof.ctypes.data, dof.size, a.ctypes.data, 24) == 0
+	assert lib.nrm_pvalue_plan_fill_many(dof.ctypes.data, dof.size, b.ctypes.data, 24) == 0
+	assert np.array_equal(a[:, [0, 1, 3]], b[:, [0, 1, 3]]) and np.abs(a[:, 2] - b[:, 2]).max() <= 1e-15 * np.abs(a[:, 2]).max()
+	assert (a[dof < 16, 3] == 0).all() and (a[dof >= 16, 3] == 1.5).all()
+	pw = np.array([0.01, 0.2877, 1.5])[None, :] ** np.arange(20)[:, None]
+	pa, pb, pabs = a[:, 4:] @ pw, b[:, 4:] @ pw, np.abs(a[:, 4:]) @ pw
+	fast = dof >= 16
+	assert (np.abs(pa - pb)[fast] <= 1e-15 * pabs[fast]).all()
+	bad = np.array([0.0])
+	assert lib.nrm_pvalue_plan_fill_many(bad.ctypes.data, 1, b.ctypes.data, 24) == _lib.NRM_E_ARG

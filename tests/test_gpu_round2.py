@@ -268,6 +268,9 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
 	assert out['n_gpus'] == 2 and out['ranks_seen_by_collective'] == 2 and out['value'] > 0
 	assert out['roofline']['bound'] == 'mfma' and out['roofline']['kernel_ms'] > 0 and 'exchange' in out['kernels_ms']
+	# the line checks itself: >= 12 pooled gene rows, their N-rank P-values against this device's own one-rank values, 1e-6
+	sc = out['self_check']
+	assert sc['ok'] and sc['ranks'] == 2 and sc['ranks_seen_by_collective'] == 2 and sc['gene_rows_checked'] >= 12 and sc['max_relative_p_difference'] <= 1e-6
 	assert out['config']['exchange'] == 'all-gather of raw fp32 blocks'  # below 2048 cells: fp64 engine, raw rows travel
 	out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'coex_c2', '--genes', '1200', '--cells', '8192', '--no-extras'],
 					 dict(NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1'))
@@ -285,6 +288,12 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
 	assert out['config']['genes'] == 768 and out['config']['cells'] == 40000 and out['dtype'].startswith('i8 digits')
 	assert 'cell chunks' in out['config']['exchange'] and out['config']['exchange_bytes_per_rank'] == 384 * 40000 * 6
 	assert out['kernels_ms']['exchange'] >= 0 and out['kernels_ms']['gram'] > 0 and out['guard']['uncertified_pairs'] == 0
+	assert out['self_check']['ok'] and out['self_check']['gene_rows_checked'] >= 12 and out['self_check']['max_relative_p_difference'] <= 1e-6
+	# ... and fails, non-zero, when a rank's P-values are not what one rank computes (one value of the last rank moved by 1e-3)
+	import subprocess
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--c5-rows', '384', '--c5-cells', '40000', '--no-extras'],
+					   env=dict(os.environ, NRM_DIST_BACKEND='gloo', NRM_SHARE_GPU='1', NRM_BENCH_FAULT='p'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+	assert r.returncode != 0 and 'failed its own check' in r.stderr, (r.returncode, r.stderr[-1500:])
 	ser = out['scaling_series']
 	assert ser['ranks'] == 2 and ser['value'] == out['value'] and ser['ms_per_step'] == out['ms_per_step'] and ser['workload'].startswith('coex_c5') and 'scaling_series' in out['config']
 	one = _run_bench(['--steps', '2', '--warmup', '1', '--c5-rows', '384', '--c5-cells', '40000', '--cpu-seconds', '0', '--e2e', '0', '--extras', 'coex_c5', '--extras-steps', '2'], {})

@@ -1,0 +1,231 @@
+"""GPU tests added in round 6: the resident single=1 and single=4 steps with nothing on the host (Single1Plan, Single4Plan: the groupings' pseudo-inverses,
+integer ranks and P-value plans on the device, the Newton-Schulz inverse with the step count of the first call, one HIP graph per step), the torch-free
+single=1 entry on the same kernels, device selection on the library's whole-problem entries.  Same parity bar as test_gpu_parity.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT
+from test_gpu_parity import close, p_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _screen(rng, nx, ny, n, nc, moi=1.0, valued=False, dup_cov=False):
+	dx = (rng.random((nx, n)) < moi / nx).astype(np.float64)
+	if valued:
+		dx[1] *= rng.uniform(0.5, 1.0, n)
+		dx[1, np.nonzero(dx[1])[0][0]] = 1.0
+	dy = rng.normal(size=(ny, n))
+	dy[:5] += 0.5 * dx[0]
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))]) if nc else np.zeros((0, n))
+	if dup_cov and nc >= 3:
+		dc[1] = dc[0]  # a covariate twice: every grouping's C_S C_S^T is rank deficient (the integer rank decides dof)
+	return dx, dy, dc
+
+
+@pytest.mark.parametrize('nc,valued,dup,dtype', [(0, False, False, np.float64), (3, True, False, np.float64), (5, False, True, np.float32), (8, True, False, np.float64)])
+def test_single1_plan_keeps_the_host_out_of_a_step(nc, valued, dup, dtype):
+	"""Single1Plan against the oracle's per-grouping loop (association.py:263-390,911-925): pseudo-inverse, INTEGER rank (a covariate given twice: rank nc - 1,
+	dof one more), ccx, vx, dof and the P-value plan of every grouping come from k_s1_group_info.  Steps 3.. are replays of one HIP graph -- a step
+	that touched the host could not have been captured -- and give the first step's bits."""
+	import torch
+	from normalisr_amd.single1 import Single1Plan, association_tests_single1
+	rng = np.random.default_rng(600 + nc)
+	nx, ny, n = 40, 70, 6000
+	dx, dy, dc = _screen(rng, nx, ny, n, nc, valued=valued, dup_cov=dup)
+	dy = dy.astype(dtype)
+	want = oracle.association_tests(dx, dy.astype(np.float64), dc, single=1, return_dot=False, lowmem=False)
+	plan = Single1Plan(torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), dc, return_dot=False, lowmem=False)
+	plan.step()
+	first = plan.results()
+	tol = 1e-6 if dtype == np.float32 else 1e-9
+	assert first[0].dtype == dtype and p_close(first[0], want[0], 1e-6) and close(first[1], want[1], tol, 1e-12) and close(first[3], want[3], tol) and close(first[4], want[4], tol)
+	if nc:
+		assert close(first[2], want[2], max(tol, 1e-8), 1e-9)
+	for _ in range(4):
+		plan.step()
+	assert plan._graph.graph is not None  # captured: no synchronisation, read-back or upload inside a step
+	again = plan.results()
+	for a, b in zip(first, again):
+		assert (a is None and b is None) or np.array_equal(a, b)
+	# the public call takes the same route (numpy in) and the round-5 route with the statistics on the host agrees with it
+	got = association_tests_single1(dx, dy, dc, return_dot=False, lowmem=False)
+	assert all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(first, got))
+	os.environ['NRM_DEBUG'] = 'single1_stats=host'
+	try:
+		host = association_tests_single1(dx, dy, dc, return_dot=False, lowmem=False)
+	finally:
+		del os.environ['NRM_DEBUG']
+	assert p_close(host[0], first[0], 1e-9) and close(host[1], first[1], 1e-9, 1e-12) and close(host[3], first[3], 1e-9)
+
+
+def test_single1_plan_raises_what_the_reference_raises():
+	"""The checks the host made between the kernels are counters now, read once in results(): a grouping with a single value on its selected cells
+	(association.py:917-918: AssertionError), too few cells for the degrees of freedom removed (RuntimeError), non-finite covariates (the SVD's ValueError)."""
+	import torch
+	from normalisr_amd.single1 import Single1Plan, association_tests_single1
+	rng = np.random.default_rng(611)
+	nx, ny, n, nc = 12, 30, 4100, 3
+	dx, dy, dc = _screen(rng, nx, ny, n, nc)
+	one = dx.copy()
+	one[:] = 0
+	for i in range(nx):
+		one[i, i::nx] = 1  # every cell carries exactly one grouping: no shared cells, grouping i is constant 1 on its own cells
+	with pytest.raises(AssertionError):
+		association_tests_single1(one, dy, dc)
+	with pytest.raises(AssertionError):
+		oracle.association_tests(one, dy, dc, single=1)
+	with pytest.raises(RuntimeError):
+		association_tests_single1(dx, dy, dc, dimreduce=n)
+	bad = dc.copy()
+	bad[0, 7] = np.nan
+	with pytest.raises(ValueError):
+		association_tests_single1(dx, dy, bad)
+	# and a plan stays usable after a failed look: the counters are cleared by it
+	plan = Single1Plan(torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), dc, dimreduce=n)
+	plan.step()
+	with pytest.raises(RuntimeError):
+		plan.results()
+	plan.dimreduce = 0
+	plan._graph.graph, plan._graph.calls = None, 0
+	plan.step()
+	want = oracle.association_tests(dx, dy, dc, single=1)
+	assert p_close(plan.results()[0], want[0])
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_single4_plan_replays_the_public_call(dtype, monkeypatch):
+	"""Single4Plan: the first step IS association_tests_single4 (rank certificate, entry lists, the Newton-Schulz start and step count); later steps are
+	that call's device work as one HIP graph -- the same bits -- and the oracle's per-grouping SVD loop (association.py:421-576) agrees.  Inputs written to
+	between steps, or a step whose counters do not stand, go back through the public call."""
+	import torch
+	from normalisr_amd.single4 import Single4Plan, association_tests_single4
+	monkeypatch.setenv('NRM_DE_SPARSE', 'force')  # (the size rule would leave so small a screen to K1 + K2)
+	rng = np.random.default_rng(640)
+	nx, ny, n, nc = 48, 90, 6000, 4
+	dx = (rng.random((nx, n)) < 0.02).astype(dtype)
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+	dy = (rng.normal(size=(ny, n)) + 0.4 * dx[3] + 0.3 * dc[0]).astype(dtype)
+	want = oracle.association_tests(dx.astype(np.float64), dy.astype(np.float64), dc, single=4, return_dot=False)
+	d_x, d_y = torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda()
+	ref = association_tests_single4(d_x, d_y, dc, return_dot=False)
+	tol = 1e-6 if dtype == np.float32 else 1e-9
+	assert p_close(ref[0], want[0], 1e-6) and close(ref[1], want[1], tol, 1e-12) and close(ref[3], want[3], tol) and close(ref[4], want[4], tol)
+	plan = Single4Plan(d_x, d_y, dc, return_dot=False)
+	plan.step()
+	assert plan.lean is True
+	first = plan.results()
+	for _ in range(4):
+		plan.step()
+	assert plan._graph.graph is not None and plan.check() and plan.fallbacks == 0
+	lean = plan.results()
+	for a, b, c in zip(ref, first, lean):
+		assert (a is None and b is None and c is None) or (np.array_equal(a, b) and np.array_equal(a, c))
+	# the expression matrix written to in place: the next step is the public call again (and decides anew), results follow the new values
+	d_y[7] += 2.0 * d_x[5]
+	plan.step()
+	changed = plan.results()
+	dy2 = d_y.cpu().numpy()
+	want2 = oracle.association_tests(dx.astype(np.float64), dy2.astype(np.float64), dc, single=4, return_dot=False)
+	assert p_close(changed[0], want2[0], 1e-6) and changed[0][5, 7] < 1e-6
+	# a dense design has no lean form: the plan keeps calling the public function
+	monkeypatch.setenv('NRM_DE_SPARSE', '0')
+	dense = Single4Plan(d_x, d_y, dc, return_dot=False)
+	dense.step()
+	dense.step()
+	assert dense.lean is False and p_close(dense.results()[0], want2[0], 1e-6)
+
+
+def test_c_entry_single1_matches_the_plan_from_a_process_without_torch():
+	"""nrm_association_tests_single1_host (numpy in / out, no torch in the process) runs the kernels of Single1Plan: the same results as the package gives
+	in this process, for 5 covariates (statistics on the device) and for 12 (on the host, as in rounds 4-5)."""
+	from normalisr_amd.single1 import association_tests_single1
+	for nc in (5, 12):
+		rng = np.random.default_rng(650 + nc)
+		dx, dy, dc = _screen(rng, 30, 50, 5000, nc, valued=True)
+		want = association_tests_single1(dx, dy, dc, return_dot=False)
+		code = r'''
+import sys, ctypes, numpy as np
+sys.modules['torch'] = None
+sys.path.insert(0, {root!r})
+from normalisr_amd import _lib
+_lib.prefer_host_entry(True)
+lib = _lib.load()
+rng = np.random.default_rng({seed})
+nx, ny, n, nc = 30, 50, 5000, {nc}
+dx = (rng.random((nx, n)) < 1.0 / nx).astype(np.float64)
+dx[1] *= rng.uniform(0.5, 1.0, n)
+dx[1, np.nonzero(dx[1])[0][0]] = 1.0
+dy = rng.normal(size=(ny, n))
+dy[:5] += 0.5 * dx[0]
+dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+p, st, vy = (np.empty((nx, ny)) for _ in range(3))
+vx = np.empty(nx)
+rc = lib.nrm_association_tests_single1_host(dx.ctypes.data, 1, nx, dy.ctypes.data, 1, ny, dc.ctypes.data, 1, nc, n, 0, 0, p.ctypes.data, st.ctypes.data, None, vx.ctypes.data, vy.ctypes.data, 1)
+assert rc == 0, lib.nrm_last_error()
+np.savez({out!r}, p=p, st=st, vx=vx, vy=vy)
+'''
+		out = os.path.join(ROOT, 'gpurun_out', 'r06_s1_entry_{}.npz'.format(nc))
+		os.makedirs(os.path.dirname(out), exist_ok=True)
+		r = subprocess.run([sys.executable, '-c', code.format(root=ROOT, seed=650 + nc, nc=nc, out=out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+		assert r.returncode == 0, r.stderr[-2000:]
+		got = np.load(out)
+		assert p_close(got['p'], want[0], 1e-10) and close(got['st'], want[1], 1e-10, 1e-13) and close(got['vx'], want[3], 1e-10) and close(got['vy'], want[4], 1e-10)
+
+
+def test_host_entries_honour_the_selected_device(tmp_path):
+	"""Round-5 advisory: the command line runs on the library's whole-problem entries, and nothing on that route looked at NORMALISR_DEVICE / device= --
+	`NORMALISR_DEVICE=3 normalisr coex ...` ran on GPU 0.  The entries are bound to the selected GPU now (nrm_set_device: this thread, the entries' helper
+	threads, the scratch pool); an index that is not there is the ValueError the torch engine raises for it."""
+	rng = np.random.default_rng(660)
+	ng, n = 60, 2500
+	dt = np.log1p(rng.poisson(2.0, (ng, n))).astype(np.float64)
+	dc = np.vstack([rng.normal(size=(1, n)), np.ones(n)])
+	np.save(tmp_path / 'exp.npy', dt)
+	np.save(tmp_path / 'cov.npy', dc)
+	cmd = [sys.executable, os.path.join(ROOT, 'bin', 'normalisr'), 'coex', str(tmp_path / 'exp.npy'), str(tmp_path / 'cov.npy'), str(tmp_path / 'pv.npy')]
+	env = {k: v for k, v in os.environ.items() if k not in ('NRM_HOST_ENTRY', 'NORMALISR_DEVICE')}
+	r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, NORMALISR_DEVICE='0'))
+	assert r.returncode == 0, r.stderr[-2000:]
+	want = oracle.coex(dt, dc)
+	assert p_close(np.load(tmp_path / 'pv.npy'), want[0])
+	r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, NORMALISR_DEVICE='97'))
+	assert r.returncode != 0 and 'GPU 97 requested' in r.stderr and 'ValueError' in r.stderr, r.stderr[-2000:]
+	# in this process: the package's keyword on the host-entry route
+	from normalisr_amd import _lib
+	from normalisr_amd.association import association_tests
+	prev = _lib.prefer_host_entry(True)
+	try:
+		with pytest.raises(ValueError, match='GPU 55 requested'):
+			association_tests(dt, None, dc, device=55)
+		got = association_tests(dt, None, dc, device=0)
+		assert p_close(got[0], want[0])
+	finally:
+		_lib.prefer_host_entry(prev)
+
+
+def test_single1_with_one_dimreduce_per_gene():
+	"""dimreduce as one value per row of dy for single=1 (association.py:374: the degrees of freedom of every (grouping, gene) pair lose their gene's value;
+	rounds 3-5 raised NotImplementedError): each gene's P-values are those of the scalar call with its value, gamma and the variances are untouched --
+	and that is what the oracle's restatement of the reference's own broadcast (a (n_y, 1) column, one tile) gives."""
+	from normalisr_amd.single1 import association_tests_single1
+	rng = np.random.default_rng(670)
+	nx, ny, n, nc = 9, 23, 3000, 3
+	dx, dy, dc = _screen(rng, nx, ny, n, nc)
+	dr = rng.integers(0, 3, ny)
+	dr[:3] = [0, 1, 2]
+	got = association_tests_single1(dx, dy, dc, dimreduce=dr, return_dot=False)
+	for v in range(3):
+		want = oracle.association_tests(dx, dy, dc, single=1, dimreduce=v, return_dot=False)
+		cols = dr == v
+		assert p_close(got[0][:, cols], want[0][:, cols]) and close(got[1], want[1], 1e-9, 1e-12) and close(got[4], want[4], 1e-9)
+	whole = oracle.association_tests(dx, dy, dc, single=1, dimreduce=dr.reshape(ny, 1), return_dot=False, bsx=nx, bsy=ny)
+	assert p_close(got[0], whole[0])
+	assert np.array_equal(association_tests_single1(dx, dy, dc, dimreduce=dr.reshape(ny, 1), return_dot=False)[0], got[0])
+	with pytest.raises(ValueError):
+		association_tests_single1(dx, dy, dc, dimreduce=dr[:-1])
