@@ -402,6 +402,9 @@ int nrm_normvar_weights(const void* d_y, int y_dtype, int64_t rows, int64_t n, i
 int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int64_t n, int64_t ldy, const double* d_lnw, const double* d_wt,
 					  const double* d_c, int64_t nc, int64_t ldc, const double* d_b, const double* d_scale, void* d_out, int out_dtype,
 					  int64_t ldo, int32_t* d_flags /* int32[4] or NULL: [1] += waves that wrote a non-finite value (norm.py:286) */, void* stream);
+/* d_out[i] = exp(d_x[i]) as the normvar kernels compute their per-gene cell weights w_k^wt_g = exp(wt_g ln w_k) (norm.py:245): a table of 2^(j/64) and a
+ * polynomial of degree 5 instead of the library's exp (csrc/nrm_normvar.hip: nv_exp).  A probe for the tests. */
+int nrm_normvar_exp_probe(const double* d_x, int64_t count, double* d_out, void* stream);
 /* Round 5: b_g, scale_g and the integer rank of every gene WITHOUT leaving the device, for 1 .. nrm_normvar_device_covariates() covariates: one pass
  * over d_y sums the per-gene moments (M_g = sum_k e_gk^2 C_k C_k^T, a_g = sum_k e_gk^2 y_gk C_k, sum y e, sum (y e)^2) in registers -- no U, V, no Gram
  * launches --, a thread per gene takes M_g^+ by the rank rule of inv_rank (association.py:77-80; the Jacobi iteration of nrm_small_pinv: same integer

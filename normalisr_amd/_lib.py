@@ -101,6 +101,7 @@ _SIGNATURES = {
 	'nrm_normvar_weights': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp], _i32),
 	'nrm_normvar_apply': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
 	'nrm_normvar_device_covariates': ([], _i64),
+	'nrm_normvar_exp_probe': ([_vp, _i64, _vp, _vp], _i32),
 	'nrm_normvar_solve': ([_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _dbl, _i32, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
 	'nrm_normvar_apply_w2': ([_vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _vp], _i32),
 	'nrm_alpha': ([_vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp], _i32),

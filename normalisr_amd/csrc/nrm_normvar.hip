@@ -7,7 +7,46 @@
 #include "nrm_common.h"
 #include "nrm_jacobi.h"
 
+#include "nrm_exp2_tab.h"
+
 #define NV_R 4
+
+// e = exp(x) for the per-gene cell weights w_k^wt_g = exp(wt_g ln w_k) (norm.py:245).  Both passes over the matrix are bound by the fp64 vector ALU, and
+// the library's exp() was most of it (round-5 verdict: normvar at 0.14 of the HBM roofline it is priced against).  Here: x = (64 k + j) ln2/64 + r with
+// |r| <= ln2/128, exp(x) = 2^k 2^(j/64) exp(r); 2^(j/64) from a 64-entry table (correctly rounded, csrc/nrm_exp2_tab.h; the workgroup's copy in LDS),
+// exp(r) as its Taylor polynomial of degree 5 (the term left out, r^6/720, is below 4e-17), ln2/64 in two parts so that the reduction is exact for
+// |k 64 + j| < 2^21.  Fourteen instructions, eleven of them at the fp64 rate, no branch; relative error <= 3e-16 on |x| <= 700 (held to
+// numpy's exp through nrm_normvar_exp_probe: tests/test_gpu_round6.py), overflow / underflow as ldexp gives them.
+__device__ __forceinline__ double nv_exp(double x, const double* __restrict__ tab) {
+	const double kd = rint(x * 92.33248261689366);  // 64 / ln 2
+	const int ki = (int)kd;
+	double r = fma(kd, -0x1.62e42fee00000p-7, x);  // ln2/64, high part (32 bits: kd * hi is exact)
+	r = fma(kd, -0x1.a39ef35793c76p-39, r);
+	double p = fma(r, 1.0 / 120, 1.0 / 24);
+	p = fma(p, r, 1.0 / 6);
+	p = fma(p, r, 0.5);
+	p = fma(p, r, 1.0);
+	p = fma(p, r, 1.0);
+	return ldexp(tab[ki & 63] * p, ki >> 6);
+}
+
+__device__ __forceinline__ void nv_exp_table(double* tab, int tid) {  // (before the workgroup's first barrier)
+	if (tid < 64) tab[tid] = kNrmExp2_64[tid];
+}
+
+__global__ void __launch_bounds__(256) k_nv_exp_probe(const double* __restrict__ x, int64_t count, double* __restrict__ out) {
+	__shared__ double tab[64];
+	nv_exp_table(tab, threadIdx.x);
+	__syncthreads();
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) out[i] = nv_exp(x[i], tab);
+}
+
+// d_out[i] = the kernels' exp(d_x[i]) (a probe for the tests: the function has no other way out of the library)
+extern "C" int nrm_normvar_exp_probe(const double* d_x, int64_t count, double* d_out, void* stream) {
+	NRM_REQUIRE(d_x && d_out && count > 0, "nrm_normvar_exp_probe: bad arguments");
+	hipLaunchKernelGGL(k_nv_exp_probe, dim3(256), dim3(256), 0, (hipStream_t)stream, d_x, count, d_out);
+	return nrm_check_launch("k_nv_exp_probe");
+}
 
 __device__ __forceinline__ double nv_wave_sum(double v) {
 #pragma unroll
@@ -21,7 +60,10 @@ __global__ void __launch_bounds__(256) k_nv_weights(const T* __restrict__ y, int
 													const double* __restrict__ lnw, const double* __restrict__ wt, double* __restrict__ U,
 													double* __restrict__ V, int64_t ldo, double* __restrict__ s1, double* __restrict__ s2) {
 	__shared__ double sm[4][2 * NV_R];
+	__shared__ double tab[64];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	nv_exp_table(tab, tid);
+	__syncthreads();
 	const int64_t row0 = (int64_t)blockIdx.x * NV_R;
 	double a1[NV_R], a2[NV_R], ex[NV_R];
 	bool live[NV_R];
@@ -37,7 +79,7 @@ __global__ void __launch_bounds__(256) k_nv_weights(const T* __restrict__ y, int
 		for (int r = 0; r < NV_R; r++) {
 			double u = 0.0, v = 0.0;
 			if (live[r] && k < n) {
-				const double e = ex[r] == 0.0 ? 1.0 : exp(ex[r] * lw);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
+				const double e = ex[r] == 0.0 ? 1.0 : nv_exp(ex[r] * lw, tab);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
 				const double yv = (double)y[(row0 + r) * ldy + k];
 				const double yp = yv * e;
 				u = e * e;
@@ -71,8 +113,10 @@ __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64
 												  const double* __restrict__ b, const double* __restrict__ scale, OutT* __restrict__ out,
 												  int64_t ldo, int32_t* __restrict__ flags) {
 	__shared__ double s_b[NV_R][64];
+	__shared__ double tab[64];
 	bool bad = false;
 	const int tid = threadIdx.x;
+	nv_exp_table(tab, tid);
 	const int64_t row0 = (int64_t)blockIdx.x * NV_R;
 	for (int i = tid; i < NV_R * nc; i += 256) {
 		const int r = i / nc, q = i % nc;
@@ -99,7 +143,7 @@ __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64
 #pragma unroll
 		for (int r = 0; r < NV_R; r++) {
 			if (row0 + r < rows) {
-				const double e = ex[r] == 0.0 ? 1.0 : exp(ex[r] * lw);
+				const double e = ex[r] == 0.0 ? 1.0 : nv_exp(ex[r] * lw, tab);
 				const OutT o = (OutT)(sc[r] * e * ((double)y[(row0 + r) * ldy + k] - fit[r]));
 				bad |= !(fabs((double)o) <= 1.7976931348623157e308);
 				out[(row0 + r) * ldo + k] = o;
@@ -200,7 +244,10 @@ __global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int
 													 const double* __restrict__ wt, const double* __restrict__ c, int64_t ldc, double* __restrict__ mom) {
 	constexpr int NP = NC * (NC + 1) / 2, NM = NP + NC + 2;
 	__shared__ double sm[4][NM];
+	__shared__ double tab[64];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	nv_exp_table(tab, tid);
+	__syncthreads();
 	const int64_t g = blockIdx.x;
 	const double ex = wt[g];
 	double acc[NM];
@@ -208,7 +255,7 @@ __global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int
 	for (int j = 0; j < NM; j++) acc[j] = 0.0;
 	const T* row = y + g * ldy;
 	for (int64_t k = tid; k < n; k += 256) {
-		const double e = ex == 0.0 ? 1.0 : exp(ex * lnw[k]);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
+		const double e = ex == 0.0 ? 1.0 : nv_exp(ex * lnw[k], tab);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
 		const double yv = (double)row[k], e2 = e * e, yp = yv * e;
 		double cv[NC];
 #pragma unroll

@@ -229,3 +229,26 @@ def test_single1_with_one_dimreduce_per_gene():
 	assert np.array_equal(association_tests_single1(dx, dy, dc, dimreduce=dr.reshape(ny, 1), return_dot=False)[0], got[0])
 	with pytest.raises(ValueError):
 		association_tests_single1(dx, dy, dc, dimreduce=dr[:-1])
+
+
+def test_normvar_exp_against_numpy():
+	"""The per-gene cell weights w_k^wt_g = exp(wt_g ln w_k) (norm.py:245) come from a table of 2^(j/64) and a degree-5 polynomial instead of the library's exp
+	(both passes of normvar were bound by it): within 4 units of the last digit of numpy's exp -- 3e-16 of the exact value -- over the arguments weights
+	produce and far beyond, exactly 1 at 0, 0 / inf where double precision ends."""
+	import torch
+	from normalisr_amd import _lib
+	from normalisr_amd.engine import get_engine
+	eng = get_engine()
+	rng = np.random.default_rng(680)
+	x = np.concatenate([rng.uniform(-6, 6, 400000), rng.uniform(-700, 700, 200000), -rng.exponential(1e-3, 1000), [0.0, 1e-300, -1e-300, 709.7, -745.2, -800.0, 720.0]])
+	d_x = torch.from_numpy(x).cuda()
+	d_o = torch.empty_like(d_x)
+	_lib.check(eng.lib.nrm_normvar_exp_probe(d_x.data_ptr(), d_x.numel(), d_o.data_ptr(), eng._stream()))
+	got, want = d_o.cpu().numpy(), np.exp(x)
+	fin = np.isfinite(want) & (want > 1e-300)
+	assert np.abs(got[fin] / want[fin] - 1).max() < 9e-16 and got[x == 0.0][0] == 1.0
+	assert got[-2] == 0.0 and np.isinf(got[-1]) and not np.isnan(got).any()
+	import mpmath as mp
+	mp.mp.dps = 40
+	idx = rng.integers(0, 600000, 2000)
+	assert max(abs(mp.mpf(float(got[i])) / mp.exp(mp.mpf(float(x[i]))) - 1) for i in idx) < 3.5e-16
