@@ -86,3 +86,46 @@ def bench_default():
 	"""One default N=1 run of bench.py (short: 3 steps, no CPU baseline, no PCIe leg), shared by the test of the line's CONTENT
 	(tests/test_gpu_round2.py) and the timing bounds (tests/test_zz_perf_gpu.py)."""
 	return run_bench(['--steps', '3', '--warmup', '1', '--cpu-seconds', '0', '--e2e', '0', '--extras-steps', '2'], {})
+
+
+def queue_get(q, procs, timeout=300):
+	"""q.get() that does not sit out its timeout when a child has already died: a rank that fails at start (no HBM left for it, a bad import) would
+	otherwise cost the suite five minutes per test -- round 6's first run on the GPU box spent 35 of its 40 minutes in seven such waits."""
+	import queue
+	import time
+	t0 = time.monotonic()
+	while True:
+		try:
+			return q.get(timeout=2)
+		except queue.Empty:
+			dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+			if dead:
+				for p in procs:
+					if p.is_alive():
+						p.terminate()
+				raise AssertionError('rank process(es) died before answering: (rank, exit code) {}'.format(dead))
+			if time.monotonic() - t0 > timeout:
+				for p in procs:
+					if p.is_alive():
+						p.terminate()
+				raise AssertionError('no answer from the rank processes in {} s'.format(timeout))
+
+
+@pytest.fixture(autouse=True)
+def _free_device_caches_before_process_tests(request):
+	"""Tests that start OTHER processes on this box's one GPU (sharded runs over gloo, bench.py, the command line) need HBM for them: what this process
+	cached while the large single-process tests ran (torch's caching allocator after the configs[4] tests holds most of the 288 GB; the library's scratch
+	pool and upload ring) is handed back first.  (In round 5's file order these tests ran before the large ones; collected last, their ranks found no memory.)"""
+	if request.node.get_closest_marker('gpu') is not None and _tier(request.node) == 3:
+		try:
+			import torch
+			if torch.cuda.is_available():
+				torch.cuda.synchronize()
+				torch.cuda.empty_cache()
+			from normalisr_amd import _lib
+			lib = _lib.load()
+			lib.nrm_release_cache()
+			lib.nrm_upload_release()
+		except Exception:  # noqa: BLE001 -- best effort: the test itself reports what is wrong
+			pass
+	yield

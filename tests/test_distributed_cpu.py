@@ -117,7 +117,8 @@ def test_gloo_sharded_coex_matches_single_process(world, exchange, monkeypatch):
 	procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
 	for p in procs:
 		p.start()
-	P, D, V = q.get(timeout=300)
+	from conftest import queue_get
+	P, D, V = queue_get(q, procs)
 	for p in procs:
 		p.join(timeout=120)
 		assert p.exitcode == 0

@@ -438,7 +438,8 @@ def test_sharded_coex_hip_backend_two_ranks_one_gpu(world, dtype):
 	procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, dtype)) for r in range(world)]
 	for p in procs:
 		p.start()
-	got = q.get(timeout=300)
+	from conftest import queue_get
+	got = queue_get(q, procs)
 	P, D, V = got[:3]
 	for p in procs:
 		p.join(timeout=120)

@@ -673,7 +673,8 @@ def test_sharded_coex_pipelined_chunk_exchange(world, dtype, monkeypatch):
 	procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, q, dtype, n)) for r in range(world)]
 	for p in procs:
 		p.start()
-	P, D, V = q.get(timeout=300)
+	from conftest import queue_get
+	P, D, V = queue_get(q, procs)
 	for p in procs:
 		p.join(timeout=120)
 		assert p.exitcode == 0
