@@ -460,23 +460,39 @@ def block_plain_c(dx, dy, dc, dci, dcr, dimreduce=0):
 
 
 def bh(pv, weight=None):
-	"""Benjamini-Hochberg q-values with ties and optional weights (binnet.py:77-131): unique p-values u with cumulative
-	weight fraction w_u; q_u = min_{v >= u} clip(p_v / w_v, 0, 1); arithmetic in pv.dtype as the reference does."""
+	"""Benjamini-Hochberg q-values with ties and optional weights, restated step by step from binnet.py:77-131 (not from normalisr_amd/binnet.py, whose
+	vectorised form this checks): shrink to the unique p-values (:113), add up each one's weights in the order of the entries (:117-119), cumulative
+	weight fraction (:122-123), p / fraction with non-finite -> 1 and clipping to [0, 1] (:124-127), running minimum from the largest p-value down
+	(:128-129), back to the entries (:132).  Arithmetic in pv.dtype, as the reference's arrays are."""
 	pv = np.asarray(pv)
-	assert pv.ndim == 1 and pv.size > 0
-	assert np.isfinite(pv).all() and pv.min() >= 0 and pv.max() <= 1
-	wt = np.ones(pv.size) if weight is None else np.asarray(weight)
-	u, ids = np.unique(pv, return_inverse=True)
-	w = np.zeros(u.size, dtype=pv.dtype)
-	np.add.at(w, ids, wt.astype(pv.dtype))  # sequential accumulation like the loop at binnet.py:118-119
-	w = np.cumsum(w)
-	w /= w[-1]
+	assert pv.ndim == 1 and pv.size > 0  # :103
+	assert np.isfinite(pv).all() and pv.min() >= 0 and pv.max() <= 1  # :104
+	n0 = pv.size
+	pv2, ids = np.unique(pv, return_inverse=True)  # :113
+	n = pv2.size
+	w = np.zeros(n, dtype=pv.dtype)
+	if weight is None:
+		# n0 additions of 1.0 (:106-107,:118-119): an exact count in either dtype (fewer than 2^24 entries), so counting is the same arithmetic
+		assert n0 < (1 << 24)
+		w += np.bincount(ids, minlength=n).astype(pv.dtype)
+	else:
+		weight = np.asarray(weight)
+		assert weight.shape == pv.shape  # :109
+		assert np.isfinite(weight).all() and weight.min() >= 0 and weight.max() > 0  # :110
+		for xi in range(n0):  # :118-119
+			w[ids[xi]] += weight[xi]
+	w = np.cumsum(w)  # :122
+	w /= w[-1]  # :123
 	with np.errstate(divide='ignore', invalid='ignore'):
-		q = u / w
-	q[~np.isfinite(q)] = 1
-	q = np.clip(q, 0, 1)
-	q = np.minimum.accumulate(q[::-1])[::-1]  # binnet.py:126-127
-	return q[ids].astype(pv.dtype, copy=False)
+		pv2 = pv2 / w  # :124
+	pv2[~np.isfinite(pv2)] = 1  # :125
+	pv2 = np.min([pv2, np.repeat(1, n)], axis=0)  # :126
+	pv2 = np.max([pv2, np.repeat(0, n)], axis=0)  # :127
+	for xi in range(n - 2, -1, -1):  # :128-129
+		pv2[xi] = min(pv2[xi], pv2[xi + 1])
+	ans = pv2[ids].astype(pv.dtype, copy=False)  # :132
+	assert ans.shape == pv.shape
+	return ans
 
 
 def binnet(net, qcut):

@@ -132,13 +132,15 @@ def test_single4_plan_replays_the_public_call(dtype, monkeypatch):
 	changed = plan.results()
 	dy2 = d_y.cpu().numpy()
 	want2 = oracle.association_tests(dx.astype(np.float64), dy2.astype(np.float64), dc, single=4, return_dot=False)
-	assert p_close(changed[0], want2[0], 1e-6) and changed[0][5, 7] < 1e-6
+	ok = want2[0] > (1e-30 if dtype == np.float32 else 1e-290)  # (fp32 outputs end at 1e-38: the pair just made significant lies far below)
+	assert not ok[5, 7] or want2[0][5, 7] < 1e-6
+	assert p_close(changed[0][ok], want2[0][ok], 1e-6) and changed[0][5, 7] < 1e-6
 	# a dense design has no lean form: the plan keeps calling the public function
 	monkeypatch.setenv('NRM_DE_SPARSE', '0')
 	dense = Single4Plan(d_x, d_y, dc, return_dot=False)
 	dense.step()
 	dense.step()
-	assert dense.lean is False and p_close(dense.results()[0], want2[0], 1e-6)
+	assert dense.lean is False and p_close(dense.results()[0][ok], want2[0][ok], 1e-6)
 
 
 def test_c_entry_single1_matches_the_plan_from_a_process_without_torch():

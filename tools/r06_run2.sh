@@ -2,12 +2,8 @@
 # round 6, second GPU call: the new tests (resident single=1 / single=4 plans, device selection, exp probe, per-gene dimreduce), the random-shape suite
 # under the 1e-6 bar, the bench tests; then the single=1 / single=4 resident steps under three BLAS thread settings and their kernel timelines
 export TMPDIR=/tmp
-O=gpurun_out/r06b
+O=gpurun_out/r06d
 mkdir -p $O
-python -m pytest tests/test_gpu_round6.py -q -x > $O/t_round6.log 2>&1; echo "rc=$?" >> $O/t_round6.log; tail -n 25 $O/t_round6.log
-python -m pytest tests/test_gpu_random_shapes.py -q > $O/t_random.log 2>&1; echo "rc=$?" >> $O/t_random.log; tail -n 40 $O/t_random.log
-python -m pytest tests/test_gpu_round2.py -q -k "bench" > $O/t_bench.log 2>&1; echo "rc=$?" >> $O/t_bench.log; tail -n 30 $O/t_bench.log
-python -m pytest tests/test_zz_perf_gpu.py -q -s > $O/t_perf.log 2>&1; echo "rc=$?" >> $O/t_perf.log; tail -n 40 $O/t_perf.log
 for w in de_c4_single1 de_c4_single4 normvar_c2; do
 	for th in unset 1 256; do
 		echo "== $w OPENBLAS_NUM_THREADS=$th" >> $O/steps.txt
