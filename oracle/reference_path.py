@@ -305,8 +305,10 @@ def _test2_block(vx, vy, dx, dy, dc, sselectx, dimreduce=0, lowmem=False):
 	dof = (sselectx.sum(axis=1) - 1 - rank.T - dimreduce).T  # :374
 	if (dof <= 0).any():
 		raise RuntimeError('Insufficient number of cells: must be greater than degrees of freedom removed + covariate + 1.')
-	for i in range(nx):
-		p[i] = pvalues(p[i], dof[i, 0])
+	for i in range(nx):  # :377 is elementwise in dof: one value per (grouping, gene) when dimreduce is a (n_y, 1) column
+		for d in np.unique(dof[i]):
+			cols = dof[i] == d
+			p[i, cols] = pvalues(p[i, cols], d)
 	return [vx, vy, p, gam, alpha, vxo, vyo]
 
 

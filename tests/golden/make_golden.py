@@ -422,6 +422,25 @@ def g15():
 	save('G15_single5', **out)
 
 
+def g16():
+	"""single=1 with one dimreduce per gene (association.py:372-377: dof = n_selected - 1 - rank - dimreduce, elementwise; the reference's own broadcast takes
+	a (n_y, 1) column and one tile): a low-MOI design, 3 covariates, dimreduce values 0 / 1 / 2 -- and the scalar calls beside it."""
+	rng = np.random.default_rng(670)
+	nx, ny, n, nc = 9, 23, 3000, 3
+	dx = (rng.random((nx, n)) < 1.0 / nx).astype(np.float64)
+	dy = rng.normal(size=(ny, n))
+	dy[:5] += 0.5 * dx[0]
+	dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+	dr = rng.integers(0, 3, ny)
+	dr[:3] = [0, 1, 2]
+	out = dict(dx=dx, dy=dy, dc=dc, dimreduce=dr)
+	p, g, a, vx, vy = association_tests(dx, dy, dc, single=1, dimreduce=dr.reshape(ny, 1), return_dot=False, bsx=nx, bsy=ny, lowmem=False)
+	out.update(p=p, gamma=g, alpha=a, vx=vx, vy=vy)
+	for v in range(3):
+		out['p_scalar%d' % v] = association_tests(dx, dy, dc, single=1, dimreduce=v, return_dot=False)[0]
+	save('G16_single1_dimreduce', **out)
+
+
 def main():
 	if len(sys.argv) > 1:  # selected fixtures only, e.g. `make_golden.py g11`
 		for name in sys.argv[1:]:
@@ -441,6 +460,7 @@ def main():
 	g13()
 	g14()
 	g15()
+	g16()
 	meta = dict(sklearn=skl, reference='lingfeiwang/normalisr v1.0.0 (/root/reference)', python=sys.version.split()[0],
 				numpy=np.__version__, scipy=scipy.__version__, g3_scipy_vs_mpmath_maxrel=worst)
 	with open(os.path.join(HERE, 'meta.json'), 'w') as f:

@@ -190,7 +190,7 @@ def test_host_entries_honour_the_selected_device(tmp_path):
 	dc = np.vstack([rng.normal(size=(1, n)), np.ones(n)])
 	np.save(tmp_path / 'exp.npy', dt)
 	np.save(tmp_path / 'cov.npy', dc)
-	cmd = [sys.executable, os.path.join(ROOT, 'bin', 'normalisr'), 'coex', str(tmp_path / 'exp.npy'), str(tmp_path / 'cov.npy'), str(tmp_path / 'pv.npy')]
+	cmd = ['bash', os.path.join(ROOT, 'bin', 'normalisr'), 'coex', str(tmp_path / 'exp.npy'), str(tmp_path / 'cov.npy'), str(tmp_path / 'pv.npy')]
 	env = {k: v for k, v in os.environ.items() if k not in ('NRM_HOST_ENTRY', 'NORMALISR_DEVICE')}
 	r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, NORMALISR_DEVICE='0'))
 	assert r.returncode == 0, r.stderr[-2000:]
@@ -211,7 +211,7 @@ def test_host_entries_honour_the_selected_device(tmp_path):
 		_lib.prefer_host_entry(prev)
 
 
-def test_single1_with_one_dimreduce_per_gene():
+def test_single1_with_one_dimreduce_per_gene(golden):
 	"""dimreduce as one value per row of dy for single=1 (association.py:374: the degrees of freedom of every (grouping, gene) pair lose their gene's value;
 	rounds 3-5 raised NotImplementedError): each gene's P-values are those of the scalar call with its value, gamma and the variances are untouched --
 	and that is what the oracle's restatement of the reference's own broadcast (a (n_y, 1) column, one tile) gives."""
@@ -231,6 +231,10 @@ def test_single1_with_one_dimreduce_per_gene():
 	assert np.array_equal(association_tests_single1(dx, dy, dc, dimreduce=dr.reshape(ny, 1), return_dot=False)[0], got[0])
 	with pytest.raises(ValueError):
 		association_tests_single1(dx, dy, dc, dimreduce=dr[:-1])
+	# the reference's own outputs for this case (G16, tests/golden/make_golden.py)
+	g = golden('G16_single1_dimreduce')
+	ref = association_tests_single1(g['dx'], g['dy'], g['dc'], dimreduce=g['dimreduce'], return_dot=False, lowmem=False)
+	assert p_close(ref[0], g['p']) and close(ref[1], g['gamma'], 1e-9, 1e-12) and close(ref[2], g['alpha'], 1e-8, 1e-9) and close(ref[3], g['vx'], 1e-9) and close(ref[4], g['vy'], 1e-9)
 
 
 def test_normvar_exp_against_numpy():

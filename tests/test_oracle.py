@@ -194,6 +194,20 @@ def test_single5_masked_golden(golden):
 			assert a is None
 
 
+def test_single1_with_one_dimreduce_per_gene_golden(golden):
+	"""G16: single=1 with a (n_y, 1) column of dimreduce values through the reference -- dof per (grouping, gene) pair (association.py:372-377).  The oracle
+	(whose restatement took the first gene's dof for a whole row until round 6) on the reference's outputs, and each gene's column equal to the scalar call
+	with that gene's value."""
+	g = golden('G16_single1_dimreduce')
+	dr = g['dimreduce']
+	ny = dr.size
+	p, gam, a, vx, vy = oracle.association_tests(g['dx'], g['dy'], g['dc'], single=1, dimreduce=dr.reshape(ny, 1), return_dot=False, bsx=g['dx'].shape[0], bsy=ny, lowmem=False)
+	assert relerr(p, g['p'], 1e-300) < 1e-10 and relerr(gam, g['gamma'], 1e-13) < 1e-10 and relerr(a, g['alpha'], 1e-12) < 1e-9 and relerr(vx, g['vx']) < 1e-12 and relerr(vy, g['vy']) < 1e-12
+	for v in range(3):
+		assert np.array_equal(g['p'][:, dr == v], g['p_scalar%d' % v][:, dr == v])
+		assert not np.array_equal(g['p'][:, dr != v], g['p_scalar%d' % v][:, dr != v])
+
+
 def test_g11_rows_that_are_hard_for_fixed_point(golden):
 	"""G11 (4096 cells, reference-generated): sparse log1p-count rows, 0/1 rows, rows with a huge mean, heavy tails and single
 	spikes under intercept-only, one-hot-batch, near-collinear and no covariates.  The oracle is fp64 like the reference, so it
