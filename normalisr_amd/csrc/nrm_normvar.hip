@@ -11,6 +11,8 @@
 
 #define NV_R 4
 
+static bool nv_aligned(const void* d_y, int y_dtype, int64_t ldy, const double* d_lnw, const double* d_c, int64_t ldc);
+
 // e = exp(x) for the per-gene cell weights w_k^wt_g = exp(wt_g ln w_k) (norm.py:245).  Both passes over the matrix are bound by the fp64 vector ALU, and
 // the library's exp() was most of it (round-5 verdict: normvar at 0.14 of the HBM roofline it is priced against).  Here: x = (64 k + j) ln2/64 + r with
 // |r| <= ln2/128, exp(x) = 2^k 2^(j/64) exp(r); 2^(j/64) from a 64-entry table (correctly rounded, csrc/nrm_exp2_tab.h; the workgroup's copy in LDS),
@@ -28,6 +30,24 @@ __device__ __forceinline__ double nv_exp(double x, const double* __restrict__ ta
 	p = fma(p, r, 1.0);
 	p = fma(p, r, 1.0);
 	return ldexp(tab[ki & 63] * p, ki >> 6);
+}
+
+// Four consecutive elements of a row as doubles.  ALIGNED (the launcher: 16-byte aligned rows): one 16-byte load (two for doubles); otherwise element loads --
+// a template switch, not a branch.  Either way the four are independent loads: round 6 found both passes of normvar bound by the LATENCY of one dependent
+// 4-byte load per thread and iteration (k_nv_apply waited for HBM once per row and cell: 39 x 4 round trips of ~1.5 us per workgroup = the 0.27 ms it took),
+// not by exp() and the multiply-adds as rounds 4-5 had it; four cells per thread and iteration, every load of an iteration issued before the first use.
+template <typename T, bool ALIGNED>
+__device__ __forceinline__ void nv_ld4(const T* __restrict__ p, double (&v)[4]) {
+	if constexpr (ALIGNED && sizeof(T) == 4) {
+		const float4 t = *reinterpret_cast<const float4*>(p);
+		v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+	} else if constexpr (ALIGNED) {
+		const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+		v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y;
+	} else {
+#pragma unroll
+		for (int j = 0; j < 4; j++) v[j] = (double)p[j];
+	}
 }
 
 __device__ __forceinline__ void nv_exp_table(double* tab, int tid) {  // (before the workgroup's first barrier)
@@ -107,7 +127,9 @@ __global__ void __launch_bounds__(256) k_nv_weights(const T* __restrict__ y, int
 }
 
 // pass 2: out = scale_g * e_gk * (y_gk - sum_c b_gc C_ck)      (norm.py:157 per gene, :259)
-template <typename T, typename OutT>
+// Four cells per thread and iteration, the loads of all NV_R rows, the weights and (batch by batch) the covariates issued before anything is used: the first
+// form loaded one 4-byte value per row and cell and waited for each (see nv_ld4).
+template <typename T, typename OutT, bool ALIGNED>
 __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy, const double* __restrict__ lnw,
 												  const double* __restrict__ wt, const double* __restrict__ c, int nc, int64_t ldc,
 												  const double* __restrict__ b, const double* __restrict__ scale, OutT* __restrict__ out,
@@ -124,13 +146,61 @@ __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64
 	}
 	__syncthreads();
 	double ex[NV_R], sc[NV_R];
+	const T* yr[NV_R];
 #pragma unroll
 	for (int r = 0; r < NV_R; r++) {
 		const bool live = row0 + r < rows;
 		ex[r] = live ? wt[row0 + r] : 0.0;
 		sc[r] = live ? scale[row0 + r] : 0.0;
+		yr[r] = y + (live ? row0 + r : rows - 1) * ldy;  // (rows past the end read the last row: every load is issued whatever the row, nothing of theirs is stored)
 	}
-	for (int64_t k = tid; k < n; k += 256) {
+	auto finish = [&](int r, double lw, double yv, double fit) {
+		const double e = ex[r] == 0.0 ? 1.0 : nv_exp(ex[r] * lw, tab);
+		const OutT o = (OutT)(sc[r] * e * (yv - fit));
+		bad |= !(fabs((double)o) <= 1.7976931348623157e308);
+		return o;
+	};
+	const int64_t n4 = n & ~(int64_t)3;
+	for (int64_t k = (int64_t)tid * 4; k < n4; k += 1024) {
+		double lw[4], yv[NV_R][4], fit[NV_R][4];
+		nv_ld4<double, ALIGNED>(lnw + k, lw);
+#pragma unroll
+		for (int r = 0; r < NV_R; r++) {
+			nv_ld4<T, ALIGNED>(yr[r] + k, yv[r]);
+#pragma unroll
+			for (int v = 0; v < 4; v++) fit[r][v] = 0.0;
+		}
+		for (int q = 0; q < nc; q++) {
+			double cv[4];
+			nv_ld4<double, ALIGNED>(c + (int64_t)q * ldc + k, cv);
+#pragma unroll
+			for (int r = 0; r < NV_R; r++)
+#pragma unroll
+				for (int v = 0; v < 4; v++) fit[r][v] = fma(s_b[r][q], cv[v], fit[r][v]);
+		}
+#pragma unroll
+		for (int r = 0; r < NV_R; r++) {
+			if (row0 + r >= rows) continue;
+			OutT o[4];
+#pragma unroll
+			for (int v = 0; v < 4; v++) o[v] = finish(r, lw[v], yv[r][v], fit[r][v]);
+			OutT* dst = out + (row0 + r) * ldo + k;
+			if constexpr (ALIGNED) {
+				typedef OutT ov_t __attribute__((ext_vector_type(16 / sizeof(OutT))));
+#pragma unroll
+				for (int h = 0; h < 4; h += 16 / (int)sizeof(OutT)) {
+					ov_t t;
+#pragma unroll
+					for (int j = 0; j < 16 / (int)sizeof(OutT); j++) t[j] = o[h + j];
+					*reinterpret_cast<ov_t*>(dst + h) = t;
+				}
+			} else {
+#pragma unroll
+				for (int v = 0; v < 4; v++) dst[v] = o[v];
+			}
+		}
+	}
+	for (int64_t k = n4 + tid; k < n; k += 256) {  // the last n % 4 cells
 		const double lw = lnw[k];
 		double fit[NV_R];
 #pragma unroll
@@ -141,14 +211,8 @@ __global__ void __launch_bounds__(256) k_nv_apply(const T* __restrict__ y, int64
 			for (int r = 0; r < NV_R; r++) fit[r] = fma(s_b[r][q], cv, fit[r]);
 		}
 #pragma unroll
-		for (int r = 0; r < NV_R; r++) {
-			if (row0 + r < rows) {
-				const double e = ex[r] == 0.0 ? 1.0 : nv_exp(ex[r] * lw, tab);
-				const OutT o = (OutT)(sc[r] * e * ((double)y[(row0 + r) * ldy + k] - fit[r]));
-				bad |= !(fabs((double)o) <= 1.7976931348623157e308);
-				out[(row0 + r) * ldo + k] = o;
-			}
-		}
+		for (int r = 0; r < NV_R; r++)
+			if (row0 + r < rows) out[(row0 + r) * ldo + k] = finish(r, lw, (double)yr[r][k], fit[r]);
 	}
 	// the reference asserts that its result is finite (norm.py:286): counted here, where the values are at hand (flags[1] += waves with one that is not)
 	if (flags && __ballot(bad) && (tid & 63) == 0) atomicAdd(&flags[1], 1);
@@ -220,12 +284,21 @@ extern "C" int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int
 	NRM_REQUIRE(d_y && d_lnw && d_wt && d_c && d_b && d_scale && d_out, "nrm_normvar_apply: null pointer");
 	dim3 grid((unsigned)((rows + NV_R - 1) / NV_R));
 	hipStream_t st = (hipStream_t)stream;
-#define NV_LAUNCH(TY, TO) hipLaunchKernelGGL((k_nv_apply<TY, TO>), grid, dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, (int)nc, ldc, d_b, d_scale, (TO*)d_out, ldo, d_flags)
+	const bool al = nv_aligned(d_y, y_dtype, ldy, d_lnw, d_c, ldc) && (uintptr_t)d_out % 16 == 0 && (ldo * (out_dtype == NRM_F64 ? 8 : 4)) % 16 == 0;
+#define NV_LAUNCH2(TY, TO, AL) hipLaunchKernelGGL((k_nv_apply<TY, TO, AL>), grid, dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, (int)nc, ldc, d_b, d_scale, (TO*)d_out, ldo, d_flags)
+#define NV_LAUNCH(TY, TO)        \
+	do {                         \
+		if (al)                  \
+			NV_LAUNCH2(TY, TO, true);  \
+		else                     \
+			NV_LAUNCH2(TY, TO, false); \
+	} while (0)
 	if (y_dtype == NRM_F64 && out_dtype == NRM_F64) NV_LAUNCH(double, double);
 	else if (y_dtype == NRM_F64) NV_LAUNCH(double, float);
 	else if (out_dtype == NRM_F64) NV_LAUNCH(float, double);
 	else NV_LAUNCH(float, float);
 #undef NV_LAUNCH
+#undef NV_LAUNCH2
 	return nrm_check_launch("k_nv_apply");
 }
 
@@ -239,7 +312,7 @@ extern "C" int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int
 // Two reads of the matrix and one write: HBM-bound; nothing crosses PCIe.
 #define NV_NC 8
 
-template <typename T, int NC>
+template <typename T, int NC, bool ALIGNED>
 __global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy, const double* __restrict__ lnw,
 													 const double* __restrict__ wt, const double* __restrict__ c, int64_t ldc, double* __restrict__ mom) {
 	constexpr int NP = NC * (NC + 1) / 2, NM = NP + NC + 2;
@@ -254,12 +327,9 @@ __global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int
 #pragma unroll
 	for (int j = 0; j < NM; j++) acc[j] = 0.0;
 	const T* row = y + g * ldy;
-	for (int64_t k = tid; k < n; k += 256) {
-		const double e = ex == 0.0 ? 1.0 : nv_exp(ex * lnw[k], tab);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
-		const double yv = (double)row[k], e2 = e * e, yp = yv * e;
-		double cv[NC];
-#pragma unroll
-		for (int q = 0; q < NC; q++) cv[q] = c[(int64_t)q * ldc + k];
+	auto cell = [&](double lw, double yv, const double (&cv)[NC]) {
+		const double e = ex == 0.0 ? 1.0 : nv_exp(ex * lw, tab);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
+		const double e2 = e * e, yp = yv * e;
 		int j = 0;
 #pragma unroll
 		for (int q = 0; q < NC; q++) {
@@ -271,6 +341,27 @@ __global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int
 		for (int q = 0; q < NC; q++, j++) acc[j] = fma(e2 * yv, cv[q], acc[j]);
 		acc[j] += yp;
 		acc[j + 1] = fma(yp, yp, acc[j + 1]);
+	};
+	const int64_t n4 = n & ~(int64_t)3;
+	for (int64_t k = (int64_t)tid * 4; k < n4; k += 1024) {  // four cells per thread: 2 + 2 NC sixteen-byte loads in flight before the first is used
+		double lw[4], yv[4], cq[NC][4];
+		nv_ld4<double, ALIGNED>(lnw + k, lw);
+		nv_ld4<T, ALIGNED>(row + k, yv);
+#pragma unroll
+		for (int q = 0; q < NC; q++) nv_ld4<double, ALIGNED>(c + (int64_t)q * ldc + k, cq[q]);
+#pragma unroll
+		for (int v = 0; v < 4; v++) {
+			double cv[NC];
+#pragma unroll
+			for (int q = 0; q < NC; q++) cv[q] = cq[q][v];
+			cell(lw[v], yv[v], cv);
+		}
+	}
+	for (int64_t k = n4 + tid; k < n; k += 256) {  // the last n % 4 cells
+		double cv[NC];
+#pragma unroll
+		for (int q = 0; q < NC; q++) cv[q] = c[(int64_t)q * ldc + k];
+		cell(lnw[k], (double)row[k], cv);
 	}
 #pragma unroll
 	for (int j = 0; j < NM; j++) {
@@ -316,6 +407,11 @@ __global__ void __launch_bounds__(64) k_nv_solve(const double* __restrict__ mom,
 	scale[g] = sc;
 }
 
+// every row of the matrix, the weights and the covariates starts on a 16-byte boundary: the vector-load instantiations
+static bool nv_aligned(const void* d_y, int y_dtype, int64_t ldy, const double* d_lnw, const double* d_c, int64_t ldc) {
+	return (uintptr_t)d_y % 16 == 0 && (ldy * (y_dtype == NRM_F64 ? 8 : 4)) % 16 == 0 && (uintptr_t)d_lnw % 16 == 0 && (uintptr_t)d_c % 16 == 0 && ldc % 2 == 0;
+}
+
 extern "C" int64_t nrm_normvar_device_covariates(void) { return NV_NC; }
 
 // d_mom: rows x (nc (nc + 1) / 2 + nc + 2) doubles of scratch; d_b (rows, nc), d_scale (rows), d_rank (rows) int64; d_flags int32[4]: [0] += genes whose
@@ -326,18 +422,22 @@ extern "C" int nrm_normvar_solve(const void* d_y, int y_dtype, int64_t rows, int
 	NRM_REQUIRE(rows > 0 && n > 0 && ldy >= n && nc >= 1 && nc <= NV_NC && ldc >= n && tol > 0, "nrm_normvar_solve: bad sizes (1 to %d covariates)", NV_NC);
 	NRM_REQUIRE(d_y && d_lnw && d_wt && d_c && d_mom && d_b && d_scale && d_rank && d_flags, "nrm_normvar_solve: null pointer");
 	hipStream_t st = (hipStream_t)stream;
+	const bool al = nv_aligned(d_y, y_dtype, ldy, d_lnw, d_c, ldc);
+#define NV_MOM(TY, NCV, AL) hipLaunchKernelGGL((k_nv_moments<TY, NCV, AL>), dim3((unsigned)rows), dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, ldc, d_mom)
 #define NV_GO(NCV)                                                                                                                                   \
 	case NCV:                                                                                                                                        \
-		if (y_dtype == NRM_F64)                                                                                                                      \
-			hipLaunchKernelGGL((k_nv_moments<double, NCV>), dim3((unsigned)rows), dim3(256), 0, st, (const double*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, ldc, d_mom); \
-		else                                                                                                                                         \
-			hipLaunchKernelGGL((k_nv_moments<float, NCV>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, ldc, d_mom);   \
+		if (y_dtype == NRM_F64) {                                                                                                                    \
+			if (al) NV_MOM(double, NCV, true); else NV_MOM(double, NCV, false);                                                                      \
+		} else {                                                                                                                                     \
+			if (al) NV_MOM(float, NCV, true); else NV_MOM(float, NCV, false);                                                                        \
+		}                                                                                                                                            \
 		hipLaunchKernelGGL((k_nv_solve<NCV>), dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, d_mom, rows, n, d_wt, tol, keepvar, d_b, d_scale, d_rank, d_flags); \
 		break;
 	switch ((int)nc) {
 		NV_GO(1) NV_GO(2) NV_GO(3) NV_GO(4) NV_GO(5) NV_GO(6) NV_GO(7) NV_GO(8)
 	}
 #undef NV_GO
+#undef NV_MOM
 	return nrm_check_launch("nrm_normvar_solve");
 }
 

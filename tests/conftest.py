@@ -89,8 +89,9 @@ def bench_default():
 
 
 def queue_get(q, procs, timeout=300):
-	"""q.get() that does not sit out its timeout when a child has already died: a rank that fails at start (no HBM left for it, a bad import) would
-	otherwise cost the suite five minutes per test -- round 6's first run on the GPU box spent 35 of its 40 minutes in seven such waits."""
+	"""q.get() that does not sit out its timeout when a child has already died: a rank that fails at start (a bad import, no HBM left for it) would
+	otherwise cost the suite five minutes per test -- round 6's first run on the GPU box spent 35 of its 40 minutes in seven such waits (a conftest.py
+	added at the repo root shadowed this file in the spawned ranks, which import `conftest` by name)."""
 	import queue
 	import time
 	t0 = time.monotonic()
@@ -113,9 +114,9 @@ def queue_get(q, procs, timeout=300):
 
 @pytest.fixture(autouse=True)
 def _free_device_caches_before_process_tests(request):
-	"""Tests that start OTHER processes on this box's one GPU (sharded runs over gloo, bench.py, the command line) need HBM for them: what this process
-	cached while the large single-process tests ran (torch's caching allocator after the configs[4] tests holds most of the 288 GB; the library's scratch
-	pool and upload ring) is handed back first.  (In round 5's file order these tests ran before the large ones; collected last, their ranks found no memory.)"""
+	"""Tests that start OTHER processes on this box's one GPU (sharded runs over gloo, bench.py, the command line) are collected last, after the large
+	single-process tests: what this process cached meanwhile (torch's caching allocator after the configs[4] tests holds a large part of the 288 GB; the
+	library's scratch pool and upload ring) is handed back first, so that the ranks' own allocations do not depend on what ran before them."""
 	if request.node.get_closest_marker('gpu') is not None and _tier(request.node) == 3:
 		try:
 			import torch
