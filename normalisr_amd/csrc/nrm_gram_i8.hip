@@ -42,6 +42,9 @@
 #define QK 32        // cells per k-step (one MFMA)
 #define QCHUNK 512   // k-steps per int32 accumulation chunk (16 384 cells)
 #define QD 3         // stages in the LDS ring
+#ifndef QI_EDGE
+#define QI_EDGE 1    // 0: the round-5 wave map on edge tiles (A/B builds: tools/build_exp.sh)
+#endif
 #ifndef QI_EXP
 #define QI_EXP 0     // timing experiments (tools/build_exp.sh): 1 no DMA, 2 every DMA from k-steps 0-3 (L2 resident), 4 no barrier
 #endif
@@ -199,27 +202,37 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 	// operand reads: lane l takes the 16 bytes of row l & 31 stored at half (l >> 5) ^ ((row >> 3) & 1)
 	const int r = lane & 31;
 	const int pos = (2 * r + ((lane >> 5) ^ ((r >> 3) & 1))) * 16;
-	const int aoff = (wm * 2) * NS * 1024 + pos;       // + i * NS * 1024 + s * 1024
-	const int boff = (4 + wn) * NS * 1024 + pos;       // + s * 1024
-	// output addressing of this wave's two 32 x 32 tiles: lane holds column lane & 31, rows (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
-	const int row_w = ti * GM + wm * 64, col_w = tj * GN + wn * 32;
 	const bool diag = symmetric && ti == tj;
+	// EDGE tile (round 6): a column tile with at most 32 valid columns -- 5000 genes = 39 x 128 + 8: the 39 off-diagonal tiles of the last tile column.
+	// In the usual wave map only waves (0, 0) and (1, 0) have work there, both on SIMD 0, 42 MFMAs each per k-step: the tile took as long as a whole one
+	// (4.9 % of K2 on configs[1]).  Here the four 32-row blocks of the tile go to waves 0-3 -- one per SIMD -- one 32 x 32 sub-tile each (21 MFMAs per
+	// k-step, the MASK = 1 copy of the k loop); waves 4-7 only feed the ring.  Same DMA roles, same stages, same slab layout (rows 32 w of the tile).
+	const bool edge = QI_EDGE && !diag && tj * GN + 32 >= n_rows;
+	const int a_blk = edge ? (wid & 3) : wm * 2, b_blk = edge ? 0 : wn;
+	const int aoff = a_blk * NS * 1024 + pos;          // + i * NS * 1024 + s * 1024
+	const int boff = (4 + b_blk) * NS * 1024 + pos;    // + s * 1024
+	// output addressing of this wave's two 32 x 32 tiles: lane holds column lane & 31, rows (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+	const int row_w = ti * GM + a_blk * 32, col_w = tj * GN + b_blk * 32;
 	// 32 x 32 sub-tiles that are pure padding, or below the diagonal of a symmetric problem, are neither stored nor -- when both of
 	// a wave's are -- computed (5000 genes: the last tile row and column hold 8 valid rows of 128); nobody reads them (K3 sweeps
 	// valid rows and, symmetric, the upper triangle), also not through the slabs of split tiles
 	bool want[2];
 #pragma unroll
 	for (int i = 0; i < 2; i++) want[i] = row_w + i * 32 < m_rows && col_w < n_rows && (!diag || col_w + 31 >= row_w + i * 32);
+	if (edge) {
+		want[0] = want[0] && wid < 4;
+		want[1] = false;
+	}
 	double* cbase;
 	int64_t pitch;
 	if (slab) {
-		cbase = slab + (wm * 64) * GN + wn * 32;
+		cbase = slab + (a_blk * 32) * GN + b_blk * 32;
 		pitch = GN;
 	} else {
 		cbase = C + (int64_t)row_w * ldc + col_w;
 		pitch = ldc;
 	}
-	const int eb_l = eb_t[wn * 32 + (lane & 31)];
+	const int eb_l = eb_t[b_blk * 32 + (lane & 31)];
 	auto flush = [&](bool first) {
 #pragma unroll
 		for (int i = 0; i < 2; i++) {
@@ -312,7 +325,9 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 		}
 	}
 	};
-	if (want[0] || want[1])  // (copies for one half only, masks 1 and 2, measured: no gain over computing both)
+	if (QI_EDGE && want[0] && !want[1])  // the first half only: the waves of an edge tile (above), and the last tile row when it holds at most 32 valid rows
+		kloop(std::integral_constant<int, 1>{});
+	else if (want[0] || want[1])  // (the second half alone -- a diagonal tile's lower-left wave -- is computed with both: no fourth copy of the loop)
 		kloop(std::integral_constant<int, 3>{});
 	else
 		kloop(std::integral_constant<int, 0>{});
