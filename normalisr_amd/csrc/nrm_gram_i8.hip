@@ -43,7 +43,7 @@
 #define QCHUNK 512   // k-steps per int32 accumulation chunk (16 384 cells)
 #define QD 3         // stages in the LDS ring
 #ifndef QI_EDGE
-#define QI_EDGE 1    // 0: the round-5 wave map on edge tiles (A/B builds: tools/build_exp.sh)
+#define QI_EDGE 0    // 1: edge tiles on four waves of one sub-tile each (round 6: built, parity-green, measured NOT to help -- see gram_piece_i8; kept for A/B builds)
 #endif
 #ifndef QI_EXP
 #define QI_EXP 0     // timing experiments (tools/build_exp.sh): 1 no DMA, 2 every DMA from k-steps 0-3 (L2 resident), 4 no barrier
@@ -203,10 +203,16 @@ __device__ __forceinline__ void gram_piece_i8(const char* __restrict__ QA, const
 	const int r = lane & 31;
 	const int pos = (2 * r + ((lane >> 5) ^ ((r >> 3) & 1))) * 16;
 	const bool diag = symmetric && ti == tj;
-	// EDGE tile (round 6): a column tile with at most 32 valid columns -- 5000 genes = 39 x 128 + 8: the 39 off-diagonal tiles of the last tile column.
-	// In the usual wave map only waves (0, 0) and (1, 0) have work there, both on SIMD 0, 42 MFMAs each per k-step: the tile took as long as a whole one
-	// (4.9 % of K2 on configs[1]).  Here the four 32-row blocks of the tile go to waves 0-3 -- one per SIMD -- one 32 x 32 sub-tile each (21 MFMAs per
-	// k-step, the MASK = 1 copy of the k loop); waves 4-7 only feed the ring.  Same DMA roles, same stages, same slab layout (rows 32 w of the tile).
+	// EDGE tile (round 6, QI_EDGE=1; off by default): a column tile with at most 32 valid columns -- 5000 genes = 39 x 128 + 8: the 39 off-diagonal tiles
+	// of the last tile column.  In the usual wave map only waves (0, 0) and (1, 0) have work there, both on SIMD 0, 42 MFMAs each per k-step, and the tile
+	// takes as long as a whole one (configs[1] on one box: 4992 genes 2.061 ms, 5000 genes 2.150 ms: 4.3 %).  With this map the four 32-row blocks of the
+	// tile go to waves 0-3 -- one per SIMD -- one 32 x 32 sub-tile each (21 MFMAs per k-step, the MASK = 1 copy of the k loop), waves 4-7 only feed the
+	// ring: same DMA roles, stages and slab layout.  Parity-green (the Gram engines' tests) and SLOWER: 2.243 ms against 2.150 in three alternating runs on
+	// that box (profiles/r06_k2_edge_wave_map.txt) -- a k-step of an edge tile is not bound by its MFMAs (a quarter of a whole tile's per SIMD here) but by
+	// what every k-step pays whatever it computes, the stage's 48 KB of DMA through a ring of three and the workgroup barrier, and a compute wave alone on its
+	// SIMD has nobody to cover its own DMA issues and operand reads (what round 3's variant (e) found with 42 MFMAs per wave holds with 21).  The bound of ANY
+	// edge treatment is the 4992-gene figure; a launch of its own for the edge (transposed, through this kernel) costs 0.136 ms for the 0.09-0.10 it saves
+	// (tools/k2_edge_exp.py, profiles/r06_k2_edge_split_launch.txt).
 	const bool edge = QI_EDGE && !diag && tj * GN + 32 >= n_rows;
 	const int a_blk = edge ? (wid & 3) : wm * 2, b_blk = edge ? 0 : wn;
 	const int aoff = a_blk * NS * 1024 + pos;          // + i * NS * 1024 + s * 1024
