@@ -45,12 +45,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
 
-# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r04.sh), newest first
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same commands (tools/profile_r06.sh), newest first
 PMC_FILES = {w: [os.path.join(ROOT, 'profiles', f) for f in fs] for w, fs in dict(
-	coex_c2=('r05_pmc_c2.json', 'r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r05_pmc_de_c3.json', 'r04_pmc_de_c3.json', 'r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
-	de_c4=('r05_pmc_de_c4.json', 'r04_pmc_de_c4_sparse.json'), de_c4_dense=('r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r05_pmc_coex_c5.json', 'r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'),
-	de_c4_single4=('r05_pmc_de_c4_single4.json', 'r04_pmc_de_c4_single4_sparse.json'), de_c4_single4_dense=('r04_pmc_de_c4_single4.json', ),
-	de_c4_single1=('r05_pmc_de_c4_single1.json', 'r04_pmc_de_c4_single1.json'), binnet_c5=('r05_pmc_binnet_c5.json', 'r04_pmc_binnet_c5.json'), normvar_c2=('r05_pmc_normvar_c2.json', )).items()}
+	coex_c2=('r06_pmc_c2.json', 'r05_pmc_c2.json', 'r04_pmc_c2.json', 'r03_pmc_c2.json', 'r02_pmc_c2.json', 'r01_pmc_c2.json'), de_c3=('r06_pmc_de_c3.json', 'r05_pmc_de_c3.json', 'r04_pmc_de_c3.json', 'r03_pmc_de_c3.json', 'r02_pmc_de_c3.json'),
+	de_c4=('r06_pmc_de_c4.json', 'r05_pmc_de_c4.json', 'r04_pmc_de_c4_sparse.json'), de_c4_dense=('r04_pmc_de_c4.json', 'r03_pmc_de_c4.json'), coex_c5=('r06_pmc_coex_c5.json', 'r05_pmc_coex_c5.json', 'r04_pmc_coex_c5.json', 'r03_pmc_coex_c5.json'),
+	de_c4_single4=('r06_pmc_de_c4_single4.json', 'r05_pmc_de_c4_single4.json', 'r04_pmc_de_c4_single4_sparse.json'), de_c4_single4_dense=('r04_pmc_de_c4_single4.json', ),
+	de_c4_single1=('r06_pmc_de_c4_single1.json', 'r05_pmc_de_c4_single1.json', 'r04_pmc_de_c4_single1.json'), binnet_c5=('r06_pmc_binnet_c5.json', 'r05_pmc_binnet_c5.json', 'r04_pmc_binnet_c5.json'),
+	normvar_c2=('r06_pmc_normvar_c2.json', 'r05_pmc_normvar_c2.json')).items()}
 
 
 def pmc_traffic(workload, roof, kernels=None):
@@ -753,7 +754,7 @@ def bench_normvar(rk, steps, warmup):
 				kernels_ms=split, numpy_in_out_ms=host_ms,
 				roofline=dict(bound='hbm', kernel='k_nv_moments + k_nv_solve + k_nv_apply', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
 							  algorithmic_bytes=byts, traffic=None, kernel_ms=kms, step_ms=ms, pmc_kernels=['k_nv_moments', 'k_nv_apply'],
-							  note='the matrix is read twice (moments, then the result); a step also uploads the covariates and weights (0.5 MB) and reads one word of flags back'))
+							  note='the matrix is read twice (moments, then the result); the result pass runs at the HBM rate, the moments pass re-reads the covariates per gene from L2 (DESIGN.md section 6); a step also uploads the covariates and weights (0.5 MB) and reads one word of flags back'))
 
 
 def bench_chain(rk, steps, warmup):

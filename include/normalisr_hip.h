@@ -560,6 +560,9 @@ int64_t nrm_single1_select_gram_blocks(void);
 int nrm_single1_select(const int64_t* d_row_ptr, const int32_t* d_cells, const double* d_vals, int64_t nx, int64_t n, int64_t nnz, const double* d_c,
 					   int64_t ldc, int64_t nc, int32_t* d_cnt, int32_t* d_code, int64_t* d_seg, int64_t* d_idx, double* d_xe, double* d_ce,
 					   double* d_rowinfo, double* d_gram_part, int64_t* d_info, void* stream);
+/* The last step of nrm_single1_select by itself (d_gram_part from d_cnt as the selection left it): a caller that passes d_gram_part = NULL to
+ * nrm_single1_select runs it where it likes -- beside nrm_single1_stream, which needs the cell codes only, on another stream. */
+int nrm_single1_common_gram(const int32_t* d_cnt, int64_t n, const double* d_c, int64_t ldc, int64_t nc, double* d_gram_part, void* stream);
 
 /*
  * Pseudo-inverses and ranks of a stack of small symmetric matrices (host only): what single=1 needs per grouping (association.py:350-351)

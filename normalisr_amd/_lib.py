@@ -83,6 +83,7 @@ _SIGNATURES = {
 	'nrm_design_fill': ([_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp], _i32),
 	'nrm_single1_select_gram_blocks': ([], _i64),
 	'nrm_single1_select': ([_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
+	'nrm_single1_common_gram': ([_vp, _i64, _vp, _i64, _i64, _vp, _vp], _i32),
 	'nrm_design_stats': ([_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp], _i32),
 	'nrm_upload': ([_vp, _vp, _i64, _i32, _vp], _i32),
 	'nrm_upload_release': ([], _i32),

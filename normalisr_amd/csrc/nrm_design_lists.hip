@@ -479,7 +479,7 @@ extern "C" int nrm_single1_select(const int64_t* d_row_ptr, const int32_t* d_cel
 								  double* d_rowinfo, double* d_gram_part, int64_t* d_info, void* stream) {
 	NRM_REQUIRE(d_row_ptr && d_cells && d_cnt && d_code && d_seg && d_idx && d_xe && d_rowinfo && d_info && nx > 0 && n > 0 && nnz >= 0 && nc >= 0 && nc <= 32,
 				"nrm_single1_select: bad arguments (at most 32 covariates)");
-	NRM_REQUIRE(nc == 0 || (d_c && d_ce && d_gram_part && ldc >= n), "nrm_single1_select: covariates missing");
+	NRM_REQUIRE(nc == 0 || (d_c && d_ce && ldc >= n), "nrm_single1_select: covariates missing");  // (d_gram_part == NULL: the caller takes the shared cells' Gram matrix itself, nrm_single1_common_gram)
 	hipStream_t st = (hipStream_t)stream;
 	NRM_HIP(hipMemsetAsync(d_cnt, 0, (size_t)n * 4, st));
 	NRM_HIP(hipMemsetAsync(d_info + 3, 0, 2 * sizeof(int64_t), st));
@@ -489,10 +489,20 @@ extern "C" int nrm_single1_select(const int64_t* d_row_ptr, const int32_t* d_cel
 	hipLaunchKernelGGL(k_s1_scan, dim3(1), dim3(1024), 0, st, d_seg, nx, d_info);
 	hipLaunchKernelGGL(k_s1_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_cnt, n, d_code, d_info);
 	hipLaunchKernelGGL(k_s1_rows<true>, dim3((unsigned)nx), dim3(64), 0, st, d_row_ptr, d_cells, d_vals, d_cnt, d_seg, nullptr, d_idx, d_xe, d_code, d_c, ldc, (int)nc, d_ce);
-	if (nc) {
+	if (nc && d_gram_part) {
 		const int nb = (int)(nc + 7) / 8;
 		hipLaunchKernelGGL(k_s1_common_gram, dim3((unsigned)nrm_single1_select_gram_blocks(), (unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, st, d_cnt, n, d_c, ldc, (int)nc,
 						   d_gram_part);
 	}
 	return nrm_check_launch("nrm_single1_select");
+}
+
+// The last step of nrm_single1_select by itself -- the covariate Gram matrix of the cells no grouping touches, from d_cnt as the selection left it -- for a
+// caller that runs it beside the stream kernel (which needs the cell codes only) on another stream: nrm_single1_select with d_gram_part == NULL, then this.
+extern "C" int nrm_single1_common_gram(const int32_t* d_cnt, int64_t n, const double* d_c, int64_t ldc, int64_t nc, double* d_gram_part, void* stream) {
+	NRM_REQUIRE(d_cnt && d_c && d_gram_part && n > 0 && nc > 0 && nc <= 32 && ldc >= n, "nrm_single1_common_gram: bad arguments");
+	const int nb = (int)(nc + 7) / 8;
+	hipLaunchKernelGGL(k_s1_common_gram, dim3((unsigned)nrm_single1_select_gram_blocks(), (unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, (hipStream_t)stream, d_cnt, n, d_c, ldc,
+					   (int)nc, d_gram_part);
+	return nrm_check_launch("k_s1_common_gram");
 }

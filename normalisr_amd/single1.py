@@ -254,6 +254,7 @@ class Single1Plan:
 			self.p, self.stat, self.vary = (torch.empty((nx, ny), dtype=tdt, device=dev) for _ in range(3))
 			self.alpha = None if lowmem else eng.zeros((nx, ny, nc), tdt)
 			self.flags = eng.zeros((8, ), torch.int32)
+			self._side = torch.cuda.Stream(device=dev)
 		from .distributed import StepGraph
 		self._graph = StepGraph(torch)
 
@@ -264,16 +265,30 @@ class Single1Plan:
 		st = eng._stream()
 		d_y = self.d_y
 		ycode = _lib.NRM_F64 if d_y.dtype == eng.torch.float64 else _lib.NRM_F32
+		torch = eng.torch
 		with _engine._Span(eng, 's1_select'):
 			_lib.check(lib.nrm_single1_select(L.row_ptr.data_ptr(), L.cells.data_ptr(), ptr(L.row_vals), nx, n, self.nnz, ptr(self.d_c), n, nc, self.cnt.data_ptr(),
 											  self.code.data_ptr(), self.seg.data_ptr(), self.idx.data_ptr(), self.xe.data_ptr(), ptr(self.ce), self.rowinfo.data_ptr(),
-											  ptr(self.gpart), self.sel_info.data_ptr(), st))
-			_lib.check(lib.nrm_single1_group_stats(self.seg.data_ptr(), self.idx.data_ptr(), self.xe.data_ptr(), ptr(self.d_c), n, nc, nx, self.gs.data_ptr(), st))
+											  0, self.sel_info.data_ptr(), st))  # (the shared cells' Gram matrix: on the second stream, below)
+		# The groupings' own statistics (a wave, then a LANE per grouping: 1000 lanes of Jacobi rotations and P-value plans, 70 us on 16 CUs) need the
+		# selection only, and the stream kernel needs nothing of them: they run beside it on a second stream (a fork and a join of the captured graph)
+		# instead of in front of it.
+		main = torch.cuda.current_stream(eng.device)
+		forked, joined = torch.cuda.Event(), torch.cuda.Event()
+		forked.record(main)
+		with torch.cuda.stream(self._side):
+			self._side.wait_event(forked)
+			ss = self._side.cuda_stream
+			if nc:
+				_lib.check(lib.nrm_single1_common_gram(self.cnt.data_ptr(), n, self.d_c.data_ptr(), n, nc, self.gpart.data_ptr(), ss))
+			_lib.check(lib.nrm_single1_group_stats(self.seg.data_ptr(), self.idx.data_ptr(), self.xe.data_ptr(), ptr(self.d_c), n, nc, nx, self.gs.data_ptr(), ss))
 			_lib.check(lib.nrm_single1_group_info(self.gs.data_ptr(), ptr(self.gpart), self.rowinfo.data_ptr(), self.sel_info.data_ptr(), nc, nx, self.dimreduce,
-												  self.info.data_ptr(), self.pitch, self.varx.data_ptr(), self.flags.data_ptr(), st))
+												  self.info.data_ptr(), self.pitch, self.varx.data_ptr(), self.flags.data_ptr(), ss))
+			joined.record(self._side)
 		with _engine._Span(eng, 's1_stream'):
 			_lib.check(lib.nrm_single1_stream(d_y.data_ptr(), ycode, d_y.stride(0), ptr(self.d_c), n, nc, self.code.data_ptr(), n, ny, self.common.data_ptr(),
 											  self.ye.data_ptr(), self.ldye, st))
+		main.wait_event(joined)
 		code_o = _lib.NRM_F64 if self.out_dtype == np.float64 else _lib.NRM_F32
 		with _engine._Span(eng, 's1_cells'):
 			_lib.check(lib.nrm_single1_cells(self.ye.data_ptr(), ycode, self.ldye, ptr(self.ce), self.xe.data_ptr(), self.seg.data_ptr(), self.common.data_ptr(),

@@ -348,6 +348,7 @@ class Single4Plan:
 				self.d_c, self.d_dci = eng.covariates(self.dc, dci) if nc else (None, None)
 				self.lists = de_sparse.lists_for(eng, self.dx)
 				self.flags = eng.zeros((8, ), torch.int32)
+				self._side = torch.cuda.Stream(device=eng.device)
 			self.versions = (self.dx._version, self.dy._version)
 		self.lean = bool(ok)
 		return out
@@ -363,12 +364,22 @@ class Single4Plan:
 		flags = self.flags  # [0] non-finite, [1] R^2 out of range (the sweep), [2] rows near the span of the covariates (k_design_stats, k_de_sparse), [5] diagonal of N~
 		rx = de_sparse.design_stats(eng, lists, d_c, d_dci, dcr, nx, nc, flags)
 		nxp = _engine._round_up(nx, _lib.ROW_TILE)
-		mt_d, _, _, _ = de_sparse.products(eng, lists, d_x, d_c, d_dci, dcr, rx.coef, nx, nx, n, nc, False, False, flags)
-		d_n, scal, small, res = _spd_inverse_fixed(eng, mt_d, nx, rx.ss, self.start, self.iters)
-		dxx = torch.empty(nx, dtype=torch.float64, device=eng.device)
-		varx = torch.empty(nx, dtype=torch.float64, device=eng.device)
-		_lib.check(eng.lib.nrm_single4_design_scalars(small.data_ptr(), nx, n, dxx.data_ptr(), varx.data_ptr(), flags.data_ptr(), eng._stream()))
+		# The design side (M~ from the design's own entries, its Newton-Schulz inverse: two dozen small launches, the 1024^3 products on 64 of the 256 CUs)
+		# and the gene side (the one pass over the expression matrix) need nothing of each other until B = G N~: a fork and a join of the captured graph --
+		# the design side runs on a second stream beside the gather kernel instead of in front of it.
+		main = torch.cuda.current_stream(eng.device)
+		forked, joined = torch.cuda.Event(), torch.cuda.Event()
+		forked.record(main)
+		with torch.cuda.stream(self._side):
+			self._side.wait_event(forked)
+			mt_d, _, _, _ = de_sparse.products(eng, lists, d_x, d_c, d_dci, dcr, rx.coef, nx, nx, n, nc, False, False, flags)
+			d_n, scal, small, res = _spd_inverse_fixed(eng, mt_d, nx, rx.ss, self.start, self.iters)
+			dxx = torch.empty(nx, dtype=torch.float64, device=eng.device)
+			varx = torch.empty(nx, dtype=torch.float64, device=eng.device)
+			_lib.check(eng.lib.nrm_single4_design_scalars(small.data_ptr(), nx, n, dxx.data_ptr(), varx.data_ptr(), flags.data_ptr(), eng._stream()))
+			joined.record(self._side)
 		g_d, ssy, _, _ = de_sparse.products(eng, lists, d_y, d_c, d_dci, dcr, rx.coef, nx, ny, n, nc, False, True, flags)
+		main.wait_event(joined)  # (what the second stream made is used on this one from here on; every such tensor outlives the step's launches)
 		bt_d = eng.gram(Residualized(ny, nxp, g_d, None, None), Residualized(nx, nxp, d_n, None, None), False)  # B^T = (Y~ X~^T) N~
 		tdt = d_y.dtype if d_y.dtype in (torch.float32, torch.float64) else torch.float64
 		p, stat, vary = (torch.empty((nx, ny), dtype=tdt, device=eng.device) for _ in range(3))
