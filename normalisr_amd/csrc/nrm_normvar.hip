@@ -312,41 +312,53 @@ extern "C" int nrm_normvar_apply(const void* d_y, int y_dtype, int64_t rows, int
 // Two reads of the matrix and one write: HBM-bound; nothing crosses PCIe.
 #define NV_NC 8
 
-template <typename T, int NC, bool ALIGNED>
+#ifndef NV_G
+#define NV_G 2  // genes per workgroup of the moments pass: they share the loads of the weights and the covariates, which every gene re-reads from L2 (480 KB per gene).
+                // configs[1] size, moments + solve: one gene 0.203 ms (121 registers, four waves per SIMD), two 0.186 (175, two waves), four 0.266 (256, one wave)
+#endif
+
+template <typename T, int NC, bool ALIGNED, int G>
 __global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int64_t rows, int64_t n, int64_t ldy, const double* __restrict__ lnw,
 													 const double* __restrict__ wt, const double* __restrict__ c, int64_t ldc, double* __restrict__ mom) {
 	constexpr int NP = NC * (NC + 1) / 2, NM = NP + NC + 2;
-	__shared__ double sm[4][NM];
+	__shared__ double sm[4][G * NM];
 	__shared__ double tab[64];
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	nv_exp_table(tab, tid);
 	__syncthreads();
-	const int64_t g = blockIdx.x;
-	const double ex = wt[g];
-	double acc[NM];
+	const int64_t g0 = (int64_t)blockIdx.x * G;
+	double ex[G];
+	const T* row[G];
+	double acc[G][NM];
 #pragma unroll
-	for (int j = 0; j < NM; j++) acc[j] = 0.0;
-	const T* row = y + g * ldy;
-	auto cell = [&](double lw, double yv, const double (&cv)[NC]) {
-		const double e = ex == 0.0 ? 1.0 : nv_exp(ex * lw, tab);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
+	for (int u = 0; u < G; u++) {
+		const int64_t g = g0 + u < rows ? g0 + u : rows - 1;  // (genes past the end repeat the last one: every load is issued, nothing of theirs is stored)
+		ex[u] = wt[g];
+		row[u] = y + g * ldy;
+#pragma unroll
+		for (int j = 0; j < NM; j++) acc[u][j] = 0.0;
+	}
+	auto cell = [&](int u, double lw, double yv, const double (&cv)[NC]) {
+		const double e = ex[u] == 0.0 ? 1.0 : nv_exp(ex[u] * lw, tab);  // w**wt, exactly 1 for wt == 0 (norm.py:245)
 		const double e2 = e * e, yp = yv * e;
 		int j = 0;
 #pragma unroll
 		for (int q = 0; q < NC; q++) {
 			const double t = e2 * cv[q];
 #pragma unroll
-			for (int d = q; d < NC; d++, j++) acc[j] = fma(t, cv[d], acc[j]);
+			for (int d = q; d < NC; d++, j++) acc[u][j] = fma(t, cv[d], acc[u][j]);
 		}
 #pragma unroll
-		for (int q = 0; q < NC; q++, j++) acc[j] = fma(e2 * yv, cv[q], acc[j]);
-		acc[j] += yp;
-		acc[j + 1] = fma(yp, yp, acc[j + 1]);
+		for (int q = 0; q < NC; q++, j++) acc[u][j] = fma(e2 * yv, cv[q], acc[u][j]);
+		acc[u][j] += yp;
+		acc[u][j + 1] = fma(yp, yp, acc[u][j + 1]);
 	};
 	const int64_t n4 = n & ~(int64_t)3;
-	for (int64_t k = (int64_t)tid * 4; k < n4; k += 1024) {  // four cells per thread: 2 + 2 NC sixteen-byte loads in flight before the first is used
-		double lw[4], yv[4], cq[NC][4];
+	for (int64_t k = (int64_t)tid * 4; k < n4; k += 1024) {  // four cells per thread: 2 + G + 2 NC sixteen-byte loads in flight before the first is used
+		double lw[4], yv[G][4], cq[NC][4];
 		nv_ld4<double, ALIGNED>(lnw + k, lw);
-		nv_ld4<T, ALIGNED>(row + k, yv);
+#pragma unroll
+		for (int u = 0; u < G; u++) nv_ld4<T, ALIGNED>(row[u] + k, yv[u]);
 #pragma unroll
 		for (int q = 0; q < NC; q++) nv_ld4<double, ALIGNED>(c + (int64_t)q * ldc + k, cq[q]);
 #pragma unroll
@@ -354,22 +366,26 @@ __global__ void __launch_bounds__(256) k_nv_moments(const T* __restrict__ y, int
 			double cv[NC];
 #pragma unroll
 			for (int q = 0; q < NC; q++) cv[q] = cq[q][v];
-			cell(lw[v], yv[v], cv);
+#pragma unroll
+			for (int u = 0; u < G; u++) cell(u, lw[v], yv[u][v], cv);
 		}
 	}
 	for (int64_t k = n4 + tid; k < n; k += 256) {  // the last n % 4 cells
 		double cv[NC];
 #pragma unroll
 		for (int q = 0; q < NC; q++) cv[q] = c[(int64_t)q * ldc + k];
-		cell(lnw[k], (double)row[k], cv);
+#pragma unroll
+		for (int u = 0; u < G; u++) cell(u, lnw[k], (double)row[u][k], cv);
 	}
 #pragma unroll
-	for (int j = 0; j < NM; j++) {
-		const double t = nv_wave_sum(acc[j]);
-		if (lane == 0) sm[wid][j] = t;
-	}
+	for (int u = 0; u < G; u++)
+#pragma unroll
+		for (int j = 0; j < NM; j++) {
+			const double t = nv_wave_sum(acc[u][j]);
+			if (lane == 0) sm[wid][u * NM + j] = t;
+		}
 	__syncthreads();
-	if (tid < NM) mom[g * NM + tid] = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
+	if (tid < G * NM && g0 + tid / NM < rows) mom[(g0 + tid / NM) * NM + tid % NM] = ((sm[0][tid] + sm[1][tid]) + sm[2][tid]) + sm[3][tid];
 }
 
 // mom (rows, NP + NC + 2) -> b (rows, NC), scale (rows), rank (rows); flags[0] += genes of rank 0
@@ -423,7 +439,7 @@ extern "C" int nrm_normvar_solve(const void* d_y, int y_dtype, int64_t rows, int
 	NRM_REQUIRE(d_y && d_lnw && d_wt && d_c && d_mom && d_b && d_scale && d_rank && d_flags, "nrm_normvar_solve: null pointer");
 	hipStream_t st = (hipStream_t)stream;
 	const bool al = nv_aligned(d_y, y_dtype, ldy, d_lnw, d_c, ldc);
-#define NV_MOM(TY, NCV, AL) hipLaunchKernelGGL((k_nv_moments<TY, NCV, AL>), dim3((unsigned)rows), dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, ldc, d_mom)
+#define NV_MOM(TY, NCV, AL) hipLaunchKernelGGL((k_nv_moments<TY, NCV, AL, NV_G>), dim3((unsigned)((rows + NV_G - 1) / NV_G)), dim3(256), 0, st, (const TY*)d_y, rows, n, ldy, d_lnw, d_wt, d_c, ldc, d_mom)
 #define NV_GO(NCV)                                                                                                                                   \
 	case NCV:                                                                                                                                        \
 		if (y_dtype == NRM_F64) {                                                                                                                    \
