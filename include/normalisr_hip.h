@@ -466,7 +466,8 @@ int nrm_association_tests_single4_host(const void* h_dx, int x_dtype, int64_t nx
 int nrm_binnet_host(const void* h_p, int p_dtype, int64_t ng, double qcut, unsigned char* h_net, int64_t* total);
 /* (Round 5) normvar's expression side at the same kind of seam (norm.py:166-289; `normalisr normvar`): h_y (rows, n) fp32 / fp64, h_lnw (n) = ln w, h_wt (rows), h_c (nc, n)
  * fp64 -> h_out (rows, n) of out_dtype = gene g times w^wt_g, the covariates C w^wt_g removed, the variance kept (keepvar != 0, norm.py:248-259); tol: the rank rule of
- * inv_rank (association.py:77).  1 .. nrm_normvar_device_covariates() covariates (NRM_E_UNSUPPORTED beyond).  *zero_rank = genes whose covariates have rank 0 (the
+ * inv_rank (association.py:77).  1 .. nrm_normvar_device_covariates() covariates entirely on the device; up to 32 through two launches of the fp64 Gram kernel and the host's
+ * threaded Jacobi stack (round 6; NRM_E_UNSUPPORTED beyond 32).  *zero_rank = genes whose covariates have rank 0 (the
  * reference raises RuntimeError, norm.py:158-159; h_out is not written then); NRM_E_NUMERIC for non-finite results (norm.py:286).  The covariates' own scaling
  * (norm.py:261-273) is element-wise on (nc, n) and stays with the caller. */
 int nrm_normvar_host(const void* h_y, int y_dtype, int64_t rows, int64_t n, const double* h_lnw, const double* h_wt, const double* h_c, int64_t nc, double tol,

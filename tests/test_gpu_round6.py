@@ -258,3 +258,29 @@ def test_normvar_exp_against_numpy():
 	mp.mp.dps = 40
 	idx = rng.integers(0, 600000, 2000)
 	assert max(abs(mp.mpf(float(got[i])) / mp.exp(mp.mpf(float(x[i]))) - 1) for i in idx) < 3.5e-16
+
+
+def test_normvar_host_entry_beyond_eight_covariates():
+	"""nrm_normvar_host with 9 .. 32 covariates (round 5: NRM_E_UNSUPPORTED, so that `normalisr normvar` needed torch there): the Gram-launch form of norm.py in
+	the library -- U = e^2, V = e^2 y, two launches of the fp64 Gram kernel, the genes' pseudo-inverses by the threaded Jacobi stack (integer ranks by inv_rank's
+	rule: a covariate given twice), one pass for the result -- against the oracle (norm.py:166-289), and equal to the package's own route."""
+	import normalisr_amd.normalisr as norm
+	from normalisr_amd import _lib
+	rng = np.random.default_rng(690)
+	for nc, ng, n, dup in ((12, 70, 3000, False), (20, 40, 2500, True), (32, 25, 2100, False)):
+		dt = rng.normal(size=(ng, n)) - 9
+		dc = np.vstack([rng.normal(size=(nc - 1, n)), np.ones((1, n))])
+		if dup:
+			dc[3] = dc[1]
+		w, wt = np.exp(0.3 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
+		wt[2] = 0.0
+		ref = oracle.normvar(dt, dc, w, wt)
+		pkg = norm.normvar(dt, dc, w, wt)
+		prev = _lib.prefer_host_entry(True)
+		try:
+			got = norm.normvar(dt, dc, w, wt)
+		finally:
+			_lib.prefer_host_entry(prev)
+		scale = np.abs(ref[0]).max()
+		assert np.abs(got[0] - ref[0]).max() < 1e-9 * scale and close(got[1], ref[1], 1e-12, 1e-15), (nc, dup)
+		assert np.abs(got[0] - pkg[0]).max() < 1e-11 * scale
