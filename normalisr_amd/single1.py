@@ -209,12 +209,21 @@ class Single1Plan:
 
 	def __init__(self, dx, dy, dc, dimreduce=0, lowmem=True, return_dot=True, lists=None, eng=None):
 		eng = self.eng = eng or _engine.get_engine()
-		torch = eng.torch
-		dev = eng.device
-		c64 = np.ascontiguousarray(np.asarray(dc, dtype=np.float64))
-		with eng.lock, torch.cuda.device(dev):
+		self._c64 = np.ascontiguousarray(np.asarray(dc, dtype=np.float64))
+		self.dimreduce, self.lowmem, self.return_dot = int(dimreduce), lowmem, return_dot
+		with eng.lock, eng.torch.cuda.device(eng.device):
 			self.d_dx = dx if _is_dev(dx) else eng.upload(_engine.as_input(np.asarray(dx)))
 			self.d_y = dy if _is_dev(dy) else eng.upload(_engine.as_input(np.asarray(dy)))
+		self._build(lists)
+
+	def _build(self, lists=None):
+		"""Everything that depends on the design tensor as it is NOW: its entry lists, the size of the stream kernel's transposed output, the step's buffers,
+		a fresh graph.  Run at construction, and again by step() when the design tensor has been written to in place since (torch counts that in ._version)."""
+		eng = self.eng
+		torch = eng.torch
+		dev = eng.device
+		c64 = self._c64
+		with eng.lock, torch.cuda.device(dev):
 			nx, n = self.d_dx.shape
 			ny, nc = self.d_y.shape[0], c64.shape[0]
 			if self.d_y.shape[1] != n or c64.shape[1] != n:
@@ -222,7 +231,8 @@ class Single1Plan:
 			if nc > _S1_DEVICE_NC:
 				raise NotImplementedError('Single1Plan: at most {} covariates (association_tests_single1 takes more)'.format(_S1_DEVICE_NC))
 			self.nx, self.ny, self.n, self.nc = nx, ny, n, nc
-			self.dimreduce, self.lowmem, self.return_dot = int(dimreduce), lowmem, return_dot
+			lowmem = self.lowmem
+			self._dx_version = self.d_dx._version
 			self.out_dtype = np.dtype(np.float32 if self.d_y.dtype == torch.float32 else np.float64)
 			tdt = torch.float64 if self.out_dtype == np.float64 else torch.float32
 			lists = self.lists = lists if lists is not None else _lists_for(eng, self.d_dx)
@@ -245,8 +255,15 @@ class Single1Plan:
 			self.gpart = f64(1, gb, 64) if nc else None
 			self.gs = f64(nx, nc * (nc + 1) // 2 + nc + 1)
 			self.ldye = _round_up(ny, 8)  # (a multiple of a 128-byte line instead: measured, no difference -- 1.74 ms either way on one box)
-			# (at most one row of YE per design entry: sized without waiting for the count of the entries that are alone in their cell)
-			self.ye = torch.empty((max(nnz, 1), self.ldye), dtype=self.d_y.dtype, device=dev)
+			# One row of YE per cell that carries exactly one grouping: the selection is run once here and that count read back (the only read-back of the
+			# plan, at construction: it depends on the design alone).  By the design's entry count instead -- no read-back at all -- the buffer of a design
+			# with a quarter of its entries set would be tens of GB.
+			ptr0 = lambda t: 0 if t is None else t.data_ptr()
+			_lib.check(eng.lib.nrm_single1_select(lists.row_ptr.data_ptr(), lists.cells.data_ptr(), ptr0(lists.row_vals), nx, n, nnz, ptr0(self.d_c), n, nc, self.cnt.data_ptr(),
+												  self.code.data_ptr(), self.seg.data_ptr(), self.idx.data_ptr(), self.xe.data_ptr(), ptr0(self.ce), self.rowinfo.data_ptr(),
+												  0, self.sel_info.data_ptr(), eng._stream()))
+			self.n_kept = int(self.sel_info.cpu()[4])
+			self.ye = torch.empty((max(self.n_kept, 1), self.ldye), dtype=self.d_y.dtype, device=dev)
 			self.common = f64(nc + 1, ny)
 			self.pitch = 26 + nc + nc * nc
 			self.info = f64(nx, self.pitch)
@@ -299,14 +316,16 @@ class Single1Plan:
 		"""One pass over the screen; results stay in HBM (results() takes them)."""
 		eng = self.eng
 		with eng.lock, eng.torch.cuda.device(eng.device):
+			if self.d_dx._version != self._dx_version:  # the design written to in place: its lists, the buffer sizes and the captured graph belong to the old values
+				self._build()
 			if eng.trace is not None:  # (bench.py's per-kernel split: events between the launches, not capturable)
 				self._launch()
 			else:
 				self._graph.run(self._launch)
 
 	def cells_kept(self):
-		"""Cells that carry exactly one grouping (the rows of YE the stream kernel writes): one small read-back, outside the steps."""
-		return int(self.sel_info.cpu()[4])
+		"""Cells that carry exactly one grouping (the rows of YE the stream kernel writes)."""
+		return self.n_kept
 
 	def check(self):
 		"""The reference's assertions and errors, from the counters of the steps since the last look."""

@@ -96,6 +96,18 @@ def test_single1_plan_raises_what_the_reference_raises():
 	plan.step()
 	want = oracle.association_tests(dx, dy, dc, single=1)
 	assert p_close(plan.results()[0], want[0])
+	# the design written to IN PLACE between steps (a captured graph and entry lists of the old values): the plan notices (._version) and builds itself anew
+	for _ in range(3):
+		plan.step()
+	assert plan._graph.graph is not None
+	d_x = plan.d_dx
+	free = torch.nonzero(d_x.sum(dim=0) == 0).flatten()[:40]
+	d_x[3, free] = 1.0  # forty more cells for grouping 3, taken from the shared ones
+	plan.step()
+	dx2 = d_x.cpu().numpy()
+	want2 = oracle.association_tests(dx2, dy, dc, single=1)
+	got2 = plan.results()
+	assert plan.n_kept == int(((dx2 != 0).sum(axis=0) == 1).sum()) and p_close(got2[0], want2[0]) and not np.array_equal(got2[0][3], want[0][3])
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
