@@ -394,8 +394,10 @@ for name, dg, single in (('s1', dg1, 1), ('s4', dg4, 4)):
 out['net'] = norm.binnet(d['pc'], 0.05)
 nv = norm.normvar(d['lcpm'], dc, d['w'], d['wt'])
 out['nv_t'], out['nv_c'] = nv[0], nv[1]
+nv12 = norm.normvar(d['lcpm'], np.vstack([dc] * 4), d['w'], d['wt'])  # 12 covariates, each given four times: the entry's Gram-launch form (round 6), ranks by inv_rank's rule
+out['nv12_t'] = nv12[0]
 try:
-	norm.normvar(d['lcpm'], np.vstack([dc] * 4), d['w'], d['wt'])  # 12 covariates: beyond the entry, needs the package's Gram-launch form, i.e. torch
+	norm.normvar(d['lcpm'], np.vstack([dc] * 11), d['w'], d['wt'])  # 33 covariates: beyond the entry, needs the package's form with numpy's stacked SVD, i.e. torch
 	out['nv_unsupported'] = 0
 except NotImplementedError:
 	out['nv_unsupported'] = 1
@@ -436,7 +438,9 @@ def test_de_methods_and_binnet_of_the_package_without_torch(tmp_path, golden):
 	assert (o['p_s1'][7] == 1).all() and (o['lfc_s1'][7] == 0).all()
 	assert np.array_equal(o['net'], g8['net_q5']) and int(o['unsupported']) == 1
 	refn = oracle.normvar(lcpm.astype(np.float64), dc, w, wt)
-	assert np.abs(o['nv_t'] - refn[0]).max() < 2e-5 * np.abs(refn[0]).max() and close(o['nv_c'], refn[1], 1e-12, 1e-15) and int(o['nv_unsupported']) == 1
+	assert np.abs(o['nv_t'] - refn[0]).max() < 1e-6 * np.abs(refn[0]).max() and close(o['nv_c'], refn[1], 1e-12, 1e-15) and int(o['nv_unsupported']) == 1
+	ref12 = oracle.normvar(lcpm.astype(np.float64), np.vstack([dc] * 4), w, wt)  # (the repeated covariates change nothing but the ranks' bookkeeping: the same projection)
+	assert np.abs(o['nv12_t'] - ref12[0]).max() < 1e-6 * np.abs(ref12[0]).max()
 
 
 _CLI_NO_TORCH = r'''
