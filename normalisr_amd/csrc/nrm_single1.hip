@@ -128,6 +128,10 @@ __device__ __forceinline__ void s1_ld(const T* __restrict__ p, T (&v)[V]) {
 // One workgroup = R gene rows, every cell.  common[(comp0 + c) * ny + y] = sum over N of y C_c (c < NC); FIRST: common[qrow * ny + y] =
 // sum over N of y^2 and YE[pos][y] = y at the cell of position pos.  Rows past ny repeat row ny - 1 (their sums are not stored; their
 // values land in the padding columns of YE, ldye >= ny rounded up to 8).
+// (Round 6, measured and not kept: the NEXT group's rows and codes requested before this group's kept values are stored -- loads and stores share one
+// in-order memory counter, and the ISA shows the wave waiting for its stores before the next iteration's loads are even issued -- 218 registers, no spill,
+// and SLOWER: 1.60-1.65 ms against 1.22-1.33 in three alternating runs, profiles/r06_s1_stream_prefetch.txt.  The same kernel writing into another
+// allocation of the same process: 1.20 against 1.25; a pitch of a whole 128-byte line instead of 8 values: no change.)
 // (Measured and not kept: YE in blocks of R rows with the positions in the order of the cells, so that a wave's stores are one
 // contiguous piece -- this kernel 1.28 -> 1.06 ms, but the sweep then gathers 32-byte pieces: 0.35 -> 0.78 ms, and the sweep is the
 // one the host waits for.  The four waves of a workgroup on R rows each, same cells at the same time (their four pieces fill a line,
