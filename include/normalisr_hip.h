@@ -464,6 +464,12 @@ int nrm_association_tests_single4_host(const void* h_dx, int x_dtype, int64_t nx
 									   int64_t nc, int64_t n_cells, const double* h_dci, int rank, int dimreduce, int return_dot, double tol, void* h_p,
 									   void* h_stat, void* h_alpha, void* h_varx, void* h_vary, int out_dtype);
 int nrm_binnet_host(const void* h_p, int p_dtype, int64_t ng, double qcut, unsigned char* h_net, int64_t* total);
+/* (Round 6) What the package needs to follow the reference's per-grouping algorithm of single=4 without torch where the closed form of
+ * nrm_association_tests_single4_host does not apply (rank-deficient A A^T, mpc / method / qr, dy=None): the Gram matrices association.py:926-968 forms with
+ * numpy.matmul, on the fp64 Gram kernel -- h_out (ra, rb) fp64 = A B^T over n cells (h_b == NULL: B = A), optionally the rows' sums of squares -- and the
+ * P-value function of association.py:563 for host arrays.  The small pseudo-inverses of the algorithm stay in numpy (normalisr_amd/single4.py). */
+int nrm_gram_host(const void* h_a, int a_dtype, int64_t ra, const void* h_b, int b_dtype, int64_t rb, int64_t n, double* h_out, double* h_ssa, double* h_ssb);
+int nrm_pvalues_host(const double* h_r2, int64_t count, double dof, double* h_p);
 /* (Round 5) normvar's expression side at the same kind of seam (norm.py:166-289; `normalisr normvar`): h_y (rows, n) fp32 / fp64, h_lnw (n) = ln w, h_wt (rows), h_c (nc, n)
  * fp64 -> h_out (rows, n) of out_dtype = gene g times w^wt_g, the covariates C w^wt_g removed, the variance kept (keepvar != 0, norm.py:248-259); tol: the rank rule of
  * inv_rank (association.py:77).  1 .. nrm_normvar_device_covariates() covariates entirely on the device; up to 32 through two launches of the fp64 Gram kernel and the host's

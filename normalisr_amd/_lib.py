@@ -109,6 +109,8 @@ _SIGNATURES = {
 	'nrm_association_tests_single1_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32], _i32),
 	'nrm_association_tests_single4_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _vp, _vp, _i32], _i32),
 	'nrm_binnet_host': ([_vp, _i32, _i64, _dbl, _vp, _vp], _i32),
+	'nrm_gram_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _vp, _vp], _i32),
+	'nrm_pvalues_host': ([_vp, _i64, _dbl, _vp], _i32),
 	'nrm_normvar_host': ([_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _i32, _vp, _i32, _vp], _i32),
 	'nrm_small_eigvals': ([_vp, _i64, _vp], _i32),
 	'nrm_association_tests_host': ([_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32,

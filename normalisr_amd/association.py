@@ -327,6 +327,40 @@ def _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka):
 	return (p, stat, alpha, varx, vary)
 
 
+def _single14_without_torch(single, dx, dy, dc, lowmem, return_dot, ka):
+	"""What is left of single=1 / single=4 when the whole-problem entries answered NRM_E_UNSUPPORTED and torch cannot be imported: one dimreduce per gene
+	(association.py:449,558: the entries once per distinct value, on the genes that share it), and for single=4 the reference's per-grouping algorithm on
+	device-computed Gram matrices (single4.association_tests_single4_hostlib: rank-deficient designs, mpc / method / qr, dy=None)."""
+	dimreduce = ka.get('dimreduce', 0)
+	if dy is not None and np.ndim(dimreduce) != 0:
+		dimreduce = np.asarray(dimreduce)
+		if single == 1:
+			dimreduce = dimreduce.reshape(-1)  # ((ny, 1) broadcasts against the (ny, nx) blocks of association_test_2 too: association.py:405)
+		if dimreduce.shape != (dy.shape[0], ):
+			raise ValueError('dimreduce must be an integer or have one entry per row of dy.')
+		if (dimreduce != dimreduce.astype(np.int64)).any():
+			raise ValueError('dimreduce must be an integer.')
+		try:
+			out = None
+			for d in np.unique(dimreduce):
+				sel = np.nonzero(dimreduce == d)[0]
+				part = _single14_host_entry(single, dx, np.ascontiguousarray(dy[sel]), dc, lowmem, return_dot, dict(ka, dimreduce=int(d)))
+				if out is None:
+					shape = lambda v: v.shape[:1] + (dy.shape[0], ) + v.shape[2:]
+					out = [None if v is None else (np.array(v) if v.ndim == 1 else np.empty(shape(v), dtype=v.dtype)) for v in part]
+				for o, v in zip(out, part):
+					if v is not None and v.ndim > 1:
+						o[:, sel] = v
+			return tuple(out)
+		except NotImplementedError:
+			if single != 4:
+				raise
+	if single != 4:
+		raise NotImplementedError('single=1: this call needs the package\'s device path (torch)')
+	from .single4 import association_tests_single4_hostlib
+	return association_tests_single4_hostlib(dx, dy, dc, lowmem=lowmem, return_dot=return_dot, **ka)
+
+
 def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=True, single=0, bs4=500,
 					  return_stats=False, device_out=False, **ka):
 	"""All-pairs association tests between rows of dx and dy (or dx with itself when dy is None).
@@ -367,7 +401,7 @@ def association_tests(dx, dy, dc, bsx=0, bsy=0, nth=1, lowmem=True, return_dot=T
 			return _single14_host_entry(single, dx, dy, dc, lowmem, return_dot, ka)
 		except NotImplementedError:
 			if not _have_torch():
-				raise
+				return _single14_without_torch(single, dx, dy, dc, lowmem, return_dot, ka)
 	if single == 1:
 		if samexy:
 			raise NotImplementedError('dy=None with single=1')

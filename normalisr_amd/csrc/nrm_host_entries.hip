@@ -586,6 +586,59 @@ extern "C" int nrm_association_tests_single1_host(const void* h_dx, int x_dtype,
 	return NRM_OK;
 }
 
+// ---- the two pieces the package needs to follow the reference's per-grouping algorithm of single=4 WITHOUT torch ------------------------------------------
+// (association.py:926-980 forms the Gram matrices of A = [dx; dc] and of dy against A with numpy.matmul and hands them to association_test_4; for designs the closed
+// form does not cover -- rank-deficient A A^T, mpc / method / qr, dy=None -- nrm_association_tests_single4_host answers NRM_E_UNSUPPORTED and normalisr_amd/single4.py
+// runs that algorithm on these products: the contractions on the fp64 Gram kernel, the small pseudo-inverses in numpy, the P-values by nrm_pvalues_host.)
+// h_out (ra, rb) fp64 = A B^T over n cells; h_b == NULL: B = A (rb = ra).  h_ssa (ra) / h_ssb (rb) or NULL: the rows' sums of squares.
+extern "C" int nrm_gram_host(const void* h_a, int a_dtype, int64_t ra, const void* h_b, int b_dtype, int64_t rb, int64_t n, double* h_out, double* h_ssa, double* h_ssb) {
+	std::lock_guard<std::mutex> serial(nrm_host_entry_mutex());
+	NRM_TRY(nrm_bind_device());
+	NRM_REQUIRE(h_a && h_out && ra > 0 && n > 0 && (a_dtype == NRM_F32 || a_dtype == NRM_F64) && (!h_b || (rb > 0 && (b_dtype == NRM_F32 || b_dtype == NRM_F64))),
+				"nrm_gram_host: bad arguments");
+	if (!h_b) rb = ra;
+	hipStream_t st = nullptr;
+	const int64_t kp = nrm_round_up(n, NRM_K_TILE), rap = nrm_round_up(ra, NRM_ROW_TILE), rbp = nrm_round_up(rb, NRM_ROW_TILE);
+	DevBuf raw, a64, b64, ssa, ssb, dot, gwork;
+	auto padded = [&](const void* h, int dtype, int64_t rows, int64_t rp, DevBuf& out, DevBuf& ss) -> int {
+		NRM_TRY(upload_matrix(h, dtype, rows, n, raw, st));
+		NRM_TRY(out.alloc((size_t)rp * kp * 8));
+		NRM_TRY(ss.alloc((size_t)rp * 8));
+		NRM_TRY(nrm_residualize(raw.p, dtype, rows, n, n, nullptr, 0, 0, nullptr, 0, out.as<double>(), kp, rp, ss.as<double>(), nullptr, st));  // no covariates: the fp64 padded copy + sums of squares
+		NRM_HIP(hipStreamSynchronize(st));
+		raw.release();
+		return NRM_OK;
+	};
+	NRM_TRY(padded(h_a, a_dtype, ra, rap, a64, ssa));
+	if (h_b) NRM_TRY(padded(h_b, b_dtype, rb, rbp, b64, ssb));
+	NRM_TRY(dot.alloc((size_t)rap * rbp * 8));
+	NRM_HIP(hipMemsetAsync(dot.p, 0, (size_t)rap * rbp * 8, st));  // (the kernel leaves pure-padding sub-blocks unwritten)
+	NRM_TRY(gwork.alloc((size_t)nrm_gram_workspace_bytes()));
+	NRM_TRY(nrm_gram_f64(a64.as<double>(), h_b ? b64.as<double>() : a64.as<double>(), rap, rbp, kp, kp, kp, dot.as<double>(), rbp, 0, ra, rb, gwork.p, st));
+	std::vector<double> hd;
+	NRM_TRY(download(hd, dot.p, (size_t)rap * rbp));
+	for (int64_t i = 0; i < ra; i++) memcpy(h_out + i * rb, &hd[(size_t)(i * rbp)], (size_t)rb * 8);
+	if (h_ssa) NRM_HIP(hipMemcpy(h_ssa, ssa.p, (size_t)ra * 8, hipMemcpyDeviceToHost));
+	if (h_ssb) NRM_HIP(hipMemcpy(h_ssb, h_b ? ssb.p : ssa.p, (size_t)rb * 8, hipMemcpyDeviceToHost));
+	return NRM_OK;
+}
+
+// h_p[i] = I_{1 - h_r2[i]}(dof / 2, 1 / 2): scipy.stats.beta.cdf(1 - R2, dof / 2, 0.5) of association.py:563 for host arrays (the device function of nrm_pvalue.h)
+extern "C" int nrm_pvalues_host(const double* h_r2, int64_t count, double dof, double* h_p) {
+	std::lock_guard<std::mutex> serial(nrm_host_entry_mutex());
+	NRM_TRY(nrm_bind_device());
+	NRM_REQUIRE(count >= 0 && (count == 0 || (h_r2 && h_p)), "nrm_pvalues_host: bad arguments");
+	if (count == 0) return NRM_OK;
+	hipStream_t st = nullptr;
+	DevBuf r2, p;
+	NRM_TRY(r2.alloc((size_t)count * 8));
+	NRM_TRY(p.alloc((size_t)count * 8));
+	NRM_HIP(hipMemcpy(r2.p, h_r2, (size_t)count * 8, hipMemcpyHostToDevice));
+	NRM_TRY(nrm_pvalues_from_r2(r2.as<double>(), count, dof, p.as<double>(), st));
+	NRM_HIP(hipMemcpy(h_p, p.p, (size_t)count * 8, hipMemcpyDeviceToHost));
+	return NRM_OK;
+}
+
 // ---- binnet (binnet.py:134-173) ------------------------------------------------------------------------------------------------------------
 extern "C" int nrm_binnet_host(const void* h_p, int p_dtype, int64_t ng, double qcut, unsigned char* h_net, int64_t* total) {
 	std::lock_guard<std::mutex> serial(nrm_host_entry_mutex());

@@ -35,9 +35,17 @@ def _round_up(v, m):
 def _pvalues_grouped(eng, r2, dof):
 	"""p = I_{1-R^2}(dof/2, 1/2) on the device for an R^2 matrix whose dof varies per entry (one launch per distinct dof:
 	the p-value plan is per dof, association.py:558-563)."""
-	torch = eng.torch
 	dof = np.broadcast_to(dof, r2.shape)
 	p = np.empty(r2.shape)
+	if eng is None:  # no torch in this process: the same device function through the library's host entry
+		for d in np.unique(dof):
+			sel = dof == d
+			v = np.ascontiguousarray(r2[sel], dtype=np.float64)
+			out = np.empty_like(v)
+			_lib.check(_lib.load().nrm_pvalues_host(v.ctypes.data, v.size, float(d), out.ctypes.data))
+			p[sel] = out
+		return p
+	torch = eng.torch
 	for d in np.unique(dof):
 		sel = dof == d
 		d_r2 = eng.upload(np.ascontiguousarray(r2[sel]))
@@ -116,6 +124,25 @@ def _pairwise_host(prod, nx, nc, n, dimreduce, eng, ka):
 	return gam, vy, r2, ranks
 
 
+def _gram_host(a, b=None, want_ss=False):
+	"""A B^T (B = A when b is None) over the cells on the fp64 Gram kernel through nrm_gram_host: numpy in, numpy out, no torch (association.py:936-968's
+	numpy.matmul products).  want_ss: also the sums of squares of the rows of the second operand."""
+	a = np.ascontiguousarray(_engine.as_input(a))
+	b = None if b is None else np.ascontiguousarray(_engine.as_input(b))
+	code = lambda v: _lib.NRM_F64 if v.dtype == np.float64 else _lib.NRM_F32
+	rb = a.shape[0] if b is None else b.shape[0]
+	out = np.empty((a.shape[0], rb))
+	ss = np.empty(rb) if want_ss else None
+	_lib.check(_lib.load().nrm_gram_host(a.ctypes.data, code(a), a.shape[0], None if b is None else b.ctypes.data, 0 if b is None else code(b), rb, a.shape[1],
+										 out.ctypes.data, None, None if ss is None else ss.ctypes.data))
+	return (out, ss) if want_ss else out
+
+
+def _stack_design(dx, dc):
+	"""A = [dx; dc] in fp64 (association.py:935)."""
+	return np.concatenate([np.asarray(dx, dtype=np.float64), np.asarray(dc, dtype=np.float64)], axis=0)
+
+
 def _single4_samexy(dx, dc, lowmem, return_dot, dimreduce, ka, eng, out_dtype):
 	"""association_tests(dx, None, dc, single=4): partial association of every pair of rows given ALL other rows and the
 	covariates (association.py:489-498,506-510,1037-1068).  Full-rank A A^T (A = [dx; dc], N its inverse): the pair (i, j)
@@ -125,19 +152,22 @@ def _single4_samexy(dx, dc, lowmem, return_dot, dimreduce, ka, eng, out_dtype):
 	(diagonal of vary = 1) and divides dot by vary again when return_dot is False."""
 	if not lowmem:
 		raise NotImplementedError('alpha for dy=None is not meaningful in the reference (symmetrised) and is not provided.')
-	torch = eng.torch
 	nx, n = dx.shape
 	nc = dc.shape[0]
 	m = nx + nc
-	from .engine import Residualized
-	mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
-	with torch.cuda.device(eng.device):
-		a_dev = eng.zeros((mp, kp), torch.float64)
-		a_dev[:nx, :n] = eng.upload(_engine.as_input(dx))
-		if nc:
-			a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
-		ra = Residualized(m, n, a_dev, None, None)
-		prod = eng.gram(ra, ra, True)[:m, :m].cpu().numpy()
+	if eng is None:
+		prod = _gram_host(_stack_design(dx, dc))
+	else:
+		torch = eng.torch
+		from .engine import Residualized
+		mp, kp = _engine._round_up(m, _lib.ROW_TILE), _engine._round_up(n, _lib.K_TILE)
+		with torch.cuda.device(eng.device):
+			a_dev = eng.zeros((mp, kp), torch.float64)
+			a_dev[:nx, :n] = eng.upload(_engine.as_input(dx))
+			if nc:
+				a_dev[nx:m, :n] = eng.upload(np.asarray(dc, dtype=np.float64))
+			ra = Residualized(m, n, a_dev, None, None)
+			prod = eng.gram(ra, ra, True)[:m, :m].cpu().numpy()
 	prod = np.triu(prod) + np.triu(prod, 1).T
 	tol, mpc = ka.get('tol', 1E-8), ka.get('mpc', 0)
 	with _engine.host_blas():
@@ -443,19 +473,8 @@ class Single4Plan:
 		return (dl(p), dl(stat), alpha, vx, dl(vary))
 
 
-def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, tol=1E-8,
-							  method='auto', mpc=0, qr=0, device_out=False, **ka):
-	"""Device path of association_tests(..., single=4); returns (p, gamma|dot, alpha|None, varx, vary) with vary of shape
-	(n_x, n_y) as the reference does for single=4.  dy=None tests every pair of rows of dx given all the others
-	(_single4_samexy).  dimreduce may be an int or one value per row of dy (association.py:449,558); tol / method / mpc /
-	qr go to inv_rank as in the reference (:527-528) -- a truncated inverse (mpc > 0) has no closed form and follows the
-	reference's per-grouping algorithm on the device-computed Gram matrices.
-	dx / dy may be torch CUDA tensors already in HBM (a resident screen: bench.py, distributed.de); device_out=True leaves p, the
-	statistic and vary there too."""
-	if ka:
-		raise TypeError("association_test_4() got an unexpected keyword argument '{}'".format(next(iter(ka))))
-	if return_stats:
-		raise NotImplementedError('return_stats is only available for single=0.')
+def _check_arguments(dx, dy, dc, dimreduce):
+	"""The argument checks of association_tests(single=4) (association.py:449-470,761-930), shared by the device path and the torch-free one."""
 	dx, dc = dx if _is_dev(dx) else np.asarray(dx), np.asarray(dc)
 	if dy is not None and not _is_dev(dy):
 		dy = np.asarray(dy)
@@ -481,6 +500,51 @@ def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_s
 		raise ValueError('Dimensions in na==0 detected.')
 	if nc == 0:
 		logging.warning('No covariate dc input.')
+	return dx, dy, dc, dimreduce
+
+
+def association_tests_single4_hostlib(dx, dy, dc, lowmem=True, return_dot=True, dimreduce=0, tol=1E-8, method='auto', mpc=0, qr=0):
+	"""single=4 in a process WITHOUT torch, for the calls nrm_association_tests_single4_host leaves (NRM_E_UNSUPPORTED): a rank-deficient A A^T, a truncated
+	or differently computed pseudo-inverse (mpc / method / qr), dy=None.  The reference's own per-grouping algorithm (association.py:421-576; per pair for
+	dy=None) on Gram matrices the fp64 Gram kernel computes (nrm_gram_host), the small pseudo-inverses in numpy, the P-values by the device function
+	(nrm_pvalues_host).  Same results as association_tests_single4 takes on its slow path; numpy arrays in and out."""
+	dx, dy, dc, dimreduce = _check_arguments(dx, dy, dc, dimreduce)
+	ik = dict(tol=tol, method=method, mpc=mpc, qr=qr)
+	nx, n = dx.shape
+	nc = dc.shape[0]
+	if dy is None:
+		out_dtype = dx.dtype if dx.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+		return _single4_samexy(dx, dc, lowmem, return_dot, dimreduce, ik, None, out_dtype)
+	out_dtype = dy.dtype if dy.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+	logging.info('single=4: no closed form (rank-deficient A A^T or truncated inverse); following the per-grouping algorithm on the host.')
+	a = _stack_design(dx, dc)
+	prod = _gram_host(a)
+	prod = np.triu(prod) + np.triu(prod, 1).T
+	prody, yy = _gram_host(a, dy, want_ss=True)  # (m, ny): A Y^T and sum y^2 (association.py:952-968)
+	with _engine.host_blas():
+		p, gam, alpha, vx, vy = _per_grouping_host(prod, np.ascontiguousarray(prody.T), yy, nx, nc, n, dimreduce, lowmem, None, ik)
+	stat = (gam.T * vx).T if return_dot else gam
+	cast = lambda v: None if v is None else v.astype(out_dtype, copy=False)
+	return (cast(p), cast(stat), cast(alpha), cast(vx), cast(vy))
+
+
+def association_tests_single4(dx, dy, dc, lowmem=True, return_dot=True, return_stats=False, dimreduce=0, tol=1E-8,
+							  method='auto', mpc=0, qr=0, device_out=False, **ka):
+	"""Device path of association_tests(..., single=4); returns (p, gamma|dot, alpha|None, varx, vary) with vary of shape
+	(n_x, n_y) as the reference does for single=4.  dy=None tests every pair of rows of dx given all the others
+	(_single4_samexy).  dimreduce may be an int or one value per row of dy (association.py:449,558); tol / method / mpc /
+	qr go to inv_rank as in the reference (:527-528) -- a truncated inverse (mpc > 0) has no closed form and follows the
+	reference's per-grouping algorithm on the device-computed Gram matrices.
+	dx / dy may be torch CUDA tensors already in HBM (a resident screen: bench.py, distributed.de); device_out=True leaves p, the
+	statistic and vary there too."""
+	if ka:
+		raise TypeError("association_test_4() got an unexpected keyword argument '{}'".format(next(iter(ka))))
+	if return_stats:
+		raise NotImplementedError('return_stats is only available for single=0.')
+	dx, dy, dc, dimreduce = _check_arguments(dx, dy, dc, dimreduce)
+	nx, n = dx.shape
+	nc = dc.shape[0]
+	ny = nx if dy is None else dy.shape[0]
 	ik = dict(tol=tol, method=method, mpc=mpc, qr=qr)  # inv_rank options (association.py:527-528)
 	eng = _engine.get_engine()
 	with eng.lock:  # one call at a time per device (engine scratch, streams and guard state are shared)

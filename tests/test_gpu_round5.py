@@ -402,7 +402,8 @@ try:
 except NotImplementedError:
 	out['nv_unsupported'] = 1
 try:
-	norm.de(dg4, dt, dc, single=4, mpc=2)  # outside the entry: needs the package's device path, i.e. torch
+	from normalisr_amd.association import association_tests
+	association_tests(dg1, None, dc, single=1)  # outside what the library's entries cover (and the reference itself has no such path)
 	out['unsupported'] = 0
 except NotImplementedError:
 	out['unsupported'] = 1

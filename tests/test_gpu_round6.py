@@ -296,3 +296,74 @@ def test_normvar_host_entry_beyond_eight_covariates():
 		scale = np.abs(ref[0]).max()
 		assert np.abs(got[0] - ref[0]).max() < 1e-9 * scale and close(got[1], ref[1], 1e-12, 1e-15), (nc, dup)
 		assert np.abs(got[0] - pkg[0]).max() < 1e-11 * scale
+
+
+_NO_TORCH_S4_REST = r"""
+import sys
+sys.modules['torch'] = None  # `import torch` raises ImportError from here on
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import normalisr.normalisr as norm            # the drop-in import name
+from normalisr_amd.association import association_tests
+d = np.load(sys.argv[2])
+dg, dt, dc, dr = d['dg'], d['dt'], d['dc'], d['dr']
+dcr = np.vstack([dc, 2.0 * dc[:1]])  # a covariate given twice: A A^T is rank deficient, no closed form
+out = {}
+def put(name, res):
+	for k, v in zip(('p', 'stat', 'alpha', 'vx', 'vy'), res):
+		if v is not None:
+			out[name + '_' + k] = v
+put('rdef', association_tests(dg, dt, dcr, single=4, lowmem=False, return_dot=False))
+put('mpc', association_tests(dg, dt, dc, single=4, lowmem=False, mpc=60))              # truncated pseudo-inverse
+put('same', association_tests(dg, None, dc, single=4))                                   # every pair of groupings given all the others
+put('samer', association_tests(dg, None, dcr, single=4, return_dot=False))
+put('dr4', association_tests(dg, dt, dc, single=4, lowmem=False, dimreduce=dr))         # one dimreduce per gene, closed form per distinct value
+put('dr4r', association_tests(dg, dt, dcr, single=4, dimreduce=dr))                     # ... and without a closed form
+put('dr1', association_tests(d['dg1'], dt, dc, single=1, lowmem=False, dimreduce=dr.reshape(-1, 1)))
+put('de', norm.de(dg, dt, dcr, single=4))
+assert not any(m == 'torch' or m.startswith('torch.') for m, v in sys.modules.items() if v is not None)
+np.savez(sys.argv[3], **out)
+"""
+
+
+def test_single4_without_a_closed_form_from_a_process_without_torch(tmp_path):
+	"""The calls nrm_association_tests_single4_host answers NRM_E_UNSUPPORTED -- a rank-deficient A A^T, mpc, dy=None -- and one dimreduce per gene, in a
+	process that cannot import torch: the package follows the reference's per-grouping algorithm (association.py:421-576) on Gram matrices from
+	nrm_gram_host with P-values from nrm_pvalues_host, numpy and the library only.  Against the oracle's restatement of that algorithm."""
+	import subprocess
+	rng = np.random.default_rng(661)
+	nx, ny, n = 24, 70, 3000
+	dc = np.vstack([rng.normal(size=(2, n)), np.ones((1, n))])
+	dg = (rng.random((nx, n)) < 0.04).astype(np.float64)
+	dcr = np.vstack([dc, 2.0 * dc[:1]])
+	dg1 = (rng.random((nx, n)) < 1.0 / nx).astype(np.float64)
+	dt = (rng.normal(size=(ny, n)) + 0.5 * dg[0] + 0.4 * dg[2] + 0.5 * dg1[1]).astype(np.float32)
+	dr = rng.integers(0, 3, ny)
+	np.savez(tmp_path / 'in.npz', dg=dg, dg1=dg1, dt=dt, dc=dc, dr=dr)
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	r = subprocess.run([sys.executable, '-c', _NO_TORCH_S4_REST, root, str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')], capture_output=True, text=True, timeout=900)
+	assert r.returncode == 0, r.stderr[-3000:]
+	o = np.load(tmp_path / 'out.npz')
+	dt64 = dt.astype(np.float64)
+
+	def same(name, ref, tol=1e-6):
+		for k, v in zip(('p', 'stat', 'alpha', 'vx', 'vy'), ref):
+			if v is None:
+				assert name + '_' + k not in o.files
+				continue
+			got = o[name + '_' + k]
+			assert got.shape == v.shape, (name, k)
+			if k == 'p':
+				assert p_close(got, v, 1e-6), (name, k)
+			else:
+				assert np.abs(got - v).max() <= tol * max(np.abs(v).max(), 1e-300), (name, k)
+
+	same('rdef', oracle.association_tests(dg, dt64, dcr, single=4, lowmem=False, return_dot=False))
+	same('mpc', oracle.association_tests(dg, dt64, dc, single=4, lowmem=False, mpc=60))
+	same('same', oracle.association_tests(dg, None, dc, single=4))
+	same('samer', oracle.association_tests(dg, None, dcr, single=4, return_dot=False))
+	same('dr4', oracle.association_tests(dg, dt64, dc, single=4, lowmem=False, dimreduce=dr))
+	same('dr4r', oracle.association_tests(dg, dt64, dcr, single=4, dimreduce=dr))
+	same('dr1', oracle.association_tests(dg1, dt64, dc, single=1, lowmem=False, dimreduce=dr.reshape(-1, 1)))
+	same('de', oracle.de(dg, dt64, dcr, single=4))
+	assert o['rdef_p'].dtype == np.float32 and o['same_p'].dtype == np.float64  # the dtype of dy (of dx for dy=None), as the reference returns
