@@ -367,3 +367,40 @@ def test_single4_without_a_closed_form_from_a_process_without_torch(tmp_path):
 	same('dr1', oracle.association_tests(dg1, dt64, dc, single=1, lowmem=False, dimreduce=dr.reshape(-1, 1)))
 	same('de', oracle.de(dg, dt64, dcr, single=4))
 	assert o['rdef_p'].dtype == np.float32 and o['same_p'].dtype == np.float64  # the dtype of dy (of dx for dy=None), as the reference returns
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_binnet_on_wide_rows_of_every_density(dtype):
+	"""k_binnet_rows on a 9000-wide matrix (the fixed tests stop at 700) whose rows are null P-values, moderately and very dense networks by turns -- with a long run
+	of ties where the threshold falls, few distinct values, thousands of zeros, nothing below the cutoff: the histogram start and the counting passes at every density
+	in one launch.  Booleans bit-exact against the oracle's restatement of binnet.py:77-173 on a sample of the rows (its loops are Python), the count the kernel
+	returns against its own mask."""
+	import torch
+	from normalisr_amd import _lib
+	from normalisr_amd.engine import get_engine
+	eng = get_engine()
+	rng = np.random.default_rng(677)
+	ng = 9000
+	p = rng.random((ng, ng))
+	p **= np.array([1.0, 3.0, 8.0, 1.0, 2.0])[np.arange(ng) % 5][:, None]
+	p[11, 100:4000] = p[11, 99]       # a long run of ties just where the threshold may fall
+	p[12] = np.round(p[12], 2)        # few distinct values
+	p[13, :5000] = 0.0                # zeros
+	p[14] = 1.0                       # nothing below the cutoff
+	pm = p.astype(dtype)
+	d_p = torch.from_numpy(pm).cuda()
+	code = _lib.NRM_F64 if dtype == np.float64 else _lib.NRM_F32
+	rows = np.concatenate([np.arange(40), rng.choice(np.arange(40, ng), 260, replace=False)])
+	for q in (0.05, 0.3):
+		ref = np.zeros((len(rows), ng), dtype=bool)
+		for k, i in enumerate(rows):
+			off = np.arange(ng) != i
+			ref[k, off] = oracle.bh(pm[i, off]) <= q
+		out = torch.zeros((ng, ng), dtype=torch.uint8, device='cuda')
+		total = torch.zeros(1, dtype=torch.int64, device='cuda')
+		flags = torch.zeros(2, dtype=torch.int32, device='cuda')
+		_lib.check(eng.lib.nrm_binnet(d_p.data_ptr(), code, ng, ng, q, out.data_ptr(), ng, total.data_ptr(), flags.data_ptr(), eng._stream()))
+		got = out.cpu().numpy().astype(bool)
+		assert int(flags[0].item()) == 0 and int(total.item()) == int(got.sum())
+		assert np.array_equal(got[rows], ref)
+		assert ref[2].sum() > 4096 and ref[13].sum() >= 5000 and ref[14].sum() == 0
