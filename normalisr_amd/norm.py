@@ -277,4 +277,80 @@ def normvar(dt, dc, w, wt, dextra=None, cat=1, nth=1, bs=500, keepvar=True, norm
 		return ans
 
 
+
+class NormvarPlan:
+	"""normvar on an expression matrix RESIDENT in HBM, step after step (the matrix rewritten in place between steps: the pipeline normvar -> coex -> binnet of
+	examples/GSE123139/code/cmd_coex.sh:38-46 over batches of one shape).  What a call of normvar does on the host for such a step -- log w, three uploads, five
+	allocations, the scaled covariates, the flags read back -- is done ONCE here; a step is the three kernels of csrc/nrm_normvar.hip (moments, a lane per gene
+	for its small system, the result pass) on the same buffers, one HIP graph from the second step on.  Same results as normvar(dt, ..., device_out=True), bit for bit
+	(the same kernels on the same inputs).  check() reads the counters of the last step and raises what normvar raises (norm.py:160,286).
+	Up to nrm_normvar_device_covariates() covariates and normmean=False; otherwise every step is the public call."""
+
+	def __init__(self, dt, dc, w, wt, cat=1, keepvar=True, tol=1E-8, eng=None):
+		from .distributed import StepGraph
+		if not _is_dev(dt):
+			raise ValueError('NormvarPlan takes an expression matrix resident in HBM (a torch CUDA tensor); normvar() is the call for host arrays.')
+		self.eng = eng = eng or _engine.get_engine(dt.device.index)
+		torch = eng.torch
+		self.dt, self.dc, self.w, self.wt = dt, np.asarray(dc), np.asarray(w), np.asarray(wt)
+		self.cat, self.keepvar, self.tol = cat, keepvar, tol
+		nt, ns = dt.shape
+		nc = self.dc.shape[0]
+		first = normvar(dt, self.dc, self.w, self.wt, cat=cat, keepvar=keepvar, tol=tol, device_out=True)  # (every argument check and error of the public call, once)
+		self.dcn = first[1]
+		self.lean = nc <= int(eng.lib.nrm_normvar_device_covariates()) and _opts.debug('normvar', 'device') != 'host' and dt.dtype in (torch.float32, torch.float64) and dt.stride(1) == 1
+		self.out = first[0]
+		self._graph = StepGraph(torch)
+		if self.lean:
+			with eng.lock, torch.cuda.device(eng.device):
+				npair = nc * (nc + 1) // 2
+				self._lnw = eng.upload(np.log(np.asarray(self.w, dtype=np.float64)))
+				self._wt = eng.upload(np.asarray(self.wt, dtype=np.float64))
+				self._c = eng.upload(np.asarray(self.dc, dtype=np.float64))
+				self._mom = torch.empty((nt, npair + nc + 2), dtype=torch.float64, device=eng.device)
+				self._b = torch.empty((nt, nc), dtype=torch.float64, device=eng.device)
+				self._scale = torch.empty((nt, ), dtype=torch.float64, device=eng.device)
+				self._rank = torch.empty((nt, ), dtype=torch.int64, device=eng.device)
+				self._flags = eng.zeros((4, ), torch.int32)
+
+	def _launch(self):
+		eng, y, out = self.eng, self.dt, self.out
+		nt, ns = y.shape
+		nc = self.dc.shape[0]
+		ycode = _lib.NRM_F64 if y.dtype == eng.torch.float64 else _lib.NRM_F32
+		ocode = _lib.NRM_F64 if out.dtype == eng.torch.float64 else _lib.NRM_F32
+		_lib.check(eng.lib.nrm_normvar_solve(y.data_ptr(), ycode, nt, ns, y.stride(0), self._lnw.data_ptr(), self._wt.data_ptr(), self._c.data_ptr(), nc, self._c.stride(0), float(self.tol),
+											 1 if self.keepvar else 0, self._mom.data_ptr(), self._b.data_ptr(), self._scale.data_ptr(), self._rank.data_ptr(), self._flags.data_ptr(), eng._stream()))
+		_lib.check(eng.lib.nrm_normvar_apply(y.data_ptr(), ycode, nt, ns, y.stride(0), self._lnw.data_ptr(), self._wt.data_ptr(), self._c.data_ptr(), nc, self._c.stride(0),
+											 self._b.data_ptr(), self._scale.data_ptr(), out.data_ptr(), ocode, ns, self._flags.data_ptr(), eng._stream()))
+
+	def step(self, timed=False):
+		"""One pass over the matrix as it stands in HBM now; the result in self.out (the same tensor every step), the scaled covariates in self.dcn."""
+		eng = self.eng
+		with eng.lock, eng.torch.cuda.device(eng.device):
+			if not self.lean:
+				self.out, self.dcn = normvar(self.dt, self.dc, self.w, self.wt, cat=self.cat, keepvar=self.keepvar, tol=self.tol, device_out=True)[:2]
+			else:
+				self._graph.run(self._launch)
+		return self.out
+
+	def check(self):
+		"""The counters of the steps since the last check (one small read-back): RuntimeError / AssertionError as normvar raises them."""
+		if not self.lean:
+			return True
+		eng = self.eng
+		with eng.lock, eng.torch.cuda.device(eng.device):
+			f = self._flags.cpu().numpy()
+			self._flags.zero_()
+		if f[0]:
+			raise RuntimeError('Zero-rank covariates found.')
+		assert not f[1]  # np.isfinite(dtn).all() (norm.py:286): counted by the kernel that wrote the values
+		return True
+
+	def results(self):
+		"""[dtn, dcn] as normvar returns them (dtn downloaded)."""
+		self.check()
+		return [self.eng.download(self.out), self.dcn]
+
+
 assert __name__ != "__main__"

@@ -404,3 +404,45 @@ def test_binnet_on_wide_rows_of_every_density(dtype):
 		assert int(flags[0].item()) == 0 and int(total.item()) == int(got.sum())
 		assert np.array_equal(got[rows], ref)
 		assert ref[2].sum() > 4096 and ref[13].sum() >= 5000 and ref[14].sum() == 0
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_normvar_plan_replays_the_public_call(dtype):
+	"""NormvarPlan: the host's share of norm.normvar done once, a step = the three kernels on the same buffers (a HIP graph from the second step on) -- the bits of
+	normvar(..., device_out=True), the oracle's per-gene loop (norm.py:232-259) within 1e-6 of the result's scale; the matrix rewritten in place between steps is
+	what the next step normalises; the reference's assertion on a result that is not finite (norm.py:286) comes out of check()."""
+	import torch
+	import normalisr_amd.normalisr as norm
+	from normalisr_amd.norm import NormvarPlan
+	rng = np.random.default_rng(690)
+	nt, ns, nc = 70, 3001, 4
+	dt = (rng.normal(size=(nt, ns)) - 9).astype(dtype)
+	dc = np.vstack([rng.normal(size=(nc - 1, ns)), np.ones((1, ns))])
+	w, wt = np.exp(0.3 * rng.normal(size=ns)), rng.uniform(0, 1.5, nt)
+	d_dt = torch.from_numpy(dt).cuda()
+	pub = norm.normvar(d_dt, dc, w, wt, device_out=True)
+	plan = NormvarPlan(d_dt, dc, w, wt)
+	assert plan.lean
+	for _ in range(4):
+		out = plan.step()
+	assert plan._graph.graph is not None and plan.check()
+	assert torch.equal(out, pub[0]) and np.array_equal(plan.dcn, pub[1]) and out.dtype == pub[0].dtype
+	ref = oracle.normvar(dt.astype(np.float64), dc, w, wt)
+	got = plan.results()
+	assert np.abs(got[0] - ref[0]).max() < 1e-6 * np.abs(ref[0]).max() and close(got[1], ref[1], 1e-12, 1e-15)
+	d_dt[3] += 0.25 * torch.from_numpy(dc[0]).cuda().to(d_dt.dtype)  # in place: the next replay reads the new values
+	out2 = plan.step()
+	dt2 = d_dt.cpu().numpy()
+	ref2 = oracle.normvar(dt2.astype(np.float64), dc, w, wt)
+	assert np.abs(plan.results()[0] - ref2[0]).max() < 1e-6 * np.abs(ref2[0]).max() and out2 is out
+	# a value that is not finite written into the resident matrix: the step runs (nothing of it is looked at on the host), check() raises the reference's
+	# assertion (norm.py:286) -- and the counters start afresh
+	d_dt[5, 17] = float('nan')
+	plan.step()
+	with pytest.raises(AssertionError):
+		plan.check()
+	d_dt[5, 17] = -9.0
+	plan.step()
+	assert plan.check()
+	with pytest.raises(AssertionError):  # covariates that are all zero: 0 / 0 in every gene's pseudo-inverse, as in the reference (association.py:77-80 keeps s >= tol * 0)
+		NormvarPlan(d_dt, np.zeros((2, ns)), w, wt)
