@@ -123,8 +123,12 @@ __global__ void __launch_bounds__(256) k_residualize(const T* __restrict__ x, in
 	if (tid < RES_R) ss[row0 + tid] = s_ss[0][tid] + s_ss[1][tid] + s_ss[2][tid] + s_ss[3][tid];
 }
 
+#ifndef K1_MINW
+#define K1_MINW 1  // (waves per SIMD the register allocation must leave room for.  Round 6 A/B, profiles/r06_k1_occupancy.txt: 3 -> 168 registers + 12 spilled, C2 0.188 -> 0.213 ms;
+                   // 4 -> 128 + 133 spilled, 0.44 ms: the 180 registers of two waves per SIMD are what the two sweeps need)
+#endif
 template <typename T, int CB, int NS, bool NT = false>
-__global__ void __launch_bounds__(256) k_residualize_v4(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
+__global__ void __launch_bounds__(256, K1_MINW) k_residualize_v4(const T* __restrict__ x, int64_t rows, int64_t n, int64_t ldx,
 														 const double* __restrict__ c, int nc, int64_t ldc,
 														 const double* __restrict__ dci, int active, double* __restrict__ out,
 														 int64_t ldo, double* __restrict__ ss, double* __restrict__ coef, QuantOut qo) {
