@@ -155,7 +155,7 @@ def test_single4_plan_replays_the_public_call(dtype, monkeypatch):
 	assert dense.lean is False and p_close(dense.results()[0][ok], want2[0][ok], 1e-6)
 
 
-def test_c_entry_single1_matches_the_plan_from_a_process_without_torch():
+def test_c_entry_single1_matches_the_plan_from_a_process_without_torch(tmp_path):
 	"""nrm_association_tests_single1_host (numpy in / out, no torch in the process) runs the kernels of Single1Plan: the same results as the package gives
 	in this process, for 5 covariates (statistics on the device) and for 12 (on the host, as in rounds 4-5)."""
 	from normalisr_amd.single1 import association_tests_single1
@@ -184,8 +184,7 @@ rc = lib.nrm_association_tests_single1_host(dx.ctypes.data, 1, nx, dy.ctypes.dat
 assert rc == 0, lib.nrm_last_error()
 np.savez({out!r}, p=p, st=st, vx=vx, vy=vy)
 '''
-		out = os.path.join(ROOT, 'gpurun_out', 'r06_s1_entry_{}.npz'.format(nc))
-		os.makedirs(os.path.dirname(out), exist_ok=True)
+		out = str(tmp_path / 's1_entry_{}.npz'.format(nc))
 		r = subprocess.run([sys.executable, '-c', code.format(root=ROOT, seed=650 + nc, nc=nc, out=out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
 		assert r.returncode == 0, r.stderr[-2000:]
 		got = np.load(out)
